@@ -1,0 +1,81 @@
+"""ctypes binding of libgswm.so (the C ABI declared in include/gswm.h).
+
+There is NO CPU fallback: if the HIP library has not been built, importing this module's `lib()` raises.
+Build it with `python -c "import __graft_entry__ as g; g.build()"` or `make -C a-watermark-for-diffusion-models_amd/csrc`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgswm.so")
+
+GSW_F32, GSW_F16, GSW_BF16, GSW_F64 = 0, 1, 2, 3
+GSW_OK, GSW_ERR_BAD_ARG, GSW_ERR_UNSUPPORTED, GSW_ERR_RAGGED, GSW_ERR_HIP = 0, 1, 2, 3, 4
+GSW_EMBED_EXACT_F64, GSW_EMBED_FAST_F32 = 0, 1
+GSW_FLAG_SATURATED, GSW_FLAG_NAN = 1, 2
+GSW_MSG_INLINE_MAX = 256
+
+_u8p = C.POINTER(C.c_uint8)
+_PROTOTYPES = {
+    "gsw_version": (C.c_int, []),
+    "gsw_strerror": (C.c_char_p, [C.c_int]),
+    "gsw_last_hip_error": (C.c_int, []),
+    "gsw_keystream": (C.c_int, [C.c_char_p, C.c_char_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "gsw_embed": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p,
+                            C.c_int, C.c_int, C.c_int64, C.c_uint32, C.c_void_p]),
+    "gsw_philox_uniform": (C.c_int, [C.c_uint64, C.c_uint64, C.c_void_p, C.c_int, C.c_int64, C.c_void_p]),
+    "gsw_extract": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                              C.c_int, C.c_int64, C.c_void_p]),
+    "gsw_bit_matches": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "gsw_ddim_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_int64, C.c_void_p]),
+    "gsw_ddim_step_cfg": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float,
+                                    C.c_int, C.c_int64, C.c_void_p]),
+    "gsw_ddim_step_extract": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_char_p,
+                                        C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64,
+                                        C.c_void_p]),
+}
+
+_lib = None
+
+
+class GswError(RuntimeError):
+    def __init__(self, status: int, what: str):
+        super().__init__(f"libgswm: {what} (status {status})")
+        self.status = status
+
+
+def lib() -> C.CDLL:
+    """Load libgswm.so (once).  Raises if it is missing -- the product path never degrades to a CPU path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: the HIP library has not been built. Run __graft_entry__.build() "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback for the watermark hot path.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOTYPES.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def exported_symbols():
+    return sorted(_PROTOTYPES)
+
+
+def check(status: int):
+    """Map a gsw_status to the exception the reference would raise for the same condition."""
+    if status == GSW_OK:
+        return
+    what = lib().gsw_strerror(status).decode()
+    if status == GSW_ERR_RAGGED:
+        raise IndexError("string index out of range")  # extract.py:98 on the short trailing segment
+    if status == GSW_ERR_BAD_ARG:
+        raise ValueError(f"libgswm: {what}")
+    if status == GSW_ERR_HIP:
+        what += f" (hipError_t {lib().gsw_last_hip_error()})"
+    raise GswError(status, what)

@@ -1,0 +1,122 @@
+/* gswm.h -- C ABI of the MI355X-native Gaussian-Shading watermark hot path (libgswm.so).
+ *
+ * Every entry point is what a binding of the reference's hot path would call; the reference
+ * (lthero-big/A-watermark-for-Diffusion-Models @ 2024_08_07) is pure Python, so "the interface this
+ * replaces" is a Python function body, cited as file:line relative to the reference root.
+ *
+ * Conventions
+ *   - plain C symbols, plain pointers and sizes; no torch / C++ types cross the boundary
+ *   - `*_dev` pointers are DEVICE (HBM) pointers owned by the caller; all other pointers are HOST
+ *     pointers that are only read during the call (key, nonce, message are copied into the kernel
+ *     arguments)
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); every call is stream-ordered
+ *     and asynchronous, never synchronises, never allocates device memory (exception: gsw_embed with a
+ *     message longer than GSW_MSG_INLINE_MAX bytes stages it with hipMallocAsync/hipFreeAsync)
+ *   - return value: 0 = GSW_OK, otherwise a gsw_status; no exceptions cross the boundary; no global
+ *     mutable state (the in-kernel RNG is fully specified by seed + image index)
+ *   - thread-safe for concurrent calls on distinct streams
+ *   - per-image lattice is the C-contiguous [4, H/8, W/8] latent, addressed by flat element index
+ *     i in [0, n_elems); batches are [B, n_elems] contiguous
+ */
+#ifndef GSWM_H
+#define GSWM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSW_VERSION 100 /* 0.1.0 */
+
+#define GSW_MSG_INLINE_MAX 256 /* message bytes carried inside the kernel arguments (2048 bit) */
+
+typedef enum gsw_dtype {
+    GSW_F32 = 0,
+    GSW_F16 = 1,
+    GSW_BF16 = 2,
+    GSW_F64 = 3
+} gsw_dtype;
+
+typedef enum gsw_status {
+    GSW_OK = 0,
+    GSW_ERR_BAD_ARG = 1,     /* null pointer, bad dtype, non-positive size, n_elems % 4 != 0 ...        */
+    GSW_ERR_UNSUPPORTED = 2, /* lattice too large for the LDS-resident vote             */
+    GSW_ERR_RAGGED = 3,      /* 8*ceil(n_elems/8) is not a multiple of msg_bits: the reference raises
+                                IndexError at extract.py:98                                             */
+    GSW_ERR_HIP = 4          /* a HIP runtime call failed; gsw_last_hip_error() has the hipError_t      */
+} gsw_status;
+
+/* embed flags */
+#define GSW_EMBED_EXACT_F64 0u /* Cephes ndtri evaluated in fp64, then rounded (== scipy to <= a few fp64 ulp) */
+#define GSW_EMBED_FAST_F32 1u  /* fp32 core on the tail-safe side of the distribution; |dz| <= 1e-5       */
+
+/* per-image flag bits written by gsw_extract */
+#define GSW_FLAG_SATURATED 1u /* some z >= 8.292361075813597: norm.cdf == 1.0, y == 2 (extract.py:84-86 raises ValueError) */
+#define GSW_FLAG_NAN 2u       /* some z is NaN (int(nan) raises ValueError at extract.py:84)            */
+
+int gsw_version(void);
+const char* gsw_strerror(int status);
+int gsw_last_hip_error(void); /* thread-local hipError_t of the last GSW_ERR_HIP on this thread */
+
+/* E2 -- gs_insert.py:45-47 / extract.py:77-78,87: the ChaCha20 stream `cryptography` (OpenSSL) produces for
+ * Cipher(algorithms.ChaCha20(key, nonce16)): nonce16[0:4] = LE32 initial block counter (carry into the next
+ * word), nonce16[4:16] = RFC 8439 nonce.  Writes `nbytes` keystream bytes to out_dev. */
+int gsw_keystream(const uint8_t key[32], const uint8_t nonce16[16], uint8_t* out_dev, size_t nbytes, void* stream);
+
+/* E1-E6 -- gs_insert.py:8-66 (and the generalised lattice of ComfyUI_GSWaterMark/nodes.py:51-123), batched.
+ *   msg/msg_bytes : the padded watermark k (gs_insert.py:9-20); plaintext = k repeated floor(n_elems/(8*msg_bytes))
+ *                   times then zeros (nodes.py:79-87)
+ *   u_dev         : optional [B, n_elems] float64 uniforms in [0,1) (the reference's np.random.uniform draws,
+ *                   gs_insert.py:62) -- bit-parity mode.  NULL => in-kernel Philox4x32-10 keyed by `seed`,
+ *                   counter = (element pair index, image_index0 + b): results do not depend on batch split
+ *                   or GPU count.
+ *   out_dev       : [B, n_elems] of out_dtype; z = ndtri((u + y) / 2) (gs_insert.py:64), y = cipher bit,
+ *                   MSB-first within each cipher byte (gs_insert.py:49)
+ *   n_elems       : 4 * (H/8) * (W/8); must be a multiple of 4 */
+int gsw_embed(const uint8_t key[32], const uint8_t nonce16[16], const uint8_t* msg, int msg_bytes,
+              const double* u_dev, uint64_t seed, uint64_t image_index0, void* out_dev, int out_dtype, int B,
+              int64_t n_elems, uint32_t flags, void* stream);
+
+/* In-kernel RNG only: writes the u the kernel would draw ([B, n_elems] float64) so a CPU oracle can be run on
+ * exactly the same inputs. */
+int gsw_philox_uniform(uint64_t seed, uint64_t image_index0, double* u_dev, int B, int64_t n_elems, void* stream);
+
+/* X3-X5 -- extract.py:72-101, batched: y = int(norm.cdf(float64(z)) * 2) per element in C order, pack MSB-first,
+ * ChaCha20-decrypt, split into msg_bits-wide segments, strict-majority vote per bit (ties -> 0).
+ *   z_dev      : [B, n_elems] of z_dtype
+ *   bits_dev   : [B, ceil(msg_bits/8)] recovered message, MSB-first (bit t -> byte t>>3, bit 7-(t&7))
+ *   counts_dev : optional [B, msg_bits] uint32 number of '1' votes per bit (NULL to skip)
+ *   flags_dev  : [B] uint32 GSW_FLAG_* (the reference raises for such images; the host wrapper does too)
+ * Returns GSW_ERR_RAGGED when the reference would raise IndexError. */
+int gsw_extract(const void* z_dev, int z_dtype, const uint8_t key[32], const uint8_t nonce16[16], int msg_bits,
+                uint8_t* bits_dev, uint32_t* counts_dev, uint32_t* flags_dev, int B, int64_t n_elems, void* stream);
+
+/* X6 -- extract.py:103-110 on device: matches_dev[b] = number of equal bits between bits_dev[b] and the
+ * reference message over the first min(msg_bits, ref_bits) positions. */
+int gsw_bit_matches(const uint8_t* bits_dev, int msg_bits, const uint8_t* ref_msg, int ref_bits,
+                    uint32_t* matches_dev, int B, void* stream);
+
+/* X2 / G1 -- the elementwise update of the DDIM (eta = 0) sampling / inversion loop
+ * (inverse_stable_diffusion_gs.pyc `backward_ddim`; diffusers DDIMScheduler/DDIMInverseScheduler.step):
+ *   out = a * x + b * model_out            (a, b precomputed per step on the host in fp64)
+ * computed in fp32, one rounding to `dtype`.  out_dev may alias x_dev. */
+int gsw_ddim_step(const void* x_dev, const void* model_out_dev, void* out_dev, float a, float b, int dtype,
+                  int64_t n, void* stream);
+
+/* G1 with classifier-free guidance fused (modified_stable_diffusion_gs.pyc: uncond + g * (text - uncond), then the
+ * scheduler step): out = a * x + b * (e_uncond + g * (e_text - e_uncond)). */
+int gsw_ddim_step_cfg(const void* x_dev, const void* e_uncond_dev, const void* e_text_dev, void* out_dev, float a,
+                      float b, float guidance, int dtype, int64_t n, void* stream);
+
+/* Last inversion step fused with the extract tail: z = a * x + b * model_out is voted on directly (and stored to
+ * z_out_dev when non-NULL, in `dtype`, after the same rounding an unfused gsw_ddim_step would apply). */
+int gsw_ddim_step_extract(const void* x_dev, const void* model_out_dev, void* z_out_dev, float a, float b, int dtype,
+                          const uint8_t key[32], const uint8_t nonce16[16], int msg_bits, uint8_t* bits_dev,
+                          uint32_t* counts_dev, uint32_t* flags_dev, int B, int64_t n_elems, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSWM_H */

@@ -1,0 +1,55 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+README_KEY = "5822ff9cce6772f714192f43863f6bad1bf54b78326973897e6b66c3186b77a7"
+README_NONCE = "05072fd1c2265f6f2e2a4080a2bfbdd8"
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _gpu_available():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    if _gpu_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container")
+    for it in items:
+        if "gpu" in it.keywords:
+            it.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def golden():
+    def load(name):
+        with open(os.path.join(GOLDEN, name)) as f:
+            return json.load(f)
+    return {
+        "chacha": load("chacha20_keystreams.json"),
+        "embed": load("embed_gs_insert.json"),
+        "extract": load("extract_recover.json"),
+        "comfy": load("embed_comfy_nodes.json"),
+        "arrays": np.load(os.path.join(GOLDEN, "arrays.npz")),
+    }
+
+
+@pytest.fixture(scope="session")
+def keys():
+    return bytes.fromhex(README_KEY), bytes.fromhex(README_NONCE)

@@ -1,0 +1,391 @@
+"""GPU parity tests: the HIP path (through the C ABI, via the package's ctypes binding) against the CPU oracle on the same
+seeded inputs, against the committed golden vectors generated from the reference, and -- at BASELINE.json's full sizes --
+through size-independent properties (embed -> extract round trip, batch-split invariance).
+
+Tolerances
+  * integer / byte / bit work (keystream, recovered bits, vote counts, flags): bit-exact
+  * embed latents, exact mode: <= 1e-5 absolute vs fp32(reference) is the north-star bound; we additionally require
+    <= 1 fp32 ulp everywhere and >= 99.9 % bit-identical fp32 values (GPU libm log vs glibc differ by fp64 ulps)
+  * embed latents, fast mode: <= 1e-5 absolute (north-star bound), measured ~1.3e-6
+  * DDIM step: <= 1 ulp of the storage dtype vs a plain torch fp32 reference of the same op
+"""
+import hashlib
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import gs_oracle as O
+from conftest import README_KEY, README_NONCE
+
+pytestmark = pytest.mark.gpu
+
+ATOL_NORTH_STAR = 1e-5
+
+
+@pytest.fixture(scope="module")
+def G():
+    import gswm_amd
+    from gswm_amd import codec, gs_insert, extract, comfy
+    assert torch.cuda.is_available()
+    gswm_amd._native.lib()  # fails loudly if libgswm.so is missing
+    return types.SimpleNamespace(codec=codec, gs_insert=gs_insert, extract=extract, comfy=comfy, native=gswm_amd._native)
+
+
+def ulp_diff32(a, b):
+    a = np.ascontiguousarray(a, dtype=np.float32).view(np.int32).astype(np.int64)
+    b = np.ascontiguousarray(b, dtype=np.float32).view(np.int32).astype(np.int64)
+    a = np.where(a < 0, -(a & 0x7FFFFFFF), a)
+    b = np.where(b < 0, -(b & 0x7FFFFFFF), b)
+    return np.abs(a - b)
+
+
+# ---------------------------------------------------------------------------------------------- E2
+def test_keystream_matches_openssl_fixtures(G, golden):
+    for name, c in golden["chacha"]["cases"].items():
+        for n in (4608, 2048, 64, 65, 1, 130):
+            ks = G.codec.keystream(bytes.fromhex(c["key_hex"]), bytes.fromhex(c["nonce_hex"]), n).cpu().numpy().tobytes()
+            assert ks.hex() == c["stream_hex"][: 2 * n], (name, n)
+
+
+def test_keystream_long_vs_oracle(G):
+    key, nonce = bytes(range(32)), bytes.fromhex("fdffffff" + "ffffffff" + "0011223344556677")  # counter carry inside the stream
+    n = 64 * 1000 + 17
+    ks = G.codec.keystream(key, nonce, n).cpu().numpy().tobytes()
+    assert ks == O.chacha20_keystream(key, nonce, n)
+
+
+def test_keystream_bad_sizes(G):
+    with pytest.raises(ValueError):
+        G.codec.keystream(b"x" * 31, b"y" * 16, 64)
+    with pytest.raises(ValueError):
+        G.codec.keystream(b"x" * 32, b"y" * 12, 64)
+
+
+# ---------------------------------------------------------------------------------------------- E1-E6 embed
+def _check_exact(z_gpu, z_ref64):
+    z32 = z_ref64.astype(np.float32)
+    g = np.asarray(z_gpu, dtype=np.float32)
+    fin = np.isfinite(z32)
+    assert np.array_equal(np.isfinite(g), fin)
+    assert np.abs(g[fin].astype(np.float64) - z32[fin]).max() <= ATOL_NORTH_STAR
+    ud = ulp_diff32(g[fin], z32[fin])
+    assert ud.max() <= 1, ud.max()
+    assert (ud == 0).mean() >= 0.999
+    assert np.array_equal(np.signbit(g), np.signbit(z32))
+
+
+def test_gs_insert_dropin_matches_reference_fixtures(G, golden, tmp_path):
+    """gs_insert.gs_watermark_init_noise twin: same signature, numpy global RNG, float64 (4,64,64), info_data.txt."""
+    log = tmp_path / "info_data.txt"
+    for name, c in golden["embed"]["cases"].items():
+        if name.startswith("_"):
+            continue
+        opt = types.SimpleNamespace(key_hex=c["key_hex"], nonce_hex=c["nonce_hex"])
+        np.random.seed(c["seed"])
+        z = G.gs_insert.gs_watermark_init_noise(opt, c["message"], log_path=str(log))
+        assert z.shape == (4, 64, 64) and z.dtype == np.float64
+        np.random.seed(c["seed"])
+        ref = O.gs_watermark_init_noise(opt, c["message"])
+        assert hashlib.sha256(ref.tobytes()).hexdigest() == c["sha256_f64"]       # oracle == reference, bit-exact
+        np.testing.assert_allclose(z, ref, rtol=0, atol=1e-12)                    # fp64 GPU vs fp64 reference
+        _check_exact(z, ref)
+        np.testing.assert_allclose(z.reshape(-1)[:8], c["head_f64"], rtol=0, atol=1e-12)
+        if "Z32_" + name in golden["arrays"].files:
+            _check_exact(z, golden["arrays"]["Z32_" + name].astype(np.float64))
+    rec = log.read_text().strip().split("----------------------\n")[-1].strip().splitlines()
+    want = golden["embed"]["cases"]["_info_data_last_record"]
+    assert rec[0].startswith("Time: ") and rec[1:] == want[1:-1] or rec[1:] == want[1:]
+
+
+def test_gs_insert_random_message_and_key(G, tmp_path):
+    """message == '' -> os.urandom watermark, key_hex == '' -> random key/nonce; the log carries what is needed to extract."""
+    log = tmp_path / "info.txt"
+    z = G.gs_insert.gs_watermark_init_noise(types.SimpleNamespace(key_hex="", nonce_hex=""), "", log_path=str(log))
+    lines = dict(l.split(": ", 1) for l in log.read_text().splitlines() if ": " in l)
+    a = types.SimpleNamespace(key=bytes.fromhex(lines["key"]), nonce=bytes.fromhex(lines["nonce"]), l=1, message_length=256)
+    bits = G.extract.recover_exactracted_message(z, a)
+    assert G.extract.calculate_bit_accuracy(lines["message"], bits)[1] == 1.0
+    assert O.recover_exactracted_message(z, a) == bits
+
+
+def test_comfy_lattices_match_reference_fixtures(G, golden, tmp_path):
+    g = golden["comfy"]
+    for name, c in g["cases"].items():
+        if name.startswith("_") or "width" not in c:
+            continue
+        z = G.comfy.gs_watermark_init_noise(g["key_hex"], g["nonce_hex"], "cpu", c["message"], 1, c["seed"], c["width"], c["height"],
+                                            c["message_length"], log_path=str(tmp_path / "i.txt"))
+        assert isinstance(z, torch.Tensor) and z.dtype == torch.float32 and not z.is_cuda and list(z.shape) == c["shape"]
+        ref = O.comfy_gs_watermark_init_noise(g["key_hex"], g["nonce_hex"], c["message"], 1, c["seed"], c["width"], c["height"], c["message_length"])
+        assert hashlib.sha256(ref.tobytes()).hexdigest() == c["sha256_f32"]
+        ud = ulp_diff32(z.numpy(), ref)
+        assert ud.max() <= 1 and (ud == 0).mean() >= 0.999, name
+        np.testing.assert_allclose(z.numpy().reshape(-1)[:8], c["head"], rtol=0, atol=ATOL_NORTH_STAR)
+    rec = (tmp_path / "i.txt").read_text().strip().split("----------------------\n")[-1].strip().splitlines()
+    assert [l.split(":")[0] for l in rec] == [l.split(":")[0] for l in g["cases"]["_info_data_last_record"]]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16, torch.float64])
+@pytest.mark.parametrize("fast", [False, True])
+def test_embed_batch_vs_oracle(G, keys, dtype, fast):
+    key, nonce = keys
+    B, shape = 5, (4, 64, 64)
+    n = 4 * 64 * 64
+    k = O.pad_message("lthero", 32)
+    u = np.random.RandomState(123).uniform(0, 1, (B, n))
+    u[0, :8] = [0.0, 2.0 ** -53, 1 - 2.0 ** -53, 0.5, 2.0 ** -30, 1 - 2.0 ** -30, 0.25, 0.75]   # extremes
+    z = G.codec.embed_batch(key, nonce, k, B, shape, u=torch.from_numpy(u).cuda(), dtype=dtype, fast=fast)
+    assert z.shape == (B, *shape) and z.dtype == dtype
+    ref = np.stack([O.embed_latent(k, key, nonce, u[b], shape) for b in range(B)])
+    ref_t = torch.from_numpy(ref).to(torch.float32).to(dtype)      # the reference caller's .float() then the pipeline cast
+    g = z.cpu().to(torch.float64).numpy()
+    r = ref_t.to(torch.float64).numpy()
+    fin = np.isfinite(r)
+    assert np.array_equal(np.isfinite(g), fin)                      # u == 0 with a 0 bit -> -inf, like norm.ppf(0)
+    assert np.array_equal(np.signbit(g), np.signbit(r))             # the sign IS the cipher bit
+    tol = ATOL_NORTH_STAR if dtype in (torch.float32, torch.float64) else (0.04 if dtype == torch.bfloat16 else 0.005)
+    assert np.abs(g[fin] - r[fin]).max() <= tol
+    if not fast and dtype == torch.float32:
+        _check_exact(g, ref)
+    if fast and dtype == torch.float64:
+        assert np.abs(g[fin] - ref[fin]).max() <= ATOL_NORTH_STAR  # vs the fp64 reference itself
+
+
+def test_embed_philox_stream_and_split_invariance(G, keys):
+    key, nonce = keys
+    k = O.pad_message("lthero", 32)
+    n = 4 * 64 * 64
+    u = G.codec.philox_uniform(seed=0xDEADBEEFCAFE, image_index0=5, batch=3, n_elems=n)
+    np.testing.assert_array_equal(u.cpu().numpy(), O.philox_uniform(0xDEADBEEFCAFE, 5, 3, n))   # bit-exact RNG restatement
+    z_rng = G.codec.embed_batch(key, nonce, k, 3, (4, 64, 64), seed=0xDEADBEEFCAFE, image_index0=5)
+    z_u = G.codec.embed_batch(key, nonce, k, 3, (4, 64, 64), u=u)
+    assert torch.equal(z_rng, z_u)
+    # the same images regardless of how the batch is split over calls / GPUs
+    z_a = G.codec.embed_batch(key, nonce, k, 1, (4, 64, 64), seed=0xDEADBEEFCAFE, image_index0=5)
+    z_b = G.codec.embed_batch(key, nonce, k, 2, (4, 64, 64), seed=0xDEADBEEFCAFE, image_index0=6)
+    assert torch.equal(torch.cat([z_a, z_b]), z_rng)
+    ref = np.stack([O.embed_latent(k, key, nonce, O.philox_uniform(0xDEADBEEFCAFE, 5, 3, n)[b], (4, 64, 64)) for b in range(3)])
+    _check_exact(z_rng.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("shape,msg_bytes", [((4, 96, 96), 128), ((4, 96, 96), 32), ((4, 17, 25), 4), ((4, 8, 8), 32), ((4, 1, 1), 1),
+                                             ((4, 64, 96), 125), ((4, 128, 128), 300)])
+def test_embed_odd_lattices_vs_oracle(G, keys, shape, msg_bytes):
+    """Ragged chunks (N % 2048 != 0), ChaCha blocks straddling rows (w = 96), message longer than the lattice, zero tail
+    (N % msg_bits != 0), message > GSW_MSG_INLINE_MAX bytes (staged through device memory)."""
+    key, nonce = keys
+    n = int(np.prod(shape))
+    k = bytes(np.random.RandomState(msg_bytes).randint(0, 256, msg_bytes, dtype=np.uint8))
+    u = np.random.RandomState(n).uniform(0, 1, (2, n))
+    z = G.codec.embed_batch(key, nonce, k, 2, shape, u=torch.from_numpy(u).cuda())
+    ref = np.stack([O.embed_latent(k, key, nonce, u[b], shape) for b in range(2)])
+    _check_exact(z.cpu().numpy(), ref)
+
+
+# ---------------------------------------------------------------------------------------------- X3-X6 extract
+def test_recover_dropin_matches_reference_fixtures(G, golden, keys):
+    key, nonce = keys
+    x, arrays = golden["extract"]["cases"], golden["arrays"]
+    z0 = arrays["Z32_s0_lthero"]
+    A = lambda ml, k=key: types.SimpleNamespace(key=k, nonce=nonce, l=1, message_length=ml)
+    R = G.extract.recover_exactracted_message
+    assert R(z0.astype(np.float64), A(256)) == x["clean_f64_256"]["bits"]
+    assert R(torch.from_numpy(z0).half()[None], A(256)) == x["clean_f16_256"]["bits"]       # what extract.py:70 hands over
+    assert R(z0[None], A(256)) == x["clean_f32_1x4x64x64_256"]["bits"]
+    assert R(torch.from_numpy(z0).bfloat16(), A(256)) == O.recover_bits(torch.from_numpy(z0).bfloat16().float().numpy(), key, nonce, 256)
+    for ml in (32, 64, 128, 512, 1024, 2048, 16384):
+        assert R(z0, A(ml)) == x["clean_f32_%d" % ml]["bits"], ml
+    for s in ("0.5", "1", "2", "4"):
+        zn, c = arrays["Znoisy16_" + s], x["noisy_sigma" + s]
+        if c.get("raises"):
+            with pytest.raises(ValueError):
+                R(zn, A(256))
+        else:
+            assert R(zn, A(256)) == c["bits"]
+        zc = np.clip(zn, np.float16(-8), np.float16(8))
+        b = R(zc, A(256))
+        assert b == x["noisy_clip8_sigma" + s]["bits"]
+        assert G.extract.calculate_bit_accuracy(golden["extract"]["msg_hex"], b)[1] == x["noisy_clip8_sigma" + s]["accuracy"]
+    assert R(z0.astype(np.float16), A(256, bytes.fromhex(x["wrong_key"]["key_hex"]))) == x["wrong_key"]["bits"]
+    # ties -> '0', all-zero / negative-zero lattices
+    zt = z0.reshape(-1).copy()
+    for t, nflip in x["ties_256"]["flip_spec"].items():
+        for c in range(nflip):
+            zt[c * 256 + int(t)] *= -1.0
+    assert R(zt.reshape(4, 64, 64), A(256)) == x["ties_256"]["bits"]
+    assert R(np.zeros((4, 64, 64), np.float32), A(256)) == x["all_pos_zero"]["bits"]
+    assert R(-np.zeros((4, 64, 64), np.float32), A(256)) == x["all_neg_zero"]["bits"]
+    assert R(-np.zeros((4, 64, 64), np.float16), A(256)) == x["all_neg_zero"]["bits"]
+
+
+def test_recover_error_semantics(G, golden, keys):
+    key, nonce = keys
+    z0 = golden["arrays"]["Z32_s0_lthero"].copy()
+    A = lambda ml: types.SimpleNamespace(key=key, nonce=nonce, l=1, message_length=ml)
+    zs = z0.copy(); zs[1, 2, 3] = 9.0
+    with pytest.raises(ValueError):
+        G.extract.recover_exactracted_message(zs, A(256))                     # saturated cdf, extract.py:86
+    with pytest.raises(IndexError):
+        G.extract.recover_exactracted_message(z0, A(1000))                    # ragged segment, extract.py:98
+    with pytest.raises(ValueError):
+        G.extract.recover_exactracted_message(np.full((4, 64, 64), np.nan, np.float32), A(256))
+    zi = z0.astype(np.float16); zi[0, 0, 0] = np.inf
+    with pytest.raises(ValueError):
+        G.extract.recover_exactracted_message(zi, A(256))
+    zi[0, 0, 0] = -np.inf                                                     # cdf(-inf) = 0: fine
+    assert G.extract.recover_exactracted_message(zi, A(256)) == O.recover_bits(zi, key, nonce, 256)
+    res = G.extract.recover_exactracted_message_batch(torch.from_numpy(np.stack([z0, zs])).cuda(), A(256))
+    assert isinstance(res[0], str) and isinstance(res[1], ValueError)
+
+
+def test_quantise_edge_scalars_all_dtypes(G, golden, keys):
+    """y = int(norm.cdf(z)*2) decision boundaries (extract.py:83-84) for every input dtype, element by element."""
+    key, nonce = keys
+    vals = [float(d["z"]) for d in golden["extract"]["cases"]["_edge_scalars"]]
+    vals += [np.nextafter(O.Y1_THRESHOLD, -1.0), np.nextafter(O.Y1_THRESHOLD, 1.0), float(np.nextafter(np.float32(O.Y1_THRESHOLD), np.float32(-1))),
+             float(np.nextafter(np.float32(O.Y1_THRESHOLD), np.float32(1))), float(np.float32(O.Y1_THRESHOLD)),
+             -5.96e-8, 5.96e-8, float(np.float16(8.29)), float(np.float16(8.30)), 8.25, 8.3125, float(np.float32(O.Y2_THRESHOLD)),
+             float(np.nextafter(np.float32(O.Y2_THRESHOLD), np.float32(0))), float(np.nextafter(np.float32(O.Y2_THRESHOLD), np.float32(9)))]
+    ks = np.unpackbits(np.frombuffer(O.chacha20_keystream(key, nonce, 8), np.uint8))
+    for np_dt, t_dt in ((np.float64, torch.float64), (np.float32, torch.float32), (np.float16, torch.float16), (None, torch.bfloat16)):
+        for v in vals:
+            t = torch.full((1, 64), -1.0, dtype=torch.float64)
+            t[0, 5] = v
+            t = t.to(t_dt)
+            zz = t.to(torch.float64).numpy().reshape(-1)
+            bits, flags, counts = G.codec.extract_batch(t.cuda(), key, nonce, 64, return_counts=True)
+            y = O.quantise(zz)
+            assert int(flags[0]) == ((1 if (y >= 2).any() else 0)), (t_dt, v)
+            want = (np.minimum(y, 1) ^ ks[:64]).astype(np.int32)             # one segment: counts are the decrypted bits
+            np.testing.assert_array_equal(counts[0].cpu().numpy(), want, err_msg=f"{t_dt} {v!r}")
+        tn = torch.full((1, 64), float("nan"), dtype=t_dt).cuda()
+        assert int(G.codec.extract_batch(tn, key, nonce, 64)[1][0]) & G.native.GSW_FLAG_NAN
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32, torch.float64])
+@pytest.mark.parametrize("shape,ml", [((4, 64, 64), 256), ((4, 64, 64), 8), ((4, 64, 64), 2048), ((4, 96, 96), 1024), ((4, 96, 96), 256),
+                                      ((4, 96, 96), 36), ((4, 96, 96), 768), ((4, 17, 25), 8), ((4, 17, 25), 24), ((4, 17, 25), 71),
+                                      ((4, 64, 64), 4), ((4, 64, 64), 1), ((4, 64, 64), 4096), ((4, 128, 128), 512), ((4, 1, 1), 8), ((4, 1, 1), 2)])
+def test_extract_batch_vs_oracle(G, keys, dtype, shape, ml):
+    """Fast vote (M%8==0, M/8 | 256) and generic vote (any divisor, N%8 != 0 right-aligned tail) against the oracle, noisy
+    latents so the votes are not unanimous; vote counts compared too."""
+    key, nonce = keys
+    n = int(np.prod(shape))
+    B = 3
+    rng = np.random.RandomState(n + ml)
+    z = torch.from_numpy(rng.standard_normal((B, n)).astype(np.float32) * 1.5).to(dtype)
+    z[1].mul_(0)                                                                   # all +0.0
+    bits, flags, counts = G.codec.extract_batch(z.cuda(), key, nonce, ml, return_counts=True)
+    zz = z.to(torch.float64).numpy()
+    for b in range(B):
+        want = O.recover_bits(zz[b], key, nonce, ml)
+        got = G.codec.bits_to_str(bits[b].cpu().numpy())
+        assert got[:ml] == want, (b, dtype, shape, ml)
+        assert set(got[ml:]) <= {"0"}
+        assert int(flags[b]) == 0
+    # counts vs a direct numpy vote
+    y = O.quantise(zz[0])
+    nb = (n + 7) // 8
+    if n % 8 == 0:
+        cb = np.packbits(y.astype(np.uint8))
+    else:
+        cb = np.concatenate([np.packbits(y[: (n // 8) * 8].astype(np.uint8)), [int("".join(str(int(v)) for v in y[(n // 8) * 8:]), 2)]]).astype(np.uint8)
+    pt = np.unpackbits(cb ^ np.frombuffer(O.chacha20_keystream(key, nonce, nb), np.uint8))
+    np.testing.assert_array_equal(counts[0].cpu().numpy(), pt.reshape(-1, ml).sum(0))
+
+
+def test_extract_ragged_raises_like_reference(G, keys):
+    key, nonce = keys
+    z = torch.zeros((1, 4 * 17 * 25), dtype=torch.float32).cuda()
+    with pytest.raises(IndexError):
+        G.codec.extract_batch(z, key, nonce, 32)       # 1704 % 32 != 0
+    with pytest.raises(IndexError):
+        O.recover_bits(z.cpu().numpy(), key, nonce, 32)
+
+
+def test_bit_matches_vs_reference_accuracy(G, golden, keys):
+    key, nonce = keys
+    z = torch.from_numpy(np.stack([np.clip(golden["arrays"]["Znoisy16_" + s], np.float16(-8), np.float16(8)) for s in ("1", "2", "4")])).cuda()
+    bits, flags = G.codec.extract_batch(z, key, nonce, 256)
+    msg = bytes.fromhex(golden["extract"]["msg_hex"])
+    m = G.codec.bit_matches(bits, 256, msg).cpu().numpy()
+    for i, s in enumerate(("1", "2", "4")):
+        assert m[i] / 256 == golden["extract"]["cases"]["noisy_clip8_sigma" + s]["accuracy"]
+    # unequal lengths: compare over the shorter (extract.py:105-107)
+    m2 = G.codec.bit_matches(bits, 256, msg[:3], 20).cpu().numpy()
+    for i in range(3):
+        s = G.codec.bits_to_str(bits[i].cpu().numpy())
+        assert m2[i] == round(O.calculate_bit_accuracy(msg[:3].hex()[:5], s[:20])[1] * 20)
+
+
+# ---------------------------------------------------------------------------------------------- X2 / G1 elementwise
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("n", [4 * 64 * 64 * 3, 1001, 7, 8])
+def test_ddim_step_vs_torch_fp32(G, dtype, n):
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(n, generator=g).to(dtype).cuda()
+    e = torch.randn(n, generator=g).to(dtype).cuda()
+    t = torch.randn(n, generator=g).to(dtype).cuda()
+    a, b = O.ddim_coefficients(O.sd_alphas_cumprod()[1], O.sd_alphas_cumprod()[21])
+    a32, b32 = np.float32(a), np.float32(b)
+    out = G.codec.ddim_step(x, e, float(a), float(b))
+    ref = (float(a32) * x.float() + float(b32) * e.float())
+    tol = {torch.float32: 5e-7, torch.float16: 1e-3, torch.bfloat16: 8e-3}[dtype]
+    assert (out.float() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+    out2 = G.codec.ddim_step_cfg(x, e, t, float(a), float(b), 7.5)
+    ref2 = float(a32) * x.float() + float(b32) * (e.float() + 7.5 * (t.float() - e.float()))
+    assert (out2.float() - ref2).abs().max().item() <= 8 * tol * max(1.0, ref2.abs().max().item())
+    xi = x.clone()
+    G.codec.ddim_step(xi, e, float(a), float(b), out=xi)       # in place
+    assert torch.equal(xi, out)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("shape,ml", [((4, 64, 64), 256), ((4, 17, 25), 8)])
+def test_ddim_step_extract_equals_unfused(G, keys, dtype, shape, ml):
+    key, nonce = keys
+    B = 4
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn((B, *shape), generator=g).to(dtype).cuda()
+    e = torch.randn((B, *shape), generator=g).to(dtype).cuda()
+    a, b = 1.0123, -0.0456
+    z = G.codec.ddim_step(x, e, a, b)
+    bits0, flags0, cnt0 = G.codec.extract_batch(z, key, nonce, ml, return_counts=True)
+    zo = torch.empty_like(x)
+    bits1, flags1, cnt1 = G.codec.ddim_step_extract(x, e, a, b, key, nonce, ml, z_out=zo, return_counts=True)
+    assert torch.equal(zo, z) and torch.equal(bits0, bits1) and torch.equal(flags0, flags1) and torch.equal(cnt0, cnt1)
+    bits2, _ = G.codec.ddim_step_extract(x, e, a, b, key, nonce, ml)
+    assert torch.equal(bits2, bits0)
+
+
+# ---------------------------------------------------------------------------------------------- full-size properties
+@pytest.mark.parametrize("B,shape,ml,fast,dtype", [
+    (64, (4, 64, 64), 256, False, torch.float32),     # north-star batch, SD2.1 512x512
+    (64, (4, 64, 64), 256, True, torch.float16),
+    (256, (4, 64, 64), 256, True, torch.float16),     # config 4 batch
+    (128, (4, 96, 96), 256, True, torch.float16),     # config 5: 768x768, 144 copies
+    (128, (4, 96, 96), 1024, False, torch.bfloat16),  # config 5 with the ComfyUI auto length, 36 copies
+    (1024, (4, 64, 64), 256, True, torch.float32),
+])
+def test_roundtrip_lossless_full_size(G, keys, B, shape, ml, fast, dtype):
+    """embed -> (cast) -> extract recovers 100 % of the bits for every image (the reference's lossless claim, README.md:15),
+    the latents are N(0,1), and each image of the batch differs."""
+    key, nonce = keys
+    k = O.pad_message("lthero-roundtrip", ml // 8)
+    z = G.codec.embed_batch(key, nonce, k, B, shape, seed=2024, dtype=dtype, fast=fast)
+    bits, flags, counts = G.codec.extract_batch(z, key, nonce, ml, return_counts=True)
+    assert int(flags.abs().sum()) == 0
+    want = torch.frombuffer(bytearray(k), dtype=torch.uint8).cuda()
+    assert bool((bits == want[None]).all())
+    nseg = int(np.prod(shape)) // ml
+    kb = torch.from_numpy(np.unpackbits(np.frombuffer(k, np.uint8)).astype(np.int32)).cuda()
+    assert bool((counts == kb[None] * nseg).all())            # unanimous votes
+    assert int(G.codec.bit_matches(bits, ml, k).min()) == ml
+    zf = z.float()
+    assert abs(zf.mean().item()) < 5e-3 and abs(zf.std().item() - 1.0) < 5e-3
+    assert not torch.equal(z[0], z[1])
+    # oracle spot check on two images of the big batch
+    for b in (0, B - 1):
+        assert O.recover_bits(z[b].float().cpu().numpy(), key, nonce, ml) == "".join(format(x, "08b") for x in k)
