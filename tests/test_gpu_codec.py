@@ -124,7 +124,10 @@ def test_comfy_lattices_match_reference_fixtures(G, golden, tmp_path):
         assert ud.max() <= 1 and (ud == 0).mean() >= 0.999, name
         np.testing.assert_allclose(z.numpy().reshape(-1)[:8], c["head"], rtol=0, atol=ATOL_NORTH_STAR)
     rec = (tmp_path / "i.txt").read_text().strip().split("----------------------\n")[-1].strip().splitlines()
-    assert [l.split(":")[0] for l in rec] == [l.split(":")[0] for l in g["cases"]["_info_data_last_record"]]
+    rec = [l for l in rec if not l.startswith("-----")]
+    want = g["cases"]["_info_data_last_record"]
+    assert [l.split(":")[0] for l in rec] == [l.split(":")[0] for l in want]
+    assert rec[1:4] == want[1:4] or rec[1:3] == want[1:3]      # key / nonce (/ message of the last case) lines verbatim
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16, torch.float64])
@@ -275,7 +278,7 @@ def test_extract_batch_vs_oracle(G, keys, dtype, shape, ml):
     n = int(np.prod(shape))
     B = 3
     rng = np.random.RandomState(n + ml)
-    z = torch.from_numpy(rng.standard_normal((B, n)).astype(np.float32) * 1.5).to(dtype)
+    z = torch.from_numpy(np.clip(rng.standard_normal((B, n)).astype(np.float32) * 1.5, -8, 8)).to(dtype)   # < 8.29: no saturation
     z[1].mul_(0)                                                                   # all +0.0
     bits, flags, counts = G.codec.extract_batch(z.cuda(), key, nonce, ml, return_counts=True)
     zz = z.to(torch.float64).numpy()
@@ -383,8 +386,11 @@ def test_roundtrip_lossless_full_size(G, keys, B, shape, ml, fast, dtype):
     kb = torch.from_numpy(np.unpackbits(np.frombuffer(k, np.uint8)).astype(np.int32)).cuda()
     assert bool((counts == kb[None] * nseg).all())            # unanimous votes
     assert int(G.codec.bit_matches(bits, ml, k).min()) == ml
+    # marginally N(0,1): |z| is half-normal.  (The batch mean is NOT ~0 to 1/sqrt(B*N): every image shares the sign pattern
+    # -- same key, nonce and message -- so the mean carries the +-1/sqrt(N) imbalance of the cipher bits.)
     zf = z.float()
-    assert abs(zf.mean().item()) < 5e-3 and abs(zf.std().item() - 1.0) < 5e-3
+    assert abs(zf.abs().mean().item() - 0.7978845608) < 4e-3 and abs(zf.pow(2).mean().item() - 1.0) < 8e-3
+    assert abs(zf.mean().item()) < 4.0 * 0.8 / np.sqrt(np.prod(shape))
     assert not torch.equal(z[0], z[1])
     # oracle spot check on two images of the big batch
     for b in (0, B - 1):
