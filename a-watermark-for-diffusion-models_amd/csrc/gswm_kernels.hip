@@ -85,7 +85,7 @@ __device__ __forceinline__ void chacha20_blocks_to_lds(const CipherRegs ck, uint
     const uint32_t b0 = col == 0 ? ck.k0 : col == 1 ? ck.k1 : col == 2 ? ck.k2 : ck.k3;
     const uint32_t c0 = col == 0 ? ck.k4 : col == 1 ? ck.k5 : col == 2 ? ck.k6 : ck.k7;
     const uint64_t ctr_base = ((uint64_t)ck.n1 << 32) | ck.n0;
-    for (uint32_t blk = tid >> 2; blk < nblocks; blk += GSW_WG / 4) {
+    for (uint32_t blk = tid >> 2; blk < nblocks; blk += blockDim.x >> 2) {
         const uint64_t ctr = ctr_base + first_block + (uint64_t)blk;
         const uint32_t d0 = col == 0 ? (uint32_t)ctr : col == 1 ? (uint32_t)(ctr >> 32) : col == 2 ? ck.n2 : ck.n3;
         uint32_t a = a0, b = b0, c = c0, d = d0;
@@ -121,11 +121,10 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
 }
 
-// numpy random_sample construction: 53 bits from two 32-bit words
-__device__ __forceinline__ double u53(uint32_t wa, uint32_t wb) {
-    const uint64_t v = ((uint64_t)(wa >> 5) << 26) | (uint64_t)(wb >> 6);
-    return (double)v * (1.0 / 9007199254740992.0);
-}
+// In-kernel uniform: ONE 32-bit word per element, u = (w + 0.5) * 2^-32 in (0, 1) -- exactly representable in fp64.
+// Group g = e >> 2 of image `img` draws Philox4x32-10(counter = (g, 0, img_lo, img_hi), key = seed); element e takes
+// word e & 3.  One Philox call per 16-byte fp32 store.
+__device__ __forceinline__ double u_from_word(uint32_t w) { return fma((double)w, 0x1p-32, 0x1p-33); }
 
 // ------------------------------------------------------------------------------------------------
 // Inverse normal CDF.
@@ -198,22 +197,35 @@ __device__ __forceinline__ double ndtri_cephes(double y0) {
 // |z_fast - ndtri_fp64| <= 4e-6 over the whole 53-bit u range (tests pin <= 1e-5).
 #include "ndtri_fast_coeffs.inc"
 
-__device__ __forceinline__ float ndtri_fast_abs(float v, float x) {
-    // |ndtri(v/2)| for v in (0,1], x = 1 - v (both rounded from exact fp64 values); v == 0 -> +inf
-    const float w = -__logf(v * (2.0f - v));
-    float r;
-    if (w < GSW_NF_SPLIT) {
-        const float t = w - GSW_NF_C0;
-        r = GSW_NF_A[0];
+__device__ __forceinline__ float ndtri_fast_tail(float w) {
+    const float t = __fsqrt_rn(w) - GSW_NF_C1;
+    float r = GSW_NF_B[0];
 #pragma unroll
-        for (int i = 1; i < GSW_NF_NA; ++i) r = fmaf(r, t, GSW_NF_A[i]);
-    } else {
-        const float t = __fsqrt_rn(w) - GSW_NF_C1;
-        r = GSW_NF_B[0];
+    for (int i = 1; i < GSW_NF_NB; ++i) r = fmaf(r, t, GSW_NF_B[i]);
+    return r;
+}
+
+// |ndtri(v/2)| for 4 elements; v in (0,1], x = 1 - v (each rounded from an exact value); v == 0 -> +inf.
+// The central polynomial covers w < 10 (v > 2.3e-5): a wave takes the tail branch for ~0.6 % of its 4-element groups.
+__device__ __forceinline__ void ndtri_fast_abs4(const float (&v)[4], const float (&x)[4], float (&a)[4]) {
+    float w[4], r[4];
 #pragma unroll
-        for (int i = 1; i < GSW_NF_NB; ++i) r = fmaf(r, t, GSW_NF_B[i]);
+    for (int k = 0; k < 4; ++k) {
+        w[k] = -0.69314718056f * __log2f(v[k] * (2.0f - v[k]));
+        const float t = w[k] - GSW_NF_C0;
+        float q = GSW_NF_A[0];
+#pragma unroll
+        for (int i = 1; i < GSW_NF_NA; ++i) q = fmaf(q, t, GSW_NF_A[i]);
+        r[k] = q;
     }
-    return r * x;
+    const float wmax = fmaxf(fmaxf(w[0], w[1]), fmaxf(w[2], w[3]));
+    if (!(wmax < GSW_NF_SPLIT)) {   // also catches w = +inf (v == 0) and NaN
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (!(w[k] < GSW_NF_SPLIT)) r[k] = ndtri_fast_tail(w[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a[k] = r[k] * x[k];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -301,7 +313,8 @@ struct EmbedArgs {
     uint64_t seed, image_index0;
     uint32_t n_elems;       // N
     uint32_t msg_bytes;     // |k|
-    uint32_t lim_elems;     // repeats * 8 * |k|: elements past it carry plaintext 0 (nodes.py:85-87)
+    uint32_t msg_bits;      // message bits (8*|k| for whole-byte messages)
+    uint32_t lim_elems;     // repeats * msg_bits: elements past it carry plaintext 0 (nodes.py:85-87)
     int32_t B;
 };
 
@@ -314,11 +327,14 @@ __device__ __forceinline__ uint32_t inline_msg_byte(uint32_t i) {
     return ka[offsetof(EmbedArgs, msg) + i];
 }
 
-template <typename OutT, bool HAS_U, bool FAST>
+// BITMSG: message length is not a multiple of 8 bits -> plaintext bit looked up per element (generic geometry)
+template <typename OutT, bool HAS_U, bool FAST, bool BITMSG>
 __global__ __launch_bounds__(GSW_WG) void gsw_embed_kernel(EmbedArgs p) {
     __shared__ uint32_t ks_words[64];  // 4 blocks x 16 words
     const uint32_t tid = threadIdx.x;
-    const uint32_t chunk = blockIdx.x;
+    // Workgroup (x, y) is dispatched to XCD (x + gridDim.x * y) % 8.  With chunk == x every XCD would only ever write
+    // addresses congruent to x * 8 KiB (mod 64 KiB), i.e. a fraction of its L2 channels; rotating by y spreads them.
+    const uint32_t chunk = (blockIdx.x + blockIdx.y) % gridDim.x;
     const uint32_t N = p.n_elems;
     const uint32_t e_chunk = chunk * GSW_CHUNK;
     const uint32_t nblk = min(4u, (N - e_chunk + 511u) / 512u);
@@ -335,102 +351,31 @@ __global__ __launch_bounds__(GSW_WG) void gsw_embed_kernel(EmbedArgs p) {
         e_r[r] = e;
         uint32_t nib = 0;
         if (e < N) {
-            const uint32_t jb = e >> 3;                       // global cipher byte
-            const uint32_t kbyte = ksb[(r * 128u) + (tid >> 1)];
-            uint32_t pbyte = 0;
-            if (e < p.lim_elems) {                            // lim is a multiple of 8: whole bytes in or out
-                const uint32_t mi = jb % p.msg_bytes;
-                pbyte = p.msg_dev ? p.msg_dev[mi] : inline_msg_byte(mi);
-            }
-            const uint32_t cbyte = kbyte ^ pbyte;
-            nib = (tid & 1u) ? (cbyte & 0xFu) : (cbyte >> 4);
-        }
-        ynib[r] = nib;
-    }
-
-    const uint32_t k0 = (uint32_t)p.seed, k1 = (uint32_t)(p.seed >> 32);
-    for (int b = blockIdx.y; b < p.B; b += gridDim.y) {
-        const uint64_t img = p.image_index0 + (uint64_t)b;
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const uint32_t e = e_r[r];
-            if (e >= N) continue;
-            const size_t off = (size_t)b * N + e;
-            double u[4];
-            if (HAS_U) {
-                const double2 ua = reinterpret_cast<const double2*>(p.u + off)[0];
-                const double2 ub = reinterpret_cast<const double2*>(p.u + off)[1];
-                u[0] = ua.x; u[1] = ua.y; u[2] = ub.x; u[3] = ub.y;
-            } else {
-                uint32_t w[4];
-                const uint32_t pair = e >> 1;
-                philox4x32_10(pair, 0u, (uint32_t)img, (uint32_t)(img >> 32), k0, k1, w);
-                u[0] = u53(w[0], w[1]); u[1] = u53(w[2], w[3]);
-                philox4x32_10(pair + 1u, 0u, (uint32_t)img, (uint32_t)(img >> 32), k0, k1, w);
-                u[2] = u53(w[0], w[1]); u[3] = u53(w[2], w[3]);
-            }
-            OutT* dst = reinterpret_cast<OutT*>(p.out) + off;
-            if (FAST) {
-                float zf[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const bool one = (ynib[r] >> (3 - k)) & 1u;
-                    const double v = one ? 1.0 - u[k] : u[k];   // exact: u is a multiple of 2^-53
-                    const double x = one ? u[k] : 1.0 - u[k];
-                    const float a = ndtri_fast_abs((float)v, (float)x);
-                    zf[k] = one ? a : -a;
-                }
-                Vec4Store<OutT>::stf(dst, zf);
-            } else {
-                double z[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const double y = (double)((ynib[r] >> (3 - k)) & 1u);
-                    z[k] = ndtri_cephes((u[k] + y) * 0.5);       // gs_insert.py:64, same operation order
-                }
-                Vec4Store<OutT>::st(dst, z);
-            }
-        }
-    }
-}
-
-// generic message geometry (message bits not a multiple of 8): per-element plaintext bit
-template <typename OutT, bool HAS_U, bool FAST>
-__global__ __launch_bounds__(GSW_WG) void gsw_embed_bitmsg_kernel(EmbedArgs p, uint32_t msg_bits) {
-    __shared__ uint32_t ks_words[64];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t chunk = blockIdx.x;
-    const uint32_t N = p.n_elems;
-    const uint32_t e_chunk = chunk * GSW_CHUNK;
-    const uint32_t nblk = min(4u, (N - e_chunk + 511u) / 512u);
-    chacha20_blocks_to_lds(GSW_CIPHER_REGS(p.ck), chunk * 4u, nblk, ks_words);
-    __syncthreads();
-    const uint8_t* ksb = reinterpret_cast<const uint8_t*>(ks_words);
-    uint32_t ynib[2], e_r[2];
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const uint32_t e = e_chunk + r * 1024u + 4u * tid;
-        e_r[r] = e;
-        uint32_t nib = 0;
-        if (e < N) {
             const uint32_t kbyte = ksb[(r * 128u) + (tid >> 1)];
             const uint32_t knib = (tid & 1u) ? (kbyte & 0xFu) : (kbyte >> 4);
-            uint32_t pn = 0;
+            uint32_t pnib = 0;
+            if (BITMSG) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint32_t i = e + k;
-                uint32_t bit = 0;
-                if (i < p.lim_elems) {
-                    const uint32_t m = i % msg_bits;
-                    const uint32_t by = p.msg_dev ? p.msg_dev[m >> 3] : inline_msg_byte(m >> 3);
-                    bit = (by >> (7u - (m & 7u))) & 1u;
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t i = e + k;
+                    uint32_t bit = 0;
+                    if (i < p.lim_elems) {
+                        const uint32_t m = i % p.msg_bits;
+                        const uint32_t by = p.msg_dev ? p.msg_dev[m >> 3] : inline_msg_byte(m >> 3);
+                        bit = (by >> (7u - (m & 7u))) & 1u;
+                    }
+                    pnib |= bit << (3 - k);
                 }
-                pn |= bit << (3 - k);
+            } else if (e < p.lim_elems) {                       // lim is a multiple of 8: whole bytes in or out
+                const uint32_t mi = (e >> 3) % p.msg_bytes;     // global cipher byte -> message byte
+                const uint32_t pbyte = p.msg_dev ? p.msg_dev[mi] : inline_msg_byte(mi);
+                pnib = (tid & 1u) ? (pbyte & 0xFu) : (pbyte >> 4);
             }
-            nib = knib ^ pn;
+            nib = knib ^ pnib;
         }
         ynib[r] = nib;
     }
+
     const uint32_t k0 = (uint32_t)p.seed, k1 = (uint32_t)(p.seed >> 32);
     for (int b = blockIdx.y; b < p.B; b += gridDim.y) {
         const uint64_t img = p.image_index0 + (uint64_t)b;
@@ -439,37 +384,47 @@ __global__ __launch_bounds__(GSW_WG) void gsw_embed_bitmsg_kernel(EmbedArgs p, u
             const uint32_t e = e_r[r];
             if (e >= N) continue;
             const size_t off = (size_t)b * N + e;
+            OutT* dst = reinterpret_cast<OutT*>(p.out) + off;
+            uint32_t w[4];
             double u[4];
             if (HAS_U) {
                 const double2 ua = reinterpret_cast<const double2*>(p.u + off)[0];
                 const double2 ub = reinterpret_cast<const double2*>(p.u + off)[1];
                 u[0] = ua.x; u[1] = ua.y; u[2] = ub.x; u[3] = ub.y;
             } else {
-                uint32_t w[4];
-                const uint32_t pair = e >> 1;
-                philox4x32_10(pair, 0u, (uint32_t)img, (uint32_t)(img >> 32), k0, k1, w);
-                u[0] = u53(w[0], w[1]); u[1] = u53(w[2], w[3]);
-                philox4x32_10(pair + 1u, 0u, (uint32_t)img, (uint32_t)(img >> 32), k0, k1, w);
-                u[2] = u53(w[0], w[1]); u[3] = u53(w[2], w[3]);
+                philox4x32_10(e >> 2, 0u, (uint32_t)img, (uint32_t)(img >> 32), k0, k1, w);
             }
-            OutT* dst = reinterpret_cast<OutT*>(p.out) + off;
             if (FAST) {
-                float zf[4];
+                float v[4], x[4], a[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const bool one = (ynib[r] >> (3 - k)) & 1u;
-                    const double v = one ? 1.0 - u[k] : u[k];
-                    const double x = one ? u[k] : 1.0 - u[k];
-                    const float a = ndtri_fast_abs((float)v, (float)x);
-                    zf[k] = one ? a : -a;
+                    if (HAS_U) {
+                        v[k] = (float)(one ? 1.0 - u[k] : u[k]);   // exact in fp64 for a 53-bit u, then one rounding
+                        x[k] = (float)(one ? u[k] : 1.0 - u[k]);
+                    } else {
+                        // u = (w + .5) 2^-32  =>  1 - u = (~w + .5) 2^-32: the tail-side quantity is an integer select
+                        const uint32_t wv = one ? ~w[k] : w[k];
+                        v[k] = fmaf((float)wv, 0x1p-32f, 0x1p-33f);   // relative precision 2^-24 on the tail side
+                        x[k] = fmaxf(1.0f - v[k], 0x1p-33f);          // absolute error <= 2^-25 (|dz| <= 4e-8); never 0, so
+                                                                      // the sign (= the cipher bit) survives as +-tiny
+                    }
+                }
+                ndtri_fast_abs4(v, x, a);
+                float zf[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t neg = ((~ynib[r] >> (3 - k)) & 1u) << 31;   // cipher bit 0 -> negative half
+                    zf[k] = __uint_as_float(__float_as_uint(a[k]) | neg);
                 }
                 Vec4Store<OutT>::stf(dst, zf);
             } else {
                 double z[4];
-#pragma unroll
+#pragma unroll 1
                 for (int k = 0; k < 4; ++k) {
+                    const double uk = HAS_U ? u[k] : u_from_word(w[k]);
                     const double y = (double)((ynib[r] >> (3 - k)) & 1u);
-                    z[k] = ndtri_cephes((u[k] + y) * 0.5);
+                    z[k] = ndtri_cephes((uk + y) * 0.5);       // gs_insert.py:64, same operation order
                 }
                 Vec4Store<OutT>::st(dst, z);
             }
@@ -480,15 +435,16 @@ __global__ __launch_bounds__(GSW_WG) void gsw_embed_bitmsg_kernel(EmbedArgs p, u
 __global__ __launch_bounds__(GSW_WG) void gsw_philox_uniform_kernel(double* __restrict__ u, uint64_t seed, uint64_t image_index0,
                                                                     int B, uint32_t N) {
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-    const uint32_t npairs = (N + 1) / 2;
+    const uint32_t ngroups = (N + 3) / 4;
     for (int b = blockIdx.y; b < B; b += gridDim.y) {
         const uint64_t img = image_index0 + (uint64_t)b;
-        for (uint32_t pr = blockIdx.x * GSW_WG + threadIdx.x; pr < npairs; pr += gridDim.x * GSW_WG) {
+        for (uint32_t g = blockIdx.x * GSW_WG + threadIdx.x; g < ngroups; g += gridDim.x * GSW_WG) {
             uint32_t w[4];
-            philox4x32_10(pr, 0u, (uint32_t)img, (uint32_t)(img >> 32), k0, k1, w);
-            const size_t off = (size_t)b * N + 2u * pr;
-            u[off] = u53(w[0], w[1]);
-            if (2u * pr + 1u < N) u[off + 1] = u53(w[2], w[3]);
+            philox4x32_10(g, 0u, (uint32_t)img, (uint32_t)(img >> 32), k0, k1, w);
+            const size_t off = (size_t)b * N + 4u * g;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (4u * g + k < N) u[off + k] = u_from_word(w[k]);
         }
     }
 }
@@ -535,7 +491,10 @@ template <> struct Load8<__hip_bfloat16> {
 #define GSW_Y2_THR (8.292361075813597)
 
 struct Thr {
-    float y1f, y2f;
+    float y1f, y2f;     // float-compare form (generic vote)
+    uint32_t nz_add;    // packed-integer form (wave vote): t + nz_add sets the top bit of the field iff |z| > T1, where T1 is the
+                        // largest magnitude with int(cdf(-|z|)*2) == 1  (0 for fp16: every non-zero half is far beyond it)
+    uint32_t sat_bits;  // smallest magnitude bit pattern with z >= Y2 (also below inf/NaN patterns)
 };
 
 // cipher byte of 8 consecutive elements, MSB-first (extract.py:86), plus error flags
@@ -561,9 +520,24 @@ __device__ __forceinline__ uint32_t quantise8d(const double (&v)[8], uint32_t& f
 }
 
 // Sources of the latent being voted on.
+// Packed-integer view used by the wave-per-image vote: one cipher byte = 8 consecutive elements =
+//   16-bit types: 4 words (2 elements per word, element 2i in the low half of word i)
+//   fp32        : 8 words
+// fp64 inputs are mapped to an fp32 surrogate that makes the same three decisions (>= Y1, >= Y2, NaN).
+template <typename T> struct WordsOf { static constexpr int NW = 8; static constexpr bool PK16 = false; };
+template <> struct WordsOf<__half> { static constexpr int NW = 4; static constexpr bool PK16 = true; };
+template <> struct WordsOf<__hip_bfloat16> { static constexpr int NW = 4; static constexpr bool PK16 = true; };
+
 template <typename InT>
 struct SrcPlain {  // z read from HBM
+    typedef InT elem_t;
     const InT* z;
+    __device__ __forceinline__ void words(size_t off, uint32_t (&w)[WordsOf<InT>::NW]) const {
+        const uint4* p = reinterpret_cast<const uint4*>(z + off);
+        const uint4 a = p[0];
+        w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
+        if constexpr (WordsOf<InT>::NW == 8) { const uint4 b = p[1]; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w; }
+    }
     __device__ __forceinline__ uint32_t byte8(size_t off, const Thr& t, uint32_t& flags) const {
         float v[8];
         Load8<InT>::ld(z + off, v);
@@ -578,7 +552,21 @@ struct SrcPlain {  // z read from HBM
 };
 template <>
 struct SrcPlain<double> {
+    typedef double elem_t;
     const double* z;
+    __device__ __forceinline__ void words(size_t off, uint32_t (&w)[8]) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const double2 d = reinterpret_cast<const double2*>(z + off)[i];
+            const double v[2] = {d.x, d.y};
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float sgt = v[j] >= GSW_Y1_THR ? (v[j] >= GSW_Y2_THR ? 16.0f : 1.0f) : -1.0f;
+                if (v[j] != v[j]) sgt = __uint_as_float(0x7FC00000u);
+                w[2 * i + j] = __float_as_uint(sgt);
+            }
+        }
+    }
     __device__ __forceinline__ uint32_t byte8(size_t off, const Thr&, uint32_t& flags) const {
         double v[8];
 #pragma unroll
@@ -624,10 +612,33 @@ template <> struct Store8<__hip_bfloat16> {
 
 template <typename T>
 struct SrcDdim {  // z = round_T(a*x + b*e): the last inversion step fused into the vote
+    typedef T elem_t;
     const T* x;
     const T* e;
     T* zout;  // nullable
     float a, b;
+    __device__ __forceinline__ void words(size_t off, uint32_t (&w)[WordsOf<T>::NW]) const {
+        float xv[8], ev[8], zv[8];
+        Load8<T>::ld(x + off, xv);
+        Load8<T>::ld(e + off, ev);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) zv[k] = fmaf(b, ev[k], a * xv[k]);
+        if constexpr (std::is_same<T, float>::value) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) w[k] = __float_as_uint(zv[k]);
+        } else if constexpr (std::is_same<T, __half>::value) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { union { __half2 h; uint32_t u; } c; c.h = __floats2half2_rn(zv[2 * i], zv[2 * i + 1]); w[i] = c.u; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { union { __hip_bfloat16 h[2]; uint32_t u; } c; c.h[0] = __float2bfloat16(zv[2 * i]); c.h[1] = __float2bfloat16(zv[2 * i + 1]); w[i] = c.u; }
+        }
+        if (zout) {
+            uint4* q = reinterpret_cast<uint4*>(zout + off);
+            q[0] = make_uint4(w[0], w[1], w[2], w[3]);
+            if constexpr (WordsOf<T>::NW == 8) q[1] = make_uint4(w[4], w[5], w[6], w[7]);
+        }
+    }
     __device__ __forceinline__ uint32_t byte8(size_t off, const Thr& t, uint32_t& flags) const {
         float xv[8], ev[8], zv[8];
         Load8<T>::ld(x + off, xv);
@@ -662,7 +673,7 @@ struct ExtractArgs {
     Thr thr;
 };
 
-// Spread the 8 bits of a decrypted byte (MSB-first: bit 7 = first message bit of that byte) into 8 byte-wide
+// Spread the 8 bits of a byte (MSB-first: bit 7 belongs to the first element of the group) into 8 byte-wide
 // counters held as two u32: lo lane k (k = 0..3) <- bit (7-k), hi lane k <- bit (3-k).
 __device__ __forceinline__ void spread_bits(uint32_t byte, uint32_t& lo, uint32_t& hi) {
     const uint32_t x = byte * 0x01010101u;                                  // byte replicated in all 4 lanes
@@ -670,77 +681,160 @@ __device__ __forceinline__ void spread_bits(uint32_t byte, uint32_t& lo, uint32_
     hi = (((x & 0x01020408u) + 0x7F7E7C78u) >> 7) & 0x01010101u;            // lane k keeps bit (3-k)
 }
 
-// Fast vote: N % 8 == 0, M % 8 == 0, (M/8) divides 256, N % M == 0.
-// One workgroup per image (grid-strided over the batch); thread t owns cipher bytes j = t + 256 r, which all map to
-// message byte t mod (M/8); per-thread counters are 8 packed byte lanes, reduced across the lanes of a wave that
-// share a message byte with __shfl_xor, then across waves with LDS atomics.
-// LDS: [keystream N/8 bytes][counters M x u32]
+typedef unsigned short gsw_us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
+    const gsw_us2 r = __builtin_elementwise_max(__builtin_bit_cast(gsw_us2, a), __builtin_bit_cast(gsw_us2, b));
+    return __builtin_bit_cast(uint32_t, r);
+}
+
+// "cipher bit is 0" indicators of one 8-element group as byte lanes (lane k of n_lo = element k, of n_hi = element 4+k),
+// from the raw bit patterns: element is a 0-bit  <=>  sign set and |z| > T1  (y = int(cdf(z)*2) == 0, extract.py:83-84).
+// Pure VALU integer work: no compare -> SGPR -> select round trips.  tmax tracks the largest magnitude pattern seen.
+template <bool PK16, int NW>
+__device__ __forceinline__ void negbits8(const uint32_t (&w)[NW], uint32_t nz_add, uint32_t& n_lo, uint32_t& n_hi, uint32_t& tmax) {
+    uint32_t n[NW];
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        const uint32_t t = w[i] & (PK16 ? 0x7FFF7FFFu : 0x7FFFFFFFu);
+        n[i] = w[i] & (t + nz_add);                       // top bit of each field: negative AND beyond T1
+        tmax = PK16 ? pk_max_u16(tmax, t) : max(tmax, t);
+    }
+    if (PK16) {   // high bytes of the 8 halves -> [e0 e1 e2 e3], [e4 e5 e6 e7]
+        n_lo = __builtin_amdgcn_perm(n[1], n[0], 0x07050301u);
+        n_hi = __builtin_amdgcn_perm(n[3], n[2], 0x07050301u);
+    } else {      // top bytes of the 8 words
+        const uint32_t a = __builtin_amdgcn_perm(n[1], n[0], 0x0C0C0703u);   // [n0.b3, n1.b3, 0, 0]
+        const uint32_t b = __builtin_amdgcn_perm(n[3], n[2], 0x0C0C0703u);
+        const uint32_t c = __builtin_amdgcn_perm(n[5], n[4], 0x0C0C0703u);
+        const uint32_t d = __builtin_amdgcn_perm(n[7], n[6], 0x0C0C0703u);
+        n_lo = __builtin_amdgcn_perm(b, a, 0x05040100u);
+        n_hi = __builtin_amdgcn_perm(d, c, 0x05040100u);
+    }
+    n_lo = (n_lo >> 7) & 0x01010101u;
+    n_hi = (n_hi >> 7) & 0x01010101u;
+}
+
+// exact flags of one image (rare path: only when a magnitude >= the saturation pattern was seen)
 template <typename Src>
-__global__ __launch_bounds__(GSW_WG) void gsw_extract_fast_kernel(ExtractArgs p, Src src) {
+__device__ __forceinline__ uint32_t wave_exact_flags(const Src& src, size_t base, uint32_t nbytes, const Thr& thr, uint32_t lane) {
+    uint32_t f = 0;
+    for (uint32_t j = lane; j < nbytes; j += 64) (void)src.byte8(base + ((size_t)j << 3), thr, f);
+    for (int s = 32; s > 0; s >>= 1) f |= __shfl_xor(f, s, 64);
+    return f;
+}
+
+// Wave-per-image vote.  Requires N % 8 == 0, M % 8 == 0, N % M == 0, Mb = M/8 a power of two <= 64*NSETS, N/M <= 65535.
+//   * LDS (per workgroup, filled once): ChaCha20 keystream of the whole lattice, then its bitwise complement in "spread"
+//     form (8 bytes per cipher byte), so that plaintext-bit byte lanes = negbits ^ spread(~keystream) is two XORs.
+//   * every wave owns whole images: lane L reads cipher bytes j = L + 64 r (16 B of fp16 per load, 1 KiB per wave
+//     instruction), which all vote for message byte (L + 64 (r % NSETS)) % Mb  ->  per-lane counters, no atomics and no
+//     barriers in the image loop; lanes sharing a message byte are combined with __shfl_xor at the end.
+template <typename Src, int NSETS>
+__global__ __launch_bounds__(1024) void gsw_extract_wave_kernel(ExtractArgs p, Src src) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    typedef typename Src::elem_t T;
+    constexpr int NW = WordsOf<T>::NW;
+    constexpr bool PK16 = WordsOf<T>::PK16;
     const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
     const uint32_t N = p.n_elems, M = p.msg_bits;
     const uint32_t nbytes = N >> 3;
     const uint32_t nblk = (nbytes + 63u) >> 6;
     const uint32_t Mb = M >> 3;
     uint32_t* ks_words = lds;
-    uint32_t* cnt = lds + nblk * 16u;
-    __shared__ uint32_t s_flags;
+    uint2* nks = reinterpret_cast<uint2*>(lds + nblk * 16u);   // spread(~keystream byte j)
 
     chacha20_blocks_to_lds(GSW_CIPHER_REGS(p.ck), 0u, nblk, ks_words);
-    const uint8_t* ksb = reinterpret_cast<const uint8_t*>(ks_words);
-    const uint32_t mbyte = tid & (Mb - 1u);  // Mb is a power of two dividing 256
-    const uint32_t nseg = N / M;
-
-    for (int b = blockIdx.x; b < p.B; b += gridDim.x) {
-        for (uint32_t i = tid; i < M; i += GSW_WG) cnt[i] = 0;
-        if (tid == 0) s_flags = 0;
-        __syncthreads();  // also orders the keystream fill on the first trip
-        const size_t base = (size_t)b * N;
-        uint32_t flags = 0;
-        uint32_t c16[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // 32-bit accumulators (wide lattices)
-        uint32_t acc_lo = 0, acc_hi = 0;
-        uint32_t in_acc = 0;
-#pragma unroll 4
-        for (uint32_t j = tid; j < nbytes; j += GSW_WG) {
-            const uint32_t cb = src.byte8(base + ((size_t)j << 3), p.thr, flags);
-            const uint32_t pb = cb ^ ksb[j];
+    __syncthreads();
+    {
+        const uint8_t* ksb = reinterpret_cast<const uint8_t*>(ks_words);
+        for (uint32_t j = tid; j < nbytes; j += blockDim.x) {
             uint32_t lo, hi;
-            spread_bits(pb, lo, hi);
-            acc_lo += lo; acc_hi += hi;
-            if (++in_acc == 255u) {
+            spread_bits((~(uint32_t)ksb[j]) & 0xFFu, lo, hi);
+            nks[j] = make_uint2(lo, hi);
+        }
+    }
+    __syncthreads();
+
+    const uint32_t nseg = N / M;
+    const uint32_t waves_per_wg = blockDim.x >> 6;
+    const uint32_t wave_global = blockIdx.x * waves_per_wg + (tid >> 6);
+    const uint32_t wave_stride = gridDim.x * waves_per_wg;
+    const uint32_t rounds = (nbytes + 63u) >> 6;
+
+    for (uint32_t b = wave_global; b < (uint32_t)p.B; b += wave_stride) {
+        const size_t base = (size_t)b * N;
+        uint32_t acc[NSETS][2];      // 8-bit lanes, flushed every 255 rounds
+        uint32_t wide[NSETS][4];     // 16-bit fields: [0] = elements 0,2  [1] = 1,3  [2] = 4,6  [3] = 5,7
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { c16[k] += (acc_lo >> (8 * k)) & 0xFFu; c16[4 + k] += (acc_hi >> (8 * k)) & 0xFFu; }
-                acc_lo = acc_hi = 0; in_acc = 0;
+        for (int s = 0; s < NSETS; ++s) { acc[s][0] = acc[s][1] = 0; wide[s][0] = wide[s][1] = wide[s][2] = wide[s][3] = 0; }
+        uint32_t tmax = 0, in_acc = 0;
+        constexpr int QB = 32 / NW;            // cipher bytes per lane per batch: 32 data VGPRs in flight
+        constexpr int PER_SET = QB / NSETS;
+        for (uint32_t r0 = 0; r0 < rounds; r0 += QB) {
+            uint32_t w[QB][NW];
+            // issue all loads of this batch first (QB independent 16/32-byte loads per lane in flight)
+#pragma unroll
+            for (int q = 0; q < QB; ++q) {
+                const uint32_t j = lane + 64u * (r0 + q);
+                if (j < nbytes) src.words(base + ((size_t)j << 3), w[q]);
+                else {
+#pragma unroll
+                    for (int i = 0; i < NW; ++i) w[q][i] = 0;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < QB; ++q) {
+                const uint32_t j = lane + 64u * (r0 + q);
+                uint32_t n_lo, n_hi;
+                negbits8<PK16, NW>(w[q], p.thr.nz_add, n_lo, n_hi, tmax);
+                if (j < nbytes) {
+                    const uint2 k = nks[j];
+                    acc[q % NSETS][0] += n_lo ^ k.x;
+                    acc[q % NSETS][1] += n_hi ^ k.y;
+                }
+            }
+            in_acc += PER_SET;
+            if (in_acc > 255u - PER_SET) {
+#pragma unroll
+                for (int s = 0; s < NSETS; ++s) {
+                    wide[s][0] += acc[s][0] & 0x00FF00FFu; wide[s][1] += (acc[s][0] >> 8) & 0x00FF00FFu;
+                    wide[s][2] += acc[s][1] & 0x00FF00FFu; wide[s][3] += (acc[s][1] >> 8) & 0x00FF00FFu;
+                    acc[s][0] = acc[s][1] = 0;
+                }
+                in_acc = 0;
             }
         }
+        // saturation / NaN: decided exactly on the rare path only
+        const uint32_t tm = PK16 ? max(tmax & 0xFFFFu, tmax >> 16) : tmax;
+        uint32_t flags = 0;
+        if (__any(tm >= p.thr.sat_bits)) flags = wave_exact_flags(src, base, nbytes, p.thr, lane);
+        if (lane == 0) p.flags[b] = flags;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { c16[k] += (acc_lo >> (8 * k)) & 0xFFu; c16[4 + k] += (acc_hi >> (8 * k)) & 0xFFu; }
-        // wave-level reduction over lanes that share the message byte (lane ^ Mb, ^2Mb, ... < 64)
-        for (uint32_t s = Mb; s < 64u; s <<= 1) {
+        for (int s = 0; s < NSETS; ++s) {
+            wide[s][0] += acc[s][0] & 0x00FF00FFu; wide[s][1] += (acc[s][0] >> 8) & 0x00FF00FFu;
+            wide[s][2] += acc[s][1] & 0x00FF00FFu; wide[s][3] += (acc[s][1] >> 8) & 0x00FF00FFu;
+            // lanes L, L+Mb, L+2Mb, ... (< 64) vote for the same message byte
+            for (uint32_t sh = Mb; sh < 64u; sh <<= 1) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) c16[k] += __shfl_xor(c16[k], (int)s, 64);
-        }
-        const uint32_t lane = tid & 63u;
-        if (lane < Mb || Mb >= 64u) {
+                for (int i = 0; i < 4; ++i) wide[s][i] += __shfl_xor(wide[s][i], (int)sh, 64);
+            }
+            const uint32_t mbyte = lane + 64u * s;
+            if (mbyte < Mb) {
+                // element k of the group = message bit 8*mbyte + k
+                const uint32_t c[8] = {wide[s][0] & 0xFFFFu, wide[s][1] & 0xFFFFu, wide[s][0] >> 16, wide[s][1] >> 16,
+                                       wide[s][2] & 0xFFFFu, wide[s][3] & 0xFFFFu, wide[s][2] >> 16, wide[s][3] >> 16};
+                uint32_t byte = 0;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) atomicAdd(&cnt[mbyte * 8u + k], c16[k]);
+                for (int k = 0; k < 8; ++k) byte |= (2u * c[k] > nseg ? 1u : 0u) << (7 - k);   // strict majority, ties -> 0
+                p.bits[(size_t)b * Mb + mbyte] = (uint8_t)byte;
+                if (p.counts) {
+                    uint4* cp = reinterpret_cast<uint4*>(p.counts + (size_t)b * M + 8u * mbyte);
+                    cp[0] = make_uint4(c[0], c[1], c[2], c[3]);
+                    cp[1] = make_uint4(c[4], c[5], c[6], c[7]);
+                }
+            }
         }
-        if (__any(flags != 0)) {
-            uint32_t f = flags;
-            for (int s = 32; s > 0; s >>= 1) f |= __shfl_xor(f, s, 64);
-            if (lane == 0) atomicOr(&s_flags, f);
-        }
-        __syncthreads();
-        for (uint32_t t = tid; t < Mb; t += GSW_WG) {
-            uint32_t byte = 0;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) byte |= (2u * cnt[t * 8u + k] > nseg ? 1u : 0u) << (7 - k);  // strict majority
-            p.bits[(size_t)b * Mb + t] = (uint8_t)byte;
-        }
-        if (p.counts) for (uint32_t i = tid; i < M; i += GSW_WG) p.counts[(size_t)b * M + i] = cnt[i];
-        if (tid == 0) p.flags[b] = s_flags;
-        __syncthreads();
     }
 }
 
@@ -875,14 +969,31 @@ static GswCipher make_cipher(const uint8_t key[32], const uint8_t nonce16[16]) {
     return c;
 }
 
-static Thr make_thr() {
+static Thr make_thr(int dtype) {
     Thr t;
     float f = (float)GSW_Y1_THR;
-    if ((double)f < GSW_Y1_THR) f = nextafterf(f, INFINITY);
+    if ((double)f < GSW_Y1_THR) f = nextafterf(f, INFINITY);   // smallest float >= Y1
     t.y1f = f;
-    f = (float)GSW_Y2_THR;
-    if ((double)f < GSW_Y2_THR) f = nextafterf(f, INFINITY);
-    t.y2f = f;
+    float g = (float)GSW_Y2_THR;
+    if ((double)g < GSW_Y2_THR) g = nextafterf(g, INFINITY);   // smallest float >= Y2
+    t.y2f = g;
+    // integer form: T1 = bit pattern of the largest magnitude m with -m >= Y1; SAT = pattern of the smallest value >= Y2
+    float m = (float)(-GSW_Y1_THR);
+    if ((double)m > -GSW_Y1_THR) m = nextafterf(m, 0.0f);
+    uint32_t t1_32, sat_32;
+    memcpy(&t1_32, &m, 4);
+    memcpy(&sat_32, &g, 4);
+    switch (dtype) {
+        case GSW_F16:   // every non-zero half (>= 2^-24) is beyond T1; 8.296875 = 0x4826 is the smallest half >= Y2
+            t.nz_add = 0x7FFFu * 0x00010001u; t.sat_bits = 0x4826u; break;
+        case GSW_BF16: {  // bf16 = top 16 bits of the float pattern: truncation gives the largest bf16 <= m; round SAT up
+            const uint32_t t1 = t1_32 >> 16;
+            const uint32_t sat = (sat_32 >> 16) + ((sat_32 & 0xFFFFu) ? 1u : 0u);
+            t.nz_add = (0x7FFFu - t1) * 0x00010001u; t.sat_bits = sat; break;
+        }
+        default:        // fp32, and the fp32 surrogate of fp64 inputs (-1 / +1 / +16 / NaN)
+            t.nz_add = 0x7FFFFFFFu - t1_32; t.sat_bits = sat_32; break;
+    }
     return t;
 }
 
@@ -925,10 +1036,10 @@ int gsw_keystream(const uint8_t key[32], const uint8_t nonce16[16], uint8_t* out
 }
 
 template <typename OutT>
-static void launch_embed(const EmbedArgs& a, bool has_u, bool fast, bool bitmsg, uint32_t msg_bits, dim3 grid, hipStream_t st) {
+static void launch_embed(const EmbedArgs& a, bool has_u, bool fast, bool bitmsg, dim3 grid, hipStream_t st) {
 #define GSW_LAUNCH_E(HU, F) \
-    do { if (bitmsg) hipLaunchKernelGGL((gsw_embed_bitmsg_kernel<OutT, HU, F>), grid, dim3(GSW_WG), 0, st, a, msg_bits); \
-         else hipLaunchKernelGGL((gsw_embed_kernel<OutT, HU, F>), grid, dim3(GSW_WG), 0, st, a); } while (0)
+    do { if (bitmsg) hipLaunchKernelGGL((gsw_embed_kernel<OutT, HU, F, true>), grid, dim3(GSW_WG), 0, st, a); \
+         else hipLaunchKernelGGL((gsw_embed_kernel<OutT, HU, F, false>), grid, dim3(GSW_WG), 0, st, a); } while (0)
     if (has_u) { if (fast) GSW_LAUNCH_E(true, true); else GSW_LAUNCH_E(true, false); }
     else       { if (fast) GSW_LAUNCH_E(false, true); else GSW_LAUNCH_E(false, false); }
 #undef GSW_LAUNCH_E
@@ -963,6 +1074,7 @@ static int embed_impl(const uint8_t key[32], const uint8_t nonce16[16], const ui
     a.image_index0 = image_index0;
     a.n_elems = (uint32_t)n_elems;
     a.msg_bytes = msg_bytes;
+    a.msg_bits = (uint32_t)msg_bits;
     a.lim_elems = (uint32_t)((n_elems / msg_bits) * msg_bits);
     a.B = B;
     const uint32_t nchunks = (uint32_t)((n_elems + GSW_CHUNK - 1) / GSW_CHUNK);
@@ -973,10 +1085,10 @@ static int embed_impl(const uint8_t key[32], const uint8_t nonce16[16], const ui
     const bool fast = (flags & GSW_EMBED_FAST_F32) != 0;
     const bool bitmsg = (msg_bits & 7) != 0;
     switch (out_dtype) {
-        case GSW_F32: launch_embed<float>(a, u_dev != nullptr, fast, bitmsg, (uint32_t)msg_bits, grid, st); break;
-        case GSW_F16: launch_embed<__half>(a, u_dev != nullptr, fast, bitmsg, (uint32_t)msg_bits, grid, st); break;
-        case GSW_BF16: launch_embed<__hip_bfloat16>(a, u_dev != nullptr, fast, bitmsg, (uint32_t)msg_bits, grid, st); break;
-        default: launch_embed<double>(a, u_dev != nullptr, fast, bitmsg, (uint32_t)msg_bits, grid, st); break;
+        case GSW_F32: launch_embed<float>(a, u_dev != nullptr, fast, bitmsg, grid, st); break;
+        case GSW_F16: launch_embed<__half>(a, u_dev != nullptr, fast, bitmsg, grid, st); break;
+        case GSW_BF16: launch_embed<__hip_bfloat16>(a, u_dev != nullptr, fast, bitmsg, grid, st); break;
+        default: launch_embed<double>(a, u_dev != nullptr, fast, bitmsg, grid, st); break;
     }
     hipError_t le = hipGetLastError();
     if (staged) (void)hipFreeAsync(staged, st);
@@ -994,8 +1106,8 @@ int gsw_embed(const uint8_t key[32], const uint8_t nonce16[16], const uint8_t* m
 int gsw_philox_uniform(uint64_t seed, uint64_t image_index0, double* u_dev, int B, int64_t n_elems, void* stream) {
     if (!u_dev || B < 0 || n_elems <= 0 || n_elems > (int64_t)0x7FFFFFF0) return GSW_ERR_BAD_ARG;
     if (B == 0) return GSW_OK;
-    const uint32_t npairs = (uint32_t)((n_elems + 1) / 2);
-    const dim3 grid(std::min<uint32_t>((npairs + GSW_WG - 1) / GSW_WG, 1024u), (uint32_t)std::min<int>(B, 65535));
+    const uint32_t ngroups = (uint32_t)((n_elems + 3) / 4);
+    const dim3 grid(std::min<uint32_t>((ngroups + GSW_WG - 1) / GSW_WG, 1024u), (uint32_t)std::min<int>(B, 65535));
     hipLaunchKernelGGL(gsw_philox_uniform_kernel, grid, dim3(GSW_WG), 0, (hipStream_t)stream, u_dev, seed, image_index0, B, (uint32_t)n_elems);
     GSW_HIP(hipGetLastError());
     return GSW_OK;
@@ -1003,31 +1115,45 @@ int gsw_philox_uniform(uint64_t seed, uint64_t image_index0, double* u_dev, int 
 
 #define GSW_MAX_DYN_LDS (160u * 1024u - 64u)
 
+template <typename Src, int NSETS>
+static int launch_extract_wave(const ExtractArgs& a, const Src& src, size_t lds, hipStream_t st) {
+    // big batches: 1024-thread workgroups (16 waves share one keystream fill, 2 workgroups per CU);
+    // small batches: 256-thread workgroups so that the images spread over more CUs
+    const uint32_t block = a.B >= 2048 ? 1024u : 256u;
+    const uint32_t waves = block / 64u;
+    const uint32_t max_grid = (uint32_t)device_cus() * (2048u / block);
+    const uint32_t grid = std::max<uint32_t>(1u, std::min<uint32_t>(((uint32_t)a.B + waves - 1u) / waves, max_grid));
+    if (lds > 48u * 1024u) GSW_HIP(hipFuncSetAttribute((const void*)gsw_extract_wave_kernel<Src, NSETS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((gsw_extract_wave_kernel<Src, NSETS>), dim3(grid), dim3(block), lds, st, a, src);
+    GSW_HIP(hipGetLastError());
+    return GSW_OK;
+}
+
 template <typename Src>
 static int launch_extract(const ExtractArgs& a, const Src& src, hipStream_t st) {
     const uint32_t N = a.n_elems, M = a.msg_bits;
     const uint32_t nbytes = (N + 7u) / 8u;
     const uint32_t nblk = (nbytes + 63u) / 64u;
     const uint32_t Mb = M / 8u;
-    const bool fast = (N % 8u == 0) && (M % 8u == 0) && Mb >= 1 && Mb <= 256u && (256u % Mb == 0) && (N % M == 0);
-    const uint32_t grid = (uint32_t)std::min<int64_t>(a.B, (int64_t)device_cus() * 8);
+    const size_t lds_wave = (size_t)nblk * 64u + (size_t)nbytes * 8u;
+    const bool fast = (N % 8u == 0) && (M % 8u == 0) && Mb >= 1 && Mb <= 256u && (256u % Mb == 0) && (N % M == 0) &&
+                      (N / M <= 65535u) && lds_wave <= GSW_MAX_DYN_LDS;
     if (fast) {
-        const size_t lds = (size_t)nblk * 64u + (size_t)M * 4u;
-        if (lds > GSW_MAX_DYN_LDS) return GSW_ERR_UNSUPPORTED;
-        if (lds > 48u * 1024u) GSW_HIP(hipFuncSetAttribute((const void*)gsw_extract_fast_kernel<Src>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((gsw_extract_fast_kernel<Src>), dim3(grid), dim3(GSW_WG), lds, st, a, src);
-    } else {
-        const size_t lds = (size_t)nblk * 64u + (size_t)((nbytes + 3u) / 4u) * 4u + (size_t)((M + 31u) / 32u) * 4u;
-        if (lds > GSW_MAX_DYN_LDS) return GSW_ERR_UNSUPPORTED;
-        if (lds > 48u * 1024u) GSW_HIP(hipFuncSetAttribute((const void*)gsw_extract_generic_kernel<Src>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((gsw_extract_generic_kernel<Src>), dim3(grid), dim3(GSW_WG), lds, st, a, src);
+        if (Mb <= 64u) return launch_extract_wave<Src, 1>(a, src, lds_wave, st);
+        if (Mb == 128u) return launch_extract_wave<Src, 2>(a, src, lds_wave, st);
+        return launch_extract_wave<Src, 4>(a, src, lds_wave, st);
     }
+    const uint32_t grid = (uint32_t)std::min<int64_t>(a.B, (int64_t)device_cus() * 8);
+    const size_t lds = (size_t)nblk * 64u + (size_t)((nbytes + 3u) / 4u) * 4u + (size_t)((M + 31u) / 32u) * 4u;
+    if (lds > GSW_MAX_DYN_LDS) return GSW_ERR_UNSUPPORTED;
+    if (lds > 48u * 1024u) GSW_HIP(hipFuncSetAttribute((const void*)gsw_extract_generic_kernel<Src>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((gsw_extract_generic_kernel<Src>), dim3(grid), dim3(GSW_WG), lds, st, a, src);
     GSW_HIP(hipGetLastError());
     return GSW_OK;
 }
 
 static int extract_check(const uint8_t* key, const uint8_t* nonce16, int msg_bits, uint8_t* bits_dev, uint32_t* flags_dev, int B,
-                         int64_t n_elems, ExtractArgs& a) {
+                         int64_t n_elems, int dtype, ExtractArgs& a) {
     if (!key || !nonce16 || msg_bits <= 0 || !bits_dev || !flags_dev || B < 0 || n_elems <= 0) return GSW_ERR_BAD_ARG;
     if (n_elems > (int64_t)0x7FFFFFF0) return GSW_ERR_UNSUPPORTED;
     const int64_t padded_bits = ((n_elems + 7) / 8) * 8;
@@ -1039,7 +1165,7 @@ static int extract_check(const uint8_t* key, const uint8_t* nonce16, int msg_bit
     a.n_elems = (uint32_t)n_elems;
     a.msg_bits = (uint32_t)msg_bits;
     a.B = B;
-    a.thr = make_thr();
+    a.thr = make_thr(dtype);
     return GSW_OK;
 }
 
@@ -1047,7 +1173,7 @@ int gsw_extract(const void* z_dev, int z_dtype, const uint8_t key[32], const uin
                 uint8_t* bits_dev, uint32_t* counts_dev, uint32_t* flags_dev, int B, int64_t n_elems, void* stream) {
     if (!z_dev) return GSW_ERR_BAD_ARG;
     ExtractArgs a;
-    const int rc = extract_check(key, nonce16, msg_bits, bits_dev, flags_dev, B, n_elems, a);
+    const int rc = extract_check(key, nonce16, msg_bits, bits_dev, flags_dev, B, n_elems, z_dtype, a);
     if (rc != GSW_OK) return rc;
     if (B == 0) return GSW_OK;
     a.counts = counts_dev;
@@ -1066,7 +1192,7 @@ int gsw_ddim_step_extract(const void* x_dev, const void* model_out_dev, void* z_
                           uint32_t* counts_dev, uint32_t* flags_dev, int B, int64_t n_elems, void* stream) {
     if (!x_dev || !model_out_dev) return GSW_ERR_BAD_ARG;
     ExtractArgs a;
-    const int rc = extract_check(key, nonce16, msg_bits, bits_dev, flags_dev, B, n_elems, a);
+    const int rc = extract_check(key, nonce16, msg_bits, bits_dev, flags_dev, B, n_elems, dtype, a);
     if (rc != GSW_OK) return rc;
     if (B == 0) return GSW_OK;
     a.counts = counts_dev;

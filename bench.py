@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""bench.py -- watermarked images/sec (embed + extract, 512x512 SD2.1 lattice 4x64x64) on N MI355X GPUs of one node.
+
+    python bench.py --gpus 1 --steps 50 --warmup 5                       # 1 GPU
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W                           # N ranks, one per GPU, RCCL
+
+Tiers
+  codec (default): one step = gsw_embed (fp32 Z_s_T for B images, in-kernel Philox u) + gsw_extract (fp16 latents of B
+         images -> 256-bit messages).  Inputs resident in HBM.  Roofline: HBM (algorithmic bytes, SURVEY.md 8d:
+         embed 4N B written, extract 2N B read per image).
+  e2e:   embed -> 50-step DDIM sampling (CFG) -> 50-step DDIM inversion -> extract with the SD2.1-shaped UNet
+         (synthetic weights).  Roofline: MFMA.   
+
+Prints ONE JSON line on rank 0.  The CPU baseline leg (rank 0, N == 1 only) times the oracle's reference-shaped scalar
+port on a bounded sample; it is a reported baseline, never the thing measured.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+README_KEY = "5822ff9cce6772f714192f43863f6bad1bf54b78326973897e6b66c3186b77a7"
+README_NONCE = "05072fd1c2265f6f2e2a4080a2bfbdd8"
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+MFMA_PEAK_TFLOPS = 2500.0  # dense bf16/fp16
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--tier", choices=["codec", "e2e"], default="codec")
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU per step (default: 16384 codec, 64 e2e)")
+    ap.add_argument("--height", type=int, default=512)
+    ap.add_argument("--width", type=int, default=512)
+    ap.add_argument("--message-length", type=int, default=256)
+    ap.add_argument("--exact", action="store_true", help="Cephes fp64 inverse CDF instead of the fp32 fast path")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-images", type=int, default=20, help="images of the CPU-baseline sample (0.7-2.2 s each)")
+    ap.add_argument("--ddim-steps", type=int, default=50)
+    return ap.parse_args()
+
+
+def cpu_baseline(n_images: int, message_length: int):
+    """Reference-shaped scalar port (oracle) on this host, 1 core: embed + recover per image."""
+    import types
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import gs_oracle as O
+    opt = types.SimpleNamespace(key_hex=README_KEY, nonce_hex=README_NONCE)
+    a = types.SimpleNamespace(key=bytes.fromhex(README_KEY), nonce=bytes.fromhex(README_NONCE), l=1, message_length=message_length)
+    np.random.seed(0)
+    t0 = time.perf_counter()
+    ok = True
+    for _ in range(n_images):
+        z = O.gs_watermark_init_noise_scalar(opt, "lthero")
+        bits = O.recover_exactracted_message_scalar(z.astype(np.float16), a)
+        ok &= O.calculate_bit_accuracy((b"lthero" + b"\0" * 26).hex(), bits)[1] == 1.0
+    dt = time.perf_counter() - t0
+    # best-CPU line: the vectorised numpy restatement
+    t1 = time.perf_counter()
+    nv = 64
+    for _ in range(nv):
+        z = O.gs_watermark_init_noise(opt, "lthero")
+        O.recover_exactracted_message(z.astype(np.float16), a)
+    dv = time.perf_counter() - t1
+    return {"value": n_images / dt, "unit": "images/s", "cores": 1, "kind": "port",
+            "sample": f"{n_images} images, 4x64x64, embed+recover, scalar scipy.stats.norm.ppf/cdf per element (reference-shaped port of "
+                      f"gs_insert.py:49-66 + extract.py:72-101), {dt:.1f} s; lossless={bool(ok)}",
+            "vectorised_numpy_images_per_s": nv / dv, "host_cpus": os.cpu_count()}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        if world == 1 and args.gpus > 1:
+            sys.exit(2)
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    if args.tier == "e2e":
+        from bench_e2e import run_e2e  # noqa
+        return run_e2e(args, rank, world, local_rank)
+
+    import gswm_amd
+    from gswm_amd import codec, dist as gdist
+
+    lib = gswm_amd._native.lib()  # raises if the HIP library is missing: no fallback
+    h, w = args.height // 8, args.width // 8
+    shape = (4, h, w)
+    n = 4 * h * w
+    M = args.message_length
+    B = args.batch or 16384
+    fast = not args.exact
+
+    # rank 0 owns the secrets; RCCL broadcast to the other ranks
+    params = gdist.broadcast_params(
+        {"key": bytes.fromhex(README_KEY), "nonce": bytes.fromhex(README_NONCE), "message": codec.pad_message("lthero", M // 8),
+         "seed": 2024, "height": args.height, "width": args.width} if rank == 0 else None, src=0)
+    key, nonce, k = params["key"], params["nonce"], params["message"]
+
+    dev = torch.device("cuda", local_rank)
+    z32 = torch.empty((B, *shape), dtype=torch.float32, device=dev)          # embed output (resident)
+    # extract input: fp16 latents of B watermarked images (what the inversion hands back, extract.py:48,70)
+    z16 = codec.embed_batch(key, nonce, k, B, shape, seed=params["seed"], image_index0=rank * B, dtype=torch.float16, fast=fast, device=dev)
+    bits_all = torch.empty((world, B, M // 8), dtype=torch.uint8, device=dev) if world > 1 else None
+
+    def step(i, ev=None):
+        idx0 = (i * world + rank) * B                                         # global image index: independent of the GPU count
+        if ev: ev[0].record()
+        codec.embed_batch(key, nonce, k, B, shape, seed=params["seed"], image_index0=idx0, fast=fast, out=z32)
+        if ev: ev[1].record()
+        bits, flags = codec.extract_batch(z16, key, nonce, M)
+        if ev: ev[2].record()
+        return bits, flags
+
+    for i in range(args.warmup):
+        bits, flags = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    handles = []
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        bits, flags = step(args.warmup + i, events[i])
+        if world > 1:  # gather of the recovered bitstrings (1 KiB-class, latency-bound), overlapped with the next step
+            handles.append(dist.all_gather_into_tensor(bits_all.view(-1), bits.view(-1), async_op=True))
+    for hd in handles:
+        hd.wait()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # correctness gate (outside the timed region): lossless => every bit of every image
+    want = torch.frombuffer(bytearray(k), dtype=torch.uint8).to(dev)
+    ok_bits = bool((bits == want[None]).all()) and int(flags.abs().sum()) == 0
+    b2, f2 = codec.extract_batch(z32.half(), key, nonce, M)                   # the images embedded in the last timed step
+    ok_bits &= bool((b2 == want[None]).all()) and int(f2.abs().sum()) == 0
+    matches = codec.bit_matches(bits, M, k).sum()
+    if world > 1:
+        dist.all_reduce(matches)
+        ok_t = torch.tensor([1 if ok_bits else 0], device=dev)
+        dist.all_reduce(ok_t, op=dist.ReduceOp.MIN)
+        ok_bits = bool(ok_t.item())
+        if rank == 0:
+            ok_bits &= bool((bits_all == want[None, None]).all())
+    bit_acc = float(matches.item()) / (world * B * M)
+
+    t_embed = sum(e[0].elapsed_time(e[1]) for e in events) / args.steps * 1e-3   # s per launch
+    t_extract = sum(e[1].elapsed_time(e[2]) for e in events) / args.steps * 1e-3
+    bytes_embed = 4.0 * n * B               # fp32 Z_s_T written (in-kernel RNG: nothing read)
+    bytes_extract = 2.0 * n * B + B * (M // 8)
+    dom = ("gsw_embed_kernel", bytes_embed, t_embed) if t_embed >= t_extract else ("gsw_extract_wave_kernel", bytes_extract, t_extract)
+
+    # HBM traffic per launch from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE), when it was collected on
+    # this very configuration; otherwise null
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_codec_pmc.json")))
+        c = pmc["config"]
+        if c["batch_per_gpu"] == B and c["lattice"] == list(shape) and c["message_bits"] == M and fast:
+            traffic = pmc["kernels"]["gsw_embed_kernel" if dom[0] == "gsw_embed_kernel" else "gsw_extract_wave_kernel"]["traffic_bytes"]
+    except Exception:
+        pass
+
+    if rank == 0:
+        total_images = world * B * args.steps
+        out = {
+            "metric": "watermarked images/sec (embed+extract, 512x512 SD2.1) + lossless bit-accuracy",
+            "value": total_images / dt, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if fast else "f64", "data": "synthetic",
+            "config": {"workload": f"codec tier: gsw_embed (fp32 out, Philox u, {'fp32 fast' if fast else 'fp64 Cephes'} ndtri) + gsw_extract "
+                                   f"(fp16 in, {M}-bit vote) on {shape[0]}x{shape[1]}x{shape[2]} lattices, inputs resident in HBM",
+                       "batch_per_gpu": B, "global_batch": world * B, "lattice": list(shape), "message_bits": M,
+                       "parallelism": f"dp{world} (images sharded, no data-path collective; async all-gather of recovered bits)"},
+            "bit_accuracy": bit_acc, "lossless": ok_bits,
+            "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": dom[1] / dom[2] / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": dom[1] / dom[2] / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": dom[1], "avg_launch_us": dom[2] * 1e6,
+                         "kernels": {"gsw_embed_kernel": {"bytes": bytes_embed, "avg_us": t_embed * 1e6, "GBps": bytes_embed / t_embed / 1e9},
+                                     "gsw_extract_wave_kernel": {"bytes": bytes_extract, "avg_us": t_extract * 1e6, "GBps": bytes_extract / t_extract / 1e9}}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_images, M)
+            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    if not ok_bits:
+        sys.exit(3)
+
+
+if __name__ == "__main__":
+    main()

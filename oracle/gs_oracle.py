@@ -343,10 +343,9 @@ def ddim_schedule(num_inference_steps: int, inverse: bool, num_train_timesteps: 
 
 
 # ----------------------------------------------------------------------------------------------
-# In-kernel RNG of the build (NOT reference behaviour): Philox4x32-10, restated so tests can check
-# the HIP kernel's `u` stream.  u for element e of image b uses counter (e>>1 low/high, b, 0),
-# key = 64-bit seed; element parity selects words (0,1) or (2,3); u = ((w_a>>5)*2^26 + (w_b>>6)) / 2^53
-# (the same 53-bit construction as numpy's random_sample).
+# In-kernel RNG of the build (NOT reference behaviour): Philox4x32-10, restated so tests can check the HIP
+# kernel's `u` stream.  Group g = e >> 2 of image `img` draws Philox(counter = (g, 0, img_lo, img_hi),
+# key = 64-bit seed); element e takes word e & 3; u = (w + 0.5) * 2^-32, exactly representable in fp64.
 # ----------------------------------------------------------------------------------------------
 _PH_M0, _PH_M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
 _PH_W0, _PH_W1 = np.uint32(0x9E3779B9), np.uint32(0xBB67AE85)
@@ -369,18 +368,15 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
 
 
 def philox_uniform(seed: int, image_index0: int, batch: int, n_elems: int) -> np.ndarray:
-    """u[b, e] of the build's in-kernel RNG (float64 in [0,1))."""
-    e = np.arange(n_elems, dtype=np.uint64)
+    """u[b, e] of the build's in-kernel RNG (float64 in (0,1))."""
+    ngroups = (n_elems + 3) // 4
+    g = np.arange(ngroups, dtype=np.uint32)
     out = np.empty((batch, n_elems), dtype=np.float64)
     k0, k1 = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
     for b in range(batch):
         img = image_index0 + b
-        pair = e >> np.uint64(1)
-        w = philox4x32_10((pair & np.uint64(0xFFFFFFFF)).astype(np.uint32), (pair >> np.uint64(32)).astype(np.uint32),
-                          np.full(n_elems, img & 0xFFFFFFFF, np.uint32), np.full(n_elems, (img >> 32) & 0xFFFFFFFF, np.uint32),
-                          k0, k1)
-        odd = (e & np.uint64(1)).astype(bool)
-        wa = np.where(odd, w[2], w[0]).astype(np.uint64)
-        wb = np.where(odd, w[3], w[1]).astype(np.uint64)
-        out[b] = ((wa >> np.uint64(5)) * np.uint64(67108864) + (wb >> np.uint64(6))).astype(np.float64) / 9007199254740992.0
+        w = philox4x32_10(g, np.zeros(ngroups, np.uint32), np.full(ngroups, img & 0xFFFFFFFF, np.uint32),
+                          np.full(ngroups, (img >> 32) & 0xFFFFFFFF, np.uint32), k0, k1)
+        words = np.stack(w, axis=1).reshape(-1)[:n_elems]
+        out[b] = (words.astype(np.float64) + 0.5) * 2.0 ** -32
     return out

@@ -41,6 +41,14 @@ def ulp_diff32(a, b):
     return np.abs(a - b)
 
 
+def oracle_counts(z, key, nonce, ml):
+    """Vectorised oracle vote counts for a batch z[B, N] (N % 8 == 0): '1'-votes per message bit."""
+    B, n = z.shape
+    y = (z.astype(np.float64) >= O.Y1_THRESHOLD).astype(np.uint8)
+    ks = np.unpackbits(np.frombuffer(O.chacha20_keystream(key, nonce, n // 8), np.uint8))
+    return (y ^ ks[None]).reshape(B, n // ml, ml).sum(1).astype(np.int32)
+
+
 # ---------------------------------------------------------------------------------------------- E2
 def test_keystream_matches_openssl_fixtures(G, golden):
     for name, c in golden["chacha"]["cases"].items():
@@ -384,7 +392,11 @@ def test_roundtrip_lossless_full_size(G, keys, B, shape, ml, fast, dtype):
     assert bool((bits == want[None]).all())
     nseg = int(np.prod(shape)) // ml
     kb = torch.from_numpy(np.unpackbits(np.frombuffer(k, np.uint8)).astype(np.int32)).cuda()
-    assert bool((counts == kb[None] * nseg).all())            # unanimous votes
+    # votes are unanimous except where a 16-bit cast flushed a tiny negative latent to -0.0 (read as a 1 bit, exactly as the
+    # reference would read it); the counts equal the oracle's in every case
+    dev_from_unanimous = (counts - kb[None] * nseg).abs()
+    assert int(dev_from_unanimous.max()) <= (0 if dtype == torch.float32 else 1)
+    assert bool((counts == torch.from_numpy(oracle_counts(z.float().cpu().numpy().reshape(B, -1), key, nonce, ml)).cuda()).all())
     assert int(G.codec.bit_matches(bits, ml, k).min()) == ml
     # marginally N(0,1): |z| is half-normal.  (The batch mean is NOT ~0 to 1/sqrt(B*N): every image shares the sign pattern
     # -- same key, nonce and message -- so the mean carries the +-1/sqrt(N) imbalance of the cipher bits.)
