@@ -1,0 +1,149 @@
+"""CPU (no GPU): the C-ABI library loads and exports every symbol include/gswm.h declares; host-side logic of the package
+(message / key handling, error mapping, sharding maths); the product path refuses to run without a GPU instead of
+falling back to a CPU path."""
+import ctypes
+import os
+import re
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import gs_oracle as O
+from conftest import README_KEY, README_NONCE, ROOT
+
+import gswm_amd
+from gswm_amd import _native as N, codec, extract as gext, dist as gdist
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "gswm.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(gsw_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = N.lib()
+    syms = header_symbols()
+    assert len(syms) >= 11
+    for s in syms:
+        assert hasattr(lib, s), f"libgswm.so does not export {s}"
+    assert sorted(N.exported_symbols()) == syms            # the ctypes prototypes cover the whole header
+    assert lib.gsw_version() == 100
+    assert lib.gsw_strerror(0) == b"ok" and b"IndexError" in lib.gsw_strerror(N.GSW_ERR_RAGGED)
+
+
+def test_constants_match_header():
+    txt = open(os.path.join(ROOT, "include", "gswm.h")).read()
+    for name in ("GSW_F32", "GSW_F16", "GSW_BF16", "GSW_F64", "GSW_OK", "GSW_ERR_BAD_ARG", "GSW_ERR_UNSUPPORTED", "GSW_ERR_RAGGED", "GSW_ERR_HIP"):
+        m = re.search(rf"\b{name}\s*=\s*(\d+)", txt)
+        assert m and int(m.group(1)) == getattr(N, name), name
+    for name in ("GSW_EMBED_FAST_F32", "GSW_FLAG_SATURATED", "GSW_FLAG_NAN", "GSW_MSG_INLINE_MAX"):
+        m = re.search(rf"#define\s+{name}\s+(\d+)", txt)
+        assert m and int(m.group(1)) == getattr(N, name), name
+
+
+def test_argument_validation_needs_no_gpu():
+    """Status codes that are decided before any HIP call (no compute is attempted on this box)."""
+    lib = N.lib()
+    key, nonce = bytes(32), bytes(16)
+    assert lib.gsw_keystream(key, nonce, None, 0, None) == N.GSW_OK
+    assert lib.gsw_keystream(None, nonce, None, 0, None) == N.GSW_ERR_BAD_ARG
+    assert lib.gsw_embed(key, nonce, b"x", 1, None, 0, 0, None, 0, 1, 16384, 0, None) == N.GSW_ERR_BAD_ARG       # null output
+    assert lib.gsw_embed(key, nonce, b"x", 1, None, 0, 0, ctypes.c_void_p(16), 0, 1, 16383, 0, None) == N.GSW_ERR_BAD_ARG  # n % 4
+    assert lib.gsw_embed(key, nonce, b"x", 1, None, 0, 0, ctypes.c_void_p(16), 9, 1, 16384, 0, None) == N.GSW_ERR_BAD_ARG  # dtype
+    assert lib.gsw_embed(key, nonce, b"x", 1, None, 0, 0, ctypes.c_void_p(16), 0, 0, 16384, 0, None) == N.GSW_OK           # empty batch
+    p = ctypes.c_void_p(16)
+    assert lib.gsw_extract(p, 1, key, nonce, 1000, p, None, p, 1, 16384, None) == N.GSW_ERR_RAGGED
+    assert lib.gsw_extract(p, 1, key, nonce, 32, p, None, p, 1, 1700, None) == N.GSW_ERR_RAGGED                 # 1704 % 32
+    assert lib.gsw_extract(p, 1, key, nonce, 256, p, None, p, 0, 16384, None) == N.GSW_OK
+    assert lib.gsw_extract(None, 1, key, nonce, 256, p, None, p, 1, 16384, None) == N.GSW_ERR_BAD_ARG
+    assert lib.gsw_ddim_step(p, p, p, 1.0, 0.0, 0, 0, None) == N.GSW_OK
+    assert lib.gsw_ddim_step(p, p, p, 1.0, 0.0, 3, 8, None) == N.GSW_ERR_BAD_ARG                                # f64 unsupported
+    assert lib.gsw_ddim_step_cfg(p, p, None, p, 1.0, 0.0, 7.5, 1, 8, None) == N.GSW_ERR_BAD_ARG
+    with pytest.raises(IndexError):
+        N.check(N.GSW_ERR_RAGGED)
+    with pytest.raises(ValueError):
+        N.check(N.GSW_ERR_BAD_ARG)
+    with pytest.raises(N.GswError):
+        N.check(N.GSW_ERR_UNSUPPORTED)
+
+
+def test_no_cpu_fallback():
+    """CPU tensors are rejected: the hot path exists only as HIP kernels."""
+    key, nonce = bytes.fromhex(README_KEY), bytes.fromhex(README_NONCE)
+    z = torch.zeros(1, 4, 64, 64)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        codec.extract_batch(z, key, nonce, 256)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        codec.ddim_step(z, z, 1.0, 0.0)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        codec.embed_batch(key, nonce, b"k" * 32, 1, (4, 64, 64), out=z)
+    # nothing under the product package imports the oracle
+    pkg = os.path.join(ROOT, "a-watermark-for-diffusion-models_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(import|from)\s+\S*oracle", src, flags=re.M), f
+                assert "gs_oracle" not in src and "importlib" not in src.replace("import importlib\n        return importlib.import_module", ""), f
+            elif f.endswith((".hip", ".h", ".inc", ".cpp")):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"#\s*include[^\n]*oracle", src), f
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(N, "_lib", None)
+    monkeypatch.setattr(N, "LIB_PATH", "/nonexistent/libgswm.so")
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        N.lib()
+
+
+def test_host_message_and_key_handling():
+    # gs_insert.py:9-20 / nodes.py:68-76
+    assert codec.pad_message("lthero", 32) == b"lthero" + b"\0" * 26 == O.pad_message("lthero", 32)
+    long = "水印测试-watermark-éè-" + "x" * 40
+    assert codec.pad_message(long, 32) == long.encode()[:32] == O.pad_message(long, 32)
+    assert codec.pad_message("abc", 128)[:3] == b"abc" and len(codec.pad_message("abc", 128)) == 128
+    r = codec.pad_message("", 32)
+    assert len(r) == 32 and r != codec.pad_message("", 32)                    # os.urandom
+    assert codec.pad_message(12345, 4) == b"1234"                               # nodes.py:69 str(message)
+    # gs_insert.py:27-42
+    k, n = codec.resolve_key_nonce(README_KEY, README_NONCE)
+    assert (k, n) == (bytes.fromhex(README_KEY), bytes.fromhex(README_NONCE))
+    k, n = codec.resolve_key_nonce(README_KEY, "")
+    assert n == bytes.fromhex(README_KEY)[8:24] == O.resolve_key_nonce(README_KEY, "")[1]
+    k, n = codec.resolve_key_nonce("", "")
+    assert len(k) == 32 and len(n) == 16
+    with pytest.raises(ValueError):
+        codec.resolve_key_nonce("zz", "00")
+    for tot in (0, 1, 2047, 2048, 4096, 8192, 16384, 32768, 36864, 1 << 20):
+        assert codec.choose_watermark_length(tot) == O.choose_watermark_length(tot)
+    with pytest.raises(ValueError):
+        codec.keystream(b"x" * 31, b"y" * 16, 64)
+    with pytest.raises(ValueError):
+        codec.extract_batch(torch.zeros(1, 16), b"x" * 32, b"y" * 12, 8)
+
+
+def test_bit_accuracy_twin(golden):
+    for c in golden["extract"]["cases"]["_bit_accuracy"]:
+        ob, acc = gext.calculate_bit_accuracy(c["hex"], c["bin"])
+        assert ob == c["original_bin"] and acc == c["accuracy"]
+    assert codec.bits_to_str(np.array([0x6C, 0x01], np.uint8)) == "0110110000000001"
+
+
+def test_shard_range_and_param_packing():
+    for total in (0, 1, 7, 8, 64, 255, 256):
+        for world in (1, 2, 3, 8):
+            spans = [gdist.shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+    p = {"key": bytes(range(32)), "nonce": bytes(range(16)), "message": b"lthero" + b"\0" * 26, "seed": 2 ** 63 + 5, "height": 768, "width": 512}
+    q = gdist.unpack_params(gdist.pack_params(p))
+    assert q == p
+    assert gdist.broadcast_params(p) == p                                       # no process group: identity
+    with pytest.raises(ValueError):
+        gdist.pack_params(dict(p, message=b"x" * 5000))
