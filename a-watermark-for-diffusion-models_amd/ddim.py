@@ -1,0 +1,125 @@
+"""DDIM (eta = 0) sampling and inversion loops -- rows G1 / X2 of SURVEY.md section 8a.
+
+Reference: extract.py:49-69 runs a stock diffusers 0.26.0 `StableDiffusionPipeline` whose scheduler is
+`DDIMInverseScheduler` (prompt "", guidance_scale 1, fp16, output_type 'latent'); the older closed form survives as
+bytecode in __pycache__/inverse_stable_diffusion_gs.cpython-38.pyc (`backward_ddim`, `backward_diffusion`).  diffusers is
+not vendored in the reference nor installed here, so the schedule below restates the published DDIM update with the SD
+scheduler constants (scaled-linear betas 0.00085..0.012, 1000 train steps, 'leading' spacing, steps_offset 1,
+set_alpha_to_one False) -- PARITY UNPINNED at this boundary.
+
+MI355X design: the per-step scalars (a_t, b_t) are computed once on the host in fp64; each step is ONE UNet evaluation
+(MFMA through hipBLASLt / MIOpen / flash attention) plus ONE fused HIP kernel for the whole scheduler step
+(x' = a x + b eps, with classifier-free guidance folded in when sampling: libgswm `gsw_ddim_step[_cfg]`), and the last
+inversion step is fused with the Gaussian-CDF quantiser and the majority vote (`gsw_ddim_step_extract`) so the inverted
+latent never makes an extra trip through HBM -- and never visits the host (the reference's `.cpu()`, extract.py:70).
+Timesteps live on the device; there is no host synchronisation inside a loop, so a loop can be captured in a HIP graph.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import codec
+
+
+def sd_alphas_cumprod(num_train_timesteps: int = 1000, beta_start: float = 0.00085, beta_end: float = 0.012) -> np.ndarray:
+    betas = np.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=np.float64) ** 2
+    return np.cumprod(1.0 - betas)
+
+
+def step_coefficients(alpha_from: float, alpha_to: float, prediction_type: str = "epsilon") -> Tuple[float, float]:
+    """(a, b) with x_to = a * x_from + b * model_out for the deterministic DDIM move alpha_from -> alpha_to."""
+    af, at = float(alpha_from), float(alpha_to)
+    if prediction_type == "epsilon":
+        return (at / af) ** 0.5, (1 - at) ** 0.5 - (at * (1 - af) / af) ** 0.5
+    if prediction_type == "v_prediction":
+        return (at * af) ** 0.5 + ((1 - at) * (1 - af)) ** 0.5, ((1 - at) * af) ** 0.5 - (at * (1 - af)) ** 0.5
+    raise ValueError(prediction_type)
+
+
+@dataclass
+class DDIMSchedule:
+    num_inference_steps: int = 50
+    num_train_timesteps: int = 1000
+    steps_offset: int = 1
+    prediction_type: str = "epsilon"
+    set_alpha_to_one: bool = False
+
+    def __post_init__(self):
+        self.alphas_cumprod = sd_alphas_cumprod(self.num_train_timesteps)
+        self.final_alpha = 1.0 if self.set_alpha_to_one else float(self.alphas_cumprod[0])
+        self.ratio = self.num_train_timesteps // self.num_inference_steps
+        ts = (np.arange(self.num_inference_steps) * self.ratio).round().astype(np.int64) + self.steps_offset
+        self.timesteps_desc = ts[::-1].copy()      # sampling order: 981, 961, ..., 1 for 50 steps
+
+    def _alpha(self, t: int) -> float:
+        return float(self.alphas_cumprod[t]) if t >= 0 else self.final_alpha
+
+    def sampling(self) -> List[Tuple[int, float, float]]:
+        """[(t, a, b)]: the model is evaluated at t, the sample moves alpha[t] -> alpha[t - ratio]."""
+        return [(int(t), *step_coefficients(self._alpha(int(t)), self._alpha(int(t) - self.ratio), self.prediction_type))
+                for t in self.timesteps_desc]
+
+    def inversion(self) -> List[Tuple[int, float, float]]:
+        """[(t, a, b)] ascending: the model is evaluated at t, the sample moves alpha[t - ratio] -> alpha[t]
+        (DDIMInverseScheduler.step; == backward_diffusion(reverse_process=True) of the recovered bytecode)."""
+        return [(int(t), *step_coefficients(self._alpha(int(t) - self.ratio), self._alpha(int(t)), self.prediction_type))
+                for t in self.timesteps_desc[::-1]]
+
+
+EpsModel = Callable[[torch.Tensor, torch.Tensor, torch.Tensor], torch.Tensor]
+
+
+def _t_tensors(ts, device):
+    # one small device tensor per step, created before the loop: no host->device traffic inside it
+    return [torch.full((), t, dtype=torch.int64, device=device) for t in ts]
+
+
+@torch.no_grad()
+def ddim_sample(eps_model: EpsModel, z_T: torch.Tensor, ctx_text: torch.Tensor, schedule: DDIMSchedule, *,
+                ctx_uncond: Optional[torch.Tensor] = None, guidance_scale: float = 7.5) -> torch.Tensor:
+    """G1: txt2img latent loop starting from the watermarked Z_s_T.  guidance_scale != 1 runs the usual 2B-row UNet batch
+    (uncond | text) and folds `uncond + g (text - uncond)` into the scheduler-step kernel."""
+    steps = schedule.sampling()
+    tt = _t_tensors([s[0] for s in steps], z_T.device)
+    x = z_T.clone()
+    use_cfg = guidance_scale != 1.0 and ctx_uncond is not None
+    ctx2 = torch.cat([ctx_uncond, ctx_text], dim=0) if use_cfg else None
+    B = x.shape[0]
+    for (t, a, b), t_dev in zip(steps, tt):
+        if use_cfg:
+            out = eps_model(torch.cat([x, x], dim=0), t_dev, ctx2)
+            codec.ddim_step_cfg(x, out[:B], out[B:], a, b, guidance_scale, out=x)
+        else:
+            codec.ddim_step(x, eps_model(x, t_dev, ctx_text), a, b, out=x)
+    return x
+
+
+@torch.no_grad()
+def ddim_invert(eps_model: EpsModel, x0: torch.Tensor, ctx: torch.Tensor, schedule: DDIMSchedule) -> torch.Tensor:
+    """X2: DDIM inversion x_0 -> x_T (prompt "", guidance 1: one UNet evaluation per step, extract.py:66-69)."""
+    steps = schedule.inversion()
+    tt = _t_tensors([s[0] for s in steps], x0.device)
+    x = x0.clone()
+    for (t, a, b), t_dev in zip(steps, tt):
+        codec.ddim_step(x, eps_model(x, t_dev, ctx), a, b, out=x)
+    return x
+
+
+@torch.no_grad()
+def ddim_invert_extract(eps_model: EpsModel, x0: torch.Tensor, ctx: torch.Tensor, schedule: DDIMSchedule, key: bytes, nonce: bytes,
+                        message_length: int, *, return_latents: bool = False, return_counts: bool = False):
+    """X2 + X3-X5 in one pass: the last scheduler step, the Gaussian-CDF quantiser and the vote are one kernel."""
+    steps = schedule.inversion()
+    tt = _t_tensors([s[0] for s in steps], x0.device)
+    x = x0.clone()
+    for (t, a, b), t_dev in zip(steps[:-1], tt[:-1]):
+        codec.ddim_step(x, eps_model(x, t_dev, ctx), a, b, out=x)
+    t, a, b = steps[-1]
+    eps = eps_model(x, tt[-1], ctx)
+    z_out = torch.empty_like(x) if return_latents else None
+    res = codec.ddim_step_extract(x, eps, a, b, key, nonce, message_length, z_out=z_out, return_counts=return_counts)
+    return (*res, z_out) if return_latents else res

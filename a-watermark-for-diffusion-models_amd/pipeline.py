@@ -1,0 +1,57 @@
+"""End-to-end Gaussian-Shading path on one GPU: embed -> (G1) DDIM sampling -> (X2) DDIM inversion -> (X3-X5) extract,
+everything resident on the device.
+
+Replaces, for the hot path, the reference's per-image flow (extract.py:46-117: `from_pretrained` per image, `.cpu()` of the
+inverted latent, scalar Python loops) and the generation loop of modified_stable_diffusion_gs.pyc: the pipeline object is
+built once, a batch of independent images moves through the loops together, and nothing returns to the host but
+`B x message_length/8` bytes.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import codec
+from .ddim import DDIMSchedule, ddim_invert_extract, ddim_sample, ddim_invert
+
+
+class GaussianShadingPipeline:
+    def __init__(self, eps_model, key: bytes, nonce: bytes, message: bytes, *, height: int = 512, width: int = 512,
+                 num_inference_steps: int = 50, dtype: torch.dtype = torch.float16, device="cuda",
+                 ctx_uncond: Optional[torch.Tensor] = None, prediction_type: str = "epsilon"):
+        self.eps_model = eps_model
+        self.key, self.nonce, self.message = key, nonce, message
+        self.shape = (4, height // 8, width // 8)
+        self.dtype, self.device = dtype, torch.device(device)
+        self.schedule = DDIMSchedule(num_inference_steps=num_inference_steps, prediction_type=prediction_type)
+        self.ctx_uncond = ctx_uncond
+        self.message_length = 8 * len(message)
+
+    # E1-E6
+    def embed(self, batch: int, *, seed: int = 0, image_index0: int = 0, fast: bool = True, u: Optional[torch.Tensor] = None) -> torch.Tensor:
+        return codec.embed_batch(self.key, self.nonce, self.message, batch, self.shape, u=u, seed=seed, image_index0=image_index0,
+                                 dtype=self.dtype, fast=fast, device=self.device)
+
+    # G1
+    def generate(self, z_T: torch.Tensor, ctx_text: torch.Tensor, guidance_scale: float = 7.5) -> torch.Tensor:
+        cu = None
+        if guidance_scale != 1.0:
+            cu = self.ctx_uncond.expand(z_T.shape[0], -1, -1) if self.ctx_uncond.shape[0] == 1 else self.ctx_uncond
+        return ddim_sample(self.eps_model, z_T, ctx_text, self.schedule, ctx_uncond=cu, guidance_scale=guidance_scale)
+
+    # X2 + X3-X5 (prompt "" -> the unconditional context, guidance 1: extract.py:66-69)
+    def invert_and_extract(self, x0: torch.Tensor, *, return_latents: bool = False):
+        ctx = self.ctx_uncond.expand(x0.shape[0], -1, -1) if self.ctx_uncond.shape[0] == 1 else self.ctx_uncond
+        return ddim_invert_extract(self.eps_model, x0, ctx, self.schedule, self.key, self.nonce, self.message_length,
+                                   return_latents=return_latents)
+
+    def invert(self, x0: torch.Tensor) -> torch.Tensor:
+        ctx = self.ctx_uncond.expand(x0.shape[0], -1, -1) if self.ctx_uncond.shape[0] == 1 else self.ctx_uncond
+        return ddim_invert(self.eps_model, x0, ctx, self.schedule)
+
+    def roundtrip(self, batch: int, ctx_text: torch.Tensor, *, seed: int = 0, image_index0: int = 0, guidance_scale: float = 7.5):
+        z_T = self.embed(batch, seed=seed, image_index0=image_index0)
+        x0 = self.generate(z_T, ctx_text, guidance_scale)
+        bits, flags = self.invert_and_extract(x0)
+        return z_T, x0, bits, flags

@@ -1,0 +1,301 @@
+"""eps-model of the DDIM loops (rows X2 / G1 of SURVEY.md section 8a): a from-scratch Stable-Diffusion-2.1-base-shaped
+conditional UNet in plain torch, used as the `eps_model(latents, t, ctx)` callable of ddim.py.
+
+Why it exists: the reference delegates this to diffusers==0.26.0 `UNet2DConditionModel` + HF weights
+`stabilityai/stable-diffusion-2-1-base` (extract.py:56-60,66-69), neither of which is available here (no network).  The
+architecture below follows the published SD 2.1-base `unet/config.json` (block_out_channels 320/640/1280/1280,
+2 resnets per block, 1 transformer layer per attention block, heads 5/10/20/20 x 64, cross_attention_dim 1024, linear
+projections, GEGLU feed-forward, 32-group GroupNorm) and keeps diffusers' parameter names, so a diffusers-layout
+safetensors state dict loads 1:1 (`load_diffusers_state_dict`).  Without a weight directory the weights are seeded
+synthetic -- throughput is representative, image content is not.
+
+GEMM / conv / attention work runs on MFMA through hipBLASLt / MIOpen / the SDPA flash kernel (fp16 or bf16).
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Sequence
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def timestep_embedding(t: torch.Tensor, dim: int, max_period: float = 10000.0) -> torch.Tensor:
+    """Sinusoidal embedding, flip_sin_to_cos=True, freq_shift=0 (SD config): [cos | sin]."""
+    half = dim // 2
+    freqs = torch.exp(-math.log(max_period) * torch.arange(half, dtype=torch.float32, device=t.device) / half)
+    args = t.float()[:, None] * freqs[None]
+    return torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+
+
+class TimestepEmbedding(nn.Module):
+    def __init__(self, in_dim, dim):
+        super().__init__()
+        self.linear_1 = nn.Linear(in_dim, dim)
+        self.linear_2 = nn.Linear(dim, dim)
+
+    def forward(self, x):
+        return self.linear_2(F.silu(self.linear_1(x)))
+
+
+class ResnetBlock2D(nn.Module):
+    def __init__(self, cin, cout, temb_dim, groups=32, eps=1e-5):
+        super().__init__()
+        self.norm1 = nn.GroupNorm(groups, cin, eps=eps)
+        self.conv1 = nn.Conv2d(cin, cout, 3, padding=1)
+        self.time_emb_proj = nn.Linear(temb_dim, cout)
+        self.norm2 = nn.GroupNorm(groups, cout, eps=eps)
+        self.conv2 = nn.Conv2d(cout, cout, 3, padding=1)
+        self.conv_shortcut = nn.Conv2d(cin, cout, 1) if cin != cout else None
+
+    def forward(self, x, temb_act):
+        h = self.conv1(F.silu(self.norm1(x)))
+        h = h + self.time_emb_proj(temb_act)[:, :, None, None]
+        h = self.conv2(F.silu(self.norm2(h)))
+        return (x if self.conv_shortcut is None else self.conv_shortcut(x)) + h
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, ctx_dim, heads, head_dim):
+        super().__init__()
+        inner = heads * head_dim
+        self.heads = heads
+        self.to_q = nn.Linear(dim, inner, bias=False)
+        self.to_k = nn.Linear(ctx_dim, inner, bias=False)
+        self.to_v = nn.Linear(ctx_dim, inner, bias=False)
+        self.to_out = nn.ModuleList([nn.Linear(inner, dim)])
+
+    def forward(self, x, ctx=None):
+        ctx = x if ctx is None else ctx
+        b, n, _ = x.shape
+        q = self.to_q(x).view(b, n, self.heads, -1).transpose(1, 2)
+        k = self.to_k(ctx).view(b, ctx.shape[1], self.heads, -1).transpose(1, 2)
+        v = self.to_v(ctx).view(b, ctx.shape[1], self.heads, -1).transpose(1, 2)
+        o = F.scaled_dot_product_attention(q, k, v)
+        return self.to_out[0](o.transpose(1, 2).reshape(b, n, -1))
+
+
+class GEGLU(nn.Module):
+    def __init__(self, dim, inner):
+        super().__init__()
+        self.proj = nn.Linear(dim, inner * 2)
+
+    def forward(self, x):
+        h, gate = self.proj(x).chunk(2, dim=-1)
+        return h * F.gelu(gate)
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim, mult=4):
+        super().__init__()
+        self.net = nn.ModuleList([GEGLU(dim, dim * mult), nn.Identity(), nn.Linear(dim * mult, dim)])
+
+    def forward(self, x):
+        return self.net[2](self.net[0](x))
+
+
+class BasicTransformerBlock(nn.Module):
+    def __init__(self, dim, ctx_dim, heads, head_dim):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim)
+        self.attn1 = Attention(dim, dim, heads, head_dim)
+        self.norm2 = nn.LayerNorm(dim)
+        self.attn2 = Attention(dim, ctx_dim, heads, head_dim)
+        self.norm3 = nn.LayerNorm(dim)
+        self.ff = FeedForward(dim)
+
+    def forward(self, x, ctx):
+        x = x + self.attn1(self.norm1(x))
+        x = x + self.attn2(self.norm2(x), ctx)
+        return x + self.ff(self.norm3(x))
+
+
+class Transformer2DModel(nn.Module):
+    def __init__(self, ch, ctx_dim, heads, head_dim, layers=1, groups=32):
+        super().__init__()
+        self.norm = nn.GroupNorm(groups, ch, eps=1e-6)
+        self.proj_in = nn.Linear(ch, ch)        # use_linear_projection=True (SD 2.x)
+        self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(ch, ctx_dim, heads, head_dim) for _ in range(layers)])
+        self.proj_out = nn.Linear(ch, ch)
+
+    def forward(self, x, ctx):
+        b, c, h, w = x.shape
+        y = self.norm(x).permute(0, 2, 3, 1).reshape(b, h * w, c)
+        y = self.proj_in(y)
+        for blk in self.transformer_blocks:
+            y = blk(y, ctx)
+        y = self.proj_out(y).reshape(b, h, w, c).permute(0, 3, 1, 2)
+        return x + y
+
+
+class Downsample2D(nn.Module):
+    def __init__(self, ch):
+        super().__init__()
+        self.conv = nn.Conv2d(ch, ch, 3, stride=2, padding=1)
+
+    def forward(self, x):
+        return self.conv(x)
+
+
+class Upsample2D(nn.Module):
+    def __init__(self, ch):
+        super().__init__()
+        self.conv = nn.Conv2d(ch, ch, 3, padding=1)
+
+    def forward(self, x):
+        return self.conv(F.interpolate(x, scale_factor=2.0, mode="nearest"))
+
+
+class DownBlock(nn.Module):
+    def __init__(self, cin, cout, temb, ctx_dim, heads, head_dim, layers, attn, down):
+        super().__init__()
+        self.resnets = nn.ModuleList([ResnetBlock2D(cin if i == 0 else cout, cout, temb) for i in range(layers)])
+        self.attentions = nn.ModuleList([Transformer2DModel(cout, ctx_dim, heads, head_dim) for _ in range(layers)]) if attn else None
+        self.downsamplers = nn.ModuleList([Downsample2D(cout)]) if down else None
+
+    def forward(self, x, temb, ctx, skips):
+        for i, r in enumerate(self.resnets):
+            x = r(x, temb)
+            if self.attentions is not None:
+                x = self.attentions[i](x, ctx)
+            skips.append(x)
+        if self.downsamplers is not None:
+            x = self.downsamplers[0](x)
+            skips.append(x)
+        return x
+
+
+class UpBlock(nn.Module):
+    def __init__(self, cin, cout, cprev, temb, ctx_dim, heads, head_dim, layers, attn, up):
+        super().__init__()
+        rs = []
+        for i in range(layers):
+            skip = cin if i == layers - 1 else cout
+            rin = cprev if i == 0 else cout
+            rs.append(ResnetBlock2D(rin + skip, cout, temb))
+        self.resnets = nn.ModuleList(rs)
+        self.attentions = nn.ModuleList([Transformer2DModel(cout, ctx_dim, heads, head_dim) for _ in range(layers)]) if attn else None
+        self.upsamplers = nn.ModuleList([Upsample2D(cout)]) if up else None
+
+    def forward(self, x, temb, ctx, skips):
+        for i, r in enumerate(self.resnets):
+            x = r(torch.cat([x, skips.pop()], dim=1), temb)
+            if self.attentions is not None:
+                x = self.attentions[i](x, ctx)
+        if self.upsamplers is not None:
+            x = self.upsamplers[0](x)
+        return x
+
+
+class MidBlock(nn.Module):
+    def __init__(self, ch, temb, ctx_dim, heads, head_dim):
+        super().__init__()
+        self.resnets = nn.ModuleList([ResnetBlock2D(ch, ch, temb), ResnetBlock2D(ch, ch, temb)])
+        self.attentions = nn.ModuleList([Transformer2DModel(ch, ctx_dim, heads, head_dim)])
+
+    def forward(self, x, temb, ctx):
+        return self.resnets[1](self.attentions[0](self.resnets[0](x, temb), ctx), temb)
+
+
+class UNet2DCondition(nn.Module):
+    """SD 2.1-base shape by default (865.9 M parameters)."""
+
+    def __init__(self, in_channels=4, out_channels=4, block_out_channels: Sequence[int] = (320, 640, 1280, 1280), layers_per_block=2,
+                 cross_attention_dim=1024, num_heads: Sequence[int] = (5, 10, 20, 20), head_dim=64,
+                 attn_blocks: Sequence[bool] = (True, True, True, False)):
+        super().__init__()
+        c0 = block_out_channels[0]
+        temb = c0 * 4
+        self.c0 = c0
+        self.conv_in = nn.Conv2d(in_channels, c0, 3, padding=1)
+        self.time_embedding = TimestepEmbedding(c0, temb)
+        self.down_blocks = nn.ModuleList()
+        ch = c0
+        n = len(block_out_channels)
+        for i, co in enumerate(block_out_channels):
+            self.down_blocks.append(DownBlock(ch, co, temb, cross_attention_dim, num_heads[i], co // num_heads[i] if head_dim is None else head_dim,
+                                              layers_per_block, attn_blocks[i], i < n - 1))
+            ch = co
+        self.mid_block = MidBlock(ch, temb, cross_attention_dim, num_heads[-1], head_dim)
+        self.up_blocks = nn.ModuleList()
+        rev = list(reversed(block_out_channels))
+        rheads = list(reversed(num_heads))
+        rattn = list(reversed(attn_blocks))
+        cprev = ch
+        for i, co in enumerate(rev):
+            cin = rev[min(i + 1, n - 1)]
+            self.up_blocks.append(UpBlock(cin, co, cprev, temb, cross_attention_dim, rheads[i], head_dim, layers_per_block + 1, rattn[i], i < n - 1))
+            cprev = co
+        self.conv_norm_out = nn.GroupNorm(32, c0, eps=1e-5)
+        self.conv_out = nn.Conv2d(c0, out_channels, 3, padding=1)
+
+    def forward(self, x: torch.Tensor, t: torch.Tensor, ctx: torch.Tensor) -> torch.Tensor:
+        """x [B,4,h,w], t [B] (or scalar tensor) timesteps, ctx [B,77,1024] -> model output [B,4,h,w]."""
+        if t.dim() == 0:
+            t = t.expand(x.shape[0])
+        temb = self.time_embedding(timestep_embedding(t, self.c0).to(x.dtype))
+        temb = F.silu(temb)                      # every resnet applies SiLU to the same embedding: do it once
+        h = self.conv_in(x)
+        skips = [h]
+        for blk in self.down_blocks:
+            h = blk(h, temb, ctx, skips)
+        h = self.mid_block(h, temb, ctx)
+        for blk in self.up_blocks:
+            h = blk(h, temb, ctx, skips)
+        # the scheduler-step / vote kernels index the lattice in C order: hand back plain NCHW even when the convolutions
+        # run channels-last
+        return self.conv_out(F.silu(self.conv_norm_out(h))).contiguous(memory_format=torch.contiguous_format)
+
+
+def synthetic_init_(model: nn.Module, seed: int = 0, out_scale: float = 1.0) -> nn.Module:
+    """Deterministic synthetic weights (no checkpoint is reachable from here): fan-in scaled normal for matrices/convs,
+    ones/zeros for norms.  Residual-branch output layers are down-scaled so activations stay O(1) through ~60 residual
+    adds, which keeps fp16 in range like a trained network does."""
+    g = torch.Generator().manual_seed(seed)
+    n_res = 0
+    for name, p in model.named_parameters():
+        if p.dim() >= 2:
+            fan_in = p[0].numel()
+            std = (1.0 / fan_in) ** 0.5
+            if name.endswith(("conv2.weight", "to_out.0.weight", "net.2.weight", "proj_out.weight")):
+                std *= 0.3
+                n_res += 1
+            if name == "conv_out.weight":
+                std *= out_scale
+            with torch.no_grad():
+                p.copy_(torch.randn(p.shape, generator=g) * std)
+        else:
+            with torch.no_grad():
+                p.fill_(1.0 if name.endswith("weight") and "norm" in name else 0.0)
+    return model
+
+
+def load_diffusers_state_dict(model: nn.Module, weight_dir: str) -> nn.Module:
+    """Load `<weight_dir>/unet/diffusion_pytorch_model.safetensors` (diffusers layout; names match this module 1:1)."""
+    import os
+    from safetensors.torch import load_file
+    path = weight_dir
+    for cand in ("unet/diffusion_pytorch_model.safetensors", "diffusion_pytorch_model.safetensors"):
+        if os.path.exists(os.path.join(weight_dir, cand)):
+            path = os.path.join(weight_dir, cand)
+            break
+    sd = load_file(path)
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    if missing or unexpected:
+        raise RuntimeError(f"state dict mismatch: missing {missing[:5]}..., unexpected {unexpected[:5]}...")
+    return model
+
+
+def count_flops_per_image(model: nn.Module, h: int = 64, w: int = 64, ctx_len: int = 77, ctx_dim: int = 1024) -> int:
+    """Forward FLOPs for one image (2 x MACs of conv / linear / attention), via torch's FlopCounterMode on meta tensors."""
+    from torch.utils.flop_counter import FlopCounterMode
+    import copy
+    m = copy.deepcopy(model).to("meta")
+    dt = next(m.parameters()).dtype
+    x = torch.empty(1, 4, h, w, device="meta", dtype=dt)
+    t = torch.empty(1, device="meta")
+    c = torch.empty(1, ctx_len, ctx_dim, device="meta", dtype=dt)
+    with FlopCounterMode(display=False) as fc:
+        m(x, t, c)
+    return int(fc.get_total_flops())

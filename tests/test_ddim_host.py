@@ -1,0 +1,38 @@
+"""CPU: host-side DDIM schedule of the product (ddim.py) against the oracle's independent restatement (both follow the
+closed form recovered from inverse_stable_diffusion_gs.pyc / the published DDIM update; PARITY UNPINNED vs diffusers)."""
+import numpy as np
+import pytest
+
+import gs_oracle as O
+import gswm_amd
+from gswm_amd import ddim
+
+
+@pytest.mark.parametrize("steps", [50, 30, 20, 10, 100])
+@pytest.mark.parametrize("pred", ["epsilon", "v_prediction"])
+def test_schedule_matches_oracle(steps, pred):
+    s = ddim.DDIMSchedule(num_inference_steps=steps, prediction_type=pred)
+    np.testing.assert_allclose(s.alphas_cumprod, O.sd_alphas_cumprod(), rtol=0, atol=0)
+    for inverse, mine in ((False, s.sampling()), (True, s.inversion())):
+        ref = O.ddim_schedule(steps, inverse=inverse, prediction_type=pred)
+        assert [t for t, _, _ in mine] == [t for t, _, _ in ref]
+        np.testing.assert_allclose([a for _, a, _ in mine], [a for _, a, _ in ref], rtol=1e-15)
+        np.testing.assert_allclose([b for _, _, b in mine], [b for _, _, b in ref], rtol=1e-13, atol=1e-16)
+
+
+def test_schedule_sd_constants():
+    s = ddim.DDIMSchedule(50)
+    assert list(s.timesteps_desc[:3]) == [981, 961, 941] and s.timesteps_desc[-1] == 1      # leading spacing, steps_offset 1
+    assert abs(s.alphas_cumprod[0] - (1 - 0.00085)) < 1e-12 and abs(s.alphas_cumprod[-1] - 0.0046600) < 1e-6
+    assert s.final_alpha == s.alphas_cumprod[0]                                               # set_alpha_to_one False
+    # sampling and inversion are exact inverses of each other when the model output is held fixed
+    x, e = np.random.RandomState(0).standard_normal((2, 100))
+    xs = x.copy()
+    for t, a, b in s.sampling():
+        xs = a * xs + b * e
+    for t, a, b in s.inversion():
+        xs = a * xs + b * e
+    np.testing.assert_allclose(xs, x, atol=1e-9)
+    # closed form of the recovered bytecode
+    t, a, b = s.sampling()[0]
+    np.testing.assert_allclose(O.backward_ddim(x, s.alphas_cumprod[981], s.alphas_cumprod[961], e), a * x + b * e, atol=1e-12)
