@@ -228,6 +228,21 @@ __device__ __forceinline__ void ndtri_fast_abs4(const float (&v)[4], const float
     for (int k = 0; k < 4; ++k) a[k] = r[k] * x[k];
 }
 
+// RNG fast path: |z| straight from the tail-side 32-bit uniform word through a piecewise-cubic table indexed by the
+// position of the leading one (logarithmic segmentation = relative resolution in the tail); no log, no branch.
+// Generated + verified by tools/fit_icdf_table.py (max |dz| 5.2e-7 vs fp64 ndtri over the whole 32-bit range).
+#include "icdf_table.inc"
+
+__device__ __forceinline__ float icdf_table_abs(uint32_t wv, const float4* __restrict__ tab /* LDS */) {
+    const uint32_t lz = wv ? (uint32_t)__builtin_clz(wv) : 32u;
+    const uint32_t norm = wv << (lz & 31u);                                     // leading one at bit 31 (0 stays 0)
+    const uint32_t sub = (norm >> (31 - GSW_ICDF_M)) & ((1u << GSW_ICDF_M) - 1u);
+    const float t = (float)(norm << (GSW_ICDF_M + 1)) * 0x1p-32f;               // position inside the sub-interval, [0,1)
+    const float4 c = tab[(lz << GSW_ICDF_M) + sub];
+    const float r = fmaf(fmaf(fmaf(c.w, t, c.z), t, c.y), t, c.x);
+    return fmaxf(r, 1.0e-10f);   // true minimum is 1.46e-10: rounding noise near v -> 1 can never zero or flip the magnitude
+}
+
 // ------------------------------------------------------------------------------------------------
 // output conversion (fp64 -> fp32 -> fp16/bf16 mirrors the caller's `.float()` then `.half()`, README.md:112)
 // ------------------------------------------------------------------------------------------------
@@ -331,7 +346,10 @@ __device__ __forceinline__ uint32_t inline_msg_byte(uint32_t i) {
 template <typename OutT, bool HAS_U, bool FAST, bool BITMSG>
 __global__ __launch_bounds__(GSW_WG) void gsw_embed_kernel(EmbedArgs p) {
     __shared__ uint32_t ks_words[64];  // 4 blocks x 16 words
+    __shared__ float4 icdf[(FAST && !HAS_U) ? GSW_ICDF_ENTRIES : 1];
     const uint32_t tid = threadIdx.x;
+    if (FAST && !HAS_U)
+        for (uint32_t i = tid; i < GSW_ICDF_ENTRIES; i += GSW_WG) icdf[i] = GSW_ICDF_TABLE[i];
     // Workgroup (x, y) is dispatched to XCD (x + gridDim.x * y) % 8.  With chunk == x every XCD would only ever write
     // addresses congruent to x * 8 KiB (mod 64 KiB), i.e. a fraction of its L2 channels; rotating by y spreads them.
     const uint32_t chunk = (blockIdx.x + blockIdx.y) % gridDim.x;
@@ -395,22 +413,23 @@ __global__ __launch_bounds__(GSW_WG) void gsw_embed_kernel(EmbedArgs p) {
                 philox4x32_10(e >> 2, 0u, (uint32_t)img, (uint32_t)(img >> 32), k0, k1, w);
             }
             if (FAST) {
-                float v[4], x[4], a[4];
+                float a[4];
+                if (HAS_U) {
+                    float v[4], x[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const bool one = (ynib[r] >> (3 - k)) & 1u;
-                    if (HAS_U) {
+                    for (int k = 0; k < 4; ++k) {
+                        const bool one = (ynib[r] >> (3 - k)) & 1u;
                         v[k] = (float)(one ? 1.0 - u[k] : u[k]);   // exact in fp64 for a 53-bit u, then one rounding
                         x[k] = (float)(one ? u[k] : 1.0 - u[k]);
-                    } else {
-                        // u = (w + .5) 2^-32  =>  1 - u = (~w + .5) 2^-32: the tail-side quantity is an integer select
-                        const uint32_t wv = one ? ~w[k] : w[k];
-                        v[k] = fmaf((float)wv, 0x1p-32f, 0x1p-33f);   // relative precision 2^-24 on the tail side
-                        x[k] = fmaxf(1.0f - v[k], 0x1p-33f);          // absolute error <= 2^-25 (|dz| <= 4e-8); never 0, so
-                                                                      // the sign (= the cipher bit) survives as +-tiny
                     }
+                    ndtri_fast_abs4(v, x, a);
+                } else {
+                    // u = (w + .5) 2^-32  =>  1 - u = (~w + .5) 2^-32: the tail-side uniform is an integer select of the
+                    // Philox word, and |z| comes from the table without ever forming u
+                    const uint32_t ones = (ynib[r] & 8u ? 1u : 0u) | (ynib[r] & 4u ? 2u : 0u) | (ynib[r] & 2u ? 4u : 0u) | (ynib[r] & 1u ? 8u : 0u);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) a[k] = icdf_table_abs(((ones >> k) & 1u) ? ~w[k] : w[k], icdf);
                 }
-                ndtri_fast_abs4(v, x, a);
                 float zf[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
