@@ -55,3 +55,35 @@ class GaussianShadingPipeline:
         x0 = self.generate(z_T, ctx_text, guidance_scale)
         bits, flags = self.invert_and_extract(x0)
         return z_T, x0, bits, flags
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# image-level stages around the latent loops (X1 / `decode_image`), and the JPEG distortion of BASELINE config 4
+# ---------------------------------------------------------------------------------------------------------------------
+@torch.no_grad()
+def decode_images(latents: torch.Tensor, vae) -> torch.Tensor:
+    """`decode_image` + `torch_to_numpy` prefix of modified_stable_diffusion_gs.pyc: [B,4,h,w] -> [B,3,8h,8w] in [0,1]."""
+    from .vae import latents_to_img
+    return latents_to_img(latents, vae)
+
+
+@torch.no_grad()
+def encode_images(images: torch.Tensor, vae) -> torch.Tensor:
+    """extract.py:39-43 on a batch already on the device."""
+    from .vae import img_to_latents
+    return img_to_latents(images, vae)
+
+
+def jpeg_roundtrip(images: torch.Tensor, quality: int = 10) -> torch.Tensor:
+    """JPEG distortion as the reference's `distortions` tool applies it (distortions:175-184: PIL save(quality=QF) / reload);
+    host-side PIL, one image at a time -- a GPU DCT stage is future work."""
+    import io
+    import numpy as np
+    from PIL import Image
+    out = []
+    for img in (images.detach().float().clamp(0, 1).cpu() * 255).round().to(torch.uint8):
+        buf = io.BytesIO()
+        Image.fromarray(img.permute(1, 2, 0).numpy()).save(buf, format="JPEG", quality=int(quality))
+        buf.seek(0)
+        out.append(torch.from_numpy(np.asarray(Image.open(buf).convert("RGB")).copy()).permute(2, 0, 1))
+    return (torch.stack(out).float() / 255.0).to(images.device, images.dtype)

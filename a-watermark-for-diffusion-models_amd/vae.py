@@ -1,0 +1,203 @@
+"""Image <-> latent stage (row X1 of SURVEY.md section 8a; `decode_image` of modified_stable_diffusion_gs.pyc for G1).
+
+Reference: extract.py:39-43 `img_to_latents` = `vae.encode(2x-1).latent_dist.mean * 0.18215` with the stock diffusers
+`AutoencoderKL` of stabilityai/stable-diffusion-2-1-base; the bytecode pipelines decode with `vae.decode(latents / 0.18215)`.
+diffusers and the weights are not available here, so this is a from-scratch torch module with the published SD VAE shape
+(block_out_channels 128/256/512/512, 2 resnets per encoder block, 3 per decoder block, one single-head attention in each
+mid block, 32-group GroupNorm eps 1e-6, latent_channels 4, 83.7 M parameters) and diffusers' parameter names so that
+`vae/diffusion_pytorch_model.safetensors` loads 1:1.  With synthetic weights it is NOT an autoencoder: it exercises the data
+path and its cost, while watermark accuracy through decode->encode is only meaningful with real weights.
+"""
+from __future__ import annotations
+
+import os
+from typing import Sequence
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+SCALING_FACTOR = 0.18215  # extract.py:42
+
+
+class VaeResnet(nn.Module):
+    def __init__(self, cin, cout, groups=32, eps=1e-6):
+        super().__init__()
+        self.norm1 = nn.GroupNorm(groups, cin, eps=eps)
+        self.conv1 = nn.Conv2d(cin, cout, 3, padding=1)
+        self.norm2 = nn.GroupNorm(groups, cout, eps=eps)
+        self.conv2 = nn.Conv2d(cout, cout, 3, padding=1)
+        self.conv_shortcut = nn.Conv2d(cin, cout, 1) if cin != cout else None
+
+    def forward(self, x):
+        h = self.conv1(F.silu(self.norm1(x)))
+        h = self.conv2(F.silu(self.norm2(h)))
+        return (x if self.conv_shortcut is None else self.conv_shortcut(x)) + h
+
+
+class VaeAttention(nn.Module):
+    def __init__(self, ch, groups=32, eps=1e-6):
+        super().__init__()
+        self.group_norm = nn.GroupNorm(groups, ch, eps=eps)
+        self.to_q = nn.Linear(ch, ch)
+        self.to_k = nn.Linear(ch, ch)
+        self.to_v = nn.Linear(ch, ch)
+        self.to_out = nn.ModuleList([nn.Linear(ch, ch)])
+
+    def forward(self, x):
+        b, c, h, w = x.shape
+        y = self.group_norm(x).reshape(b, c, h * w).transpose(1, 2)
+        q, k, v = self.to_q(y)[:, None], self.to_k(y)[:, None], self.to_v(y)[:, None]   # one head of width c
+        o = F.scaled_dot_product_attention(q, k, v)[:, 0]
+        return x + self.to_out[0](o).transpose(1, 2).reshape(b, c, h, w)
+
+
+class VaeMid(nn.Module):
+    def __init__(self, ch):
+        super().__init__()
+        self.resnets = nn.ModuleList([VaeResnet(ch, ch), VaeResnet(ch, ch)])
+        self.attentions = nn.ModuleList([VaeAttention(ch)])
+
+    def forward(self, x):
+        return self.resnets[1](self.attentions[0](self.resnets[0](x)))
+
+
+class _Down(nn.Module):
+    def __init__(self, ch):
+        super().__init__()
+        self.conv = nn.Conv2d(ch, ch, 3, stride=2, padding=0)
+
+    def forward(self, x):
+        return self.conv(F.pad(x, (0, 1, 0, 1)))     # diffusers' asymmetric padding for the VAE downsampler
+
+
+class _Up(nn.Module):
+    def __init__(self, ch):
+        super().__init__()
+        self.conv = nn.Conv2d(ch, ch, 3, padding=1)
+
+    def forward(self, x):
+        return self.conv(F.interpolate(x, scale_factor=2.0, mode="nearest"))
+
+
+class _EncBlock(nn.Module):
+    def __init__(self, cin, cout, down):
+        super().__init__()
+        self.resnets = nn.ModuleList([VaeResnet(cin, cout), VaeResnet(cout, cout)])
+        self.downsamplers = nn.ModuleList([_Down(cout)]) if down else None
+
+    def forward(self, x):
+        for r in self.resnets:
+            x = r(x)
+        return x if self.downsamplers is None else self.downsamplers[0](x)
+
+
+class _DecBlock(nn.Module):
+    def __init__(self, cin, cout, up):
+        super().__init__()
+        self.resnets = nn.ModuleList([VaeResnet(cin if i == 0 else cout, cout) for i in range(3)])
+        self.upsamplers = nn.ModuleList([_Up(cout)]) if up else None
+
+    def forward(self, x):
+        for r in self.resnets:
+            x = r(x)
+        return x if self.upsamplers is None else self.upsamplers[0](x)
+
+
+class Encoder(nn.Module):
+    def __init__(self, chs: Sequence[int], latent=4):
+        super().__init__()
+        self.conv_in = nn.Conv2d(3, chs[0], 3, padding=1)
+        self.down_blocks = nn.ModuleList([_EncBlock(chs[max(i - 1, 0)], c, i < len(chs) - 1) for i, c in enumerate(chs)])
+        self.mid_block = VaeMid(chs[-1])
+        self.conv_norm_out = nn.GroupNorm(32, chs[-1], eps=1e-6)
+        self.conv_out = nn.Conv2d(chs[-1], 2 * latent, 3, padding=1)
+
+    def forward(self, x):
+        x = self.conv_in(x)
+        for b in self.down_blocks:
+            x = b(x)
+        return self.conv_out(F.silu(self.conv_norm_out(self.mid_block(x))))
+
+
+class Decoder(nn.Module):
+    def __init__(self, chs: Sequence[int], latent=4):
+        super().__init__()
+        rev = list(reversed(chs))
+        self.conv_in = nn.Conv2d(latent, rev[0], 3, padding=1)
+        self.mid_block = VaeMid(rev[0])
+        self.up_blocks = nn.ModuleList([_DecBlock(rev[max(i - 1, 0)], c, i < len(rev) - 1) for i, c in enumerate(rev)])
+        self.conv_norm_out = nn.GroupNorm(32, rev[-1], eps=1e-6)
+        self.conv_out = nn.Conv2d(rev[-1], 3, 3, padding=1)
+
+    def forward(self, z):
+        x = self.mid_block(self.conv_in(z))
+        for b in self.up_blocks:
+            x = b(x)
+        return self.conv_out(F.silu(self.conv_norm_out(x)))
+
+
+class AutoencoderKL(nn.Module):
+    def __init__(self, block_out_channels: Sequence[int] = (128, 256, 512, 512), latent_channels: int = 4):
+        super().__init__()
+        self.encoder = Encoder(block_out_channels, latent_channels)
+        self.decoder = Decoder(block_out_channels, latent_channels)
+        self.quant_conv = nn.Conv2d(2 * latent_channels, 2 * latent_channels, 1)
+        self.post_quant_conv = nn.Conv2d(latent_channels, latent_channels, 1)
+        self.latent_channels = latent_channels
+
+    def encode_mean(self, x: torch.Tensor) -> torch.Tensor:
+        """`vae.encode(x).latent_dist.mean` (extract.py:41-42): first half of the moments."""
+        return self.quant_conv(self.encoder(x))[:, : self.latent_channels]
+
+    def decode(self, z: torch.Tensor) -> torch.Tensor:
+        return self.decoder(self.post_quant_conv(z))
+
+
+@torch.no_grad()
+def img_to_latents(x: torch.Tensor, vae: AutoencoderKL) -> torch.Tensor:
+    """extract.py:39-43: x in [0,1] -> 2x-1 -> posterior mean * 0.18215."""
+    return (vae.encode_mean(2.0 * x - 1.0) * SCALING_FACTOR).contiguous()
+
+
+@torch.no_grad()
+def latents_to_img(latents: torch.Tensor, vae: AutoencoderKL) -> torch.Tensor:
+    """`decode_image` + `torch_to_numpy` prefix of the bytecode pipelines: vae.decode(latents / 0.18215) -> (x/2+0.5).clamp(0,1)."""
+    return (vae.decode(latents / SCALING_FACTOR) / 2 + 0.5).clamp(0, 1)
+
+
+def synthetic_init_(model: nn.Module, seed: int = 0) -> nn.Module:
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if p.dim() >= 2:
+                std = (1.0 / p[0].numel()) ** 0.5
+                if name.endswith(("conv2.weight", "to_out.0.weight")):
+                    std *= 0.3
+                p.copy_(torch.randn(p.shape, generator=g) * std)
+            else:
+                p.fill_(1.0 if name.endswith("weight") and "norm" in name else 0.0)
+    return model
+
+
+def load_diffusers_state_dict(model: nn.Module, weight_dir: str) -> nn.Module:
+    from safetensors.torch import load_file
+    path = weight_dir
+    for cand in ("vae/diffusion_pytorch_model.safetensors", "diffusion_pytorch_model.safetensors"):
+        if os.path.exists(os.path.join(weight_dir, cand)):
+            path = os.path.join(weight_dir, cand)
+            break
+    sd = load_file(path)
+    # older diffusers checkpoints name the mid-block attention projections query/key/value/proj_attn
+    ren = {"query": "to_q", "key": "to_k", "value": "to_v", "proj_attn": "to_out.0"}
+    fixed = {}
+    for k, v in sd.items():
+        for old, new in ren.items():
+            k = k.replace(f"attentions.0.{old}.", f"attentions.0.{new}.")
+        if k.endswith(("to_q.weight", "to_k.weight", "to_v.weight", "to_out.0.weight")) and v.dim() == 4:
+            v = v[:, :, 0, 0]
+        fixed[k] = v
+    missing, unexpected = model.load_state_dict(fixed, strict=False)
+    if missing or unexpected:
+        raise RuntimeError(f"VAE state dict mismatch: missing {missing[:5]}, unexpected {unexpected[:5]}")
+    return model

@@ -1,0 +1,103 @@
+"""GPU: the extract.py twin end to end -- PNG files -> Lanczos resize -> VAE encode -> DDIM inversion -> vote -> stdout /
+result.txt, with the full-size SD2.1-shaped UNet + VAE (synthetic weights: no checkpoint is reachable here, so the recovered
+bits are compared with the oracle run on the very same inverted latents, not with a known message)."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import gs_oracle as O
+from conftest import README_KEY, README_NONCE
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def E():
+    import gswm_amd
+    from gswm_amd import extract
+    return extract
+
+
+def _args(**kw):
+    a = types.SimpleNamespace(model_id="stabilityai/stable-diffusion-2-1-base", key_hex=README_KEY, nonce_hex=README_NONCE,
+                              key=bytes.fromhex(README_KEY), nonce=bytes.fromhex(README_NONCE), original_message_hex=(b"lthero" + b"\0" * 26).hex(),
+                              num_inference_steps=3, scheduler="DDIM", is_traverse_subdirectories=0, l=1, width=128, height=128,
+                              message_length=256, images_directory_path="", single_image_path="")
+    a.__dict__.update(kw)
+    return a
+
+
+def _write_images(d, n, size=(96, 80)):
+    from PIL import Image
+    rng = np.random.RandomState(len(str(d)))
+    paths = []
+    for i in range(n):
+        p = os.path.join(d, f"img{i}.png" if i % 2 == 0 else f"img{i}.jpg")
+        Image.fromarray(rng.randint(0, 256, (size[1], size[0], 3), dtype=np.uint8)).save(p)
+        paths.append(p)
+    return paths
+
+
+def test_single_image_flow(E, tmp_path, capsys):
+    p = _write_images(str(tmp_path), 1)[0]
+    args = _args(single_image_path=p)
+    lat = E.exactract_latents(args)
+    assert lat.shape == (1, 4, 16, 16) and lat.dtype == torch.float16 and not lat.is_cuda      # extract.py:70 contract
+    ob, eb, acc = E.get_result_for_one_image(args)
+    out = capsys.readouterr().out
+    assert out.startswith(f"img0.png\nOriginal Message: {ob} \nExtracted Message: {eb}\nBit Accuracy: {acc}\n")
+    assert len(eb) == 256 and set(eb) <= {"0", "1"}
+    assert (ob, acc) == O.calculate_bit_accuracy(args.original_message_hex, eb)
+    # same bits as the oracle on the same inverted latents (the MIOpen / hipBLASLt kernels are not run-to-run deterministic,
+    # so two inversions agree only approximately; the vote is compared on ONE inversion)
+    latb = E.exactract_latents_batch([p], args)
+    assert (latb.cpu().float() - lat.float()).abs().max().item() < 0.05
+    assert E.recover_exactracted_message(latb, args) == O.recover_bits(latb.cpu().numpy(), args.key, args.nonce, 256)
+
+
+def test_directory_harness_result_files(E, tmp_path):
+    root = tmp_path / "root"
+    sub = root / "setA"
+    sub.mkdir(parents=True)
+    paths = _write_images(str(sub), 3)
+    (sub / "broken.png").write_bytes(b"not an image")
+    args = _args(images_directory_path=str(root), is_traverse_subdirectories=1)
+    E.process_directory(args)
+    txt = (sub / "result.txt").read_text().splitlines()
+    assert txt[0] == "=" * 40 + "Batch Info" + "=" * 40 and txt[7] == "=" * 40 + "Batch Start" + "=" * 40
+    body = [l for l in txt[8:] if l]
+    good = [l for l in body if ", Bit Accuracy, " in l and not l.startswith("Average")]
+    errs = [l for l in body if l.startswith("Error processing ")]
+    assert len(good) + len(errs) == 4 and len(errs) >= 1
+    avg = [l for l in body if l.startswith("Average Bit Accuracy, ")]
+    if good:
+        vals = [float(l.split(", ")[2]) for l in good]
+        assert len(avg) == 1 and abs(float(avg[0].split(", ")[1]) - sum(vals) / len(vals)) < 1e-12
+        assert body[-1] == "=" * 40 + "Batch End" + "=" * 40
+        roll = (root / "result.txt").read_text().splitlines()
+        assert any(l.startswith("setA, Average Bit Accuracy, ") for l in roll)
+        assert roll[0] == "=" * 40 + "Batch Info" + "=" * 40 and roll[-2] == "=" * 40 + "Batch End" + "=" * 40
+
+
+def test_image_level_roundtrip_runs(E, keys):
+    """embed -> sample -> VAE decode -> JPEG QF 10 -> VAE encode -> invert -> vote: config 4's data path (synthetic weights:
+    accuracy is not gated, only that every stage runs on the batch and returns well-formed results)."""
+    import gswm_amd
+    from gswm_amd import codec, pipeline as P
+    key, nonce = keys
+    m = E.load_models("stabilityai/stable-diffusion-2-1-base")
+    k = codec.pad_message("lthero", 32)
+    pipe = P.GaussianShadingPipeline(m.unet, key, nonce, k, height=128, width=128, num_inference_steps=2, ctx_uncond=m.ctx_empty)
+    B = 2
+    zT = pipe.embed(B, seed=1)
+    x0 = pipe.generate(zT, m.ctx_empty.expand(B, -1, -1).contiguous(), guidance_scale=7.5)
+    img = P.decode_images(x0, m.vae)
+    assert img.shape == (B, 3, 128, 128)
+    img2 = P.jpeg_roundtrip(img, 10)
+    lat = P.encode_images(img2, m.vae)
+    assert lat.shape == x0.shape and torch.isfinite(lat).all()
+    bits, flags = pipe.invert_and_extract(lat)
+    assert bits.shape == (B, 32) and flags.shape == (B,)
