@@ -35,6 +35,9 @@ _PROTOTYPES = {
     "gsw_ddim_step_extract": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_char_p,
                                         C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64,
                                         C.c_void_p]),
+    "gsw_groupnorm_silu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_float, C.c_int, C.c_int, C.c_void_p]),
+    "gsw_geglu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
 }
 
 _lib = None

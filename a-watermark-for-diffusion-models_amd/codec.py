@@ -204,3 +204,34 @@ def ddim_step_extract(x: torch.Tensor, model_out: torch.Tensor, a: float, b: flo
                                               a, b, _dt(x.dtype), key, nonce, M, bits.data_ptr(),
                                               counts.data_ptr() if return_counts else None, flags.data_ptr(), B, n, _stream_ptr()))
     return (bits, flags, counts) if return_counts else (bits, flags)
+
+
+# ------------------------------------------------------------------------------------------------ eps-model fusions (X2 / G1)
+def groupnorm_silu(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float, *, act: bool = True,
+                   pre_bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = act(GroupNorm(x + pre_bias[:, :, None, None]) * gamma + beta) for NCHW x in one kernel (2 HBM passes)."""
+    _need_gpu(x, "x")
+    B, C = x.shape[0], x.shape[1]
+    HW = x.numel() // max(B * C, 1)
+    if out is None:
+        out = torch.empty_like(x)
+    pb = None
+    if pre_bias is not None:
+        pre_bias = pre_bias.to(x.dtype).contiguous()
+        _need_gpu(pre_bias, "pre_bias")
+        pb = pre_bias.data_ptr()
+    with torch.cuda.device(x.device):
+        N.check(N.lib().gsw_groupnorm_silu(x.data_ptr(), pb, gamma.data_ptr(), beta.data_ptr(), out.data_ptr(), B, C, HW, groups, eps,
+                                           1 if act else 0, _dt(x.dtype), _stream_ptr()))
+    return out
+
+
+def geglu(x: torch.Tensor) -> torch.Tensor:
+    """[..., 2*I] -> [..., I]: x[..., :I] * gelu(x[..., I:]) in one pass."""
+    _need_gpu(x, "x")
+    inner = x.shape[-1] // 2
+    rows = x.numel() // (2 * inner)
+    out = torch.empty((*x.shape[:-1], inner), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        N.check(N.lib().gsw_geglu(x.data_ptr(), out.data_ptr(), rows, inner, _dt(x.dtype), _stream_ptr()))
+    return out

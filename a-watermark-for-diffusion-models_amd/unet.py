@@ -21,6 +21,27 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+# Fused HIP elementwise kernels (libgswm: gsw_groupnorm_silu, gsw_geglu) replace torch's GroupNorm -> SiLU (-> broadcast add)
+# and GELU -> mul chains on the GPU; the plain torch ops remain for CPU / meta tensors (FLOP counting, CPU baseline).
+FUSED_KERNELS = True
+
+
+def _fusable(x: torch.Tensor) -> bool:
+    return FUSED_KERNELS and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16, torch.float32) and x.is_contiguous() \
+        and (x.shape[-1] * x.shape[-2]) % 8 == 0
+
+
+def gn_act(x: torch.Tensor, norm: nn.GroupNorm, act: bool = True, pre_bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """act(GroupNorm(x + pre_bias[:, :, None, None]))"""
+    if _fusable(x):
+        from . import codec
+        return codec.groupnorm_silu(x, norm.weight, norm.bias, norm.num_groups, norm.eps, act=act, pre_bias=pre_bias)
+    if pre_bias is not None:
+        x = x + pre_bias[:, :, None, None]
+    y = norm(x)
+    return F.silu(y) if act else y
+
+
 def timestep_embedding(t: torch.Tensor, dim: int, max_period: float = 10000.0) -> torch.Tensor:
     """Sinusoidal embedding, flip_sin_to_cos=True, freq_shift=0 (SD config): [cos | sin]."""
     half = dim // 2
@@ -50,9 +71,8 @@ class ResnetBlock2D(nn.Module):
         self.conv_shortcut = nn.Conv2d(cin, cout, 1) if cin != cout else None
 
     def forward(self, x, temb_act):
-        h = self.conv1(F.silu(self.norm1(x)))
-        h = h + self.time_emb_proj(temb_act)[:, :, None, None]
-        h = self.conv2(F.silu(self.norm2(h)))
+        h = self.conv1(gn_act(x, self.norm1))
+        h = self.conv2(gn_act(h, self.norm2, pre_bias=self.time_emb_proj(temb_act)))     # temb add folded into the norm kernel
         return (x if self.conv_shortcut is None else self.conv_shortcut(x)) + h
 
 
@@ -82,7 +102,11 @@ class GEGLU(nn.Module):
         self.proj = nn.Linear(dim, inner * 2)
 
     def forward(self, x):
-        h, gate = self.proj(x).chunk(2, dim=-1)
+        y = self.proj(x)
+        if FUSED_KERNELS and y.is_cuda and y.is_contiguous() and (y.shape[-1] // 2) % 8 == 0:
+            from . import codec
+            return codec.geglu(y)
+        h, gate = y.chunk(2, dim=-1)
         return h * F.gelu(gate)
 
 
@@ -121,7 +145,7 @@ class Transformer2DModel(nn.Module):
 
     def forward(self, x, ctx):
         b, c, h, w = x.shape
-        y = self.norm(x).permute(0, 2, 3, 1).reshape(b, h * w, c)
+        y = gn_act(x, self.norm, act=False).permute(0, 2, 3, 1).reshape(b, h * w, c)
         y = self.proj_in(y)
         for blk in self.transformer_blocks:
             y = blk(y, ctx)
@@ -245,7 +269,7 @@ class UNet2DCondition(nn.Module):
             h = blk(h, temb, ctx, skips)
         # the scheduler-step / vote kernels index the lattice in C order: hand back plain NCHW even when the convolutions
         # run channels-last
-        return self.conv_out(F.silu(self.conv_norm_out(h))).contiguous(memory_format=torch.contiguous_format)
+        return self.conv_out(gn_act(h, self.conv_norm_out)).contiguous(memory_format=torch.contiguous_format)
 
 
 def synthetic_init_(model: nn.Module, seed: int = 0, out_scale: float = 1.0) -> nn.Module:

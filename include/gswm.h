@@ -70,7 +70,8 @@ int gsw_keystream(const uint8_t key[32], const uint8_t nonce16[16], uint8_t* out
  *                   times then zeros (nodes.py:79-87)
  *   u_dev         : optional [B, n_elems] float64 uniforms in [0,1) (the reference's np.random.uniform draws,
  *                   gs_insert.py:62) -- bit-parity mode.  NULL => in-kernel Philox4x32-10 keyed by `seed`,
- *                   counter = (element pair index, image_index0 + b): results do not depend on batch split
+ *                   counter = (element index >> 2, image_index0 + b), one 32-bit word per element, u = (w + 1/2) 2^-32:
+ *                   results do not depend on batch split
  *                   or GPU count.
  *   out_dev       : [B, n_elems] of out_dtype; z = ndtri((u + y) / 2) (gs_insert.py:64), y = cipher bit,
  *                   MSB-first within each cipher byte (gs_insert.py:49)
@@ -115,6 +116,15 @@ int gsw_ddim_step_cfg(const void* x_dev, const void* e_uncond_dev, const void* e
 int gsw_ddim_step_extract(const void* x_dev, const void* model_out_dev, void* z_out_dev, float a, float b, int dtype,
                           const uint8_t key[32], const uint8_t nonce16[16], int msg_bits, uint8_t* bits_dev,
                           uint32_t* counts_dev, uint32_t* flags_dev, int B, int64_t n_elems, void* stream);
+
+/* X2 / G1 -- elementwise fusions inside the eps model (the UNet the DDIM loops call; in the reference this is diffusers'
+ * ResnetBlock2D / GEGLU running as separate torch kernels):
+ *   gsw_groupnorm_silu: out = act(GroupNorm_groups(x + pre_bias[b, c]) * gamma[c] + beta[c]); x, out: [B, C, HW] (NCHW), HW % 8 == 0;
+ *                       pre_bias: optional [B, C] (the time-embedding projection added before norm2); act: 0 none, 1 SiLU
+ *   gsw_geglu:          out[r, i] = in[r, i] * gelu(in[r, inner + i]); in: [rows, 2*inner], out: [rows, inner], inner % 8 == 0 */
+int gsw_groupnorm_silu(const void* x_dev, const void* pre_bias_dev, const void* gamma_dev, const void* beta_dev, void* out_dev, int B, int C,
+                       int HW, int groups, float eps, int act, int dtype, void* stream);
+int gsw_geglu(const void* in_dev, void* out_dev, int64_t rows, int inner, int dtype, void* stream);
 
 #ifdef __cplusplus
 }
