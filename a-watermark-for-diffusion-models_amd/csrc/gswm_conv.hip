@@ -1,0 +1,252 @@
+// gswm_conv.hip -- hand-written MFMA implicit-GEMM convolution for the eps model (rows X2 / G1), gfx950 only.
+//
+// Activation format "padded-flat NHWC" (PF): an image batch [B, H, W, C] is stored with a one-pixel zero border as a 2-D
+// matrix X[(b, y, x) -> b*Hp*Wp + y*Wp + x][C] (Hp = H+2, Wp = W+2), plus G = Wp+1 guard rows of zeros in front and behind.
+// In that domain a 3x3 tap is a CONSTANT row offset ((kh-1)*Wp + (kw-1)), so the convolution is one GEMM
+//     Y[m, n] = sum_t sum_c X[row(m) + off_t, c] * Wt[n, t*C + c]  (+ bias[n] + rowbias[b(m), n] + residual[m, n])
+// whose A-tile loader is a plain strided copy: no im2col buffer, no boundary tests in the K loop (border pixels read the
+// zero padding).  Border rows of Y are written as zeros so the result is again a valid PF tensor.  1x1 convolutions and
+// stride-2 downsampling are the same kernel with a different tap table / row map.
+//
+// Kernel: BM = 256 pixels x BN = 64 channels x BK = 64, 256 threads = 4 waves, each wave a 64 x 64 sub-tile as 2 x 2
+// v_mfma_f32_32x32x16 tiles (weights as the A operand, activations as the B operand, so a lane ends up with 4 consecutive
+// output channels of one pixel).  Operands are staged with global_load_lds (16 B per lane, 1 KiB per wave instruction) into
+// an LDS image whose 16-byte chunks are XOR-swizzled with (row >> 1) & 7 on the SOURCE address, which makes every
+// ds_read_b128 fragment read conflict-free.  ~3 workgroups per CU overlap each other's load and MFMA phases.
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+#include <algorithm>
+
+#include "../../include/gswm.h"
+
+typedef _Float16 gsw_h8 __attribute__((ext_vector_type(8)));
+typedef __bf16 gsw_b8 __attribute__((ext_vector_type(8)));
+typedef float gsw_f16v __attribute__((ext_vector_type(16)));
+
+#define CV_BM 256
+#define CV_BN 64
+#define CV_BK 64
+#define CV_THREADS 256
+#define CV_OUT_STRIDE 136   // bytes per row of the epilogue image (128 + 8: conflict-free ds_write_b64, 8-byte aligned reads)
+
+struct ConvArgs {
+    const void* x;        // PF activations, pointer to row 0 (guards live at negative rows)
+    const void* w;        // [N][T*C] K-contiguous weights
+    const void* bias;     // [N] or null
+    const void* rowbias;  // [B][N] or null (time-embedding projection)
+    const void* resid;    // [M][N] or null (PF, same geometry as the output)
+    void* y;              // [M][N] PF output
+    int32_t tap_off[9];   // row offset of each tap in the INPUT PF domain
+    int32_t ntaps;
+    int32_t C, N;         // input / output channels
+    int32_t M;            // output rows = B * Hp * Wp (output geometry)
+    int32_t Hp, Wp;       // output padded geometry
+    int32_t in_Hp, in_Wp; // input padded geometry
+    int32_t stride;       // 1 or 2
+    int32_t ldx;          // row stride of x in elements (>= C; lets the input be a channel slice of a wider tensor)
+};
+
+template <typename T> struct Mfma;
+template <> struct Mfma<_Float16> {
+    typedef gsw_h8 frag;
+    static __device__ __forceinline__ gsw_f16v mma(frag a, frag b, gsw_f16v c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ uint16_t cvt(float f) { return __half_as_ushort(__float2half_rn(f)); }
+    static __device__ __forceinline__ float up(uint16_t h) { return __half2float(__ushort_as_half(h)); }
+};
+template <> struct Mfma<__bf16> {
+    typedef gsw_b8 frag;
+    static __device__ __forceinline__ gsw_f16v mma(frag a, frag b, gsw_f16v c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ uint16_t cvt(float f) {
+        union { __hip_bfloat16 h; uint16_t u; } c; c.h = __float2bfloat16(f); return c.u;
+    }
+    static __device__ __forceinline__ float up(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+};
+
+template <typename T>
+__global__ __launch_bounds__(CV_THREADS) void gsw_conv_gemm_kernel(ConvArgs p) {
+    // one LDS array (a second __shared__ object would make hipcc drain vmcnt before every ds_read, cdna guide 5/4a)
+    __shared__ __attribute__((aligned(16))) uint8_t lds[(CV_BM + CV_BN) * CV_BK * 2];
+    uint8_t* ldsX = lds;                         // [256 rows][128 B], chunk-swizzled
+    uint8_t* ldsW = lds + CV_BM * CV_BK * 2;     // [64 rows][128 B]
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    // XCD-aware tile order: hardware block b runs on XCD b % 8 (its own L2).  Give every XCD a contiguous range of logical
+    // tiles (bijective remap, cdna guide T1), N tiles fastest, so the workgroups that share an activation tile run back to
+    // back on the SAME XCD and find it in that L2 instead of each pulling it from HBM.
+    const uint32_t nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7u;
+    const uint32_t xcd = blockIdx.x & 7u, idx = blockIdx.x >> 3;
+    const uint32_t logical = (xcd < r8 ? xcd * (q8 + 1u) : r8 * (q8 + 1u) + (xcd - r8) * q8) + idx;
+    const uint32_t ntn = (uint32_t)p.N / CV_BN;
+    const uint32_t tile_n = logical % ntn, tile_m = logical / ntn;
+    const int32_t m0 = (int32_t)tile_m * CV_BM, n0 = (int32_t)tile_n * CV_BN;
+    const int32_t HpWp = p.Hp * p.Wp;
+
+    // per-lane source rows of the 8 activation loads this wave issues per K block (input-domain row of output row m)
+    int32_t xrow[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int32_t r = (int32_t)wave * 64 + i * 8 + (int32_t)(lane >> 3);
+        int32_t m = m0 + r;
+        if (m >= p.M) m = p.M - 1;
+        int32_t src = m;
+        if (p.stride == 2) {   // output pixel (yo, xo) reads input rows (2yo - 1 + kh) -> padded (2yo + kh) = base + kh*in_Wp + kw
+            const int32_t b = m / HpWp, q = m - b * HpWp;
+            int32_t yo = q / p.Wp - 1, xo = q - (q / p.Wp) * p.Wp - 1;
+            yo = yo < 0 ? 0 : yo; xo = xo < 0 ? 0 : xo;
+            const int32_t Ho = p.Hp - 2, Wo = p.Wp - 2;
+            yo = yo >= Ho ? Ho - 1 : yo; xo = xo >= Wo ? Wo - 1 : xo;
+            src = b * p.in_Hp * p.in_Wp + (2 * yo) * p.in_Wp + 2 * xo;
+        }
+        xrow[i] = src;
+    }
+    const uint32_t pc = lane & 7u;               // physical 16-byte chunk this lane fills in its LDS row
+    const T* X = reinterpret_cast<const T*>(p.x);
+    const T* W = reinterpret_cast<const T*>(p.w);
+    const int32_t Ktot = p.ntaps * p.C;
+
+    gsw_f16v acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+    const int32_t kc_per_tap = p.C / CV_BK;
+    for (int32_t t = 0; t < p.ntaps; ++t) {
+        const int32_t off = p.tap_off[t];
+        for (int32_t kc = 0; kc < kc_per_tap; ++kc) {
+            // ---- stage: activations (8 x 1 KiB per wave) and weights (2 x 1 KiB per wave)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const uint32_t r = wave * 64u + i * 8u + (lane >> 3);
+                const uint32_t c = pc ^ ((r >> 1) & 7u);                       // logical chunk stored at physical chunk pc
+                const T* src = X + (int64_t)(xrow[i] + off) * p.ldx + kc * CV_BK + c * 8;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(ldsX + (wave * 64u + i * 8u) * 128u), 16, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const uint32_t r = wave * 16u + i * 8u + (lane >> 3);
+                const uint32_t c = pc ^ ((r >> 1) & 7u);
+                const T* src = W + (int64_t)(n0 + (int32_t)r) * Ktot + t * p.C + kc * CV_BK + c * 8;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(ldsW + (wave * 16u + i * 8u) * 128u), 16, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            // ---- compute: 4 k-steps x (2 x 2) MFMA tiles
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                typename Mfma<T>::frag wf[2], xf[2];
+                const uint32_t lc = (uint32_t)ks * 2u + (lane >> 5);           // logical chunk of this lane's 8 k-values
+#pragma unroll
+                for (int in = 0; in < 2; ++in) {
+                    const uint32_t r = (uint32_t)in * 32u + (lane & 31u);
+                    wf[in] = *reinterpret_cast<const typename Mfma<T>::frag*>(ldsW + r * 128u + ((lc ^ ((r >> 1) & 7u)) << 4));
+                }
+#pragma unroll
+                for (int im = 0; im < 2; ++im) {
+                    const uint32_t r = wave * 64u + (uint32_t)im * 32u + (lane & 31u);
+                    xf[im] = *reinterpret_cast<const typename Mfma<T>::frag*>(ldsX + r * 128u + ((lc ^ ((r >> 1) & 7u)) << 4));
+                }
+#pragma unroll
+                for (int in = 0; in < 2; ++in)
+#pragma unroll
+                    for (int im = 0; im < 2; ++im) acc[in][im] = Mfma<T>::mma(wf[in], xf[im], acc[in][im]);
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: D[n][m] fragments -> LDS image [m][n] (bias added) -> coalesced 16-byte row stores
+    // lane: m = wave*64 + im*32 + (lane & 31); n = in*32 + 8*rg + 4*(lane >> 5) + j   (j = 0..3 = reg & 3, rg = reg >> 2)
+    const T* bias = reinterpret_cast<const T*>(p.bias);
+#pragma unroll
+    for (int in = 0; in < 2; ++in)
+#pragma unroll
+        for (int im = 0; im < 2; ++im) {
+            const uint32_t m = wave * 64u + (uint32_t)im * 32u + (lane & 31u);
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const uint32_t n = (uint32_t)in * 32u + 8u * rg + 4u * (lane >> 5);
+                uint16_t h[4];
+                uint2 bw = make_uint2(0, 0);
+                if (bias) bw = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(bias) + n0 + n);
+                const uint16_t bh[4] = {(uint16_t)bw.x, (uint16_t)(bw.x >> 16), (uint16_t)bw.y, (uint16_t)(bw.y >> 16)};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) h[j] = Mfma<T>::cvt(acc[in][im][rg * 4 + j] + (bias ? Mfma<T>::up(bh[j]) : 0.f));
+                uint2 pk;
+                pk.x = (uint32_t)h[0] | ((uint32_t)h[1] << 16);
+                pk.y = (uint32_t)h[2] | ((uint32_t)h[3] << 16);
+                *reinterpret_cast<uint2*>(lds + m * CV_OUT_STRIDE + n * 2u) = pk;
+            }
+        }
+    __syncthreads();
+    const uint16_t* rowbias = reinterpret_cast<const uint16_t*>(p.rowbias);
+    const uint16_t* resid = reinterpret_cast<const uint16_t*>(p.resid);
+    uint16_t* Y = reinterpret_cast<uint16_t*>(p.y);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint32_t q = tid + 256u * i;
+        const uint32_t r = q >> 3, cc = q & 7u;
+        const int32_t m = m0 + (int32_t)r;
+        if (m >= p.M) continue;
+        const int32_t b = m / HpWp, qq = m - b * HpWp;
+        const int32_t yy = qq / p.Wp, xx = qq - yy * p.Wp;
+        const bool border = (yy == 0) | (yy == p.Hp - 1) | (xx == 0) | (xx == p.Wp - 1);
+        uint4 o = make_uint4(0, 0, 0, 0);
+        if (!border) {
+            const uint2 lo = *reinterpret_cast<const uint2*>(lds + r * CV_OUT_STRIDE + cc * 16u);
+            const uint2 hi = *reinterpret_cast<const uint2*>(lds + r * CV_OUT_STRIDE + cc * 16u + 8u);
+            uint32_t w4[4] = {lo.x, lo.y, hi.x, hi.y};
+            if (rowbias || resid) {
+                uint4 rb = make_uint4(0, 0, 0, 0), rs = make_uint4(0, 0, 0, 0);
+                if (rowbias) rb = *reinterpret_cast<const uint4*>(rowbias + (int64_t)b * p.N + n0 + cc * 8);
+                if (resid) rs = *reinterpret_cast<const uint4*>(resid + (int64_t)m * p.N + n0 + cc * 8);
+                const uint32_t rbw[4] = {rb.x, rb.y, rb.z, rb.w}, rsw[4] = {rs.x, rs.y, rs.z, rs.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float a0 = Mfma<T>::up((uint16_t)w4[k]) + Mfma<T>::up((uint16_t)rbw[k]) + Mfma<T>::up((uint16_t)rsw[k]);
+                    const float a1 = Mfma<T>::up((uint16_t)(w4[k] >> 16)) + Mfma<T>::up((uint16_t)(rbw[k] >> 16)) + Mfma<T>::up((uint16_t)(rsw[k] >> 16));
+                    w4[k] = (uint32_t)Mfma<T>::cvt(a0) | ((uint32_t)Mfma<T>::cvt(a1) << 16);
+                }
+            }
+            o = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+        }
+        *reinterpret_cast<uint4*>(Y + (int64_t)m * p.N + n0 + cc * 8) = o;
+    }
+}
+
+// host ---------------------------------------------------------------------------------------------
+static thread_local int g_conv_hip_error = 0;
+
+int gsw_conv_pf(const void* x_dev, const void* w_dev, const void* bias_dev, const void* rowbias_dev, const void* resid_dev, void* y_dev,
+                int B, int H, int W, int C, int N, int ksize, int stride, int ldx, int dtype, void* stream) {
+    // H, W: OUTPUT spatial size; input spatial size is (H*stride, W*stride)
+    if (!x_dev || !w_dev || !y_dev || B <= 0 || H <= 0 || W <= 0 || C <= 0 || N <= 0) return GSW_ERR_BAD_ARG;
+    if ((ksize != 1 && ksize != 3) || (stride != 1 && stride != 2) || (ksize == 1 && stride != 1)) return GSW_ERR_BAD_ARG;
+    if (C % CV_BK || N % CV_BN || ldx < C || (ldx & 7)) return GSW_ERR_UNSUPPORTED;
+    if (dtype != GSW_F16 && dtype != GSW_BF16) return GSW_ERR_BAD_ARG;
+    ConvArgs a;
+    a.x = x_dev; a.w = w_dev; a.bias = bias_dev; a.rowbias = rowbias_dev; a.resid = resid_dev; a.y = y_dev;
+    a.C = C; a.N = N; a.Hp = H + 2; a.Wp = W + 2; a.stride = stride; a.ldx = ldx;
+    a.in_Hp = H * stride + 2; a.in_Wp = W * stride + 2;
+    const int64_t M = (int64_t)B * a.Hp * a.Wp;
+    if (M > 0x7FFFFF00 || M * (int64_t)std::max(C, N) > (int64_t)1 << 40) return GSW_ERR_UNSUPPORTED;
+    a.M = (int32_t)M;
+    a.ntaps = ksize * ksize;
+    for (int i = 0; i < 9; ++i) a.tap_off[i] = 0;
+    if (ksize == 3) {
+        for (int kh = 0; kh < 3; ++kh)
+            for (int kw = 0; kw < 3; ++kw)
+                a.tap_off[kh * 3 + kw] = stride == 1 ? (kh - 1) * a.in_Wp + (kw - 1) : kh * a.in_Wp + kw;
+    }
+    const uint32_t grid = (uint32_t)(((M + CV_BM - 1) / CV_BM) * (N / CV_BN));
+    if (dtype == GSW_F16) hipLaunchKernelGGL((gsw_conv_gemm_kernel<_Float16>), dim3(grid), dim3(CV_THREADS), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((gsw_conv_gemm_kernel<__bf16>), dim3(grid), dim3(CV_THREADS), 0, (hipStream_t)stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { g_conv_hip_error = (int)e; return GSW_ERR_HIP; }
+    return GSW_OK;
+}

@@ -1,0 +1,92 @@
+"""Padded-flat NHWC ("PF") activations and the MFMA implicit-GEMM convolution built on them (csrc/gswm_conv.hip).
+
+A PF tensor stores [B, H, W, C] with a one-pixel zero border as a matrix rows x C, row(b, y, x) = b*(H+2)*(W+2) + y*(W+2) + x,
+with G = W+3 zero guard rows at both ends of the allocation.  A 3x3 tap is then a constant row offset, so a convolution is a
+single GEMM whose operand loader needs no boundary logic (see the kernel header)."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _native as N
+from .codec import _dt, _stream_ptr
+
+
+class PF:
+    __slots__ = ("buf", "B", "H", "W", "C")
+
+    def __init__(self, buf: torch.Tensor, B: int, H: int, W: int, C: int):
+        self.buf, self.B, self.H, self.W, self.C = buf, B, H, W, C
+
+    @property
+    def G(self) -> int:
+        return self.W + 3
+
+    @property
+    def M(self) -> int:
+        return self.B * (self.H + 2) * (self.W + 2)
+
+    @property
+    def rows(self) -> torch.Tensor:
+        """[M, C] view of the payload rows (borders included, guards excluded)."""
+        return self.buf[self.G:self.G + self.M]
+
+    @property
+    def grid(self) -> torch.Tensor:
+        """[B, H+2, W+2, C] view."""
+        return self.rows.view(self.B, self.H + 2, self.W + 2, self.C)
+
+    @property
+    def interior(self) -> torch.Tensor:
+        """[B, H, W, C] strided view of the real pixels."""
+        return self.grid[:, 1:-1, 1:-1, :]
+
+    @staticmethod
+    def empty(B, H, W, C, dtype, device) -> "PF":
+        G = W + 3
+        M = B * (H + 2) * (W + 2)
+        buf = torch.empty((M + 2 * G, C), dtype=dtype, device=device)
+        buf[:G].zero_()
+        buf[G + M:].zero_()
+        return PF(buf, B, H, W, C)
+
+    @staticmethod
+    def zeros(B, H, W, C, dtype, device) -> "PF":
+        G = W + 3
+        return PF(torch.zeros((B * (H + 2) * (W + 2) + 2 * G, C), dtype=dtype, device=device), B, H, W, C)
+
+    @staticmethod
+    def from_nchw(x: torch.Tensor) -> "PF":
+        B, C, H, W = x.shape
+        p = PF.zeros(B, H, W, C, x.dtype, x.device)
+        p.interior.copy_(x.permute(0, 2, 3, 1))
+        return p
+
+    def to_nchw(self) -> torch.Tensor:
+        return self.interior.permute(0, 3, 1, 2).contiguous()
+
+    def tokens(self) -> torch.Tensor:
+        """[B, H*W, C] dense copy of the real pixels (transformer input)."""
+        return self.interior.reshape(self.B, self.H * self.W, self.C)
+
+
+def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
+    """[N, C, kh, kw] -> [N, kh*kw*C] (tap-major, channel-minor), the K order of the PF GEMM."""
+    return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
+
+
+def conv_pf(x: PF, w_packed: torch.Tensor, bias: Optional[torch.Tensor], *, ksize: int = 3, stride: int = 1,
+            rowbias: Optional[torch.Tensor] = None, resid: Optional[PF] = None, cin: Optional[int] = None, cin_offset: int = 0) -> PF:
+    """y = conv(x) (+ bias + rowbias[b] + resid) as one MFMA implicit GEMM; border rows of y are zero."""
+    C = x.C if cin is None else cin
+    Nn = w_packed.shape[0]
+    Ho, Wo = x.H // stride, x.W // stride
+    y = PF.empty(x.B, Ho, Wo, Nn, x.buf.dtype, x.buf.device)
+    xp = x.rows.data_ptr() + cin_offset * x.buf.element_size()
+    with torch.cuda.device(x.buf.device):
+        N.check(N.lib().gsw_conv_pf(xp, w_packed.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                    rowbias.data_ptr() if rowbias is not None else None,
+                                    resid.rows.data_ptr() if resid is not None else None, y.rows.data_ptr(),
+                                    x.B, Ho, Wo, C, Nn, ksize, stride, x.C, _dt(x.buf.dtype), _stream_ptr()))
+    return y

@@ -126,6 +126,16 @@ int gsw_groupnorm_silu(const void* x_dev, const void* pre_bias_dev, const void* 
                        int HW, int groups, float eps, int act, int dtype, void* stream);
 int gsw_geglu(const void* in_dev, void* out_dev, int64_t rows, int inner, int dtype, void* stream);
 
+/* X2 / G1 -- convolution of the eps model as an MFMA implicit GEMM on "padded-flat NHWC" (PF) activations
+ * (replaces diffusers' Conv2d -> MIOpen in ResnetBlock2D / Downsample2D / conv_shortcut):
+ *   PF tensor: [B*(H+2)*(W+2)] rows x C channels, row (b, y, x) = b*(H+2)*(W+2) + y*(W+2) + x, zero border, plus (W+3) zero guard
+ *              rows before row 0 and after the last row (x_dev points at row 0).
+ *   y[m, n] = sum_taps sum_c x[row(m) + off_tap, c] * w[n, tap*C + c] + bias[n] + rowbias[b(m), n] + resid[m, n]; border rows = 0
+ *   w_dev: [N][ksize*ksize*C] (tap-major, channel-minor), ksize 1 or 3, stride 1 or 2 (3x3 only); H, W = OUTPUT size;
+ *   ldx: row stride of x in elements; C % 64 == 0, N % 64 == 0; dtype GSW_F16 / GSW_BF16; bias / rowbias / resid optional. */
+int gsw_conv_pf(const void* x_dev, const void* w_dev, const void* bias_dev, const void* rowbias_dev, const void* resid_dev, void* y_dev,
+                int B, int H, int W, int C, int N, int ksize, int stride, int ldx, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
