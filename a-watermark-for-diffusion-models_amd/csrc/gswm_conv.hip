@@ -219,6 +219,119 @@ __global__ __launch_bounds__(CV_THREADS) void gsw_conv_gemm_kernel(ConvArgs p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// GroupNorm (+SiLU) on PF activations.  Channels of a group are NOT contiguous across pixels in NHWC, so the statistics
+// are a two-kernel reduction: (1) every workgroup walks a slab of padded pixels with (C/8) x P threads -- thread = one
+// 16-byte channel vector of one pixel lane, fully coalesced rows -- and reduces per-channel partial sums into 32 group
+// partials (borders are zero, so they drop out of the sums); (2) the apply kernel folds the slab partials of its image,
+// then normalises + activates and writes either a PF tensor (borders zero) or dense tokens [B, H*W, C] for the transformer.
+// ------------------------------------------------------------------------------------------------
+#define GN_MAX_GROUPS 64
+
+__device__ __forceinline__ void ld8h(const uint16_t* p, float (&v)[8], bool bf) {
+    const uint4 u = *reinterpret_cast<const uint4*>(p);
+    const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (bf) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xFFFF0000u); }
+        else { v[2 * i] = __half2float(__ushort_as_half((uint16_t)w[i])); v[2 * i + 1] = __half2float(__ushort_as_half((uint16_t)(w[i] >> 16))); }
+    }
+}
+__device__ __forceinline__ uint16_t cvt_h(float f, bool bf) {
+    if (bf) { union { __hip_bfloat16 h; uint16_t u; } c; c.h = __float2bfloat16(f); return c.u; }
+    return __half_as_ushort(__float2half_rn(f));
+}
+
+__global__ __launch_bounds__(512) void gsw_gn_pf_stats_kernel(const uint16_t* __restrict__ x, float* __restrict__ partial, int32_t C, int32_t G,
+                                                             int32_t HpWp, int32_t slab_len, int32_t P, int bf) {
+    __shared__ float s_sum[GN_MAX_GROUPS], s_sq[GN_MAX_GROUPS];
+    const int32_t b = blockIdx.y, s = blockIdx.x, nslab = gridDim.x;
+    const int32_t cv = C >> 3, tid = threadIdx.x;
+    const int32_t cvec = tid % cv, prow = tid / cv;
+    if (tid < GN_MAX_GROUPS) { s_sum[tid] = 0.f; s_sq[tid] = 0.f; }
+    __syncthreads();
+    float sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int32_t i0 = s * slab_len, i1 = min(HpWp, i0 + slab_len);
+    const uint16_t* base = x + ((int64_t)b * HpWp) * C + cvec * 8;
+    for (int32_t i = i0 + prow; i < i1; i += P) {
+        float v[8];
+        ld8h(base + (int64_t)i * C, v, bf);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { sum[k] += v[k]; sq[k] = fmaf(v[k], v[k], sq[k]); }
+    }
+    const int32_t cpg = C / G;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int32_t g = (cvec * 8 + k) / cpg;
+        atomicAdd(&s_sum[g], sum[k]);
+        atomicAdd(&s_sq[g], sq[k]);
+    }
+    __syncthreads();
+    if (tid < G) {
+        float* o = partial + (((int64_t)b * nslab + s) * G + tid) * 2;
+        o[0] = s_sum[tid]; o[1] = s_sq[tid];
+    }
+}
+
+__global__ __launch_bounds__(512) void gsw_gn_pf_apply_kernel(const uint16_t* __restrict__ x, const float* __restrict__ partial, const uint16_t* __restrict__ gamma,
+                                                             const uint16_t* __restrict__ beta, uint16_t* __restrict__ y, int32_t C, int32_t G, int32_t Hp, int32_t Wp,
+                                                             int32_t nslab_stats, int32_t slab_len, int32_t P, float eps, int act, int tokens, int bf) {
+    __shared__ float s_mean[GN_MAX_GROUPS], s_rstd[GN_MAX_GROUPS];
+    const int32_t b = blockIdx.y, s = blockIdx.x;
+    const int32_t cv = C >> 3, tid = threadIdx.x;
+    const int32_t cvec = tid % cv, prow = tid / cv;
+    const int32_t HpWp = Hp * Wp, H = Hp - 2, W = Wp - 2, cpg = C / G;
+    if (tid < G) {
+        float sm = 0.f, sq = 0.f;
+        for (int32_t k = 0; k < nslab_stats; ++k) {
+            const float* o = partial + (((int64_t)b * nslab_stats + k) * G + tid) * 2;
+            sm += o[0]; sq += o[1];
+        }
+        const float n = (float)(H * W * cpg);
+        const float mean = sm / n;
+        const float var = fmaxf(sq / n - mean * mean, 0.f);
+        s_mean[tid] = mean; s_rstd[tid] = rsqrtf(var + eps);
+    }
+    __syncthreads();
+    float sc[8], sh[8];
+    {
+        float ga[8], be[8];
+        ld8h(gamma + cvec * 8, ga, bf);
+        ld8h(beta + cvec * 8, be, bf);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int32_t g = (cvec * 8 + k) / cpg;
+            sc[k] = ga[k] * s_rstd[g];
+            sh[k] = be[k] - s_mean[g] * sc[k];
+        }
+    }
+    const int32_t i0 = s * slab_len, i1 = min(HpWp, i0 + slab_len);
+    const uint16_t* base = x + ((int64_t)b * HpWp) * C + cvec * 8;
+    for (int32_t i = i0 + prow; i < i1; i += P) {
+        const int32_t yy = i / Wp, xx = i - yy * Wp;
+        const bool border = (yy == 0) | (yy == Hp - 1) | (xx == 0) | (xx == Wp - 1);
+        uint4 o = make_uint4(0, 0, 0, 0);
+        if (!border) {
+            float v[8];
+            ld8h(base + (int64_t)i * C, v, bf);
+            uint16_t h[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float t = fmaf(v[k], sc[k], sh[k]);
+                if (act) t = t / (1.0f + __expf(-t));
+                h[k] = cvt_h(t, bf);
+            }
+            o = make_uint4((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16),
+                           (uint32_t)h[4] | ((uint32_t)h[5] << 16), (uint32_t)h[6] | ((uint32_t)h[7] << 16));
+        }
+        if (tokens) {
+            if (!border) *reinterpret_cast<uint4*>(y + (((int64_t)b * H + (yy - 1)) * W + (xx - 1)) * C + cvec * 8) = o;
+        } else {
+            *reinterpret_cast<uint4*>(y + ((int64_t)b * HpWp + i) * C + cvec * 8) = o;
+        }
+    }
+}
+
 // host ---------------------------------------------------------------------------------------------
 static thread_local int g_conv_hip_error = 0;
 
@@ -246,6 +359,30 @@ int gsw_conv_pf(const void* x_dev, const void* w_dev, const void* bias_dev, cons
     const uint32_t grid = (uint32_t)(((M + CV_BM - 1) / CV_BM) * (N / CV_BN));
     if (dtype == GSW_F16) hipLaunchKernelGGL((gsw_conv_gemm_kernel<_Float16>), dim3(grid), dim3(CV_THREADS), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((gsw_conv_gemm_kernel<__bf16>), dim3(grid), dim3(CV_THREADS), 0, (hipStream_t)stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { g_conv_hip_error = (int)e; return GSW_ERR_HIP; }
+    return GSW_OK;
+}
+
+int gsw_groupnorm_pf(const void* x_dev, const void* gamma_dev, const void* beta_dev, void* out_dev, float* workspace_dev, int B, int H, int W,
+                     int C, int groups, float eps, int act, int out_tokens, int dtype, void* stream) {
+    // workspace_dev: >= B * 64 * groups * 2 floats
+    if (!x_dev || !gamma_dev || !beta_dev || !out_dev || !workspace_dev || B <= 0 || H <= 0 || W <= 0 || C <= 0 || groups <= 0) return GSW_ERR_BAD_ARG;
+    if ((C & 7) || C % groups || groups > GN_MAX_GROUPS || (C >> 3) > 512) return GSW_ERR_UNSUPPORTED;
+    if (dtype != GSW_F16 && dtype != GSW_BF16) return GSW_ERR_BAD_ARG;
+    const int cv = C >> 3;
+    const int P = std::max(1, 320 / cv);
+    const int threads = cv * P;
+    const int HpWp = (H + 2) * (W + 2);
+    // enough workgroups to fill the chip: ~2048 in total, at most 64 slabs per image (workspace bound)
+    int nslab = std::max(1, std::min(64, std::min((2048 + B - 1) / B, (HpWp + P - 1) / P)));
+    const int slab_len = (HpWp + nslab - 1) / nslab;
+    nslab = (HpWp + slab_len - 1) / slab_len;
+    hipStream_t st = (hipStream_t)stream;
+    const int bf = dtype == GSW_BF16;
+    hipLaunchKernelGGL(gsw_gn_pf_stats_kernel, dim3(nslab, B), dim3(threads), 0, st, (const uint16_t*)x_dev, workspace_dev, C, groups, HpWp, slab_len, P, bf);
+    hipLaunchKernelGGL(gsw_gn_pf_apply_kernel, dim3(nslab, B), dim3(threads), 0, st, (const uint16_t*)x_dev, (const float*)workspace_dev, (const uint16_t*)gamma_dev,
+                       (const uint16_t*)beta_dev, (uint16_t*)out_dev, C, groups, H + 2, W + 2, nslab, slab_len, P, eps, act, out_tokens, bf);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g_conv_hip_error = (int)e; return GSW_ERR_HIP; }
     return GSW_OK;

@@ -90,3 +90,29 @@ def conv_pf(x: PF, w_packed: torch.Tensor, bias: Optional[torch.Tensor], *, ksiz
                                     resid.rows.data_ptr() if resid is not None else None, y.rows.data_ptr(),
                                     x.B, Ho, Wo, C, Nn, ksize, stride, x.C, _dt(x.buf.dtype), _stream_ptr()))
     return y
+
+
+_GN_WS = {}
+
+
+def _gn_workspace(device, B, groups):
+    k = (str(device), B * 64 * groups * 2)
+    if k not in _GN_WS:
+        _GN_WS[k] = torch.empty(k[1], dtype=torch.float32, device=device)
+    return _GN_WS[k]
+
+
+def groupnorm_pf(x: PF, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float, *, act: bool = True, tokens: bool = False):
+    """act(GroupNorm(x)) on a PF tensor -> PF (zero border) or dense tokens [B, H*W, C] (tokens=True)."""
+    dev = x.buf.device
+    ws = _gn_workspace(dev, x.B, groups)
+    if tokens:
+        out = torch.empty((x.B, x.H * x.W, x.C), dtype=x.buf.dtype, device=dev)
+        optr, res = out.data_ptr(), out
+    else:
+        y = PF.empty(x.B, x.H, x.W, x.C, x.buf.dtype, dev)
+        optr, res = y.rows.data_ptr(), y
+    with torch.cuda.device(dev):
+        N.check(N.lib().gsw_groupnorm_pf(x.rows.data_ptr(), gamma.data_ptr(), beta.data_ptr(), optr, ws.data_ptr(), x.B, x.H, x.W, x.C, groups,
+                                         eps, 1 if act else 0, 1 if tokens else 0, _dt(x.buf.dtype), _stream_ptr()))
+    return res

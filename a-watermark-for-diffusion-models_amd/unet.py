@@ -42,6 +42,26 @@ def gn_act(x: torch.Tensor, norm: nn.GroupNorm, act: bool = True, pre_bias: Opti
     return F.silu(y) if act else y
 
 
+# Padded-flat NHWC path: every 3x3 / 1x1 / stride-2 convolution of the UNet runs as the hand-written MFMA implicit GEMM
+# (csrc/gswm_conv.hip) with bias, time-embedding and residual adds fused into its epilogue, GroupNorm+SiLU as the PF kernels;
+# only conv_in / conv_out (4 channels), the upsampler's nearest-neighbour copy and the transformer blocks stay on torch ops.
+USE_PF = True
+
+
+def _pw(conv: nn.Conv2d) -> torch.Tensor:
+    w = getattr(conv, "_gsw_packed", None)
+    if w is None or w.device != conv.weight.device or w.dtype != conv.weight.dtype:
+        from .pf import pack_conv_weight
+        w = pack_conv_weight(conv.weight.detach())
+        conv._gsw_packed = w
+    return w
+
+
+def _gn_pf(x, norm: nn.GroupNorm, act=True, tokens=False):
+    from .pf import groupnorm_pf
+    return groupnorm_pf(x, norm.weight, norm.bias, norm.num_groups, norm.eps, act=act, tokens=tokens)
+
+
 def timestep_embedding(t: torch.Tensor, dim: int, max_period: float = 10000.0) -> torch.Tensor:
     """Sinusoidal embedding, flip_sin_to_cos=True, freq_shift=0 (SD config): [cos | sin]."""
     half = dim // 2
@@ -74,6 +94,12 @@ class ResnetBlock2D(nn.Module):
         h = self.conv1(gn_act(x, self.norm1))
         h = self.conv2(gn_act(h, self.norm2, pre_bias=self.time_emb_proj(temb_act)))     # temb add folded into the norm kernel
         return (x if self.conv_shortcut is None else self.conv_shortcut(x)) + h
+
+    def forward_pf(self, x, temb_act):
+        from .pf import conv_pf
+        h = conv_pf(_gn_pf(x, self.norm1), _pw(self.conv1), self.conv1.bias, rowbias=self.time_emb_proj(temb_act).contiguous())
+        sc = x if self.conv_shortcut is None else conv_pf(x, _pw(self.conv_shortcut), self.conv_shortcut.bias, ksize=1)
+        return conv_pf(_gn_pf(h, self.norm2), _pw(self.conv2), self.conv2.bias, resid=sc)    # residual add in the GEMM epilogue
 
 
 class Attention(nn.Module):
@@ -152,6 +178,13 @@ class Transformer2DModel(nn.Module):
         y = self.proj_out(y).reshape(b, h, w, c).permute(0, 3, 1, 2)
         return x + y
 
+    def forward_pf(self, x, ctx):
+        y = self.proj_in(_gn_pf(x, self.norm, act=False, tokens=True))      # GroupNorm writes dense tokens directly
+        for blk in self.transformer_blocks:
+            y = blk(y, ctx)
+        x.interior.add_(self.proj_out(y).view(x.B, x.H, x.W, x.C))          # residual, in place (x has no other reader)
+        return x
+
 
 class Downsample2D(nn.Module):
     def __init__(self, ch):
@@ -161,6 +194,10 @@ class Downsample2D(nn.Module):
     def forward(self, x):
         return self.conv(x)
 
+    def forward_pf(self, x):
+        from .pf import conv_pf
+        return conv_pf(x, _pw(self.conv), self.conv.bias, stride=2)
+
 
 class Upsample2D(nn.Module):
     def __init__(self, ch):
@@ -169,6 +206,15 @@ class Upsample2D(nn.Module):
 
     def forward(self, x):
         return self.conv(F.interpolate(x, scale_factor=2.0, mode="nearest"))
+
+    def forward_pf(self, x):
+        from .pf import PF, conv_pf
+        up = PF.zeros(x.B, 2 * x.H, 2 * x.W, x.C, x.buf.dtype, x.buf.device)
+        xi, g = x.interior, up.grid
+        for dy in (0, 1):
+            for dx in (0, 1):
+                g[:, 1 + dy:1 + dy + 2 * x.H:2, 1 + dx:1 + dx + 2 * x.W:2, :].copy_(xi)
+        return conv_pf(up, _pw(self.conv), self.conv.bias)
 
 
 class DownBlock(nn.Module):
@@ -186,6 +232,18 @@ class DownBlock(nn.Module):
             skips.append(x)
         if self.downsamplers is not None:
             x = self.downsamplers[0](x)
+            skips.append(x)
+        return x
+
+    def forward_pf(self, x, temb, ctx, skips):
+        from .pf import PF
+        for i, r in enumerate(self.resnets):
+            x = r.forward_pf(x, temb)
+            if self.attentions is not None:
+                x = self.attentions[i].forward_pf(x, ctx)
+            skips.append(x)
+        if self.downsamplers is not None:
+            x = self.downsamplers[0].forward_pf(x)
             skips.append(x)
         return x
 
@@ -211,6 +269,17 @@ class UpBlock(nn.Module):
             x = self.upsamplers[0](x)
         return x
 
+    def forward_pf(self, x, temb, ctx, skips):
+        from .pf import PF
+        for i, r in enumerate(self.resnets):
+            sk = skips.pop()
+            x = r.forward_pf(PF(torch.cat([x.buf, sk.buf], dim=1), x.B, x.H, x.W, x.C + sk.C), temb)
+            if self.attentions is not None:
+                x = self.attentions[i].forward_pf(x, ctx)
+        if self.upsamplers is not None:
+            x = self.upsamplers[0].forward_pf(x)
+        return x
+
 
 class MidBlock(nn.Module):
     def __init__(self, ch, temb, ctx_dim, heads, head_dim):
@@ -220,6 +289,9 @@ class MidBlock(nn.Module):
 
     def forward(self, x, temb, ctx):
         return self.resnets[1](self.attentions[0](self.resnets[0](x, temb), ctx), temb)
+
+    def forward_pf(self, x, temb, ctx):
+        return self.resnets[1].forward_pf(self.attentions[0].forward_pf(self.resnets[0].forward_pf(x, temb), ctx), temb)
 
 
 class UNet2DCondition(nn.Module):
@@ -260,6 +332,8 @@ class UNet2DCondition(nn.Module):
             t = t.expand(x.shape[0])
         temb = self.time_embedding(timestep_embedding(t, self.c0).to(x.dtype))
         temb = F.silu(temb)                      # every resnet applies SiLU to the same embedding: do it once
+        if self._pf_ok(x):
+            return self._forward_pf(x, temb, ctx)
         h = self.conv_in(x)
         skips = [h]
         for blk in self.down_blocks:
@@ -270,6 +344,35 @@ class UNet2DCondition(nn.Module):
         # the scheduler-step / vote kernels index the lattice in C order: hand back plain NCHW even when the convolutions
         # run channels-last
         return self.conv_out(gn_act(h, self.conv_norm_out)).contiguous(memory_format=torch.contiguous_format)
+
+
+def _unet_pf_ok(self, x: torch.Tensor) -> bool:
+    if not (USE_PF and FUSED_KERNELS and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16)):
+        return False
+    ok = getattr(self, "_pf_shapes_ok", None)
+    if ok is None:
+        ok = all(m.in_channels % 64 == 0 and m.out_channels % 64 == 0 for n, m in self.named_modules()
+                 if isinstance(m, nn.Conv2d) and n not in ("conv_in", "conv_out"))
+        self._pf_shapes_ok = ok
+    n_down = len(self.down_blocks) - 1
+    return ok and x.shape[-1] % (1 << n_down) == 0 and x.shape[-2] % (1 << n_down) == 0
+
+
+def _unet_forward_pf(self, x: torch.Tensor, temb: torch.Tensor, ctx: torch.Tensor) -> torch.Tensor:
+    from .pf import PF
+    h = PF.from_nchw(self.conv_in(x))
+    skips = [h]
+    for blk in self.down_blocks:
+        h = blk.forward_pf(h, temb, ctx, skips)
+    h = self.mid_block.forward_pf(h, temb, ctx)
+    for blk in self.up_blocks:
+        h = blk.forward_pf(h, temb, ctx, skips)
+    h = _gn_pf(h, self.conv_norm_out, act=True)
+    return self.conv_out(h.to_nchw()).contiguous(memory_format=torch.contiguous_format)
+
+
+UNet2DCondition._pf_ok = _unet_pf_ok
+UNet2DCondition._forward_pf = _unet_forward_pf
 
 
 def synthetic_init_(model: nn.Module, seed: int = 0, out_scale: float = 1.0) -> nn.Module:

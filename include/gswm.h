@@ -136,6 +136,11 @@ int gsw_geglu(const void* in_dev, void* out_dev, int64_t rows, int inner, int dt
 int gsw_conv_pf(const void* x_dev, const void* w_dev, const void* bias_dev, const void* rowbias_dev, const void* resid_dev, void* y_dev,
                 int B, int H, int W, int C, int N, int ksize, int stride, int ldx, int dtype, void* stream);
 
+/* GroupNorm (+SiLU) on a PF tensor: out = act(GroupNorm(x) * gamma + beta); out is a PF tensor (zero border) or, with out_tokens = 1,
+ * dense tokens [B, H*W, C] (the transformer's input).  workspace_dev: >= B * 64 * groups * 2 floats.  C % 8 == 0, groups <= 64. */
+int gsw_groupnorm_pf(const void* x_dev, const void* gamma_dev, const void* beta_dev, void* out_dev, float* workspace_dev, int B, int H, int W,
+                     int C, int groups, float eps, int act, int out_tokens, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

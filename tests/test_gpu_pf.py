@@ -1,0 +1,80 @@
+"""GPU: padded-flat NHWC kernels (MFMA implicit-GEMM convolution, GroupNorm) vs torch fp32 references, and the PF UNet path
+vs the plain torch path."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def G():
+    import gswm_amd
+    from gswm_amd import pf, unet
+    import types
+    return types.SimpleNamespace(pf=pf, unet=unet)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("B,C,N,H,W,k,stride", [(2, 64, 64, 8, 8, 3, 1), (3, 128, 64, 10, 6, 3, 1), (2, 64, 128, 8, 12, 1, 1), (2, 64, 64, 8, 16, 3, 2),
+                                                 (1, 320, 320, 32, 32, 3, 1), (5, 192, 64, 7, 9, 3, 1), (2, 128, 192, 16, 16, 3, 2)])
+def test_conv_pf_vs_torch_fp32(G, dtype, B, C, N, H, W, k, stride):
+    g = torch.Generator().manual_seed(C + N + H)
+    x = torch.randn(B, C, H, W, generator=g).to(dtype).cuda()
+    w = (torch.randn(N, C, k, k, generator=g) * (1.0 / (C * k * k)) ** 0.5).to(dtype).cuda()
+    b = torch.randn(N, generator=g).to(dtype).cuda()
+    rb = torch.randn(B, N, generator=g).to(dtype).cuda()
+    Ho, Wo = H // stride, W // stride
+    res = torch.randn(B, N, Ho, Wo, generator=g).to(dtype).cuda()
+    ref = F.conv2d(x.float(), w.float(), b.float(), padding=k // 2, stride=stride) + rb.float()[:, :, None, None] + res.float()
+    y = G.pf.conv_pf(G.pf.PF.from_nchw(x), G.pf.pack_conv_weight(w), b, ksize=k, stride=stride, rowbias=rb, resid=G.pf.PF.from_nchw(res))
+    assert (y.B, y.H, y.W, y.C) == (B, Ho, Wo, N)
+    tol = 2e-3 if dtype == torch.float16 else 1.6e-2          # one rounding of the storage dtype at the output magnitude
+    assert (y.to_nchw().float() - ref).abs().max().item() <= tol * ref.abs().max().item()
+    grid = y.grid.float()
+    assert grid[:, 0].abs().max() == 0 and grid[:, -1].abs().max() == 0 and grid[:, :, 0].abs().max() == 0 and grid[:, :, -1].abs().max() == 0
+    # no optional operands
+    y2 = G.pf.conv_pf(G.pf.PF.from_nchw(x), G.pf.pack_conv_weight(w), None, ksize=k, stride=stride)
+    ref2 = F.conv2d(x.float(), w.float(), None, padding=k // 2, stride=stride)
+    assert (y2.to_nchw().float() - ref2).abs().max().item() <= tol * max(1.0, ref2.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("B,C,H,W", [(3, 320, 64, 64), (2, 640, 32, 32), (2, 1280, 8, 8), (2, 960, 16, 16), (1, 2560, 16, 16), (2, 64, 4, 6), (2, 1920, 8, 8), (3, 128, 5, 7)])
+@pytest.mark.parametrize("act", [True, False])
+def test_groupnorm_pf_vs_torch_fp32(G, dtype, B, C, H, W, act):
+    g = torch.Generator().manual_seed(C + H)
+    x = (torch.randn(B, C, H, W, generator=g) * 1.5 + 0.3).to(dtype).cuda()
+    gamma = (1 + 0.2 * torch.randn(C, generator=g)).to(dtype).cuda()
+    beta = (0.2 * torch.randn(C, generator=g)).to(dtype).cuda()
+    ref = F.group_norm(x.float(), 32, gamma.float(), beta.float(), 1e-5)
+    ref = F.silu(ref) if act else ref
+    xp = G.pf.PF.from_nchw(x)
+    y = G.pf.groupnorm_pf(xp, gamma, beta, 32, 1e-5, act=act)
+    tol = 4e-3 if dtype == torch.float16 else 3e-2
+    assert (y.to_nchw().float() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+    assert y.grid[:, 0].abs().max() == 0 and y.grid[:, :, -1].abs().max() == 0
+    t = G.pf.groupnorm_pf(xp, gamma, beta, 32, 1e-5, act=act, tokens=True)
+    assert t.shape == (B, H * W, C)
+    assert (t.float() - ref.permute(0, 2, 3, 1).reshape(B, H * W, C)).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+
+
+def test_unet_pf_path_equals_torch_path(G):
+    U = G.unet
+    m = U.synthetic_init_(U.UNet2DCondition(block_out_channels=(64, 128, 128, 128), cross_attention_dim=64, num_heads=(2, 4, 4, 4), head_dim=32), 0)
+    m = m.cuda().half().eval()
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(3, 4, 32, 32, generator=g).cuda().half()
+    c = torch.randn(3, 77, 64, generator=g).cuda().half()
+    t = torch.tensor([981, 500, 1]).cuda()
+    with torch.no_grad():
+        U.USE_PF = True
+        assert m._pf_ok(x)
+        y1 = m(x, t, c)
+        U.USE_PF = False
+        y0 = m(x, t, c)
+        U.USE_PF = True
+        yref = m.float()(x.float(), t, c.float())
+    e1 = (y1.float() - yref).abs().max().item()
+    e0 = (y0.float() - yref).abs().max().item()
+    assert y1.shape == y0.shape and e1 <= max(2 * e0, 2e-2), (e1, e0)
