@@ -235,3 +235,21 @@ def geglu(x: torch.Tensor) -> torch.Tensor:
     with torch.cuda.device(x.device):
         N.check(N.lib().gsw_geglu(x.data_ptr(), out.data_ptr(), rows, inner, _dt(x.dtype), _stream_ptr()))
     return out
+
+
+def add_layernorm(x: torch.Tensor, delta: Optional[torch.Tensor], weight: torch.Tensor, bias: torch.Tensor, eps: float):
+    """(x + delta, LayerNorm(x + delta)) in one kernel; delta=None -> (x, LayerNorm(x))."""
+    _need_gpu(x, "x")
+    C = x.shape[-1]
+    rows = x.numel() // C
+    y = torch.empty_like(x)
+    xnew = x
+    dptr = None
+    if delta is not None:
+        _need_gpu(delta, "delta")
+        xnew = torch.empty_like(x)
+        dptr = delta.data_ptr()
+    with torch.cuda.device(x.device):
+        N.check(N.lib().gsw_add_layernorm(x.data_ptr(), dptr, weight.data_ptr(), bias.data_ptr(), xnew.data_ptr() if delta is not None else None,
+                                          y.data_ptr(), rows, C, eps, _dt(x.dtype), _stream_ptr()))
+    return xnew, y

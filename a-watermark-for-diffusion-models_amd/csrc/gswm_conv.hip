@@ -332,6 +332,88 @@ __global__ __launch_bounds__(512) void gsw_gn_pf_apply_kernel(const uint16_t* __
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Residual add + LayerNorm of the transformer blocks: x_new = x + delta (optional), y = LN(x_new) * gamma + beta.
+// One wave per token row (C <= 1536): the row lives in registers, mean and centred variance are exact two-pass fp32,
+// gamma / beta stay packed in registers across the rows a wave processes.  4 HBM passes (read x, delta; write x_new, y)
+// instead of add (3) + LayerNorm (2).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gsw_add_layernorm_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ delta, const uint16_t* __restrict__ gamma,
+                                                               const uint16_t* __restrict__ beta, uint16_t* __restrict__ xnew, uint16_t* __restrict__ y, int64_t rows,
+                                                               int32_t C, float eps, int bf) {
+    const int32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int32_t nv = C >> 3;
+    uint4 gpk[3], bpk[3];
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+        const int32_t v = lane + 64 * it;
+        gpk[it] = v < nv ? *reinterpret_cast<const uint4*>(gamma + v * 8) : make_uint4(0, 0, 0, 0);
+        bpk[it] = v < nv ? *reinterpret_cast<const uint4*>(beta + v * 8) : make_uint4(0, 0, 0, 0);
+    }
+    const float invC = 1.0f / (float)C;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+        float val[3][8];
+        float sum = 0.f;
+#pragma unroll
+        for (int it = 0; it < 3; ++it) {
+            const int32_t v = lane + 64 * it;
+            if (v < nv) {
+                ld8h(x + row * C + v * 8, val[it], bf);
+                if (delta) {
+                    float d[8];
+                    ld8h(delta + row * C + v * 8, d, bf);
+                    uint16_t h[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { h[k] = cvt_h(val[it][k] + d[k], bf); }
+                    // LN sees the stored (rounded) sum, exactly like add followed by LayerNorm
+                    const uint4 o = make_uint4((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16),
+                                               (uint32_t)h[4] | ((uint32_t)h[5] << 16), (uint32_t)h[6] | ((uint32_t)h[7] << 16));
+                    *reinterpret_cast<uint4*>(xnew + row * C + v * 8) = o;
+                    const uint32_t w4[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (bf) { val[it][2 * i] = __uint_as_float(w4[i] << 16); val[it][2 * i + 1] = __uint_as_float(w4[i] & 0xFFFF0000u); }
+                        else { val[it][2 * i] = __half2float(__ushort_as_half((uint16_t)w4[i])); val[it][2 * i + 1] = __half2float(__ushort_as_half((uint16_t)(w4[i] >> 16))); }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) sum += val[it][k];
+            }
+        }
+        for (int s = 32; s > 0; s >>= 1) sum += __shfl_xor(sum, s, 64);
+        const float mean = sum * invC;
+        float sq = 0.f;
+#pragma unroll
+        for (int it = 0; it < 3; ++it) {
+            if (lane + 64 * it < nv) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { const float d = val[it][k] - mean; sq = fmaf(d, d, sq); }
+            }
+        }
+        for (int s = 32; s > 0; s >>= 1) sq += __shfl_xor(sq, s, 64);
+        const float rstd = rsqrtf(sq * invC + eps);
+#pragma unroll
+        for (int it = 0; it < 3; ++it) {
+            const int32_t v = lane + 64 * it;
+            if (v < nv) {
+                const uint32_t gw[4] = {gpk[it].x, gpk[it].y, gpk[it].z, gpk[it].w}, bw[4] = {bpk[it].x, bpk[it].y, bpk[it].z, bpk[it].w};
+                uint16_t h[8];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float g0, g1, b0, b1;
+                    if (bf) { g0 = __uint_as_float(gw[i] << 16); g1 = __uint_as_float(gw[i] & 0xFFFF0000u); b0 = __uint_as_float(bw[i] << 16); b1 = __uint_as_float(bw[i] & 0xFFFF0000u); }
+                    else { g0 = __half2float(__ushort_as_half((uint16_t)gw[i])); g1 = __half2float(__ushort_as_half((uint16_t)(gw[i] >> 16)));
+                           b0 = __half2float(__ushort_as_half((uint16_t)bw[i])); b1 = __half2float(__ushort_as_half((uint16_t)(bw[i] >> 16))); }
+                    h[2 * i] = cvt_h(fmaf((val[it][2 * i] - mean) * rstd, g0, b0), bf);
+                    h[2 * i + 1] = cvt_h(fmaf((val[it][2 * i + 1] - mean) * rstd, g1, b1), bf);
+                }
+                *reinterpret_cast<uint4*>(y + row * C + v * 8) = make_uint4((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16),
+                                                                            (uint32_t)h[4] | ((uint32_t)h[5] << 16), (uint32_t)h[6] | ((uint32_t)h[7] << 16));
+            }
+        }
+    }
+}
+
 // host ---------------------------------------------------------------------------------------------
 static thread_local int g_conv_hip_error = 0;
 
@@ -383,6 +465,20 @@ int gsw_groupnorm_pf(const void* x_dev, const void* gamma_dev, const void* beta_
     hipLaunchKernelGGL(gsw_gn_pf_stats_kernel, dim3(nslab, B), dim3(threads), 0, st, (const uint16_t*)x_dev, workspace_dev, C, groups, HpWp, slab_len, P, bf);
     hipLaunchKernelGGL(gsw_gn_pf_apply_kernel, dim3(nslab, B), dim3(threads), 0, st, (const uint16_t*)x_dev, (const float*)workspace_dev, (const uint16_t*)gamma_dev,
                        (const uint16_t*)beta_dev, (uint16_t*)out_dev, C, groups, H + 2, W + 2, nslab, slab_len, P, eps, act, out_tokens, bf);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { g_conv_hip_error = (int)e; return GSW_ERR_HIP; }
+    return GSW_OK;
+}
+
+int gsw_add_layernorm(const void* x_dev, const void* delta_dev, const void* gamma_dev, const void* beta_dev, void* xnew_dev, void* y_dev,
+                      int64_t rows, int C, float eps, int dtype, void* stream) {
+    if (!x_dev || !gamma_dev || !beta_dev || !y_dev || rows < 0 || C <= 0 || (delta_dev && !xnew_dev)) return GSW_ERR_BAD_ARG;
+    if ((C & 7) || C > 1536) return GSW_ERR_UNSUPPORTED;
+    if (dtype != GSW_F16 && dtype != GSW_BF16) return GSW_ERR_BAD_ARG;
+    if (rows == 0) return GSW_OK;
+    const uint32_t grid = (uint32_t)std::min<int64_t>((rows + 3) / 4, 256 * 16);
+    hipLaunchKernelGGL(gsw_add_layernorm_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x_dev, (const uint16_t*)delta_dev,
+                       (const uint16_t*)gamma_dev, (const uint16_t*)beta_dev, (uint16_t*)xnew_dev, (uint16_t*)y_dev, rows, C, eps, dtype == GSW_BF16);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g_conv_hip_error = (int)e; return GSW_ERR_HIP; }
     return GSW_OK;

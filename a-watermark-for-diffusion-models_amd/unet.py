@@ -156,6 +156,13 @@ class BasicTransformerBlock(nn.Module):
         self.ff = FeedForward(dim)
 
     def forward(self, x, ctx):
+        if FUSED_KERNELS and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and x.is_contiguous() and x.shape[-1] % 8 == 0 \
+                and x.shape[-1] <= 1536:
+            from .codec import add_layernorm     # residual add fused into the following LayerNorm
+            _, n = add_layernorm(x, None, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+            x, n = add_layernorm(x, self.attn1(n).contiguous(), self.norm2.weight, self.norm2.bias, self.norm2.eps)
+            x, n = add_layernorm(x, self.attn2(n, ctx).contiguous(), self.norm3.weight, self.norm3.bias, self.norm3.eps)
+            return x + self.ff(n)
         x = x + self.attn1(self.norm1(x))
         x = x + self.attn2(self.norm2(x), ctx)
         return x + self.ff(self.norm3(x))
@@ -358,17 +365,38 @@ def _unet_pf_ok(self, x: torch.Tensor) -> bool:
     return ok and x.shape[-1] % (1 << n_down) == 0 and x.shape[-2] % (1 << n_down) == 0
 
 
+def _edge_conv_weights(self):
+    """conv_in (4 -> 320) and conv_out (320 -> 4) for the PF GEMM: the 4-channel side is zero-padded to one 64-wide tile."""
+    cache = getattr(self, "_gsw_edge", None)
+    w_in, w_out = self.conv_in.weight, self.conv_out.weight
+    if cache is None or cache[0].device != w_in.device or cache[0].dtype != w_in.dtype:
+        from .pf import pack_conv_weight
+        wi = torch.zeros((w_in.shape[0], 64, 3, 3), dtype=w_in.dtype, device=w_in.device)
+        wi[:, : w_in.shape[1]] = w_in.detach()
+        wo = torch.zeros((64, w_out.shape[1], 3, 3), dtype=w_out.dtype, device=w_out.device)
+        wo[: w_out.shape[0]] = w_out.detach()
+        bo = torch.zeros(64, dtype=w_out.dtype, device=w_out.device)
+        bo[: w_out.shape[0]] = self.conv_out.bias.detach()
+        cache = (pack_conv_weight(wi), pack_conv_weight(wo), bo)
+        self._gsw_edge = cache
+    return cache
+
+
 def _unet_forward_pf(self, x: torch.Tensor, temb: torch.Tensor, ctx: torch.Tensor) -> torch.Tensor:
-    from .pf import PF
-    h = PF.from_nchw(self.conv_in(x))
+    from .pf import PF, conv_pf
+    w_in, w_out, b_out = _edge_conv_weights(self)
+    B, cin, H, W = x.shape
+    xin = PF.zeros(B, H, W, 64, x.dtype, x.device)
+    xin.interior[..., :cin].copy_(x.permute(0, 2, 3, 1))
+    h = conv_pf(xin, w_in, self.conv_in.bias)
     skips = [h]
     for blk in self.down_blocks:
         h = blk.forward_pf(h, temb, ctx, skips)
     h = self.mid_block.forward_pf(h, temb, ctx)
     for blk in self.up_blocks:
         h = blk.forward_pf(h, temb, ctx, skips)
-    h = _gn_pf(h, self.conv_norm_out, act=True)
-    return self.conv_out(h.to_nchw()).contiguous(memory_format=torch.contiguous_format)
+    y = conv_pf(_gn_pf(h, self.conv_norm_out, act=True), w_out, b_out)
+    return y.interior[..., : self.conv_out.out_channels].permute(0, 3, 1, 2).contiguous()
 
 
 UNet2DCondition._pf_ok = _unet_pf_ok

@@ -141,6 +141,11 @@ int gsw_conv_pf(const void* x_dev, const void* w_dev, const void* bias_dev, cons
 int gsw_groupnorm_pf(const void* x_dev, const void* gamma_dev, const void* beta_dev, void* out_dev, float* workspace_dev, int B, int H, int W,
                      int C, int groups, float eps, int act, int out_tokens, int dtype, void* stream);
 
+/* Transformer blocks of the eps model: xnew = x + delta (skipped when delta_dev is NULL), y = LayerNorm(xnew) * gamma + beta;
+ * x, delta, xnew, y: [rows, C]; C % 8 == 0, C <= 1536; GSW_F16 / GSW_BF16. */
+int gsw_add_layernorm(const void* x_dev, const void* delta_dev, const void* gamma_dev, const void* beta_dev, void* xnew_dev, void* y_dev,
+                      int64_t rows, int C, float eps, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -46,6 +46,23 @@ def test_geglu_vs_torch_fp32(G, dtype, shape):
     assert (y.float() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("rows,C", [(4096 * 3, 320), (1024, 640), (257, 1280), (5, 64), (77, 1536)])
+@pytest.mark.parametrize("with_delta", [True, False])
+def test_add_layernorm_vs_torch_fp32(G, dtype, rows, C, with_delta):
+    g = torch.Generator().manual_seed(C + rows)
+    x = (torch.randn(rows, C, generator=g) * 2 + 0.5).to(dtype).cuda()
+    d = torch.randn(rows, C, generator=g).to(dtype).cuda() if with_delta else None
+    w = (1 + 0.2 * torch.randn(C, generator=g)).to(dtype).cuda()
+    b = (0.2 * torch.randn(C, generator=g)).to(dtype).cuda()
+    xn, y = G.codec.add_layernorm(x, d, w, b, 1e-5)
+    xs = (x + d) if with_delta else x                           # the stored (rounded) sum is what gets normalised
+    assert torch.equal(xn, xs)
+    ref = F.layer_norm(xs.float(), (C,), w.float(), b.float(), 1e-5)
+    tol = 4e-3 if dtype == torch.float16 else 3e-2
+    assert (y.float() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+
+
 def test_unet_fused_equals_unfused(G):
     U = G.unet
     m = U.synthetic_init_(U.UNet2DCondition(block_out_channels=(64, 128, 128, 128), cross_attention_dim=64, num_heads=(2, 4, 4, 4), head_dim=32), 0)
