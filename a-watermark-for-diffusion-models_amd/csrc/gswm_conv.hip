@@ -18,6 +18,7 @@
 #include <hip/hip_bf16.h>
 #include <stdint.h>
 #include <algorithm>
+#include <stdlib.h>
 
 #include "../../include/gswm.h"
 
@@ -216,6 +217,178 @@ __global__ __launch_bounds__(CV_THREADS) void gsw_conv_gemm_kernel(ConvArgs p) {
             o = make_uint4(w4[0], w4[1], w4[2], w4[3]);
         }
         *reinterpret_cast<uint4*>(Y + (int64_t)m * p.N + n0 + cc * 8) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Wide-N variant for the UNet's body (every N there is a multiple of 160): BM = 128 pixels x BN = 160 channels x BK = 64,
+// 4 waves as 2 (M) x 2 (N), each 64 x 80 as 4 x 5 v_mfma_f32_16x16x32 tiles.  Per K block the workgroup stages
+// (128 + 160) x 128 B = 36 KiB for 2.6 MFLOP -- 1.4x less L2 -> LDS traffic per flop than the 256 x 64 tile, which is what
+// bounds that kernel.  Same PF addressing, swizzle and fused epilogue.
+// ------------------------------------------------------------------------------------------------
+typedef float gsw_f4v __attribute__((ext_vector_type(4)));
+#define CW_BM 128
+#define CW_BN 160
+#define CW_OUT_STRIDE 168   // bytes per row of the 80-column epilogue image (160 + 8)
+
+template <typename T> struct Mfma16;
+template <> struct Mfma16<_Float16> {
+    static __device__ __forceinline__ gsw_f4v mma(gsw_h8 a, gsw_h8 b, gsw_f4v c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+template <> struct Mfma16<__bf16> {
+    static __device__ __forceinline__ gsw_f4v mma(gsw_b8 a, gsw_b8 b, gsw_f4v c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void gsw_conv_gemm_wide_kernel(ConvArgs p) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds[(CW_BM + CW_BN) * CV_BK * 2];
+    uint8_t* ldsX = lds;                         // [128 rows][128 B]
+    uint8_t* ldsW = lds + CW_BM * CV_BK * 2;     // [160 rows][128 B]
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t wm = wave & 1u, wn = wave >> 1;
+    const uint32_t nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7u;
+    const uint32_t xcd = blockIdx.x & 7u, idx = blockIdx.x >> 3;
+    const uint32_t logical = (xcd < r8 ? xcd * (q8 + 1u) : r8 * (q8 + 1u) + (xcd - r8) * q8) + idx;
+    const uint32_t ntn = (uint32_t)p.N / CW_BN;
+    const uint32_t tile_n = logical % ntn, tile_m = logical / ntn;
+    const int32_t m0 = (int32_t)tile_m * CW_BM, n0 = (int32_t)tile_n * CW_BN;
+    const int32_t HpWp = p.Hp * p.Wp;
+    const int32_t Ktot = p.ntaps * p.C;
+    const T* X = reinterpret_cast<const T*>(p.x);
+    const T* W = reinterpret_cast<const T*>(p.w);
+    const uint32_t pc = lane & 7u;
+
+    // 36 staging instructions (1 KiB each) per K block: j < 16 -> activation rows 8j.., else weight rows 8(j-16)..; 9 per wave
+    int64_t src_off[9];     // element offset of this lane's 16-byte source chunk, without the tap / K-block terms
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const uint32_t j = wave * 9u + i;
+        if (j < 16u) {
+            const uint32_t r = j * 8u + (lane >> 3);
+            int32_t m = m0 + (int32_t)r;
+            if (m >= p.M) m = p.M - 1;
+            int32_t src = m;
+            if (p.stride == 2) {
+                const int32_t b = m / HpWp, q = m - b * HpWp;
+                int32_t yo = q / p.Wp - 1, xo = q - (q / p.Wp) * p.Wp - 1;
+                const int32_t Ho = p.Hp - 2, Wo = p.Wp - 2;
+                yo = yo < 0 ? 0 : (yo >= Ho ? Ho - 1 : yo);
+                xo = xo < 0 ? 0 : (xo >= Wo ? Wo - 1 : xo);
+                src = b * p.in_Hp * p.in_Wp + (2 * yo) * p.in_Wp + 2 * xo;
+            }
+            src_off[i] = (int64_t)src * p.ldx + (int64_t)((pc ^ ((r >> 1) & 7u)) * 8u);
+        } else {
+            const uint32_t r = (j - 16u) * 8u + (lane >> 3);
+            src_off[i] = (int64_t)(n0 + (int32_t)r) * Ktot + (int64_t)((pc ^ ((r >> 1) & 7u)) * 8u);
+        }
+    }
+
+    gsw_f4v acc[5][4];
+#pragma unroll
+    for (int a = 0; a < 5; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = gsw_f4v{0.f, 0.f, 0.f, 0.f};
+
+    const int32_t kc_per_tap = p.C / CV_BK;
+    for (int32_t t = 0; t < p.ntaps; ++t) {
+        const int64_t xoff = (int64_t)p.tap_off[t] * p.ldx;
+        const int32_t woff = t * p.C;
+        for (int32_t kc = 0; kc < kc_per_tap; ++kc) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                const uint32_t j = wave * 9u + i;     // wave-uniform
+                if (j < 16u) {
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + src_off[i] + xoff + kc * CV_BK),
+                                                     (__attribute__((address_space(3))) void*)(ldsX + j * 1024u), 16, 0, 0);
+                } else {
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W + src_off[i] + woff + kc * CV_BK),
+                                                     (__attribute__((address_space(3))) void*)(ldsW + (j - 16u) * 1024u), 16, 0, 0);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const uint32_t lc = (uint32_t)ks * 4u + (lane >> 4);
+                typename Mfma<T>::frag xf[4];
+#pragma unroll
+                for (int im = 0; im < 4; ++im) {
+                    const uint32_t r = wm * 64u + (uint32_t)im * 16u + (lane & 15u);
+                    xf[im] = *reinterpret_cast<const typename Mfma<T>::frag*>(ldsX + r * 128u + ((lc ^ ((r >> 1) & 7u)) << 4));
+                }
+#pragma unroll
+                for (int in = 0; in < 5; ++in) {
+                    const uint32_t r = wn * 80u + (uint32_t)in * 16u + (lane & 15u);
+                    const typename Mfma<T>::frag wf = *reinterpret_cast<const typename Mfma<T>::frag*>(ldsW + r * 128u + ((lc ^ ((r >> 1) & 7u)) << 4));
+#pragma unroll
+                    for (int im = 0; im < 4; ++im) acc[in][im] = Mfma16<T>::mma(wf, xf[im], acc[in][im]);
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    // epilogue in two column halves (wn = 0, then wn = 1): D[n][m]: m = lane & 15 (+16 im), n = (lane >> 4) * 4 + reg (+16 in)
+    const uint16_t* bias = reinterpret_cast<const uint16_t*>(p.bias);
+    const uint16_t* rowbias = reinterpret_cast<const uint16_t*>(p.rowbias);
+    const uint16_t* resid = reinterpret_cast<const uint16_t*>(p.resid);
+    uint16_t* Y = reinterpret_cast<uint16_t*>(p.y);
+    for (uint32_t half = 0; half < 2; ++half) {
+        if (wn == half) {
+#pragma unroll
+            for (int in = 0; in < 5; ++in) {
+                const uint32_t n = (uint32_t)in * 16u + (lane >> 4) * 4u;          // column inside the 80-wide half
+                uint2 bw = make_uint2(0, 0);
+                if (bias) bw = *reinterpret_cast<const uint2*>(bias + n0 + half * 80u + n);
+                const uint16_t bh[4] = {(uint16_t)bw.x, (uint16_t)(bw.x >> 16), (uint16_t)bw.y, (uint16_t)(bw.y >> 16)};
+#pragma unroll
+                for (int im = 0; im < 4; ++im) {
+                    const uint32_t m = wm * 64u + (uint32_t)im * 16u + (lane & 15u);
+                    uint16_t h[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) h[j] = Mfma<T>::cvt(acc[in][im][j] + (bias ? Mfma<T>::up(bh[j]) : 0.f));
+                    uint2 pk;
+                    pk.x = (uint32_t)h[0] | ((uint32_t)h[1] << 16);
+                    pk.y = (uint32_t)h[2] | ((uint32_t)h[3] << 16);
+                    *reinterpret_cast<uint2*>(lds + m * CW_OUT_STRIDE + n * 2u) = pk;
+                }
+            }
+        }
+        __syncthreads();
+        // 128 rows x 10 chunks of 16 B = 1280 chunks, 5 per thread
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const uint32_t q = tid + 256u * i;
+            const uint32_t r = q / 10u, cc = q - r * 10u;
+            const int32_t m = m0 + (int32_t)r;
+            if (m < p.M) {
+                const int32_t b = m / HpWp, qq = m - b * HpWp;
+                const int32_t yy = qq / p.Wp, xx = qq - yy * p.Wp;
+                const bool border = (yy == 0) | (yy == p.Hp - 1) | (xx == 0) | (xx == p.Wp - 1);
+                uint4 o = make_uint4(0, 0, 0, 0);
+                const int64_t col = n0 + (int32_t)(half * 80u + cc * 8u);
+                if (!border) {
+                    const uint2 lo = *reinterpret_cast<const uint2*>(lds + r * CW_OUT_STRIDE + cc * 16u);
+                    const uint2 hi = *reinterpret_cast<const uint2*>(lds + r * CW_OUT_STRIDE + cc * 16u + 8u);
+                    uint32_t w4[4] = {lo.x, lo.y, hi.x, hi.y};
+                    if (rowbias || resid) {
+                        uint4 rb = make_uint4(0, 0, 0, 0), rs = make_uint4(0, 0, 0, 0);
+                        if (rowbias) rb = *reinterpret_cast<const uint4*>(rowbias + (int64_t)b * p.N + col);
+                        if (resid) rs = *reinterpret_cast<const uint4*>(resid + (int64_t)m * p.N + col);
+                        const uint32_t rbw[4] = {rb.x, rb.y, rb.z, rb.w}, rsw[4] = {rs.x, rs.y, rs.z, rs.w};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float a0 = Mfma<T>::up((uint16_t)w4[k]) + Mfma<T>::up((uint16_t)rbw[k]) + Mfma<T>::up((uint16_t)rsw[k]);
+                            const float a1 = Mfma<T>::up((uint16_t)(w4[k] >> 16)) + Mfma<T>::up((uint16_t)(rbw[k] >> 16)) + Mfma<T>::up((uint16_t)(rsw[k] >> 16));
+                            w4[k] = (uint32_t)Mfma<T>::cvt(a0) | ((uint32_t)Mfma<T>::cvt(a1) << 16);
+                        }
+                    }
+                    o = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+                }
+                *reinterpret_cast<uint4*>(Y + (int64_t)m * p.N + col) = o;
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -438,9 +611,16 @@ int gsw_conv_pf(const void* x_dev, const void* w_dev, const void* bias_dev, cons
             for (int kw = 0; kw < 3; ++kw)
                 a.tap_off[kh * 3 + kw] = stride == 1 ? (kh - 1) * a.in_Wp + (kw - 1) : kh * a.in_Wp + kw;
     }
-    const uint32_t grid = (uint32_t)(((M + CV_BM - 1) / CV_BM) * (N / CV_BN));
-    if (dtype == GSW_F16) hipLaunchKernelGGL((gsw_conv_gemm_kernel<_Float16>), dim3(grid), dim3(CV_THREADS), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((gsw_conv_gemm_kernel<__bf16>), dim3(grid), dim3(CV_THREADS), 0, (hipStream_t)stream, a);
+    static const bool narrow_only = getenv("GSW_CONV_NARROW") != nullptr;      // A/B switch for profiling
+    if (N % CW_BN == 0 && !narrow_only) {
+        const uint32_t grid = (uint32_t)(((M + CW_BM - 1) / CW_BM) * (N / CW_BN));
+        if (dtype == GSW_F16) hipLaunchKernelGGL((gsw_conv_gemm_wide_kernel<_Float16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((gsw_conv_gemm_wide_kernel<__bf16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    } else {
+        const uint32_t grid = (uint32_t)(((M + CV_BM - 1) / CV_BM) * (N / CV_BN));
+        if (dtype == GSW_F16) hipLaunchKernelGGL((gsw_conv_gemm_kernel<_Float16>), dim3(grid), dim3(CV_THREADS), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((gsw_conv_gemm_kernel<__bf16>), dim3(grid), dim3(CV_THREADS), 0, (hipStream_t)stream, a);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g_conv_hip_error = (int)e; return GSW_ERR_HIP; }
     return GSW_OK;
