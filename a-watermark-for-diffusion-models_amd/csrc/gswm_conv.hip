@@ -239,19 +239,25 @@ template <> struct Mfma16<__bf16> {
     static __device__ __forceinline__ gsw_f4v mma(gsw_b8 a, gsw_b8 b, gsw_f4v c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 };
 
-template <typename T>
-__global__ __launch_bounds__(256) void gsw_conv_gemm_wide_kernel(ConvArgs p) {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[(CW_BM + CW_BN) * CV_BK * 2];
-    uint8_t* ldsX = lds;                         // [128 rows][128 B]
-    uint8_t* ldsW = lds + CW_BM * CV_BK * 2;     // [160 rows][128 B]
+// WM = waves along M (2 -> 128-row tile, 256 threads; 4 -> 256-row tile, 512 threads)
+template <typename T, int WM, bool DB>
+__global__ __launch_bounds__(128 * WM) void gsw_conv_gemm_wide_kernel(ConvArgs p) {
+    constexpr int BM = 64 * WM;
+    constexpr int NTHR = 128 * WM;
+    constexpr int NWAVE = 2 * WM;
+    constexpr int XI = BM / 8;                       // activation staging instructions per K block
+    constexpr int TI = XI + CW_BN / 8;               // + weight staging instructions
+    constexpr int PER_WAVE = (TI + NWAVE - 1) / NWAVE;
+    constexpr uint32_t STAGE_BYTES = (BM + CW_BN) * CV_BK * 2;
+    __shared__ __attribute__((aligned(16))) uint8_t lds[STAGE_BYTES * (DB ? 2 : 1)];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t wm = wave & 1u, wn = wave >> 1;
+    const uint32_t wm = wave % WM, wn = wave / WM;
     const uint32_t nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7u;
     const uint32_t xcd = blockIdx.x & 7u, idx = blockIdx.x >> 3;
     const uint32_t logical = (xcd < r8 ? xcd * (q8 + 1u) : r8 * (q8 + 1u) + (xcd - r8) * q8) + idx;
     const uint32_t ntn = (uint32_t)p.N / CW_BN;
     const uint32_t tile_n = logical % ntn, tile_m = logical / ntn;
-    const int32_t m0 = (int32_t)tile_m * CW_BM, n0 = (int32_t)tile_n * CW_BN;
+    const int32_t m0 = (int32_t)tile_m * BM, n0 = (int32_t)tile_n * CW_BN;
     const int32_t HpWp = p.Hp * p.Wp;
     const int32_t Ktot = p.ntaps * p.C;
     const T* X = reinterpret_cast<const T*>(p.x);
@@ -259,11 +265,12 @@ __global__ __launch_bounds__(256) void gsw_conv_gemm_wide_kernel(ConvArgs p) {
     const uint32_t pc = lane & 7u;
 
     // 36 staging instructions (1 KiB each) per K block: j < 16 -> activation rows 8j.., else weight rows 8(j-16)..; 9 per wave
-    int64_t src_off[9];     // element offset of this lane's 16-byte source chunk, without the tap / K-block terms
+    int64_t src_off[PER_WAVE];     // element offset of this lane's 16-byte source chunk, without the tap / K-block terms
 #pragma unroll
-    for (int i = 0; i < 9; ++i) {
-        const uint32_t j = wave * 9u + i;
-        if (j < 16u) {
+    for (int i = 0; i < PER_WAVE; ++i) {
+        const uint32_t j = wave * PER_WAVE + i;
+        src_off[i] = 0;
+        if (j < (uint32_t)XI) {
             const uint32_t r = j * 8u + (lane >> 3);
             int32_t m = m0 + (int32_t)r;
             if (m >= p.M) m = p.M - 1;
@@ -277,8 +284,8 @@ __global__ __launch_bounds__(256) void gsw_conv_gemm_wide_kernel(ConvArgs p) {
                 src = b * p.in_Hp * p.in_Wp + (2 * yo) * p.in_Wp + 2 * xo;
             }
             src_off[i] = (int64_t)src * p.ldx + (int64_t)((pc ^ ((r >> 1) & 7u)) * 8u);
-        } else {
-            const uint32_t r = (j - 16u) * 8u + (lane >> 3);
+        } else if (j < (uint32_t)TI) {
+            const uint32_t r = (j - XI) * 8u + (lane >> 3);
             src_off[i] = (int64_t)(n0 + (int32_t)r) * Ktot + (int64_t)((pc ^ ((r >> 1) & 7u)) * 8u);
         }
     }
@@ -290,40 +297,62 @@ __global__ __launch_bounds__(256) void gsw_conv_gemm_wide_kernel(ConvArgs p) {
         for (int b = 0; b < 4; ++b) acc[a][b] = gsw_f4v{0.f, 0.f, 0.f, 0.f};
 
     const int32_t kc_per_tap = p.C / CV_BK;
-    for (int32_t t = 0; t < p.ntaps; ++t) {
-        const int64_t xoff = (int64_t)p.tap_off[t] * p.ldx;
-        const int32_t woff = t * p.C;
-        for (int32_t kc = 0; kc < kc_per_tap; ++kc) {
+    const int32_t nkb = p.ntaps * kc_per_tap;
+    auto stage = [&](int32_t kb, uint8_t* buf) {
+        const int32_t t = kb / kc_per_tap, kc = kb - t * kc_per_tap;
+        const int64_t xoff = (int64_t)p.tap_off[t] * p.ldx + kc * CV_BK;
+        const int32_t woff = t * p.C + kc * CV_BK;
 #pragma unroll
-            for (int i = 0; i < 9; ++i) {
-                const uint32_t j = wave * 9u + i;     // wave-uniform
-                if (j < 16u) {
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + src_off[i] + xoff + kc * CV_BK),
-                                                     (__attribute__((address_space(3))) void*)(ldsX + j * 1024u), 16, 0, 0);
-                } else {
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W + src_off[i] + woff + kc * CV_BK),
-                                                     (__attribute__((address_space(3))) void*)(ldsW + (j - 16u) * 1024u), 16, 0, 0);
-                }
+        for (int i = 0; i < PER_WAVE; ++i) {
+            const uint32_t j = wave * PER_WAVE + i;     // wave-uniform
+            if (j < (uint32_t)XI) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + src_off[i] + xoff),
+                                                 (__attribute__((address_space(3))) void*)(buf + j * 1024u), 16, 0, 0);
+            } else if (j < (uint32_t)TI) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W + src_off[i] + woff),
+                                                 (__attribute__((address_space(3))) void*)(buf + BM * CV_BK * 2 + (j - XI) * 1024u), 16, 0, 0);
             }
+        }
+    };
+    auto compute = [&](const uint8_t* buf) {
+        const uint8_t* ldsX = buf;
+        const uint8_t* ldsW = buf + BM * CV_BK * 2;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const uint32_t lc = (uint32_t)ks * 4u + (lane >> 4);
+            typename Mfma<T>::frag xf[4];
+#pragma unroll
+            for (int im = 0; im < 4; ++im) {
+                const uint32_t r = wm * 64u + (uint32_t)im * 16u + (lane & 15u);
+                xf[im] = *reinterpret_cast<const typename Mfma<T>::frag*>(ldsX + r * 128u + ((lc ^ ((r >> 1) & 7u)) << 4));
+            }
+#pragma unroll
+            for (int in = 0; in < 5; ++in) {
+                const uint32_t r = wn * 80u + (uint32_t)in * 16u + (lane & 15u);
+                const typename Mfma<T>::frag wf = *reinterpret_cast<const typename Mfma<T>::frag*>(ldsW + r * 128u + ((lc ^ ((r >> 1) & 7u)) << 4));
+#pragma unroll
+                for (int im = 0; im < 4; ++im) acc[in][im] = Mfma16<T>::mma(wf, xf[im], acc[in][im]);
+            }
+        }
+    };
+    if (DB) {
+        // two LDS stages: K block kb+1 streams in (LDS-DMA) while kb is multiplied; one barrier per K block
+        stage(0, lds);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int32_t kb = 0; kb < nkb; ++kb) {
+            uint8_t* cur = lds + (kb & 1) * STAGE_BYTES;
+            if (kb + 1 < nkb) stage(kb + 1, lds + ((kb + 1) & 1) * STAGE_BYTES);
+            compute(cur);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const uint32_t lc = (uint32_t)ks * 4u + (lane >> 4);
-                typename Mfma<T>::frag xf[4];
-#pragma unroll
-                for (int im = 0; im < 4; ++im) {
-                    const uint32_t r = wm * 64u + (uint32_t)im * 16u + (lane & 15u);
-                    xf[im] = *reinterpret_cast<const typename Mfma<T>::frag*>(ldsX + r * 128u + ((lc ^ ((r >> 1) & 7u)) << 4));
-                }
-#pragma unroll
-                for (int in = 0; in < 5; ++in) {
-                    const uint32_t r = wn * 80u + (uint32_t)in * 16u + (lane & 15u);
-                    const typename Mfma<T>::frag wf = *reinterpret_cast<const typename Mfma<T>::frag*>(ldsW + r * 128u + ((lc ^ ((r >> 1) & 7u)) << 4));
-#pragma unroll
-                    for (int im = 0; im < 4; ++im) acc[in][im] = Mfma16<T>::mma(wf, xf[im], acc[in][im]);
-                }
-            }
+        }
+    } else {
+        for (int32_t kb = 0; kb < nkb; ++kb) {
+            stage(kb, lds);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            compute(lds);
             __syncthreads();
         }
     }
@@ -355,10 +384,10 @@ __global__ __launch_bounds__(256) void gsw_conv_gemm_wide_kernel(ConvArgs p) {
             }
         }
         __syncthreads();
-        // 128 rows x 10 chunks of 16 B = 1280 chunks, 5 per thread
+        // BM rows x 10 chunks of 16 B, 5 per thread
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
-            const uint32_t q = tid + 256u * i;
+            const uint32_t q = tid + (uint32_t)NTHR * i;
             const uint32_t r = q / 10u, cc = q - r * 10u;
             const int32_t m = m0 + (int32_t)r;
             if (m < p.M) {
@@ -613,9 +642,15 @@ int gsw_conv_pf(const void* x_dev, const void* w_dev, const void* bias_dev, cons
     }
     static const bool narrow_only = getenv("GSW_CONV_NARROW") != nullptr;      // A/B switch for profiling
     if (N % CW_BN == 0 && !narrow_only) {
-        const uint32_t grid = (uint32_t)(((M + CW_BM - 1) / CW_BM) * (N / CW_BN));
-        if (dtype == GSW_F16) hipLaunchKernelGGL((gsw_conv_gemm_wide_kernel<_Float16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
-        else hipLaunchKernelGGL((gsw_conv_gemm_wide_kernel<__bf16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+        static const int db_env = getenv("GSW_CONV_DB") ? atoi(getenv("GSW_CONV_DB")) : 0;   // A/B switch: 1 = two LDS stages (measured 3-12 % slower: fewer workgroups per CU)
+        const uint32_t grid = (uint32_t)(((M + 127) / 128) * (N / CW_BN));
+        if (db_env) {
+            if (dtype == GSW_F16) hipLaunchKernelGGL((gsw_conv_gemm_wide_kernel<_Float16, 2, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+            else hipLaunchKernelGGL((gsw_conv_gemm_wide_kernel<__bf16, 2, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+        } else {
+            if (dtype == GSW_F16) hipLaunchKernelGGL((gsw_conv_gemm_wide_kernel<_Float16, 2, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+            else hipLaunchKernelGGL((gsw_conv_gemm_wide_kernel<__bf16, 2, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+        }
     } else {
         const uint32_t grid = (uint32_t)(((M + CV_BM - 1) / CV_BM) * (N / CV_BN));
         if (dtype == GSW_F16) hipLaunchKernelGGL((gsw_conv_gemm_kernel<_Float16>), dim3(grid), dim3(CV_THREADS), 0, (hipStream_t)stream, a);

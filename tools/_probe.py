@@ -1,26 +1,14 @@
-import sys, torch, time, os
-sys.path.insert(0,'.')
-import torch.nn.functional as F
+import sys, time, os, torch
+sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT','.'))
 import gswm_amd
-from gswm_amd import pf as P
-dev='cuda'
-def tm(f, it=10):
-    for _ in range(3): f()
-    torch.cuda.synchronize(); s,e=torch.cuda.Event(enable_timing=True),torch.cuda.Event(enable_timing=True)
-    s.record()
-    for _ in range(it): f()
-    e.record(); torch.cuda.synchronize(); return s.elapsed_time(e)/it
-def run(B,C,O,H,k=3,stride=1,dt=torch.float16):
-    g=torch.Generator().manual_seed(C+O+H)
-    x=torch.randn(B,C,H,H,generator=g).to(dt).to(dev); w=(torch.randn(O,C,k,k,generator=g)*(1.0/(C*k*k))**0.5).to(dt).to(dev); b=torch.randn(O,generator=g).to(dt).to(dev)
-    Ho=H//stride
-    ref=F.conv2d(x,w,b,padding=k//2,stride=stride).float()
-    xp=P.PF.from_nchw(x); wp=P.pack_conv_weight(w)
-    y=P.conv_pf(xp,wp,b,ksize=k,stride=stride)
-    err=(y.to_nchw().float()-ref).abs().max().item()/ref.abs().max().item()
-    t=tm(lambda: P.conv_pf(xp,wp,b,ksize=k,stride=stride))
-    fl=2*B*Ho*Ho*C*O*k*k
-    print(f'{os.environ.get("GSW_CONV_NARROW","wide")} k={k} s={stride} C={C:5d} O={O:5d} H={H:3d}: relerr {err:.1e} | gsw {t*1e3:7.0f} us {fl/t/1e9:5.0f} TF', flush=True)
-B=128
-for (C,O,H) in ((320,320,64),(640,320,64),(960,320,64),(640,640,32),(1280,640,32),(1920,640,32),(1280,1280,16),(2560,1280,16),(1280,1280,8)):
-    run(B,C,O,H)
+from gswm_amd import unet as U
+dev='cuda'; dt=torch.float16
+m = U.synthetic_init_(U.UNet2DCondition(), 0).to(dev, dt).eval()
+B=int(sys.argv[1]) if len(sys.argv)>1 else 128
+x=torch.randn(B,4,64,64,device=dev,dtype=dt); t=torch.full((),500,device=dev); c=torch.randn(B,77,1024,device=dev,dtype=dt)
+with torch.no_grad():
+    for _ in range(3): y=m(x,t,c)
+    torch.cuda.synchronize(); t0=time.perf_counter()
+    for _ in range(4): y=m(x,t,c)
+    torch.cuda.synchronize(); d=(time.perf_counter()-t0)/4
+print(f"B={B}: {d*1e3:.1f} ms {B*0.804/d:.0f} TFLOP/s", flush=True)
