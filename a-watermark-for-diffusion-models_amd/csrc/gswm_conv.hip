@@ -47,6 +47,9 @@ struct ConvArgs {
     int32_t in_Hp, in_Wp; // input padded geometry
     int32_t stride;       // 1 or 2
     int32_t ldx;          // row stride of x in elements (>= C; lets the input be a channel slice of a wider tensor)
+    int32_t dense;        // 1: plain GEMM on a dense [M, C] matrix (no border rows, no row map)
+    int32_t geglu;        // 1: every 160-wide N tile holds [80 value | 80 gate] columns; the epilogue writes value * gelu(gate)
+    int32_t ldy;          // row stride of y in elements (N, or N/2 with geglu)
 };
 
 template <typename T> struct Mfma;
@@ -194,9 +197,14 @@ __global__ __launch_bounds__(CV_THREADS) void gsw_conv_gemm_kernel(ConvArgs p) {
         const uint32_t r = q >> 3, cc = q & 7u;
         const int32_t m = m0 + (int32_t)r;
         if (m >= p.M) continue;
-        const int32_t b = m / HpWp, qq = m - b * HpWp;
-        const int32_t yy = qq / p.Wp, xx = qq - yy * p.Wp;
-        const bool border = (yy == 0) | (yy == p.Hp - 1) | (xx == 0) | (xx == p.Wp - 1);
+        int32_t b = 0;
+        bool border = false;
+        if (!p.dense) {
+            b = m / HpWp;
+            const int32_t qq = m - b * HpWp;
+            const int32_t yy = qq / p.Wp, xx = qq - yy * p.Wp;
+            border = (yy == 0) | (yy == p.Hp - 1) | (xx == 0) | (xx == p.Wp - 1);
+        }
         uint4 o = make_uint4(0, 0, 0, 0);
         if (!border) {
             const uint2 lo = *reinterpret_cast<const uint2*>(lds + r * CV_OUT_STRIDE + cc * 16u);
@@ -362,48 +370,58 @@ __global__ __launch_bounds__(128 * WM) void gsw_conv_gemm_wide_kernel(ConvArgs p
     const uint16_t* rowbias = reinterpret_cast<const uint16_t*>(p.rowbias);
     const uint16_t* resid = reinterpret_cast<const uint16_t*>(p.resid);
     uint16_t* Y = reinterpret_cast<uint16_t*>(p.y);
-    for (uint32_t half = 0; half < 2; ++half) {
-        if (wn == half) {
+    auto put_half = [&](bool gelu_it) {          // this wave's 64 x 80 accumulators (+bias) -> LDS image [m][80]
 #pragma unroll
-            for (int in = 0; in < 5; ++in) {
-                const uint32_t n = (uint32_t)in * 16u + (lane >> 4) * 4u;          // column inside the 80-wide half
-                uint2 bw = make_uint2(0, 0);
-                if (bias) bw = *reinterpret_cast<const uint2*>(bias + n0 + half * 80u + n);
-                const uint16_t bh[4] = {(uint16_t)bw.x, (uint16_t)(bw.x >> 16), (uint16_t)bw.y, (uint16_t)(bw.y >> 16)};
+        for (int in = 0; in < 5; ++in) {
+            const uint32_t n = (uint32_t)in * 16u + (lane >> 4) * 4u;
+            uint2 bw = make_uint2(0, 0);
+            if (bias) bw = *reinterpret_cast<const uint2*>(bias + n0 + wn * 80u + n);
+            const uint16_t bh[4] = {(uint16_t)bw.x, (uint16_t)(bw.x >> 16), (uint16_t)bw.y, (uint16_t)(bw.y >> 16)};
 #pragma unroll
-                for (int im = 0; im < 4; ++im) {
-                    const uint32_t m = wm * 64u + (uint32_t)im * 16u + (lane & 15u);
-                    uint16_t h[4];
+            for (int im = 0; im < 4; ++im) {
+                const uint32_t m = wm * 64u + (uint32_t)im * 16u + (lane & 15u);
+                uint16_t h[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) h[j] = Mfma<T>::cvt(acc[in][im][j] + (bias ? Mfma<T>::up(bh[j]) : 0.f));
-                    uint2 pk;
-                    pk.x = (uint32_t)h[0] | ((uint32_t)h[1] << 16);
-                    pk.y = (uint32_t)h[2] | ((uint32_t)h[3] << 16);
-                    *reinterpret_cast<uint2*>(lds + m * CW_OUT_STRIDE + n * 2u) = pk;
+                for (int j = 0; j < 4; ++j) {
+                    float v = acc[in][im][j] + (bias ? Mfma<T>::up(bh[j]) : 0.f);
+                    if (gelu_it) {       // torch: F.gelu(gate) on the stored (rounded) gate, result rounded again
+                        v = Mfma<T>::up(Mfma<T>::cvt(v));
+                        v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+                    }
+                    h[j] = Mfma<T>::cvt(v);
                 }
+                uint2 pk;
+                pk.x = (uint32_t)h[0] | ((uint32_t)h[1] << 16);
+                pk.y = (uint32_t)h[2] | ((uint32_t)h[3] << 16);
+                *reinterpret_cast<uint2*>(lds + m * CW_OUT_STRIDE + n * 2u) = pk;
             }
         }
-        __syncthreads();
-        // BM rows x 10 chunks of 16 B, 5 per thread
+    };
+    auto store_image = [&](int64_t col0, int32_t ld) {   // LDS image [BM][80] -> Y[m][col0 ..+80] (+rowbias +resid, borders zero)
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
             const uint32_t q = tid + (uint32_t)NTHR * i;
             const uint32_t r = q / 10u, cc = q - r * 10u;
             const int32_t m = m0 + (int32_t)r;
             if (m < p.M) {
-                const int32_t b = m / HpWp, qq = m - b * HpWp;
-                const int32_t yy = qq / p.Wp, xx = qq - yy * p.Wp;
-                const bool border = (yy == 0) | (yy == p.Hp - 1) | (xx == 0) | (xx == p.Wp - 1);
+                int32_t b = 0;
+                bool border = false;
+                if (!p.dense) {
+                    b = m / HpWp;
+                    const int32_t qq = m - b * HpWp;
+                    const int32_t yy = qq / p.Wp, xx = qq - yy * p.Wp;
+                    border = (yy == 0) | (yy == p.Hp - 1) | (xx == 0) | (xx == p.Wp - 1);
+                }
                 uint4 o = make_uint4(0, 0, 0, 0);
-                const int64_t col = n0 + (int32_t)(half * 80u + cc * 8u);
+                const int64_t col = col0 + cc * 8u;
                 if (!border) {
                     const uint2 lo = *reinterpret_cast<const uint2*>(lds + r * CW_OUT_STRIDE + cc * 16u);
                     const uint2 hi = *reinterpret_cast<const uint2*>(lds + r * CW_OUT_STRIDE + cc * 16u + 8u);
                     uint32_t w4[4] = {lo.x, lo.y, hi.x, hi.y};
                     if (rowbias || resid) {
                         uint4 rb = make_uint4(0, 0, 0, 0), rs = make_uint4(0, 0, 0, 0);
-                        if (rowbias) rb = *reinterpret_cast<const uint4*>(rowbias + (int64_t)b * p.N + col);
-                        if (resid) rs = *reinterpret_cast<const uint4*>(resid + (int64_t)m * p.N + col);
+                        if (rowbias) rb = *reinterpret_cast<const uint4*>(rowbias + (int64_t)b * ld + col);
+                        if (resid) rs = *reinterpret_cast<const uint4*>(resid + (int64_t)m * ld + col);
                         const uint32_t rbw[4] = {rb.x, rb.y, rb.z, rb.w}, rsw[4] = {rs.x, rs.y, rs.z, rs.w};
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
@@ -414,10 +432,47 @@ __global__ __launch_bounds__(128 * WM) void gsw_conv_gemm_wide_kernel(ConvArgs p
                     }
                     o = make_uint4(w4[0], w4[1], w4[2], w4[3]);
                 }
-                *reinterpret_cast<uint4*>(Y + (int64_t)m * p.N + col) = o;
+                *reinterpret_cast<uint4*>(Y + (int64_t)m * ld + col) = o;
+            }
+        }
+    };
+    if (p.geglu) {
+        // wn = 1 waves hold the gate columns, wn = 0 waves the value columns of the SAME 80 outputs, with identical lane
+        // mapping: gate -> gelu -> LDS; barrier; value waves multiply in place; barrier; one 80-column store
+        if (wn == 1) put_half(true);
+        __syncthreads();
+        if (wn == 0) {
+#pragma unroll
+            for (int in = 0; in < 5; ++in) {
+                const uint32_t n = (uint32_t)in * 16u + (lane >> 4) * 4u;
+                uint2 bw = make_uint2(0, 0);
+                if (bias) bw = *reinterpret_cast<const uint2*>(bias + n0 + n);
+                const uint16_t bh[4] = {(uint16_t)bw.x, (uint16_t)(bw.x >> 16), (uint16_t)bw.y, (uint16_t)(bw.y >> 16)};
+#pragma unroll
+                for (int im = 0; im < 4; ++im) {
+                    const uint32_t m = wm * 64u + (uint32_t)im * 16u + (lane & 15u);
+                    uint2* cell = reinterpret_cast<uint2*>(lds + m * CW_OUT_STRIDE + n * 2u);
+                    const uint2 g = *cell;
+                    const uint16_t gh[4] = {(uint16_t)g.x, (uint16_t)(g.x >> 16), (uint16_t)g.y, (uint16_t)(g.y >> 16)};
+                    uint16_t h[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float v = Mfma<T>::up(Mfma<T>::cvt(acc[in][im][j] + (bias ? Mfma<T>::up(bh[j]) : 0.f)));
+                        h[j] = Mfma<T>::cvt(v * Mfma<T>::up(gh[j]));
+                    }
+                    *cell = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+                }
             }
         }
         __syncthreads();
+        store_image((int64_t)tile_n * 80, p.ldy);
+    } else {
+        for (uint32_t half = 0; half < 2; ++half) {
+            if (wn == half) put_half(false);
+            __syncthreads();
+            store_image((int64_t)n0 + half * 80u, p.ldy);
+            __syncthreads();
+        }
     }
 }
 
@@ -618,6 +673,7 @@ __global__ __launch_bounds__(256) void gsw_add_layernorm_kernel(const uint16_t* 
 
 // host ---------------------------------------------------------------------------------------------
 static thread_local int g_conv_hip_error = 0;
+static int launch_conv_gemm(ConvArgs& a, int64_t M, int N, int dtype, void* stream);
 
 int gsw_conv_pf(const void* x_dev, const void* w_dev, const void* bias_dev, const void* rowbias_dev, const void* resid_dev, void* y_dev,
                 int B, int H, int W, int C, int N, int ksize, int stride, int ldx, int dtype, void* stream) {
@@ -640,6 +696,11 @@ int gsw_conv_pf(const void* x_dev, const void* w_dev, const void* bias_dev, cons
             for (int kw = 0; kw < 3; ++kw)
                 a.tap_off[kh * 3 + kw] = stride == 1 ? (kh - 1) * a.in_Wp + (kw - 1) : kh * a.in_Wp + kw;
     }
+    a.dense = 0; a.geglu = 0; a.ldy = N;
+    return launch_conv_gemm(a, M, N, dtype, stream);
+}
+
+static int launch_conv_gemm(ConvArgs& a, int64_t M, int N, int dtype, void* stream) {
     static const bool narrow_only = getenv("GSW_CONV_NARROW") != nullptr;      // A/B switch for profiling
     if (N % CW_BN == 0 && !narrow_only) {
         static const int db_env = getenv("GSW_CONV_DB") ? atoi(getenv("GSW_CONV_DB")) : 0;   // A/B switch: 1 = two LDS stages (measured 3-12 % slower: fewer workgroups per CU)
@@ -697,4 +758,19 @@ int gsw_add_layernorm(const void* x_dev, const void* delta_dev, const void* gamm
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g_conv_hip_error = (int)e; return GSW_ERR_HIP; }
     return GSW_OK;
+}
+
+int gsw_linear(const void* x_dev, const void* w_dev, const void* bias_dev, const void* resid_dev, void* y_dev, int64_t M, int K, int N,
+               int geglu, int dtype, void* stream) {
+    // y[M, N] = x[M, K] @ w[N, K]^T + bias (+ resid); geglu: w rows are tile-interleaved [80 value | 80 gate], y is [M, N/2]
+    if (!x_dev || !w_dev || !y_dev || M <= 0 || K <= 0 || N <= 0) return GSW_ERR_BAD_ARG;
+    if (K % CV_BK || N % CW_BN || M > 0x7FFFFF00 || (geglu && resid_dev)) return GSW_ERR_UNSUPPORTED;
+    if (dtype != GSW_F16 && dtype != GSW_BF16) return GSW_ERR_BAD_ARG;
+    ConvArgs a;
+    a.x = x_dev; a.w = w_dev; a.bias = bias_dev; a.rowbias = nullptr; a.resid = resid_dev; a.y = y_dev;
+    a.C = K; a.N = N; a.M = (int32_t)M; a.Hp = 0; a.Wp = 1; a.in_Hp = 0; a.in_Wp = 1; a.stride = 1; a.ldx = K;
+    a.ntaps = 1;
+    for (int i = 0; i < 9; ++i) a.tap_off[i] = 0;
+    a.dense = 1; a.geglu = geglu ? 1 : 0; a.ldy = geglu ? N / 2 : N;
+    return launch_conv_gemm(a, M, N, dtype, stream);
 }

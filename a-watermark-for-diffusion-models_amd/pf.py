@@ -116,3 +116,29 @@ def groupnorm_pf(x: PF, gamma: torch.Tensor, beta: torch.Tensor, groups: int, ep
         N.check(N.lib().gsw_groupnorm_pf(x.rows.data_ptr(), gamma.data_ptr(), beta.data_ptr(), optr, ws.data_ptr(), x.B, x.H, x.W, x.C, groups,
                                          eps, 1 if act else 0, 1 if tokens else 0, _dt(x.buf.dtype), _stream_ptr()))
     return res
+
+
+def pack_geglu_weight(w: torch.Tensor, b: Optional[torch.Tensor]):
+    """GEGLU projection [2I, K] (rows: I value then I gate) -> rows interleaved per 160-wide output tile as
+    [80 value | 80 gate], so one GEMM tile holds both factors of 80 outputs (I % 80 == 0)."""
+    I = w.shape[0] // 2
+    v = w[:I].reshape(I // 80, 80, -1)
+    g = w[I:].reshape(I // 80, 80, -1)
+    wp = torch.cat([v, g], dim=1).reshape(2 * I, -1).contiguous()
+    bp = None
+    if b is not None:
+        bp = torch.cat([b[:I].reshape(I // 80, 80), b[I:].reshape(I // 80, 80)], dim=1).reshape(2 * I).contiguous()
+    return wp, bp
+
+
+def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], *, resid: Optional[torch.Tensor] = None, geglu: bool = False) -> torch.Tensor:
+    """x[..., K] @ w[N, K]^T + bias (+ resid) on the MFMA GEMM kernel; geglu=True expects pack_geglu_weight operands."""
+    K = x.shape[-1]
+    M = x.numel() // K
+    Nn = w.shape[0]
+    out = torch.empty((*x.shape[:-1], Nn // 2 if geglu else Nn), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        N.check(N.lib().gsw_linear(x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                   resid.data_ptr() if resid is not None else None, out.data_ptr(), M, K, Nn, 1 if geglu else 0,
+                                   _dt(x.dtype), _stream_ptr()))
+    return out

@@ -57,6 +57,25 @@ def _pw(conv: nn.Conv2d) -> torch.Tensor:
     return w
 
 
+GEMM_MAX_K = 0        # linear layers with K <= this would run on the hand-written GEMM (gsw_linear).  Measured on MI355X: it only
+                      # beats hipBLASLt on [524288,320]x[320,320] (398 vs 343 TFLOP/s) and loses elsewhere, incl. the fused GEGLU
+                      # form (output-bound epilogue), so the transformer linears stay on the library GEMM; set > 0 to experiment.
+
+
+def _own_gemm_ok(x: torch.Tensor, K: int, N: int) -> bool:
+    return USE_PF and FUSED_KERNELS and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and x.is_contiguous() \
+        and K % 64 == 0 and N % 160 == 0 and K <= GEMM_MAX_K
+
+
+def _lin(x: torch.Tensor, lin: nn.Linear, resid: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Linear (+ residual) on the own GEMM when the shape favours it, else torch."""
+    if _own_gemm_ok(x, lin.in_features, lin.out_features) and (resid is None or resid.is_contiguous()):
+        from .pf import linear
+        return linear(x, lin.weight, lin.bias, resid=resid)
+    y = lin(x)
+    return y if resid is None else y + resid
+
+
 def _gn_pf(x, norm: nn.GroupNorm, act=True, tokens=False):
     from .pf import groupnorm_pf
     return groupnorm_pf(x, norm.weight, norm.bias, norm.num_groups, norm.eps, act=act, tokens=tokens)
@@ -115,11 +134,11 @@ class Attention(nn.Module):
     def forward(self, x, ctx=None):
         ctx = x if ctx is None else ctx
         b, n, _ = x.shape
-        q = self.to_q(x).view(b, n, self.heads, -1).transpose(1, 2)
-        k = self.to_k(ctx).view(b, ctx.shape[1], self.heads, -1).transpose(1, 2)
-        v = self.to_v(ctx).view(b, ctx.shape[1], self.heads, -1).transpose(1, 2)
+        q = _lin(x, self.to_q).view(b, n, self.heads, -1).transpose(1, 2)
+        k = _lin(ctx, self.to_k).view(b, ctx.shape[1], self.heads, -1).transpose(1, 2)
+        v = _lin(ctx, self.to_v).view(b, ctx.shape[1], self.heads, -1).transpose(1, 2)
         o = F.scaled_dot_product_attention(q, k, v)
-        return self.to_out[0](o.transpose(1, 2).reshape(b, n, -1))
+        return _lin(o.transpose(1, 2).reshape(b, n, -1), self.to_out[0])
 
 
 class GEGLU(nn.Module):
@@ -128,6 +147,14 @@ class GEGLU(nn.Module):
         self.proj = nn.Linear(dim, inner * 2)
 
     def forward(self, x):
+        inner = self.proj.out_features // 2
+        if _own_gemm_ok(x, self.proj.in_features, self.proj.out_features) and inner % 80 == 0:
+            from .pf import linear, pack_geglu_weight     # value * gelu(gate) in the GEMM epilogue: no [M, 2I] intermediate
+            c = getattr(self, "_gsw_geglu", None)
+            if c is None or c[0].device != x.device or c[0].dtype != x.dtype:
+                c = pack_geglu_weight(self.proj.weight.detach(), self.proj.bias.detach())
+                self._gsw_geglu = c
+            return linear(x, c[0], c[1], geglu=True)
         y = self.proj(x)
         if FUSED_KERNELS and y.is_cuda and y.is_contiguous() and (y.shape[-1] // 2) % 8 == 0:
             from . import codec
@@ -141,8 +168,8 @@ class FeedForward(nn.Module):
         super().__init__()
         self.net = nn.ModuleList([GEGLU(dim, dim * mult), nn.Identity(), nn.Linear(dim * mult, dim)])
 
-    def forward(self, x):
-        return self.net[2](self.net[0](x))
+    def forward(self, x, resid=None):
+        return _lin(self.net[0](x), self.net[2], resid)
 
 
 class BasicTransformerBlock(nn.Module):
@@ -162,7 +189,7 @@ class BasicTransformerBlock(nn.Module):
             _, n = add_layernorm(x, None, self.norm1.weight, self.norm1.bias, self.norm1.eps)
             x, n = add_layernorm(x, self.attn1(n).contiguous(), self.norm2.weight, self.norm2.bias, self.norm2.eps)
             x, n = add_layernorm(x, self.attn2(n, ctx).contiguous(), self.norm3.weight, self.norm3.bias, self.norm3.eps)
-            return x + self.ff(n)
+            return self.ff(n, resid=x)            # residual folded into the output GEMM's epilogue when it runs on the own kernel
         x = x + self.attn1(self.norm1(x))
         x = x + self.attn2(self.norm2(x), ctx)
         return x + self.ff(self.norm3(x))
@@ -186,10 +213,10 @@ class Transformer2DModel(nn.Module):
         return x + y
 
     def forward_pf(self, x, ctx):
-        y = self.proj_in(_gn_pf(x, self.norm, act=False, tokens=True))      # GroupNorm writes dense tokens directly
+        y = _lin(_gn_pf(x, self.norm, act=False, tokens=True), self.proj_in)      # GroupNorm writes dense tokens directly
         for blk in self.transformer_blocks:
             y = blk(y, ctx)
-        x.interior.add_(self.proj_out(y).view(x.B, x.H, x.W, x.C))          # residual, in place (x has no other reader)
+        x.interior.add_(_lin(y, self.proj_out).view(x.B, x.H, x.W, x.C))     # residual, in place (x has no other reader)
         return x
 
 

@@ -59,6 +59,29 @@ def test_groupnorm_pf_vs_torch_fp32(G, dtype, B, C, H, W, act):
     assert (t.float() - ref.permute(0, 2, 3, 1).reshape(B, H * W, C)).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,K,N", [(4096, 320, 320), (1000, 64, 160), (777, 640, 960), (4096, 320, 2560), (130, 128, 320)])
+def test_linear_vs_torch_fp32(G, dtype, M, K, N):
+    g = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g).to(dtype).cuda()
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(dtype).cuda()
+    b = torch.randn(N, generator=g).to(dtype).cuda()
+    r = torch.randn(M, N, generator=g).to(dtype).cuda()
+    tol = 2e-3 if dtype == torch.float16 else 1.6e-2
+    ref = x.float() @ w.float().t() + b.float()
+    y = G.pf.linear(x, w, b)
+    assert (y.float() - ref).abs().max().item() <= tol * ref.abs().max().item()
+    y2 = G.pf.linear(x, w, b, resid=r)
+    assert (y2.float() - (ref + r.float())).abs().max().item() <= tol * (ref + r.float()).abs().max().item()
+    # fused GEGLU == value * gelu(gate) of the same projection (torch rounds the projection and the gelu to the storage dtype)
+    wp, bp = G.pf.pack_geglu_weight(w, b)
+    yg = G.pf.linear(x, wp, bp, geglu=True)
+    proj = ref.to(dtype).float()
+    refg = proj[:, : N // 2] * F.gelu(proj[:, N // 2:]).to(dtype).float()
+    assert yg.shape == (M, N // 2)
+    assert (yg.float() - refg).abs().max().item() <= 2 * tol * max(1.0, refg.abs().max().item())
+
+
 def test_unet_pf_path_equals_torch_path(G):
     U = G.unet
     m = U.synthetic_init_(U.UNet2DCondition(block_out_channels=(64, 128, 128, 128), cross_attention_dim=64, num_heads=(2, 4, 4, 4), head_dim=32), 0)
