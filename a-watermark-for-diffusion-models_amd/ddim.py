@@ -123,3 +123,78 @@ def ddim_invert_extract(eps_model: EpsModel, x0: torch.Tensor, ctx: torch.Tensor
     z_out = torch.empty_like(x) if return_latents else None
     res = codec.ddim_step_extract(x, eps, a, b, key, nonce, message_length, z_out=z_out, return_counts=return_counts)
     return (*res, z_out) if return_latents else res
+
+
+# =====================================================================================================================
+# `--scheduler DPMs` of the reference (extract.py:49-50): diffusers' DPMSolverMultistepInverseScheduler with its defaults on the
+# SD scheduler config -- DPM-Solver++ (data prediction), solver_order 2, midpoint, 'linspace' timestep spacing,
+# lower_order_final (only effective below 15 steps), no Karras sigmas.  Restated from the published algorithm
+# (Lu et al., "DPM-Solver++", multistep 2M) in diffusers' sigma parametrisation; PARITY UNPINNED like the DDIM loop.
+# Every update is linear in (x, eps, previous x0 prediction), so a step is 2-3 launches of the fused scheduler-step kernel.
+# =====================================================================================================================
+@dataclass
+class DPMSolverInverseSchedule:
+    num_inference_steps: int = 50
+    num_train_timesteps: int = 1000
+    prediction_type: str = "epsilon"
+    solver_order: int = 2
+    lower_order_final: bool = True
+
+    def __post_init__(self):
+        ac = sd_alphas_cumprod(self.num_train_timesteps)
+        S = self.num_inference_steps
+        noisiest = self.num_train_timesteps - 1
+        ts = np.linspace(0, noisiest, S + 1).round()[:-1].astype(np.int64)            # ascending: 0 ... < 999
+        all_sigmas = ((1 - ac) / ac) ** 0.5
+        sig = np.interp(ts, np.arange(len(all_sigmas)), all_sigmas)
+        self.timesteps = ts
+        self.sigmas = np.concatenate([sig, [all_sigmas[noisiest]]])                   # sigma_{S} = the noisiest level
+
+    @staticmethod
+    def _alpha_sigma(sigma):
+        alpha = 1.0 / (sigma * sigma + 1.0) ** 0.5
+        return alpha, sigma * alpha
+
+    def steps(self):
+        """[(t, (P, Q), (A, B, C))]: m0 = P x + Q eps (x0 prediction); x' = A x + B m0 + C m1 (m1 = previous x0 prediction)."""
+        out = []
+        S = self.num_inference_steps
+        for i, t in enumerate(self.timesteps):
+            a_s0, s_s0 = self._alpha_sigma(self.sigmas[i])
+            a_t, s_t = self._alpha_sigma(self.sigmas[i + 1])
+            if self.prediction_type == "epsilon":
+                P, Q = 1.0 / a_s0, -s_s0 / a_s0
+            elif self.prediction_type == "v_prediction":
+                P, Q = a_s0, -s_s0
+            else:
+                raise ValueError(self.prediction_type)
+            lam_t, lam_s0 = np.log(a_t) - np.log(s_t), np.log(a_s0) - np.log(s_s0)
+            h = lam_t - lam_s0
+            A = s_t / s_s0
+            k = -a_t * (np.exp(-h) - 1.0)
+            first_order = self.solver_order == 1 or i == 0 or (self.lower_order_final and i == S - 1 and S < 15)
+            if first_order:
+                B, C = k, 0.0
+            else:
+                a_s1, s_s1 = self._alpha_sigma(self.sigmas[i - 1])
+                lam_s1 = np.log(a_s1) - np.log(s_s1)
+                r0 = (lam_s0 - lam_s1) / h
+                B, C = k * (1.0 + 0.5 / r0), -k * 0.5 / r0
+            out.append((int(t), (float(P), float(Q)), (float(A), float(B), float(C))))
+        return out
+
+
+@torch.no_grad()
+def dpms_invert(eps_model: EpsModel, x0: torch.Tensor, ctx: torch.Tensor, schedule: DPMSolverInverseSchedule) -> torch.Tensor:
+    """X2 with `--scheduler DPMs`: DPM-Solver++(2M) inversion x_0 -> x_T."""
+    steps = schedule.steps()
+    tt = _t_tensors([s[0] for s in steps], x0.device)
+    x = x0.clone()
+    m_prev = None
+    for (t, (P, Q), (A, B, C)), t_dev in zip(steps, tt):
+        m0 = codec.ddim_step(x, eps_model(x, t_dev, ctx), P, Q)          # x0 prediction of this step
+        codec.ddim_step(x, m0, A, B, out=x)
+        if C != 0.0:
+            codec.ddim_step(x, m_prev, 1.0, C, out=x)
+        m_prev = m0
+    return x

@@ -165,19 +165,22 @@ def _scheduler_steps(args, models):
     if args.scheduler == "DDIM":
         return DDIMSchedule(num_inference_steps=int(args.num_inference_steps), prediction_type=models.prediction_type)
     if args.scheduler == "DPMs":
-        raise NotImplementedError("DPMSolverMultistepInverseScheduler (extract.py:49-50) is not part of this path yet; use --scheduler DDIM")
+        from .ddim import DPMSolverInverseSchedule
+        return DPMSolverInverseSchedule(num_inference_steps=int(args.num_inference_steps), prediction_type=models.prediction_type)
     raise ValueError("Please choose 'DPMs' or 'DDIM' for the scheduler.")     # extract.py:54
 
 
 @torch.no_grad()
 def exactract_latents_batch(image_paths, args, *, device="cuda") -> torch.Tensor:
     """Batch form of exactract_latents: [B,4,h,w] fp16 latents on the DEVICE."""
-    from .ddim import ddim_invert
+    from .ddim import ddim_invert, dpms_invert, DPMSolverInverseSchedule
     models = load_models(args.model_id, device)
     sched = _scheduler_steps(args, models)
     imgs = torch.cat([load_image(p, [args.width, args.height]) for p in image_paths]).to(models.device, models.dtype)
     latents = img_to_latents(imgs, models.vae)
     ctx = models.ctx_empty.expand(latents.shape[0], -1, -1)
+    if isinstance(sched, DPMSolverInverseSchedule):
+        return dpms_invert(models.unet, latents, ctx, sched)
     return ddim_invert(models.unet, latents, ctx, sched)
 
 

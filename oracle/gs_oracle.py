@@ -342,6 +342,44 @@ def ddim_schedule(num_inference_steps: int, inverse: bool, num_train_timesteps: 
     return out
 
 
+def dpms_invert_reference(eps_fn, x0, num_inference_steps, num_train_timesteps=1000):
+    """DPM-Solver++(2M) inversion written step by step the way diffusers' DPMSolverMultistepInverseScheduler does it
+    (convert_model_output -> x0 prediction list -> first-order / second-order multistep update; linspace spacing, midpoint,
+    lower_order_final below 15 steps).  float64; eps_fn(x, t) -> eps.  PARITY UNPINNED (no diffusers here)."""
+    ac = sd_alphas_cumprod(num_train_timesteps)
+    S = num_inference_steps
+    ts = np.linspace(0, num_train_timesteps - 1, S + 1).round()[:-1].astype(np.int64)
+    all_sig = ((1 - ac) / ac) ** 0.5
+    sigmas = np.concatenate([np.interp(ts, np.arange(len(all_sig)), all_sig), [all_sig[-1]]])
+
+    def a_s(sig):
+        a = 1.0 / np.sqrt(sig * sig + 1.0)
+        return a, sig * a
+
+    x = np.array(x0, dtype=np.float64)
+    outs = []
+    lower_order_nums = 0
+    for i, t in enumerate(ts):
+        eps = eps_fn(x, int(t))
+        a0, s0 = a_s(sigmas[i])
+        outs.append((x - s0 * eps) / a0)                       # data prediction
+        at, st = a_s(sigmas[i + 1])
+        lam_t, lam_s0 = np.log(at) - np.log(st), np.log(a0) - np.log(s0)
+        h = lam_t - lam_s0
+        final_lower = (i == S - 1) and S < 15
+        if lower_order_nums < 1 or final_lower:
+            x = (st / s0) * x - at * (np.exp(-h) - 1.0) * outs[-1]
+        else:
+            a1, s1 = a_s(sigmas[i - 1])
+            lam_s1 = np.log(a1) - np.log(s1)
+            r0 = (lam_s0 - lam_s1) / h
+            D0, D1 = outs[-1], (1.0 / r0) * (outs[-1] - outs[-2])
+            x = (st / s0) * x - at * (np.exp(-h) - 1.0) * D0 - 0.5 * at * (np.exp(-h) - 1.0) * D1
+        if lower_order_nums < 2:
+            lower_order_nums += 1
+    return x
+
+
 # ----------------------------------------------------------------------------------------------
 # In-kernel RNG of the build (NOT reference behaviour): Philox4x32-10, restated so tests can check the HIP
 # kernel's `u` stream.  Group g = e >> 2 of image `img` draws Philox(counter = (g, 0, img_lo, img_hi),

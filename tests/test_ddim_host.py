@@ -36,3 +36,21 @@ def test_schedule_sd_constants():
     # closed form of the recovered bytecode
     t, a, b = s.sampling()[0]
     np.testing.assert_allclose(O.backward_ddim(x, s.alphas_cumprod[981], s.alphas_cumprod[961], e), a * x + b * e, atol=1e-12)
+
+
+@pytest.mark.parametrize("steps", [50, 30, 10])
+def test_dpms_inverse_coefficient_form_equals_stepwise_form(steps):
+    """Product: per-step linear coefficients; oracle: diffusers-style step-by-step update.  Same eps function, float64."""
+    sched = ddim.DPMSolverInverseSchedule(num_inference_steps=steps)
+    assert sched.timesteps[0] == 0 and len(sched.timesteps) == steps and sched.timesteps[-1] < 999
+    rng = np.random.RandomState(0)
+    x0 = rng.standard_normal(500)
+    eps_fn = lambda x, t: 0.3 * np.tanh(x) + 0.05 * np.sin(3 * x + 0.01 * t)
+    ref = O.dpms_invert_reference(eps_fn, x0, steps)
+    x, m_prev = x0.copy(), None
+    for t, (P, Q), (A, B, C) in sched.steps():
+        m0 = P * x + Q * eps_fn(x, t)
+        x = A * x + B * m0 + (C * m_prev if C != 0.0 else 0.0)
+        m_prev = m0
+    np.testing.assert_allclose(x, ref, rtol=0, atol=1e-10)
+    assert np.isfinite(ref).all()

@@ -99,3 +99,15 @@ def test_small_unet_roundtrip_is_lossless(P, keys):
     for b in range(B):
         assert P.codec.bits_to_str(bits[b].cpu().numpy()) == O.recover_bits(zi[b].cpu().numpy(), key, nonce, 256)
     assert ((zi >= 0) == (zT >= 0)).float().mean().item() > 0.9
+
+
+def test_dpms_inversion_vs_numpy_oracle(P, keys):
+    key, nonce = keys
+    B = 2
+    zT = P.codec.embed_batch(key, nonce, O.pad_message("x", 32), B, (4, 64, 64), seed=9, dtype=torch.float32)
+    sched = P.ddim.DPMSolverInverseSchedule(20)
+    ctx = torch.zeros(B, 1, 1, device="cuda")
+    x0 = (zT * 0.2).contiguous()
+    zi = P.ddim.dpms_invert(analytic_eps, x0, ctx, sched)
+    ref = O.dpms_invert_reference(lambda x, t: analytic_eps_np(x, t), x0.cpu().double().numpy(), 20)
+    np.testing.assert_allclose(zi.cpu().numpy(), ref, rtol=0, atol=1e-3 * max(1.0, np.abs(ref).max()))
