@@ -273,7 +273,7 @@ __global__ __launch_bounds__(128 * WM) void gsw_conv_gemm_wide_kernel(ConvArgs p
     const uint32_t pc = lane & 7u;
 
     // 36 staging instructions (1 KiB each) per K block: j < 16 -> activation rows 8j.., else weight rows 8(j-16)..; 9 per wave
-    int64_t src_off[PER_WAVE];     // element offset of this lane's 16-byte source chunk, without the tap / K-block terms
+    int32_t src_off[PER_WAVE];     // element offset (< 2^31, checked on the host) of this lane's 16-byte source chunk, w/o tap / K terms
 #pragma unroll
     for (int i = 0; i < PER_WAVE; ++i) {
         const uint32_t j = wave * PER_WAVE + i;
@@ -291,10 +291,10 @@ __global__ __launch_bounds__(128 * WM) void gsw_conv_gemm_wide_kernel(ConvArgs p
                 xo = xo < 0 ? 0 : (xo >= Wo ? Wo - 1 : xo);
                 src = b * p.in_Hp * p.in_Wp + (2 * yo) * p.in_Wp + 2 * xo;
             }
-            src_off[i] = (int64_t)src * p.ldx + (int64_t)((pc ^ ((r >> 1) & 7u)) * 8u);
+            src_off[i] = src * p.ldx + (int32_t)((pc ^ ((r >> 1) & 7u)) * 8u);
         } else if (j < (uint32_t)TI) {
             const uint32_t r = (j - XI) * 8u + (lane >> 3);
-            src_off[i] = (int64_t)(n0 + (int32_t)r) * Ktot + (int64_t)((pc ^ ((r >> 1) & 7u)) * 8u);
+            src_off[i] = (n0 + (int32_t)r) * Ktot + (int32_t)((pc ^ ((r >> 1) & 7u)) * 8u);
         }
     }
 
@@ -314,10 +314,10 @@ __global__ __launch_bounds__(128 * WM) void gsw_conv_gemm_wide_kernel(ConvArgs p
         for (int i = 0; i < PER_WAVE; ++i) {
             const uint32_t j = wave * PER_WAVE + i;     // wave-uniform
             if (j < (uint32_t)XI) {
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + src_off[i] + xoff),
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + ((int64_t)src_off[i] + xoff)),
                                                  (__attribute__((address_space(3))) void*)(buf + j * 1024u), 16, 0, 0);
             } else if (j < (uint32_t)TI) {
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W + src_off[i] + woff),
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W + ((int64_t)src_off[i] + woff)),
                                                  (__attribute__((address_space(3))) void*)(buf + BM * CV_BK * 2 + (j - XI) * 1024u), 16, 0, 0);
             }
         }
@@ -687,7 +687,8 @@ int gsw_conv_pf(const void* x_dev, const void* w_dev, const void* bias_dev, cons
     a.C = C; a.N = N; a.Hp = H + 2; a.Wp = W + 2; a.stride = stride; a.ldx = ldx;
     a.in_Hp = H * stride + 2; a.in_Wp = W * stride + 2;
     const int64_t M = (int64_t)B * a.Hp * a.Wp;
-    if (M > 0x7FFFFF00 || M * (int64_t)std::max(C, N) > (int64_t)1 << 40) return GSW_ERR_UNSUPPORTED;
+    if (M > 0x7FFFFF00 || ((int64_t)B * a.in_Hp * a.in_Wp + 2 * a.in_Wp) * ldx >= ((int64_t)1 << 31) || (int64_t)N * ksize * ksize * C >= ((int64_t)1 << 31))
+        return GSW_ERR_UNSUPPORTED;     // 32-bit element offsets inside the kernel
     a.M = (int32_t)M;
     a.ntaps = ksize * ksize;
     for (int i = 0; i < 9; ++i) a.tap_off[i] = 0;
@@ -704,6 +705,15 @@ static int launch_conv_gemm(ConvArgs& a, int64_t M, int N, int dtype, void* stre
     static const bool narrow_only = getenv("GSW_CONV_NARROW") != nullptr;      // A/B switch for profiling
     if (N % CW_BN == 0 && !narrow_only) {
         static const int db_env = getenv("GSW_CONV_DB") ? atoi(getenv("GSW_CONV_DB")) : 0;   // A/B switch: 1 = two LDS stages (measured 3-12 % slower: fewer workgroups per CU)
+        static const int wm_env = getenv("GSW_CONV_WM") ? atoi(getenv("GSW_CONV_WM")) : 2;
+        if (wm_env == 4) {
+            const uint32_t grid4 = (uint32_t)(((M + 255) / 256) * (N / CW_BN));
+            if (dtype == GSW_F16) hipLaunchKernelGGL((gsw_conv_gemm_wide_kernel<_Float16, 4, false>), dim3(grid4), dim3(512), 0, (hipStream_t)stream, a);
+            else hipLaunchKernelGGL((gsw_conv_gemm_wide_kernel<__bf16, 4, false>), dim3(grid4), dim3(512), 0, (hipStream_t)stream, a);
+            hipError_t e4 = hipGetLastError();
+            if (e4 != hipSuccess) { g_conv_hip_error = (int)e4; return GSW_ERR_HIP; }
+            return GSW_OK;
+        }
         const uint32_t grid = (uint32_t)(((M + 127) / 128) * (N / CW_BN));
         if (db_env) {
             if (dtype == GSW_F16) hipLaunchKernelGGL((gsw_conv_gemm_wide_kernel<_Float16, 2, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
@@ -764,7 +774,8 @@ int gsw_linear(const void* x_dev, const void* w_dev, const void* bias_dev, const
                int geglu, int dtype, void* stream) {
     // y[M, N] = x[M, K] @ w[N, K]^T + bias (+ resid); geglu: w rows are tile-interleaved [80 value | 80 gate], y is [M, N/2]
     if (!x_dev || !w_dev || !y_dev || M <= 0 || K <= 0 || N <= 0) return GSW_ERR_BAD_ARG;
-    if (K % CV_BK || N % CW_BN || M > 0x7FFFFF00 || (geglu && resid_dev)) return GSW_ERR_UNSUPPORTED;
+    if (K % CV_BK || N % CW_BN || M > 0x7FFFFF00 || (geglu && resid_dev) || M * K >= ((int64_t)1 << 31) || (int64_t)N * K >= ((int64_t)1 << 31))
+        return GSW_ERR_UNSUPPORTED;
     if (dtype != GSW_F16 && dtype != GSW_BF16) return GSW_ERR_BAD_ARG;
     ConvArgs a;
     a.x = x_dev; a.w = w_dev; a.bias = bias_dev; a.rowbias = nullptr; a.resid = resid_dev; a.y = y_dev;
