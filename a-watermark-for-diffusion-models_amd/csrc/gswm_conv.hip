@@ -248,8 +248,9 @@ template <> struct Mfma16<__bf16> {
 };
 
 // WM = waves along M (2 -> 128-row tile, 256 threads; 4 -> 256-row tile, 512 threads)
-template <typename T, int WM, bool DB>
-__global__ __launch_bounds__(128 * WM) void gsw_conv_gemm_wide_kernel(ConvArgs p) {
+// LIN = 1 compiles in the dense-matrix / GEGLU epilogue of gsw_linear; the convolution instantiation (LIN = 0) stays lean
+template <typename T, int WM, bool DB, bool LIN>
+__global__ __launch_bounds__(128 * WM, WM == 4 ? 4 : 1) void gsw_conv_gemm_wide_kernel(ConvArgs p) {
     constexpr int BM = 64 * WM;
     constexpr int NTHR = 128 * WM;
     constexpr int NWAVE = 2 * WM;
@@ -406,7 +407,7 @@ __global__ __launch_bounds__(128 * WM) void gsw_conv_gemm_wide_kernel(ConvArgs p
             if (m < p.M) {
                 int32_t b = 0;
                 bool border = false;
-                if (!p.dense) {
+                if (!(LIN && p.dense)) {
                     b = m / HpWp;
                     const int32_t qq = m - b * HpWp;
                     const int32_t yy = qq / p.Wp, xx = qq - yy * p.Wp;
@@ -436,7 +437,7 @@ __global__ __launch_bounds__(128 * WM) void gsw_conv_gemm_wide_kernel(ConvArgs p
             }
         }
     };
-    if (p.geglu) {
+    if (LIN && p.geglu) {
         // wn = 1 waves hold the gate columns, wn = 0 waves the value columns of the SAME 80 outputs, with identical lane
         // mapping: gate -> gelu -> LDS; barrier; value waves multiply in place; barrier; one 80-column store
         if (wn == 1) put_half(true);
@@ -702,30 +703,27 @@ int gsw_conv_pf(const void* x_dev, const void* w_dev, const void* bias_dev, cons
 }
 
 static int launch_conv_gemm(ConvArgs& a, int64_t M, int N, int dtype, void* stream) {
-    static const bool narrow_only = getenv("GSW_CONV_NARROW") != nullptr;      // A/B switch for profiling
+    static const bool narrow_only = getenv("GSW_CONV_NARROW") != nullptr;      // A/B switches for profiling
+    static const int wm_env = getenv("GSW_CONV_WM") ? atoi(getenv("GSW_CONV_WM")) : 2;
+    hipStream_t st = (hipStream_t)stream;
     if (N % CW_BN == 0 && !narrow_only) {
-        static const int db_env = getenv("GSW_CONV_DB") ? atoi(getenv("GSW_CONV_DB")) : 0;   // A/B switch: 1 = two LDS stages (measured 3-12 % slower: fewer workgroups per CU)
-        static const int wm_env = getenv("GSW_CONV_WM") ? atoi(getenv("GSW_CONV_WM")) : 2;
-        if (wm_env == 4) {
-            const uint32_t grid4 = (uint32_t)(((M + 255) / 256) * (N / CW_BN));
-            if (dtype == GSW_F16) hipLaunchKernelGGL((gsw_conv_gemm_wide_kernel<_Float16, 4, false>), dim3(grid4), dim3(512), 0, (hipStream_t)stream, a);
-            else hipLaunchKernelGGL((gsw_conv_gemm_wide_kernel<__bf16, 4, false>), dim3(grid4), dim3(512), 0, (hipStream_t)stream, a);
-            hipError_t e4 = hipGetLastError();
-            if (e4 != hipSuccess) { g_conv_hip_error = (int)e4; return GSW_ERR_HIP; }
-            return GSW_OK;
-        }
-        const uint32_t grid = (uint32_t)(((M + 127) / 128) * (N / CW_BN));
-        if (db_env) {
-            if (dtype == GSW_F16) hipLaunchKernelGGL((gsw_conv_gemm_wide_kernel<_Float16, 2, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
-            else hipLaunchKernelGGL((gsw_conv_gemm_wide_kernel<__bf16, 2, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+        if (a.dense) {
+            const uint32_t grid = (uint32_t)(((M + 127) / 128) * (N / CW_BN));
+            if (dtype == GSW_F16) hipLaunchKernelGGL((gsw_conv_gemm_wide_kernel<_Float16, 2, false, true>), dim3(grid), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((gsw_conv_gemm_wide_kernel<__bf16, 2, false, true>), dim3(grid), dim3(256), 0, st, a);
+        } else if (wm_env == 4) {
+            const uint32_t grid = (uint32_t)(((M + 255) / 256) * (N / CW_BN));
+            if (dtype == GSW_F16) hipLaunchKernelGGL((gsw_conv_gemm_wide_kernel<_Float16, 4, false, false>), dim3(grid), dim3(512), 0, st, a);
+            else hipLaunchKernelGGL((gsw_conv_gemm_wide_kernel<__bf16, 4, false, false>), dim3(grid), dim3(512), 0, st, a);
         } else {
-            if (dtype == GSW_F16) hipLaunchKernelGGL((gsw_conv_gemm_wide_kernel<_Float16, 2, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
-            else hipLaunchKernelGGL((gsw_conv_gemm_wide_kernel<__bf16, 2, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+            const uint32_t grid = (uint32_t)(((M + 127) / 128) * (N / CW_BN));
+            if (dtype == GSW_F16) hipLaunchKernelGGL((gsw_conv_gemm_wide_kernel<_Float16, 2, false, false>), dim3(grid), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((gsw_conv_gemm_wide_kernel<__bf16, 2, false, false>), dim3(grid), dim3(256), 0, st, a);
         }
     } else {
         const uint32_t grid = (uint32_t)(((M + CV_BM - 1) / CV_BM) * (N / CV_BN));
-        if (dtype == GSW_F16) hipLaunchKernelGGL((gsw_conv_gemm_kernel<_Float16>), dim3(grid), dim3(CV_THREADS), 0, (hipStream_t)stream, a);
-        else hipLaunchKernelGGL((gsw_conv_gemm_kernel<__bf16>), dim3(grid), dim3(CV_THREADS), 0, (hipStream_t)stream, a);
+        if (dtype == GSW_F16) hipLaunchKernelGGL((gsw_conv_gemm_kernel<_Float16>), dim3(grid), dim3(CV_THREADS), 0, st, a);
+        else hipLaunchKernelGGL((gsw_conv_gemm_kernel<__bf16>), dim3(grid), dim3(CV_THREADS), 0, st, a);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g_conv_hip_error = (int)e; return GSW_ERR_HIP; }
