@@ -118,9 +118,9 @@ __global__ __launch_bounds__(CV_THREADS) void gsw_conv_gemm_kernel(ConvArgs p) {
             for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
 
     const int32_t kc_per_tap = p.C / CV_BK;
-    for (int32_t t = 0; t < p.ntaps; ++t) {
-        const int32_t off = p.tap_off[t];
-        for (int32_t kc = 0; kc < kc_per_tap; ++kc) {
+    for (int32_t kc = 0; kc < kc_per_tap; ++kc) {        // channel-block-major, tap-minor (L2 reuse across taps)
+        for (int32_t t = 0; t < p.ntaps; ++t) {
+            const int32_t off = p.tap_off[t];
             // ---- stage: activations (8 x 1 KiB per wave) and weights (2 x 1 KiB per wave)
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -308,7 +308,10 @@ __global__ __launch_bounds__(128 * WM, WM == 4 ? 4 : 1) void gsw_conv_gemm_wide_
     const int32_t kc_per_tap = p.C / CV_BK;
     const int32_t nkb = p.ntaps * kc_per_tap;
     auto stage = [&](int32_t kb, uint8_t* buf) {
-        const int32_t t = kb / kc_per_tap, kc = kb - t * kc_per_tap;
+        // channel-block-major, tap-minor: the 9 taps of one 64-channel block read (almost) the same rows, shifted by a few
+        // pixels, so consecutive K blocks hit L2 instead of streaming every tap's shifted copy of the whole tensor from
+        // HBM (tap-major order: L2 hit rate 69 %, 13 GB fetched per launch for a 1.1 GB activation tensor)
+        const int32_t kc = kb / p.ntaps, t = kb - kc * p.ntaps;
         const int64_t xoff = (int64_t)p.tap_off[t] * p.ldx + kc * CV_BK;
         const int32_t woff = t * p.C + kc * CV_BK;
 #pragma unroll
