@@ -140,11 +140,11 @@ def run_e2e(args, rank, world, local_rank):
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"e2e latent level: gsw_embed -> {S}-step DDIM sampling (CFG 7.5, 2B-row UNet) -> {S}-step DDIM inversion -> "
-                                   f"fused last step + {M}-bit vote; SD2.1-base-shaped UNet (865.9 M params, synthetic weights), no VAE",
+                                   f"fused last step + {M}-bit vote; SD2.1-base-shaped UNet (865.9 M params, synthetic weights; convolutions on the hand-written MFMA implicit GEMM), no VAE",
                        "batch_per_gpu": B, "global_batch": world * B, "lattice": [4, h, w], "message_bits": M, "ddim_steps": S,
                        "parallelism": f"dp{world} (images sharded, UNet replicated, no data-path collective)"},
             "bit_accuracy": bit_acc, "lossless": bit_acc == 1.0 and int(flagged.item()) == 0, "flagged_images": int(flagged.item()),
-            "roofline": {"bound": "mfma", "kernel": "UNet2DCondition forward (hipBLASLt/MIOpen/flash-attention kernels, aggregate)",
+            "roofline": {"bound": "mfma", "kernel": "UNet2DCondition forward, aggregate (gsw_conv_gemm_wide_kernel ~40 % of it, flash attention ~15 %, hipBLASLt GEMMs ~24 %, gsw_* elementwise fusions ~16 %; per-kernel shares in profiles/r01_unet_forward_b128_kernel_stats.csv)",
                          "achieved": sm["tflops"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": sm["tflops"] / MFMA_PEAK_TFLOPS,
                          "traffic": None, "algorithmic_flops_per_launch": sm["flops_per_call_avg"], "avg_launch_us": sm["avg_ms"] * 1e3,
                          "calls": sm["calls"], "unet_time_fraction": sm["total_ms"] * 1e-3 / dt, "flops_per_image_forward": flops_row},
