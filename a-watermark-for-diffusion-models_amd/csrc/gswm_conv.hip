@@ -481,6 +481,181 @@ __global__ __launch_bounds__(128 * WM, WM == 4 ? 4 : 1) void gsw_conv_gemm_wide_
 }
 
 // ------------------------------------------------------------------------------------------------
+// Halo variant for stride-1 3x3 convolutions (the bulk of the UNet): the 128 output rows of a tile are CONSECUTIVE PF rows,
+// so the rows any tap needs are the contiguous range [m0 - (Wp+1), m0 + 128 + (Wp+1)).  That halo'd activation tile is
+// staged into LDS ONCE per 64-channel block and all 9 taps read their MFMA fragments from it at a row offset; only the
+// 20 KiB weight tile (L2-hot: every workgroup reads the same weights) is re-staged per tap.  L2 -> LDS traffic per
+// (tile, channel block) drops from 9 x 36 KiB to 34 + 9 x 20 KiB, and eight of nine load phases wait only on L2 hits.
+// Dynamic LDS: [(128 + 2*HP) rows x 128 B activations][160 rows x 128 B weights], HP = Wp+1 rounded up to 8.
+// ------------------------------------------------------------------------------------------------
+// WDB: two weight stages -- tap t+1's weights stream in while tap t is multiplied (one barrier per tap instead of two)
+template <typename T, bool WDB>
+__global__ __launch_bounds__(256) void gsw_conv3x3_halo_kernel(ConvArgs p, int32_t HP) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int32_t xrows = CW_BM + 2 * HP;
+    uint8_t* ldsX = lds;
+    uint8_t* ldsW = lds + (uint32_t)xrows * 128u;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t wm = wave & 1u, wn = wave >> 1;
+    const uint32_t nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7u;
+    const uint32_t xcd = blockIdx.x & 7u, idx = blockIdx.x >> 3;
+    const uint32_t logical = (xcd < r8 ? xcd * (q8 + 1u) : r8 * (q8 + 1u) + (xcd - r8) * q8) + idx;
+    const uint32_t ntn = (uint32_t)p.N / CW_BN;
+    const uint32_t tile_n = logical % ntn, tile_m = logical / ntn;
+    const int32_t m0 = (int32_t)tile_m * CW_BM, n0 = (int32_t)tile_n * CW_BN;
+    const int32_t HpWp = p.Hp * p.Wp;
+    const int32_t Ktot = 9 * p.C;
+    const T* X = reinterpret_cast<const T*>(p.x);
+    const T* W = reinterpret_cast<const T*>(p.w);
+    const uint32_t pc = lane & 7u;
+    const int32_t G = p.Wp + 1;                          // guard rows that exist before row 0 / after row M-1
+    const int32_t nxi = xrows >> 3;                      // activation staging instructions (8 rows each)
+    const int32_t nxi_wave = (nxi + 3) >> 2;
+
+    gsw_f4v acc[5][4];
+#pragma unroll
+    for (int a = 0; a < 5; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = gsw_f4v{0.f, 0.f, 0.f, 0.f};
+
+    // weight staging: 20 instructions, 5 per wave; per-lane element offset without the (tap, channel block) term
+    int32_t w_off[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const uint32_t r = (wave * 5u + i) * 8u + (lane >> 3);
+        w_off[i] = (n0 + (int32_t)r) * Ktot + (int32_t)((pc ^ ((r >> 1) & 7u)) * 8u);
+    }
+    int32_t lrow[4];                                     // LDS row (tap offset excluded) of this lane's 4 activation fragments
+#pragma unroll
+    for (int im = 0; im < 4; ++im) lrow[im] = HP + (int32_t)(wm * 64u + (uint32_t)im * 16u + (lane & 15u));
+
+    const int32_t kc_blocks = p.C / CV_BK;
+    auto stage_x = [&](int32_t kc) {       // halo'd activation tile of one channel block (once for all 9 taps)
+        for (int32_t i = 0; i < nxi_wave; ++i) {
+            const int32_t j = (int32_t)wave * nxi_wave + i;
+            if (j < nxi) {
+                const int32_t r = j * 8 + (int32_t)(lane >> 3);                 // LDS row
+                int32_t src = m0 - HP + r;                                      // PF row; rows outside the guards are never used
+                src = src < -G ? -G : (src > p.M + G - 1 ? p.M + G - 1 : src);
+                const T* sp = X + ((int64_t)src * p.ldx + kc * CV_BK + (int32_t)((pc ^ (((uint32_t)r >> 1) & 7u)) * 8u));
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sp,
+                                                 (__attribute__((address_space(3))) void*)(ldsX + (uint32_t)j * 1024u), 16, 0, 0);
+            }
+        }
+    };
+    auto stage_w = [&](int32_t kc, int32_t t, uint8_t* wbuf) {
+        const int32_t woff = t * p.C + kc * CV_BK;
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W + ((int64_t)w_off[i] + woff)),
+                                             (__attribute__((address_space(3))) void*)(wbuf + (wave * 5u + i) * 1024u), 16, 0, 0);
+    };
+    auto compute = [&](int32_t t, const uint8_t* wbuf) {
+        const int32_t toff = p.tap_off[t];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const uint32_t lc = (uint32_t)ks * 4u + (lane >> 4);
+            typename Mfma<T>::frag xf[4];
+#pragma unroll
+            for (int im = 0; im < 4; ++im) {
+                const uint32_t r = (uint32_t)(lrow[im] + toff);
+                xf[im] = *reinterpret_cast<const typename Mfma<T>::frag*>(ldsX + r * 128u + ((lc ^ ((r >> 1) & 7u)) << 4));
+            }
+#pragma unroll
+            for (int in = 0; in < 5; ++in) {
+                const uint32_t r = wn * 80u + (uint32_t)in * 16u + (lane & 15u);
+                const typename Mfma<T>::frag wf = *reinterpret_cast<const typename Mfma<T>::frag*>(wbuf + r * 128u + ((lc ^ ((r >> 1) & 7u)) << 4));
+#pragma unroll
+                for (int im = 0; im < 4; ++im) acc[in][im] = Mfma16<T>::mma(wf, xf[im], acc[in][im]);
+            }
+        }
+    };
+    for (int32_t kc = 0; kc < kc_blocks; ++kc) {
+        stage_x(kc);
+        if (WDB) {
+            stage_w(kc, 0, ldsW);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            for (int32_t t = 0; t < 9; ++t) {
+                uint8_t* cur = ldsW + (uint32_t)(t & 1) * (CW_BN * 128u);
+                if (t < 8) stage_w(kc, t + 1, ldsW + (uint32_t)((t + 1) & 1) * (CW_BN * 128u));
+                compute(t, cur);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();      // next weights landed; everyone is done with `cur` (and, after tap 8, with the halo tile)
+            }
+        } else {
+            for (int32_t t = 0; t < 9; ++t) {
+                stage_w(kc, t, ldsW);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                compute(t, ldsW);
+                __syncthreads();
+            }
+        }
+    }
+
+    // ---- epilogue (same as the wide kernel): two 80-column halves through an LDS image
+    const uint16_t* bias = reinterpret_cast<const uint16_t*>(p.bias);
+    const uint16_t* rowbias = reinterpret_cast<const uint16_t*>(p.rowbias);
+    const uint16_t* resid = reinterpret_cast<const uint16_t*>(p.resid);
+    uint16_t* Y = reinterpret_cast<uint16_t*>(p.y);
+    for (uint32_t half = 0; half < 2; ++half) {
+        if (wn == half) {
+#pragma unroll
+            for (int in = 0; in < 5; ++in) {
+                const uint32_t n = (uint32_t)in * 16u + (lane >> 4) * 4u;
+                uint2 bw = make_uint2(0, 0);
+                if (bias) bw = *reinterpret_cast<const uint2*>(bias + n0 + half * 80u + n);
+                const uint16_t bh[4] = {(uint16_t)bw.x, (uint16_t)(bw.x >> 16), (uint16_t)bw.y, (uint16_t)(bw.y >> 16)};
+#pragma unroll
+                for (int im = 0; im < 4; ++im) {
+                    const uint32_t m = wm * 64u + (uint32_t)im * 16u + (lane & 15u);
+                    uint16_t h[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) h[j] = Mfma<T>::cvt(acc[in][im][j] + (bias ? Mfma<T>::up(bh[j]) : 0.f));
+                    *reinterpret_cast<uint2*>(lds + m * CW_OUT_STRIDE + n * 2u) =
+                        make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const uint32_t q = tid + 256u * i;
+            const uint32_t r = q / 10u, cc = q - r * 10u;
+            const int32_t m = m0 + (int32_t)r;
+            if (m < p.M) {
+                const int32_t b = m / HpWp, qq = m - b * HpWp;
+                const int32_t yy = qq / p.Wp, xx = qq - yy * p.Wp;
+                const bool border = (yy == 0) | (yy == p.Hp - 1) | (xx == 0) | (xx == p.Wp - 1);
+                uint4 o = make_uint4(0, 0, 0, 0);
+                const int64_t col = n0 + (int32_t)(half * 80u + cc * 8u);
+                if (!border) {
+                    const uint2 lo = *reinterpret_cast<const uint2*>(lds + r * CW_OUT_STRIDE + cc * 16u);
+                    const uint2 hi = *reinterpret_cast<const uint2*>(lds + r * CW_OUT_STRIDE + cc * 16u + 8u);
+                    uint32_t w4[4] = {lo.x, lo.y, hi.x, hi.y};
+                    if (rowbias || resid) {
+                        uint4 rb = make_uint4(0, 0, 0, 0), rs = make_uint4(0, 0, 0, 0);
+                        if (rowbias) rb = *reinterpret_cast<const uint4*>(rowbias + (int64_t)b * p.N + col);
+                        if (resid) rs = *reinterpret_cast<const uint4*>(resid + (int64_t)m * p.N + col);
+                        const uint32_t rbw[4] = {rb.x, rb.y, rb.z, rb.w}, rsw[4] = {rs.x, rs.y, rs.z, rs.w};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float a0 = Mfma<T>::up((uint16_t)w4[k]) + Mfma<T>::up((uint16_t)rbw[k]) + Mfma<T>::up((uint16_t)rsw[k]);
+                            const float a1 = Mfma<T>::up((uint16_t)(w4[k] >> 16)) + Mfma<T>::up((uint16_t)(rbw[k] >> 16)) + Mfma<T>::up((uint16_t)(rsw[k] >> 16));
+                            w4[k] = (uint32_t)Mfma<T>::cvt(a0) | ((uint32_t)Mfma<T>::cvt(a1) << 16);
+                        }
+                    }
+                    o = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+                }
+                *reinterpret_cast<uint4*>(Y + (int64_t)m * p.N + col) = o;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // GroupNorm (+SiLU) on PF activations.  Channels of a group are NOT contiguous across pixels in NHWC, so the statistics
 // are a two-kernel reduction: (1) every workgroup walks a slab of padded pixels with (C/8) x P threads -- thread = one
 // 16-byte channel vector of one pixel lane, fully coalesced rows -- and reduces per-channel partial sums into 32 group
@@ -677,6 +852,7 @@ __global__ __launch_bounds__(256) void gsw_add_layernorm_kernel(const uint16_t* 
 
 // host ---------------------------------------------------------------------------------------------
 static thread_local int g_conv_hip_error = 0;
+#define GSW_CONV_HIP(call) do { hipError_t _e = (call); if (_e != hipSuccess) { g_conv_hip_error = (int)_e; return GSW_ERR_HIP; } } while (0)
 static int launch_conv_gemm(ConvArgs& a, int64_t M, int N, int dtype, void* stream);
 
 int gsw_conv_pf(const void* x_dev, const void* w_dev, const void* bias_dev, const void* rowbias_dev, const void* resid_dev, void* y_dev,
@@ -710,7 +886,28 @@ static int launch_conv_gemm(ConvArgs& a, int64_t M, int N, int dtype, void* stre
     static const int wm_env = getenv("GSW_CONV_WM") ? atoi(getenv("GSW_CONV_WM")) : 2;
     hipStream_t st = (hipStream_t)stream;
     if (N % CW_BN == 0 && !narrow_only) {
-        if (a.dense) {
+        static const bool no_halo = getenv("GSW_CONV_NOHALO") != nullptr;
+        const int32_t HP = ((a.Wp + 1) + 7) & ~7;
+        static const int wdb_env = getenv("GSW_CONV_WDB") ? atoi(getenv("GSW_CONV_WDB")) : 1;
+        const size_t halo_lds = (size_t)(CW_BM + 2 * HP) * 128u + (size_t)CW_BN * 128u * (wdb_env ? 2u : 1u);
+        if (!a.dense && a.ntaps == 9 && a.stride == 1 && !no_halo && halo_lds <= 80u * 1024u) {
+            const uint32_t grid = (uint32_t)(((M + 127) / 128) * (N / CW_BN));
+            if (wdb_env) {
+                if (halo_lds > 48u * 1024u) {
+                    GSW_CONV_HIP(hipFuncSetAttribute((const void*)gsw_conv3x3_halo_kernel<_Float16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+                    GSW_CONV_HIP(hipFuncSetAttribute((const void*)gsw_conv3x3_halo_kernel<__bf16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+                }
+                if (dtype == GSW_F16) hipLaunchKernelGGL((gsw_conv3x3_halo_kernel<_Float16, true>), dim3(grid), dim3(256), halo_lds, st, a, HP);
+                else hipLaunchKernelGGL((gsw_conv3x3_halo_kernel<__bf16, true>), dim3(grid), dim3(256), halo_lds, st, a, HP);
+            } else {
+                if (halo_lds > 48u * 1024u) {
+                    GSW_CONV_HIP(hipFuncSetAttribute((const void*)gsw_conv3x3_halo_kernel<_Float16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+                    GSW_CONV_HIP(hipFuncSetAttribute((const void*)gsw_conv3x3_halo_kernel<__bf16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+                }
+                if (dtype == GSW_F16) hipLaunchKernelGGL((gsw_conv3x3_halo_kernel<_Float16, false>), dim3(grid), dim3(256), halo_lds, st, a, HP);
+                else hipLaunchKernelGGL((gsw_conv3x3_halo_kernel<__bf16, false>), dim3(grid), dim3(256), halo_lds, st, a, HP);
+            }
+        } else if (a.dense) {
             const uint32_t grid = (uint32_t)(((M + 127) / 128) * (N / CW_BN));
             if (dtype == GSW_F16) hipLaunchKernelGGL((gsw_conv_gemm_wide_kernel<_Float16, 2, false, true>), dim3(grid), dim3(256), 0, st, a);
             else hipLaunchKernelGGL((gsw_conv_gemm_wide_kernel<__bf16, 2, false, true>), dim3(grid), dim3(256), 0, st, a);
