@@ -50,6 +50,10 @@ struct ConvArgs {
     int32_t dense;        // 1: plain GEMM on a dense [M, C] matrix (no border rows, no row map)
     int32_t geglu;        // 1: every 160-wide N tile holds [80 value | 80 gate] columns; the epilogue writes value * gelu(gate)
     int32_t ldy;          // row stride of y in elements (N, or N/2 with geglu)
+    // halo kernel only: up to two extra 1x1 operand segments appended to the K loop (the resnet's conv_shortcut folded in,
+    // its concatenated input given as two tensors): K = 9*C + C1 + C2, weights [N][9*C | C1 | C2]
+    const void* x1; const void* x2;
+    int32_t C1, C2;
 };
 
 template <typename T> struct Mfma;
@@ -490,11 +494,11 @@ __global__ __launch_bounds__(128 * WM, WM == 4 ? 4 : 1) void gsw_conv_gemm_wide_
 // ------------------------------------------------------------------------------------------------
 // WDB: two weight stages -- tap t+1's weights stream in while tap t is multiplied (one barrier per tap instead of two)
 template <typename T, bool WDB>
-__global__ __launch_bounds__(256) void gsw_conv3x3_halo_kernel(ConvArgs p, int32_t HP) {
+__global__ __launch_bounds__(256, 2) void gsw_conv3x3_halo_kernel(ConvArgs p, int32_t HP) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int32_t xrows = CW_BM + 2 * HP;
-    uint8_t* ldsX = lds;
-    uint8_t* ldsW = lds + (uint32_t)xrows * 128u;
+    uint8_t* ldsX = lds;                                                    // halo tile, or two plain 128-row stages (1x1 segments)
+    uint8_t* ldsW = lds + (uint32_t)max(xrows, 2 * CW_BM) * 128u;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t wm = wave & 1u, wn = wave >> 1;
     const uint32_t nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7u;
@@ -504,7 +508,7 @@ __global__ __launch_bounds__(256) void gsw_conv3x3_halo_kernel(ConvArgs p, int32
     const uint32_t tile_n = logical % ntn, tile_m = logical / ntn;
     const int32_t m0 = (int32_t)tile_m * CW_BM, n0 = (int32_t)tile_n * CW_BN;
     const int32_t HpWp = p.Hp * p.Wp;
-    const int32_t Ktot = 9 * p.C;
+    const int32_t Ktot = 9 * p.C + (p.x1 ? p.C1 : 0) + (p.x2 ? p.C2 : 0);
     const T* X = reinterpret_cast<const T*>(p.x);
     const T* W = reinterpret_cast<const T*>(p.w);
     const uint32_t pc = lane & 7u;
@@ -530,21 +534,20 @@ __global__ __launch_bounds__(256) void gsw_conv3x3_halo_kernel(ConvArgs p, int32
     for (int im = 0; im < 4; ++im) lrow[im] = HP + (int32_t)(wm * 64u + (uint32_t)im * 16u + (lane & 15u));
 
     const int32_t kc_blocks = p.C / CV_BK;
-    auto stage_x = [&](int32_t kc) {       // halo'd activation tile of one channel block (once for all 9 taps)
+    auto stage_x = [&](const T* Xs, int32_t ld, int32_t kc) {   // halo'd activation tile of one channel block (once for all 9 taps)
         for (int32_t i = 0; i < nxi_wave; ++i) {
             const int32_t j = (int32_t)wave * nxi_wave + i;
             if (j < nxi) {
                 const int32_t r = j * 8 + (int32_t)(lane >> 3);                 // LDS row
                 int32_t src = m0 - HP + r;                                      // PF row; rows outside the guards are never used
                 src = src < -G ? -G : (src > p.M + G - 1 ? p.M + G - 1 : src);
-                const T* sp = X + ((int64_t)src * p.ldx + kc * CV_BK + (int32_t)((pc ^ (((uint32_t)r >> 1) & 7u)) * 8u));
+                const T* sp = Xs + ((int64_t)src * ld + kc * CV_BK + (int32_t)((pc ^ (((uint32_t)r >> 1) & 7u)) * 8u));
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sp,
                                                  (__attribute__((address_space(3))) void*)(ldsX + (uint32_t)j * 1024u), 16, 0, 0);
             }
         }
     };
-    auto stage_w = [&](int32_t kc, int32_t t, uint8_t* wbuf) {
-        const int32_t woff = t * p.C + kc * CV_BK;
+    auto stage_w = [&](int32_t woff, uint8_t* wbuf) {
 #pragma unroll
         for (int i = 0; i < 5; ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W + ((int64_t)w_off[i] + woff)),
@@ -571,25 +574,91 @@ __global__ __launch_bounds__(256) void gsw_conv3x3_halo_kernel(ConvArgs p, int32
         }
     };
     for (int32_t kc = 0; kc < kc_blocks; ++kc) {
-        stage_x(kc);
+        stage_x(X, p.ldx, kc);
         if (WDB) {
-            stage_w(kc, 0, ldsW);
+            stage_w(kc * CV_BK, ldsW);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             for (int32_t t = 0; t < 9; ++t) {
                 uint8_t* cur = ldsW + (uint32_t)(t & 1) * (CW_BN * 128u);
-                if (t < 8) stage_w(kc, t + 1, ldsW + (uint32_t)((t + 1) & 1) * (CW_BN * 128u));
+                if (t < 8) stage_w((t + 1) * p.C + kc * CV_BK, ldsW + (uint32_t)((t + 1) & 1) * (CW_BN * 128u));
                 compute(t, cur);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();      // next weights landed; everyone is done with `cur` (and, after tap 8, with the halo tile)
             }
         } else {
             for (int32_t t = 0; t < 9; ++t) {
-                stage_w(kc, t, ldsW);
+                stage_w(t * p.C + kc * CV_BK, ldsW);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
                 compute(t, ldsW);
                 __syncthreads();
+            }
+        }
+    }
+    // extra 1x1 segments (conv_shortcut folded in, its concatenated input read as two tensors): K blocks at weight offset
+    // 9*C (+C1).  No halo needed: the activation area holds two plain 128-row stages, so both operands are double-buffered.
+    {
+        const int32_t n1 = (p.x1 && p.C1 > 0) ? p.C1 / CV_BK : 0;
+        const int32_t n2 = (p.x2 && p.C2 > 0) ? p.C2 / CV_BK : 0;
+        const int32_t nsteps = n1 + n2;
+        auto stage_seg = [&](int32_t step, uint32_t sel) {
+            const bool second = step >= n1;
+            const T* Xs = reinterpret_cast<const T*>(second ? p.x2 : p.x1);
+            const int32_t ld = second ? p.C2 : p.C1;
+            const int32_t kc = second ? step - n1 : step;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {                       // 16 instructions x 8 rows = the 128 tile rows
+                const uint32_t j = wave * 4u + i;
+                const uint32_t r = j * 8u + (lane >> 3);
+                int32_t src = m0 + (int32_t)r;
+                src = src > p.M + G - 1 ? p.M + G - 1 : src;
+                const T* sp = Xs + ((int64_t)src * ld + kc * CV_BK + (int32_t)((pc ^ ((r >> 1) & 7u)) * 8u));
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sp,
+                                                 (__attribute__((address_space(3))) void*)(ldsX + sel * (CW_BM * 128u) + j * 1024u), 16, 0, 0);
+            }
+            stage_w(9 * p.C + (second ? p.C1 : 0) + kc * CV_BK, ldsW + sel * (CW_BN * 128u));
+        };
+        auto compute_seg = [&](uint32_t sel) {
+            const uint8_t* xb = ldsX + sel * (CW_BM * 128u);
+            const uint8_t* wb = ldsW + sel * (CW_BN * 128u);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const uint32_t lc = (uint32_t)ks * 4u + (lane >> 4);
+                typename Mfma<T>::frag xf[4];
+#pragma unroll
+                for (int im = 0; im < 4; ++im) {
+                    const uint32_t r = wm * 64u + (uint32_t)im * 16u + (lane & 15u);
+                    xf[im] = *reinterpret_cast<const typename Mfma<T>::frag*>(xb + r * 128u + ((lc ^ ((r >> 1) & 7u)) << 4));
+                }
+#pragma unroll
+                for (int in = 0; in < 5; ++in) {
+                    const uint32_t r = wn * 80u + (uint32_t)in * 16u + (lane & 15u);
+                    const typename Mfma<T>::frag wf = *reinterpret_cast<const typename Mfma<T>::frag*>(wb + r * 128u + ((lc ^ ((r >> 1) & 7u)) << 4));
+#pragma unroll
+                    for (int im = 0; im < 4; ++im) acc[in][im] = Mfma16<T>::mma(wf, xf[im], acc[in][im]);
+                }
+            }
+        };
+        if (nsteps > 0) {
+            if (WDB) {
+                stage_seg(0, 0u);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                for (int32_t i = 0; i < nsteps; ++i) {
+                    if (i + 1 < nsteps) stage_seg(i + 1, (uint32_t)((i + 1) & 1));
+                    compute_seg((uint32_t)(i & 1));
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                }
+            } else {
+                for (int32_t i = 0; i < nsteps; ++i) {
+                    stage_seg(i, 0u);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                    compute_seg(0u);
+                    __syncthreads();
+                }
             }
         }
     }
@@ -678,7 +747,9 @@ __device__ __forceinline__ uint16_t cvt_h(float f, bool bf) {
     return __half_as_ushort(__float2half_rn(f));
 }
 
-__global__ __launch_bounds__(512) void gsw_gn_pf_stats_kernel(const uint16_t* __restrict__ x, float* __restrict__ partial, int32_t C, int32_t G,
+// x2 != null: the normalised tensor is the channel concatenation [x (Ca channels) | x2 (C - Ca channels)] read in place
+__global__ __launch_bounds__(512) void gsw_gn_pf_stats_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ x2, int32_t Ca,
+                                                             float* __restrict__ partial, int32_t C, int32_t G,
                                                              int32_t HpWp, int32_t slab_len, int32_t P, int bf) {
     __shared__ float s_sum[GN_MAX_GROUPS], s_sq[GN_MAX_GROUPS];
     const int32_t b = blockIdx.y, s = blockIdx.x, nslab = gridDim.x;
@@ -688,10 +759,12 @@ __global__ __launch_bounds__(512) void gsw_gn_pf_stats_kernel(const uint16_t* __
     __syncthreads();
     float sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const int32_t i0 = s * slab_len, i1 = min(HpWp, i0 + slab_len);
-    const uint16_t* base = x + ((int64_t)b * HpWp) * C + cvec * 8;
+    const bool second = x2 && cvec * 8 >= Ca;
+    const int32_t ld = x2 ? (second ? C - Ca : Ca) : C;
+    const uint16_t* base = (second ? x2 + (cvec * 8 - Ca) : x + cvec * 8) + ((int64_t)b * HpWp) * ld;
     for (int32_t i = i0 + prow; i < i1; i += P) {
         float v[8];
-        ld8h(base + (int64_t)i * C, v, bf);
+        ld8h(base + (int64_t)i * ld, v, bf);
 #pragma unroll
         for (int k = 0; k < 8; ++k) { sum[k] += v[k]; sq[k] = fmaf(v[k], v[k], sq[k]); }
     }
@@ -709,7 +782,8 @@ __global__ __launch_bounds__(512) void gsw_gn_pf_stats_kernel(const uint16_t* __
     }
 }
 
-__global__ __launch_bounds__(512) void gsw_gn_pf_apply_kernel(const uint16_t* __restrict__ x, const float* __restrict__ partial, const uint16_t* __restrict__ gamma,
+__global__ __launch_bounds__(512) void gsw_gn_pf_apply_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ x2, int32_t Ca,
+                                                             const float* __restrict__ partial, const uint16_t* __restrict__ gamma,
                                                              const uint16_t* __restrict__ beta, uint16_t* __restrict__ y, int32_t C, int32_t G, int32_t Hp, int32_t Wp,
                                                              int32_t nslab_stats, int32_t slab_len, int32_t P, float eps, int act, int tokens, int bf) {
     __shared__ float s_mean[GN_MAX_GROUPS], s_rstd[GN_MAX_GROUPS];
@@ -742,14 +816,16 @@ __global__ __launch_bounds__(512) void gsw_gn_pf_apply_kernel(const uint16_t* __
         }
     }
     const int32_t i0 = s * slab_len, i1 = min(HpWp, i0 + slab_len);
-    const uint16_t* base = x + ((int64_t)b * HpWp) * C + cvec * 8;
+    const bool second = x2 && cvec * 8 >= Ca;
+    const int32_t ld = x2 ? (second ? C - Ca : Ca) : C;
+    const uint16_t* base = (second ? x2 + (cvec * 8 - Ca) : x + cvec * 8) + ((int64_t)b * HpWp) * ld;
     for (int32_t i = i0 + prow; i < i1; i += P) {
         const int32_t yy = i / Wp, xx = i - yy * Wp;
         const bool border = (yy == 0) | (yy == Hp - 1) | (xx == 0) | (xx == Wp - 1);
         uint4 o = make_uint4(0, 0, 0, 0);
         if (!border) {
             float v[8];
-            ld8h(base + (int64_t)i * C, v, bf);
+            ld8h(base + (int64_t)i * ld, v, bf);
             uint16_t h[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -878,6 +954,7 @@ int gsw_conv_pf(const void* x_dev, const void* w_dev, const void* bias_dev, cons
                 a.tap_off[kh * 3 + kw] = stride == 1 ? (kh - 1) * a.in_Wp + (kw - 1) : kh * a.in_Wp + kw;
     }
     a.dense = 0; a.geglu = 0; a.ldy = N;
+    a.x1 = nullptr; a.x2 = nullptr; a.C1 = 0; a.C2 = 0;
     return launch_conv_gemm(a, M, N, dtype, stream);
 }
 
@@ -889,7 +966,7 @@ static int launch_conv_gemm(ConvArgs& a, int64_t M, int N, int dtype, void* stre
         static const bool no_halo = getenv("GSW_CONV_NOHALO") != nullptr;
         const int32_t HP = ((a.Wp + 1) + 7) & ~7;
         static const int wdb_env = getenv("GSW_CONV_WDB") ? atoi(getenv("GSW_CONV_WDB")) : 1;
-        const size_t halo_lds = (size_t)(CW_BM + 2 * HP) * 128u + (size_t)CW_BN * 128u * (wdb_env ? 2u : 1u);
+        const size_t halo_lds = (size_t)std::max(CW_BM + 2 * HP, 2 * CW_BM) * 128u + (size_t)CW_BN * 128u * (wdb_env ? 2u : 1u);
         if (!a.dense && a.ntaps == 9 && a.stride == 1 && !no_halo && halo_lds <= 80u * 1024u) {
             const uint32_t grid = (uint32_t)(((M + 127) / 128) * (N / CW_BN));
             if (wdb_env) {
@@ -930,8 +1007,10 @@ static int launch_conv_gemm(ConvArgs& a, int64_t M, int N, int dtype, void* stre
     return GSW_OK;
 }
 
-int gsw_groupnorm_pf(const void* x_dev, const void* gamma_dev, const void* beta_dev, void* out_dev, float* workspace_dev, int B, int H, int W,
-                     int C, int groups, float eps, int act, int out_tokens, int dtype, void* stream) {
+int gsw_groupnorm_pf2(const void* x_dev, const void* x2_dev, int Ca, const void* gamma_dev, const void* beta_dev, void* out_dev, float* workspace_dev,
+                      int B, int H, int W, int C, int groups, float eps, int act, int out_tokens, int dtype, void* stream) {
+    // x2_dev != NULL: GroupNorm over the channel concatenation [x (Ca) | x2 (C - Ca)] without materialising it
+    if (x2_dev && (Ca <= 0 || Ca >= C || (Ca & 7))) return GSW_ERR_BAD_ARG;
     // workspace_dev: >= B * 64 * groups * 2 floats
     if (!x_dev || !gamma_dev || !beta_dev || !out_dev || !workspace_dev || B <= 0 || H <= 0 || W <= 0 || C <= 0 || groups <= 0) return GSW_ERR_BAD_ARG;
     if ((C & 7) || C % groups || groups > GN_MAX_GROUPS || (C >> 3) > 512) return GSW_ERR_UNSUPPORTED;
@@ -946,12 +1025,17 @@ int gsw_groupnorm_pf(const void* x_dev, const void* gamma_dev, const void* beta_
     nslab = (HpWp + slab_len - 1) / slab_len;
     hipStream_t st = (hipStream_t)stream;
     const int bf = dtype == GSW_BF16;
-    hipLaunchKernelGGL(gsw_gn_pf_stats_kernel, dim3(nslab, B), dim3(threads), 0, st, (const uint16_t*)x_dev, workspace_dev, C, groups, HpWp, slab_len, P, bf);
-    hipLaunchKernelGGL(gsw_gn_pf_apply_kernel, dim3(nslab, B), dim3(threads), 0, st, (const uint16_t*)x_dev, (const float*)workspace_dev, (const uint16_t*)gamma_dev,
+    hipLaunchKernelGGL(gsw_gn_pf_stats_kernel, dim3(nslab, B), dim3(threads), 0, st, (const uint16_t*)x_dev, (const uint16_t*)x2_dev, Ca, workspace_dev, C, groups, HpWp, slab_len, P, bf);
+    hipLaunchKernelGGL(gsw_gn_pf_apply_kernel, dim3(nslab, B), dim3(threads), 0, st, (const uint16_t*)x_dev, (const uint16_t*)x2_dev, Ca, (const float*)workspace_dev, (const uint16_t*)gamma_dev,
                        (const uint16_t*)beta_dev, (uint16_t*)out_dev, C, groups, H + 2, W + 2, nslab, slab_len, P, eps, act, out_tokens, bf);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g_conv_hip_error = (int)e; return GSW_ERR_HIP; }
     return GSW_OK;
+}
+
+int gsw_groupnorm_pf(const void* x_dev, const void* gamma_dev, const void* beta_dev, void* out_dev, float* workspace_dev, int B, int H, int W,
+                     int C, int groups, float eps, int act, int out_tokens, int dtype, void* stream) {
+    return gsw_groupnorm_pf2(x_dev, nullptr, 0, gamma_dev, beta_dev, out_dev, workspace_dev, B, H, W, C, groups, eps, act, out_tokens, dtype, stream);
 }
 
 int gsw_add_layernorm(const void* x_dev, const void* delta_dev, const void* gamma_dev, const void* beta_dev, void* xnew_dev, void* y_dev,
@@ -981,5 +1065,39 @@ int gsw_linear(const void* x_dev, const void* w_dev, const void* bias_dev, const
     a.ntaps = 1;
     for (int i = 0; i < 9; ++i) a.tap_off[i] = 0;
     a.dense = 1; a.geglu = geglu ? 1 : 0; a.ldy = geglu ? N / 2 : N;
+    a.x1 = nullptr; a.x2 = nullptr; a.C1 = 0; a.C2 = 0;
     return launch_conv_gemm(a, M, N, dtype, stream);
+}
+
+int gsw_conv3x3_res_pf(const void* x_dev, const void* w_dev, const void* bias_dev, const void* rowbias_dev, const void* resid_dev, void* y_dev,
+                       int B, int H, int W, int C, int N, const void* x1_dev, int C1, const void* x2_dev, int C2, int dtype, void* stream) {
+    // 3x3 stride-1 convolution of x plus 1x1 convolutions of x1 (C1 channels) and x2 (C2 channels) in ONE GEMM:
+    // w_dev = [N][9*C + C1 + C2].  The resnet's conv2 + conv_shortcut(cat(x1, x2)) + residual in a single kernel.
+    if (!x_dev || !w_dev || !y_dev || B <= 0 || H <= 0 || W <= 0 || C <= 0 || N <= 0) return GSW_ERR_BAD_ARG;
+    if ((x1_dev && C1 <= 0) || (x2_dev && (C2 <= 0 || !x1_dev))) return GSW_ERR_BAD_ARG;
+    if (C % CV_BK || N % CW_BN || (x1_dev && C1 % CV_BK) || (x2_dev && C2 % CV_BK)) return GSW_ERR_UNSUPPORTED;
+    if (dtype != GSW_F16 && dtype != GSW_BF16) return GSW_ERR_BAD_ARG;
+    ConvArgs a;
+    a.x = x_dev; a.w = w_dev; a.bias = bias_dev; a.rowbias = rowbias_dev; a.resid = resid_dev; a.y = y_dev;
+    a.C = C; a.N = N; a.Hp = H + 2; a.Wp = W + 2; a.stride = 1; a.ldx = C; a.in_Hp = a.Hp; a.in_Wp = a.Wp;
+    const int64_t M = (int64_t)B * a.Hp * a.Wp;
+    const int64_t cmax = std::max<int64_t>(C, std::max(C1, C2));
+    if (M > 0x7FFFFF00 || (M + 2 * a.Wp) * cmax >= ((int64_t)1 << 31) || (int64_t)N * (9 * (int64_t)C + C1 + C2) >= ((int64_t)1 << 31)) return GSW_ERR_UNSUPPORTED;
+    a.M = (int32_t)M; a.ntaps = 9;
+    for (int kh = 0; kh < 3; ++kh)
+        for (int kw = 0; kw < 3; ++kw) a.tap_off[kh * 3 + kw] = (kh - 1) * a.Wp + (kw - 1);
+    a.dense = 0; a.geglu = 0; a.ldy = N;
+    a.x1 = x1_dev; a.x2 = x2_dev; a.C1 = x1_dev ? C1 : 0; a.C2 = x2_dev ? C2 : 0;
+    const int32_t HP = ((a.Wp + 1) + 7) & ~7;
+    const size_t halo_lds = (size_t)std::max(CW_BM + 2 * HP, 2 * CW_BM) * 128u + (size_t)CW_BN * 128u * 2u;
+    if (halo_lds > 80u * 1024u) return GSW_ERR_UNSUPPORTED;
+    const uint32_t grid = (uint32_t)(((M + 127) / 128) * (N / CW_BN));
+    if (halo_lds > 48u * 1024u) {
+        GSW_CONV_HIP(hipFuncSetAttribute((const void*)gsw_conv3x3_halo_kernel<_Float16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        GSW_CONV_HIP(hipFuncSetAttribute((const void*)gsw_conv3x3_halo_kernel<__bf16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    }
+    if (dtype == GSW_F16) hipLaunchKernelGGL((gsw_conv3x3_halo_kernel<_Float16, true>), dim3(grid), dim3(256), halo_lds, (hipStream_t)stream, a, HP);
+    else hipLaunchKernelGGL((gsw_conv3x3_halo_kernel<__bf16, true>), dim3(grid), dim3(256), halo_lds, (hipStream_t)stream, a, HP);
+    GSW_CONV_HIP(hipGetLastError());
+    return GSW_OK;
 }

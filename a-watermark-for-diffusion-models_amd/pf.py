@@ -141,3 +141,39 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], *, re
                                    resid.data_ptr() if resid is not None else None, out.data_ptr(), M, K, Nn, 1 if geglu else 0,
                                    _dt(x.dtype), _stream_ptr()))
     return out
+
+
+def groupnorm_pf2(x: PF, x2: Optional[PF], gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float, *, act: bool = True) -> PF:
+    """act(GroupNorm(cat([x, x2], channels))) -> one PF tensor, without materialising the concatenation."""
+    if x2 is None:
+        return groupnorm_pf(x, gamma, beta, groups, eps, act=act)
+    dev = x.buf.device
+    C = x.C + x2.C
+    ws = _gn_workspace(dev, x.B, groups)
+    y = PF.empty(x.B, x.H, x.W, C, x.buf.dtype, dev)
+    with torch.cuda.device(dev):
+        N.check(N.lib().gsw_groupnorm_pf2(x.rows.data_ptr(), x2.rows.data_ptr(), x.C, gamma.data_ptr(), beta.data_ptr(), y.rows.data_ptr(),
+                                          ws.data_ptr(), x.B, x.H, x.W, C, groups, eps, 1 if act else 0, 0, _dt(x.buf.dtype), _stream_ptr()))
+    return y
+
+
+def conv3x3_res_fusable(x: PF, n_out: int) -> bool:
+    """The fused conv2 + shortcut kernel needs N % 160 == 0, C % 64 == 0 and a halo tile that fits LDS."""
+    hp = ((x.W + 3) + 7) & ~7
+    return n_out % 160 == 0 and x.C % 64 == 0 and max(128 + 2 * hp, 256) * 128 + 2 * 160 * 128 <= 80 * 1024
+
+
+def conv3x3_res_pf(x: PF, w_cat: torch.Tensor, bias: Optional[torch.Tensor], *, rowbias: Optional[torch.Tensor] = None,
+                   resid: Optional[PF] = None, x1: Optional[PF] = None, x2: Optional[PF] = None) -> PF:
+    """y = conv3x3(x) + conv1x1(cat([x1, x2])) + bias (+ rowbias + resid) in one GEMM; w_cat = [N, 9*C | C1 | C2]."""
+    Nn = w_cat.shape[0]
+    y = PF.empty(x.B, x.H, x.W, Nn, x.buf.dtype, x.buf.device)
+    with torch.cuda.device(x.buf.device):
+        N.check(N.lib().gsw_conv3x3_res_pf(x.rows.data_ptr(), w_cat.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                           rowbias.data_ptr() if rowbias is not None else None,
+                                           resid.rows.data_ptr() if resid is not None else None, y.rows.data_ptr(),
+                                           x.B, x.H, x.W, x.C, Nn,
+                                           x1.rows.data_ptr() if x1 is not None else None, x1.C if x1 is not None else 0,
+                                           x2.rows.data_ptr() if x2 is not None else None, x2.C if x2 is not None else 0,
+                                           _dt(x.buf.dtype), _stream_ptr()))
+    return y

@@ -114,11 +114,28 @@ class ResnetBlock2D(nn.Module):
         h = self.conv2(gn_act(h, self.norm2, pre_bias=self.time_emb_proj(temb_act)))     # temb add folded into the norm kernel
         return (x if self.conv_shortcut is None else self.conv_shortcut(x)) + h
 
-    def forward_pf(self, x, temb_act):
-        from .pf import conv_pf
-        h = conv_pf(_gn_pf(x, self.norm1), _pw(self.conv1), self.conv1.bias, rowbias=self.time_emb_proj(temb_act).contiguous())
-        sc = x if self.conv_shortcut is None else conv_pf(x, _pw(self.conv_shortcut), self.conv_shortcut.bias, ksize=1)
-        return conv_pf(_gn_pf(h, self.norm2), _pw(self.conv2), self.conv2.bias, resid=sc)    # residual add in the GEMM epilogue
+    def forward_pf(self, x, temb_act, x2=None):
+        """x2: optional second PF tensor -- the block's input is the channel concatenation [x | x2] (a skip connection), which is
+        never materialised: GroupNorm and the shortcut read both tensors in place."""
+        from .pf import PF, conv_pf, conv3x3_res_pf, conv3x3_res_fusable, groupnorm_pf2
+        cout = self.conv2.out_channels
+        fuse = self.conv_shortcut is not None and conv3x3_res_fusable(x, cout) and (x2 is None or x2.C % 64 == 0)
+        if x2 is not None and not fuse:
+            x, x2 = PF(torch.cat([x.buf, x2.buf], dim=1), x.B, x.H, x.W, x.C + x2.C), None
+        n1 = groupnorm_pf2(x, x2, self.norm1.weight, self.norm1.bias, self.norm1.num_groups, self.norm1.eps, act=True)
+        h = conv_pf(n1, _pw(self.conv1), self.conv1.bias, rowbias=self.time_emb_proj(temb_act).contiguous())
+        h = _gn_pf(h, self.norm2)
+        if self.conv_shortcut is None:
+            return conv_pf(h, _pw(self.conv2), self.conv2.bias, resid=x)                 # residual add in the GEMM epilogue
+        if not fuse:
+            sc = conv_pf(x, _pw(self.conv_shortcut), self.conv_shortcut.bias, ksize=1)
+            return conv_pf(h, _pw(self.conv2), self.conv2.bias, resid=sc)
+        c = getattr(self, "_gsw_res", None)                                              # [N, 9*C | C_shortcut], summed biases
+        if c is None or c[0].device != h.buf.device or c[0].dtype != h.buf.dtype:
+            w = torch.cat([_pw(self.conv2), self.conv_shortcut.weight.detach()[:, :, 0, 0]], dim=1).contiguous()
+            c = (w, (self.conv2.bias.detach() + self.conv_shortcut.bias.detach()).contiguous())
+            self._gsw_res = c
+        return conv3x3_res_pf(h, c[0], c[1], x1=x, x2=x2)                                # conv2 + conv_shortcut in one GEMM
 
 
 class Attention(nn.Module):
@@ -306,8 +323,7 @@ class UpBlock(nn.Module):
     def forward_pf(self, x, temb, ctx, skips):
         from .pf import PF
         for i, r in enumerate(self.resnets):
-            sk = skips.pop()
-            x = r.forward_pf(PF(torch.cat([x.buf, sk.buf], dim=1), x.B, x.H, x.W, x.C + sk.C), temb)
+            x = r.forward_pf(x, temb, x2=skips.pop())
             if self.attentions is not None:
                 x = self.attentions[i].forward_pf(x, ctx)
         if self.upsamplers is not None:

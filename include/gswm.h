@@ -141,6 +141,16 @@ int gsw_conv_pf(const void* x_dev, const void* w_dev, const void* bias_dev, cons
 int gsw_groupnorm_pf(const void* x_dev, const void* gamma_dev, const void* beta_dev, void* out_dev, float* workspace_dev, int B, int H, int W,
                      int C, int groups, float eps, int act, int out_tokens, int dtype, void* stream);
 
+/* Same with two sources: GroupNorm over the channel concatenation [x (Ca channels) | x2 (C - Ca channels)] read in place (the UNet's
+ * skip connections are never materialised as a torch.cat). */
+int gsw_groupnorm_pf2(const void* x_dev, const void* x2_dev, int Ca, const void* gamma_dev, const void* beta_dev, void* out_dev, float* workspace_dev,
+                      int B, int H, int W, int C, int groups, float eps, int act, int out_tokens, int dtype, void* stream);
+
+/* ResnetBlock2D tail in ONE GEMM: y = conv3x3(x) + conv1x1([x1 | x2]) + bias + rowbias + resid on PF tensors.
+ * w_dev: [N][9*C + C1 + C2] (3x3 taps first, then the shortcut's columns), x1 / x2 optional (x2 requires x1). */
+int gsw_conv3x3_res_pf(const void* x_dev, const void* w_dev, const void* bias_dev, const void* rowbias_dev, const void* resid_dev, void* y_dev,
+                       int B, int H, int W, int C, int N, const void* x1_dev, int C1, const void* x2_dev, int C2, int dtype, void* stream);
+
 /* Transformer blocks of the eps model: xnew = x + delta (skipped when delta_dev is NULL), y = LayerNorm(xnew) * gamma + beta;
  * x, delta, xnew, y: [rows, C]; C % 8 == 0, C <= 1536; GSW_F16 / GSW_BF16. */
 int gsw_add_layernorm(const void* x_dev, const void* delta_dev, const void* gamma_dev, const void* beta_dev, void* xnew_dev, void* y_dev,

@@ -82,9 +82,47 @@ def test_linear_vs_torch_fp32(G, dtype, M, K, N):
     assert (yg.float() - refg).abs().max().item() <= 2 * tol * max(1.0, refg.abs().max().item())
 
 
-def test_unet_pf_path_equals_torch_path(G):
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("B,C,N,C1,C2,H,W", [(2, 64, 160, 64, 0, 8, 8), (2, 128, 320, 64, 128, 10, 6), (1, 320, 320, 640, 320, 16, 16), (2, 64, 160, 0, 0, 6, 8)])
+def test_conv3x3_res_and_dual_groupnorm_vs_torch_fp32(G, dtype, B, C, N, C1, C2, H, W):
+    g = torch.Generator().manual_seed(C + N + C1 + C2)
+    rnd = lambda *s: torch.randn(*s, generator=g)
+    x = rnd(B, C, H, W).to(dtype).cuda()
+    w3 = (rnd(N, C, 3, 3) * (1.0 / (9 * C)) ** 0.5).to(dtype).cuda()
+    b = rnd(N).to(dtype).cuda()
+    rb = rnd(B, N).to(dtype).cuda()
+    ref = F.conv2d(x.float(), w3.float(), b.float(), padding=1) + rb.float()[:, :, None, None]
+    wcat = [G.pf.pack_conv_weight(w3)]
+    x1 = x2 = None
+    if C1:
+        x1 = rnd(B, C1, H, W).to(dtype).cuda()
+        xs = x1
+        if C2:
+            x2 = rnd(B, C2, H, W).to(dtype).cuda()
+            xs = torch.cat([x1, x2], dim=1)
+        w1 = (rnd(N, C1 + C2) * (1.0 / (C1 + C2)) ** 0.5).to(dtype).cuda()
+        wcat.append(w1)
+        ref = ref + F.conv2d(xs.float(), w1.float()[:, :, None, None])
+    P = G.pf.PF.from_nchw
+    y = G.pf.conv3x3_res_pf(P(x), torch.cat(wcat, dim=1).contiguous(), b, rowbias=rb, x1=P(x1) if C1 else None, x2=P(x2) if C2 else None)
+    tol = 2e-3 if dtype == torch.float16 else 1.6e-2
+    assert (y.to_nchw().float() - ref).abs().max().item() <= tol * ref.abs().max().item()
+    assert y.grid[:, 0].abs().max() == 0 and y.grid[:, :, -1].abs().max() == 0
+    if C1 and C2 and (C1 + C2) % 32 == 0:       # dual-source GroupNorm == GroupNorm of the concatenation
+        gamma = (1 + 0.2 * rnd(C1 + C2)).to(dtype).cuda()
+        beta = (0.2 * rnd(C1 + C2)).to(dtype).cuda()
+        refn = F.silu(F.group_norm(torch.cat([x1, x2], 1).float(), 32, gamma.float(), beta.float(), 1e-5))
+        yn = G.pf.groupnorm_pf2(P(x1), P(x2), gamma, beta, 32, 1e-5, act=True)
+        tn = 4e-3 if dtype == torch.float16 else 3e-2
+        assert (yn.to_nchw().float() - refn).abs().max().item() <= tn * max(1.0, refn.abs().max().item())
+
+
+@pytest.mark.parametrize("chs,heads", [((64, 128, 128, 128), (2, 4, 4, 4)), ((320, 640, 640, 640), (10, 20, 20, 20))])
+def test_unet_pf_path_equals_torch_path(G, chs, heads):
+    """(320, 640, ...) exercises the fused conv2 + shortcut + skip-concat kernel and the dual-source GroupNorm (N % 160 == 0);
+    (64, 128, ...) the fallback that materialises the concatenation."""
     U = G.unet
-    m = U.synthetic_init_(U.UNet2DCondition(block_out_channels=(64, 128, 128, 128), cross_attention_dim=64, num_heads=(2, 4, 4, 4), head_dim=32), 0)
+    m = U.synthetic_init_(U.UNet2DCondition(block_out_channels=chs, cross_attention_dim=64, num_heads=heads, head_dim=32), 0)
     m = m.cuda().half().eval()
     g = torch.Generator().manual_seed(0)
     x = torch.randn(3, 4, 32, 32, generator=g).cuda().half()
