@@ -16,6 +16,8 @@ GSW_OK, GSW_ERR_BAD_ARG, GSW_ERR_UNSUPPORTED, GSW_ERR_RAGGED, GSW_ERR_HIP = 0, 1
 GSW_EMBED_EXACT_F64, GSW_EMBED_FAST_F32 = 0, 1
 GSW_FLAG_SATURATED, GSW_FLAG_NAN = 1, 2
 GSW_MSG_INLINE_MAX = 256
+GSW_IMG_U8_HWC, GSW_IMG_F16_CHW, GSW_IMG_F32_CHW = 0, 1, 2
+GSW_PW_BRIGHTNESS, GSW_PW_CONTRAST, GSW_PW_INVERT, GSW_PW_GRAY, GSW_PW_HFLIP, GSW_PW_VFLIP, GSW_PW_NOISE = range(7)
 
 _u8p = C.POINTER(C.c_uint8)
 _PROTOTYPES = {
@@ -48,6 +50,15 @@ _PROTOTYPES = {
                                     C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "gsw_conv3x3_res_pf": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "gsw_lanczos_plan": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
+    "gsw_resize_lanczos": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "gsw_tensor_to_image": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "gsw_jpeg_quant_tables": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p]),
+    "gsw_jpeg_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "gsw_jpeg_roundtrip": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "gsw_image_pointwise": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_uint64, C.c_void_p, C.c_int,
+                                      C.c_void_p, C.c_void_p]),
     "gsw_linear": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
                              C.c_void_p]),
 }

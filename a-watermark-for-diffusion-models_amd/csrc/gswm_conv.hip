@@ -927,7 +927,8 @@ __global__ __launch_bounds__(256) void gsw_add_layernorm_kernel(const uint16_t* 
 }
 
 // host ---------------------------------------------------------------------------------------------
-static thread_local int g_conv_hip_error = 0;
+extern __attribute__((visibility("hidden"))) thread_local int g_last_hip_error;   // gswm_kernels.hip; read by gsw_last_hip_error()
+#define g_conv_hip_error g_last_hip_error
 #define GSW_CONV_HIP(call) do { hipError_t _e = (call); if (_e != hipSuccess) { g_conv_hip_error = (int)_e; return GSW_ERR_HIP; } } while (0)
 static int launch_conv_gemm(ConvArgs& a, int64_t M, int N, int dtype, void* stream);
 

@@ -1100,7 +1100,7 @@ __global__ __launch_bounds__(256) void gsw_geglu_kernel(const T* __restrict__ in
 // ================================================================================================
 // host side of the C ABI
 // ================================================================================================
-static thread_local int g_last_hip_error = 0;
+__attribute__((visibility("hidden"))) thread_local int g_last_hip_error = 0;   // shared with gswm_conv.hip / gswm_image.hip
 
 static inline int hip_fail(hipError_t e) {
     g_last_hip_error = (int)e;

@@ -70,6 +70,54 @@ class PF:
         return self.interior.reshape(self.B, self.H * self.W, self.C)
 
 
+class ConvTimer:
+    """HIP events around every convolution launch, on the stream the kernel is launched on (torch's current stream), bucketed
+    by the kernel libgswm picks for the shape.  bench.py installs one as `pf.CONV_TIMER` for its timed region."""
+
+    def __init__(self):
+        self.ev = []
+
+    def start(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def stop(self, e0, kernel: str, flops: float):
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        self.ev.append((kernel, flops, e0, e1))
+
+    def summary(self):
+        out = {}
+        for k, f, a, b in self.ev:
+            d = out.setdefault(k, {"calls": 0, "flops": 0.0, "ms": 0.0})
+            d["calls"] += 1
+            d["flops"] += f
+            d["ms"] += a.elapsed_time(b)
+        for d in out.values():
+            d["avg_us"] = d["ms"] * 1e3 / d["calls"]
+            d["flops_per_launch"] = d["flops"] / d["calls"]
+            d["tflops"] = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] else 0.0
+        return out
+
+
+CONV_TIMER: Optional[ConvTimer] = None
+
+
+def _halo_lds_bytes(W: int) -> int:
+    hp = ((W + 3) + 7) & ~7
+    return max(128 + 2 * hp, 256) * 128 + 2 * 160 * 128
+
+
+def _conv_kernel_name(W: int, n_out: int, ksize: int, stride: int) -> str:
+    """Which kernel launch_conv_gemm (csrc/gswm_conv.hip) selects -- for the timer's buckets only."""
+    if n_out % 160:
+        return "gsw_conv_gemm_kernel"
+    if ksize == 3 and stride == 1 and _halo_lds_bytes(W) <= 80 * 1024:
+        return "gsw_conv3x3_halo_kernel"
+    return "gsw_conv_gemm_wide_kernel"
+
+
 def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
     """[N, C, kh, kw] -> [N, kh*kw*C] (tap-major, channel-minor), the K order of the PF GEMM."""
     return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
@@ -83,11 +131,15 @@ def conv_pf(x: PF, w_packed: torch.Tensor, bias: Optional[torch.Tensor], *, ksiz
     Ho, Wo = x.H // stride, x.W // stride
     y = PF.empty(x.B, Ho, Wo, Nn, x.buf.dtype, x.buf.device)
     xp = x.rows.data_ptr() + cin_offset * x.buf.element_size()
+    tm = CONV_TIMER
     with torch.cuda.device(x.buf.device):
+        e0 = tm.start() if tm is not None else None
         N.check(N.lib().gsw_conv_pf(xp, w_packed.data_ptr(), bias.data_ptr() if bias is not None else None,
                                     rowbias.data_ptr() if rowbias is not None else None,
                                     resid.rows.data_ptr() if resid is not None else None, y.rows.data_ptr(),
                                     x.B, Ho, Wo, C, Nn, ksize, stride, x.C, _dt(x.buf.dtype), _stream_ptr()))
+        if tm is not None:
+            tm.stop(e0, _conv_kernel_name(Wo, Nn, ksize, stride), 2.0 * x.B * Ho * Wo * Nn * ksize * ksize * C)
     return y
 
 
@@ -159,8 +211,7 @@ def groupnorm_pf2(x: PF, x2: Optional[PF], gamma: torch.Tensor, beta: torch.Tens
 
 def conv3x3_res_fusable(x: PF, n_out: int) -> bool:
     """The fused conv2 + shortcut kernel needs N % 160 == 0, C % 64 == 0 and a halo tile that fits LDS."""
-    hp = ((x.W + 3) + 7) & ~7
-    return n_out % 160 == 0 and x.C % 64 == 0 and max(128 + 2 * hp, 256) * 128 + 2 * 160 * 128 <= 80 * 1024
+    return n_out % 160 == 0 and x.C % 64 == 0 and _halo_lds_bytes(x.W) <= 80 * 1024
 
 
 def conv3x3_res_pf(x: PF, w_cat: torch.Tensor, bias: Optional[torch.Tensor], *, rowbias: Optional[torch.Tensor] = None,
@@ -168,7 +219,9 @@ def conv3x3_res_pf(x: PF, w_cat: torch.Tensor, bias: Optional[torch.Tensor], *, 
     """y = conv3x3(x) + conv1x1(cat([x1, x2])) + bias (+ rowbias + resid) in one GEMM; w_cat = [N, 9*C | C1 | C2]."""
     Nn = w_cat.shape[0]
     y = PF.empty(x.B, x.H, x.W, Nn, x.buf.dtype, x.buf.device)
+    tm = CONV_TIMER
     with torch.cuda.device(x.buf.device):
+        e0 = tm.start() if tm is not None else None
         N.check(N.lib().gsw_conv3x3_res_pf(x.rows.data_ptr(), w_cat.data_ptr(), bias.data_ptr() if bias is not None else None,
                                            rowbias.data_ptr() if rowbias is not None else None,
                                            resid.rows.data_ptr() if resid is not None else None, y.rows.data_ptr(),
@@ -176,4 +229,7 @@ def conv3x3_res_pf(x: PF, w_cat: torch.Tensor, bias: Optional[torch.Tensor], *, 
                                            x1.rows.data_ptr() if x1 is not None else None, x1.C if x1 is not None else 0,
                                            x2.rows.data_ptr() if x2 is not None else None, x2.C if x2 is not None else 0,
                                            _dt(x.buf.dtype), _stream_ptr()))
+        if tm is not None:
+            k = 9 * x.C + (x1.C if x1 is not None else 0) + (x2.C if x2 is not None else 0)
+            tm.stop(e0, "gsw_conv3x3_halo_kernel", 2.0 * x.B * x.H * x.W * Nn * k)
     return y

@@ -163,6 +163,58 @@ int gsw_add_layernorm(const void* x_dev, const void* delta_dev, const void* gamm
 int gsw_linear(const void* x_dev, const void* w_dev, const void* bias_dev, const void* resid_dev, void* y_dev, int64_t M, int K, int N,
                int geglu, int dtype, void* stream);
 
+/* =====================================================================================================================
+ * Image-side stages either side of the latent loops.  Images are uint8 [B, H, W, 3]
+ * (what np.asarray(PIL image) gives); every function restates, bit for bit, what Pillow / libjpeg compute for the call the
+ * reference makes.
+ * ===================================================================================================================== */
+typedef enum gsw_image_mode {
+    GSW_IMG_U8_HWC = 0,  /* uint8 [B, H, W, 3]: a PIL image                                                           */
+    GSW_IMG_F16_CHW = 1, /* fp16 [B, 3, H, W] = fp16(2 * fp16(v / 255) - 1): extract.py:37,48,40 (ToTensor -> .to(float16)
+                            -> img_to_latents' 2.*x - 1.), i.e. exactly what the VAE encoder is fed                     */
+    GSW_IMG_F32_CHW = 2  /* fp32 [B, 3, H, W] = v / 255: torchvision ToTensor (extract.py:37)                          */
+} gsw_image_mode;
+
+/* extract.py:35-36 / distortions:229-230 `pil_img.resize(size, Image.Resampling.LANCZOS)`: Pillow's Resample.c
+ * precompute_coeffs + normalize_coeffs_8bpc (double precision, host libm) for one axis.  Fills bounds[out_size*2] (first source
+ * index, count) and kk[out_size*ksize] (22-bit fixed point); returns ksize > 0, or -gsw_status.  bounds == kk == NULL: returns
+ * ksize only.  Pure host function (a "plan": upload both arrays once per (in_size, out_size)). */
+int gsw_lanczos_plan(int in_size, int out_size, int32_t* bounds, int32_t* kk, int kk_capacity);
+
+/* The two resampling passes of ImagingResample on device (horizontal first, uint8 in between; a pass whose size is unchanged is
+ * skipped like Pillow does), with the conversion to `out_mode` fused into the last pass.  tmp_dev: [B, Hin, Wout, 3] uint8 scratch,
+ * needed when a horizontal pass is followed by anything (may be NULL otherwise).  *_dev plan arrays: gsw_lanczos_plan output for
+ * (Win -> Wout) and (Hin -> Hout); NULL for a skipped pass. */
+int gsw_resize_lanczos(const uint8_t* in_dev, int B, int Hin, int Win, void* out_dev, int Hout, int Wout, int out_mode, uint8_t* tmp_dev,
+                       const int32_t* hbounds_dev, const int32_t* hkk_dev, int hksize, const int32_t* vbounds_dev, const int32_t* vkk_dev,
+                       int vksize, void* stream);
+
+/* `decode_image` tail + diffusers numpy_to_pil (modified_stable_diffusion_gs.pyc src :207-220): [B, 3, H, W] float tensor ->
+ * uint8 [B, H, W, 3] = (x * 255).round(); denormalise != 0 first applies (x / 2 + 0.5).clamp(0, 1) in the tensor's dtype. */
+int gsw_tensor_to_image(const void* in_dev, int dtype, int B, int H, int W, int denormalise, uint8_t* out_dev, void* stream);
+
+/* distortions:175-184 "compression": `image.save(buf, format="JPEG", quality=q)` then `Image.open(buf)`, minus the (lossless)
+ * entropy coding: RGB -> YCbCr 4:2:0, islow FDCT, IJG quality-scaled tables (force_baseline), dequantise, islow IDCT, fancy h2v2
+ * upsampling, YCbCr -> RGB.  workspace_dev: gsw_jpeg_workspace_bytes(B, H, W) bytes. */
+int gsw_jpeg_quant_tables(int quality, uint8_t luma[64], uint8_t chroma[64]);
+size_t gsw_jpeg_workspace_bytes(int B, int H, int W);
+int gsw_jpeg_roundtrip(const uint8_t* rgb_dev, int B, int H, int W, int quality, void* out_dev, int out_mode, uint8_t* workspace_dev,
+                       void* stream);
+
+/* Point-wise attacks of distortions:131-224. */
+typedef enum gsw_pointwise_op {
+    GSW_PW_BRIGHTNESS = 0, /* ImageEnhance.Brightness(image).enhance(strength)  (distortions:131-139)                  */
+    GSW_PW_CONTRAST = 1,   /* ImageEnhance.Contrast(image).enhance(strength)    (distortions:141-148); workspace: [B] uint64 */
+    GSW_PW_INVERT = 2,     /* F.invert                                          (distortions:222-223)                  */
+    GSW_PW_GRAY = 3,       /* F.rgb_to_grayscale, replicated to 3 channels      (distortions:201-202)                  */
+    GSW_PW_HFLIP = 4,      /* F.hflip                                           (distortions:203-204)                  */
+    GSW_PW_VFLIP = 5,      /* F.vflip                                           (distortions:205-206)                  */
+    GSW_PW_NOISE = 6       /* (x + strength * N(0,1)).clamp(0,1); Philox keyed by (seed; pixel, image_index0 + b) -- the
+                              reference draws torch.randn on the host (distortions:166-173): statistical parity only      */
+} gsw_pointwise_op;
+int gsw_image_pointwise(const uint8_t* rgb_dev, int B, int H, int W, int op, float strength, uint64_t seed, uint64_t image_index0,
+                        void* out_dev, int out_mode, uint64_t* workspace_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
