@@ -11,6 +11,7 @@ from __future__ import annotations
 import os
 from typing import Optional, Sequence, Tuple
 
+import numpy as np
 import torch
 
 from . import _native as N
@@ -119,6 +120,33 @@ def philox_uniform(seed: int, image_index0: int, batch: int, n_elems: int, devic
     out = torch.empty((batch, n_elems), dtype=torch.float64, device=device)
     with torch.cuda.device(out.device):
         N.check(N.lib().gsw_philox_uniform(seed & (2**64 - 1), image_index0, out.data_ptr(), batch, n_elems, _stream_ptr()))
+    return out
+
+
+def mt19937_seed(seed: int) -> np.ndarray:
+    """NumPy's legacy integer seeding (RandomState(seed) / np.random.seed(seed)): the 624 key words; pos starts at 624."""
+    if not 0 <= int(seed) <= 0xFFFFFFFF:
+        raise ValueError("Seed must be between 0 and 2**32 - 1")
+    key = np.empty(624, dtype=np.uint32)
+    N.lib().gsw_mt19937_seed(int(seed), key.ctypes.data)
+    return key
+
+
+def mt19937_uniform(n: int, rng=None, *, device="cuda") -> torch.Tensor:
+    """n draws of `rng.uniform(0, 1)` (== legacy `random_sample`) generated ON THE DEVICE from the generator's current state:
+    returns float64 [n] on the device and advances `rng` (a np.random.RandomState, or None for NumPy's global generator) exactly as
+    the n host draws would -- gs_insert.py:62 / nodes.py:114-117 without shipping the uniforms over PCIe."""
+    target = np.random if rng is None else rng
+    state = target.get_state()
+    if state[0] != "MT19937":
+        raise ValueError("only the legacy MT19937 generator is supported")
+    key = np.ascontiguousarray(state[1], dtype=np.uint32)
+    out = torch.empty(int(n), dtype=torch.float64, device=device)
+    st = torch.empty(625, dtype=torch.int32, device=device)
+    with torch.cuda.device(out.device):
+        N.check(N.lib().gsw_mt19937_uniform(key.ctypes.data, int(state[2]), out.data_ptr(), int(n), st.data_ptr(), _stream_ptr()))
+    new = st.cpu().numpy().view(np.uint32)
+    target.set_state(("MT19937", new[:624].copy(), int(new[624]), state[3], state[4]))
     return out
 
 

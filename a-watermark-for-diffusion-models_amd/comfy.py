@@ -22,8 +22,8 @@ def gs_watermark_init_noise(key_hex, nonce_hex, device, message, use_seed, rando
     bits = message_length if message_length != -1 else choose_watermark_length(n)      # :61-66
     k = codec.pad_message(message, bits // 8)                                           # :68-76
     key, nonce = codec.resolve_key_nonce(key_hex, nonce_hex)                            # :90-99
-    rng = np.random.RandomState(seed=randomSeed) if int(use_seed) == 1 else np.random
-    u = torch.from_numpy(rng.uniform(0, 1, n)).to(compute_device).view(1, -1)
+    rng = np.random.RandomState(seed=randomSeed) if int(use_seed) == 1 else None
+    u = codec.mt19937_uniform(n, rng, device=compute_device).view(1, -1)           # :114-117, drawn on the device
     z = codec.embed_batch(key, nonce, k, 1, (4, h, w), u=u, dtype=torch.float32, device=compute_device)
     if log_path:
         _write_info(log_path, key, nonce, k, extra=(f"randomSeed: {randomSeed}", f"height: {height}", f"width: {width}",

@@ -1100,6 +1100,83 @@ __global__ __launch_bounds__(256) void gsw_geglu_kernel(const T* __restrict__ in
 // ================================================================================================
 // host side of the C ABI
 // ================================================================================================
+// ---------------------------------------------------------------------------------------------------------------------------
+// E4 in bit-parity mode -- gs_insert.py:62 `np.random.uniform(0, 1)` (nodes.py:114-117 `rng.uniform(0, 1)`): NumPy's legacy MT19937
+// `random_sample`, continued on the device from a host-supplied generator state so that the uniforms never cross PCIe.
+// MT19937 is one serial stream (the reference draws image after image from ONE generator), so this is a single workgroup: the
+// 624-word twist runs as three data-parallel phases (k < 227 | k < 454 | k < 624: each phase only reads words the previous
+// phases finished), tempering and the 53-bit double (a >> 5, b >> 6) are element-parallel.  Throughput mode uses Philox instead.
+// ---------------------------------------------------------------------------------------------------------------------------
+struct Mt19937State { uint32_t key[624]; };
+
+__device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+}
+
+__global__ __launch_bounds__(256) void gsw_mt19937_kernel(Mt19937State st, int32_t pos, double* __restrict__ out, int64_t n, uint32_t* __restrict__ state_out) {
+    __shared__ uint32_t mt[624];
+    const int tid = threadIdx.x;
+    {
+        typedef const uint32_t __attribute__((address_space(4))) * kernarg_words;       // the state is kernel argument 0
+        kernarg_words ka = (kernarg_words)__builtin_amdgcn_kernarg_segment_ptr();
+        for (int i = tid; i < 624; i += 256) mt[i] = ka[i];
+    }
+    __syncthreads();
+    int64_t o = 0;              // doubles written so far
+    int wpos = pos;             // next unconsumed word of the current block (624 = block exhausted)
+    bool has_carry = false;     // an unpaired high word is waiting for the first word of the next block
+    uint32_t carry = 0;
+    while (o < n) {
+        if (wpos >= 624) {
+            // genrand twist, in place: new[k] = old_or_new[(k + 397) % 624] ^ f(old[k], old[(k + 1) % 624])
+            for (int ph = 0; ph < 3; ++ph) {
+                const int lo = ph * 227, hi = ph == 2 ? 624 : lo + 227;
+                const int k = lo + tid;
+                uint32_t v = 0;
+                if (k < hi) {
+                    const int kn = k == 623 ? 0 : k + 1, km = k + 397 >= 624 ? k + 397 - 624 : k + 397;
+                    const uint32_t y = (mt[k] & 0x80000000u) | (mt[kn] & 0x7fffffffu);
+                    v = mt[km] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+                }
+                __syncthreads();
+                if (k < hi) mt[k] = v;
+                __syncthreads();
+            }
+            wpos = 0;
+        }
+        int first = wpos;       // first word of the first (a, b) pair taken wholly from this block
+        if (has_carry) {
+            if (tid == 0) out[o] = ((double)(carry >> 5) * 67108864.0 + (double)(mt_temper(mt[0]) >> 6)) / 9007199254740992.0;
+            o += 1;
+            first = 1;
+            has_carry = false;
+        }
+        const int64_t want = n - o;
+        const int pairs_avail = (624 - first) >> 1;
+        const int pairs = (int)(want < (int64_t)pairs_avail ? want : (int64_t)pairs_avail);
+        for (int i = tid; i < pairs; i += 256) {
+            const uint32_t a = mt_temper(mt[first + 2 * i]) >> 5, b = mt_temper(mt[first + 2 * i + 1]) >> 6;
+            out[o + i] = ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+        }
+        o += pairs;
+        wpos = first + 2 * pairs;
+        if (o < n && wpos == 623) {          // odd leftover and more to draw: its partner is word 0 of the next block
+            carry = mt_temper(mt[623]);
+            has_carry = true;
+            wpos = 624;
+        }
+        __syncthreads();
+    }
+    if (state_out) {
+        for (int i = tid; i < 624; i += 256) state_out[i] = mt[i];
+        if (tid == 0) state_out[624] = (uint32_t)wpos;
+    }
+}
+
 __attribute__((visibility("hidden"))) thread_local int g_last_hip_error = 0;   // shared with gswm_conv.hip / gswm_image.hip
 
 static inline int hip_fail(hipError_t e) {
@@ -1257,6 +1334,24 @@ int gsw_philox_uniform(uint64_t seed, uint64_t image_index0, double* u_dev, int 
     const uint32_t ngroups = (uint32_t)((n_elems + 3) / 4);
     const dim3 grid(std::min<uint32_t>((ngroups + GSW_WG - 1) / GSW_WG, 1024u), (uint32_t)std::min<int>(B, 65535));
     hipLaunchKernelGGL(gsw_philox_uniform_kernel, grid, dim3(GSW_WG), 0, (hipStream_t)stream, u_dev, seed, image_index0, B, (uint32_t)n_elems);
+    GSW_HIP(hipGetLastError());
+    return GSW_OK;
+}
+
+void gsw_mt19937_seed(uint32_t seed, uint32_t key[624]) {
+    // numpy/random/src/mt19937/mt19937.c mt19937_seed: what RandomState(seed=int) / np.random.seed(int) run; pos starts at 624
+    for (int pos = 0; pos < 624; ++pos) {
+        key[pos] = seed;
+        seed = 1812433253u * (seed ^ (seed >> 30)) + (uint32_t)pos + 1u;
+    }
+}
+
+int gsw_mt19937_uniform(const uint32_t key[624], int pos, double* u_dev, int64_t n, uint32_t* state_out_dev, void* stream) {
+    if (!key || !u_dev || n < 0 || pos < 0 || pos > 624) return GSW_ERR_BAD_ARG;
+    if (n == 0 && !state_out_dev) return GSW_OK;
+    Mt19937State st;
+    memcpy(st.key, key, sizeof(st.key));
+    hipLaunchKernelGGL(gsw_mt19937_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, st, (int32_t)pos, u_dev, n, state_out_dev);
     GSW_HIP(hipGetLastError());
     return GSW_OK;
 }

@@ -154,6 +154,29 @@ def load_image(imgname, target_size=None) -> torch.Tensor:
     return torch.from_numpy(a.copy()).permute(2, 0, 1).float().div_(255.0)[None]
 
 
+def load_images_device(image_paths, target_size=None, *, device="cuda", out="f16") -> torch.Tensor:
+    """Batch form of load_image + the `.to(float16)` / `2.*x - 1.` that follow it (extract.py:31-37,48,40), resized and normalised on
+    the device (imaging.resize_lanczos, bit-identical to the PIL / torchvision chain).  File decoding stays on the host; images of
+    one call must share a size (they do in the reference's use: all outputs of one generation run)."""
+    from PIL import Image
+    from . import imaging
+    arrs = [np.asarray(Image.open(p).convert("RGB"), dtype=np.uint8) for p in image_paths]
+    if isinstance(target_size, int):
+        target_size = (target_size, target_size)
+    groups = {}
+    for i, a in enumerate(arrs):
+        groups.setdefault(a.shape, []).append(i)
+    outs = [None] * len(arrs)
+    for shape, idx in groups.items():
+        dev = torch.from_numpy(np.stack([arrs[i] for i in idx])).to(device)
+        res = imaging.resize_lanczos(dev, None if target_size is None else tuple(target_size), out=out)
+        for j, i in enumerate(idx):
+            outs[i] = res[j]
+    if len({tuple(o.shape) for o in outs}) != 1:
+        raise ValueError("images of one batch must have one size after resizing (pass target_size)")
+    return torch.stack(outs)
+
+
 def img_to_latents(x: torch.Tensor, vae):
     """extract.py:39-43."""
     from . import vae as V
@@ -176,8 +199,12 @@ def exactract_latents_batch(image_paths, args, *, device="cuda") -> torch.Tensor
     from .ddim import ddim_invert, dpms_invert, DPMSolverInverseSchedule
     models = load_models(args.model_id, device)
     sched = _scheduler_steps(args, models)
-    imgs = torch.cat([load_image(p, [args.width, args.height]) for p in image_paths]).to(models.device, models.dtype)
-    latents = img_to_latents(imgs, models.vae)
+    from . import vae as V
+    if models.dtype == torch.float16:
+        xn = load_images_device(image_paths, [args.width, args.height], device=models.device, out="f16")      # = 2 * fp16(ToTensor) - 1
+    else:
+        xn = 2.0 * load_images_device(image_paths, [args.width, args.height], device=models.device, out="f32").to(models.dtype) - 1.0
+    latents = V.normalised_img_to_latents(xn, models.vae)
     ctx = models.ctx_empty.expand(latents.shape[0], -1, -1)
     if isinstance(sched, DPMSolverInverseSchedule):
         return dpms_invert(models.unet, latents, ctx, sched)

@@ -31,12 +31,12 @@ def gs_watermark_init_noise(opt, message="", *, log_path="info_data.txt", device
 
     Returns a float64 ndarray (4, 64, 64).  The uniforms are drawn from the GLOBAL numpy RNG exactly like the reference
     (`np.random.uniform(0, 1)` per element == `np.random.uniform(0, 1, N)`), so seeding numpy reproduces the reference's
-    output; ChaCha20, bit expansion and norm.ppf run on the GPU (Cephes ndtri in fp64).
+    output (and leaves the global generator where the reference leaves it); the MT19937 draws, ChaCha20, bit expansion and
+    norm.ppf all run on the GPU (Cephes ndtri in fp64).
     """
     k = codec.pad_message(message, 32)                                  # :9-20
     key, nonce = codec.resolve_key_nonce(opt.key_hex, opt.nonce_hex)    # :27-42
-    u = np.random.uniform(0, 1, 4 * 64 * 64)                            # :62 (same stream as 16384 scalar draws)
-    u_dev = torch.from_numpy(u).to(device)
+    u_dev = codec.mt19937_uniform(4 * 64 * 64, device=device)           # :62: the 16384 np.random.uniform(0, 1) draws, made on the device
     z = codec.embed_batch(key, nonce, k, 1, (4, 64, 64), u=u_dev.view(1, -1), dtype=torch.float64, device=device)
     out = z[0].cpu().numpy()
     if log_path:
@@ -56,7 +56,7 @@ def gs_watermark_init_noise_batch(opt, message="", n_samples=1, *, dtype=torch.f
     key, nonce = codec.resolve_key_nonce(opt.key_hex, opt.nonce_hex)
     u_dev = None
     if seed is None:
-        u_dev = torch.from_numpy(np.random.uniform(0, 1, n_samples * 16384)).to(device).view(n_samples, -1)
+        u_dev = codec.mt19937_uniform(n_samples * 16384, device=device).view(n_samples, -1)
     z = codec.embed_batch(key, nonce, k, n_samples, (4, 64, 64), u=u_dev, seed=seed or 0, image_index0=image_index0,
                           dtype=dtype, fast=fast, device=device)
     if log_path:

@@ -75,8 +75,16 @@ def encode_images(images: torch.Tensor, vae) -> torch.Tensor:
 
 
 def jpeg_roundtrip(images: torch.Tensor, quality: int = 10) -> torch.Tensor:
-    """JPEG distortion as the reference's `distortions` tool applies it (distortions:175-184: PIL save(quality=QF) / reload);
-    host-side PIL, one image at a time -- a GPU DCT stage is future work."""
+    """JPEG distortion as the reference's `distortions` tool applies it (distortions:175-184: PIL save(quality=QF) / reload) on a
+    [B,3,H,W] tensor in [0,1]: quantise to uint8 like numpy_to_pil, run the libjpeg-exact lossy stages on the device
+    (imaging.jpeg_roundtrip), return ToTensor values in the input dtype."""
+    from . import imaging
+    u8 = imaging.tensor_to_image(images)
+    return imaging.jpeg_roundtrip(u8, quality, out="f32").to(images.dtype)
+
+
+def jpeg_roundtrip_pil(images: torch.Tensor, quality: int = 10) -> torch.Tensor:
+    """The same through host-side PIL, one image at a time (what the reference does); kept as the checker for the device path."""
     import io
     import numpy as np
     from PIL import Image

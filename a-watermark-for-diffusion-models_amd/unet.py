@@ -141,6 +141,8 @@ class ResnetBlock2D(nn.Module):
 class Attention(nn.Module):
     def __init__(self, dim, ctx_dim, heads, head_dim):
         super().__init__()
+        if head_dim is None:                     # SD 1.x: a fixed NUMBER of heads (8), head_dim = dim / heads (40 / 80 / 160)
+            head_dim = dim // heads
         inner = heads * head_dim
         self.heads = heads
         self.to_q = nn.Linear(dim, inner, bias=False)
@@ -345,7 +347,14 @@ class MidBlock(nn.Module):
 
 
 class UNet2DCondition(nn.Module):
-    """SD 2.1-base shape by default (865.9 M parameters)."""
+    """SD 2.1-base shape by default (865.9 M parameters); `UNet2DCondition.sd15()` gives the SD 1.5 shape of BASELINE config 5."""
+
+    @classmethod
+    def sd15(cls) -> "UNet2DCondition":
+        """runwayml/stable-diffusion-v1-5 `unet/config.json`: 8 heads everywhere (head_dim 40/80/160/160), cross_attention_dim 768.
+        Its proj_in / proj_out are 1x1 convolutions, numerically the linear layers used here (load_diffusers_state_dict squeezes
+        the [C, C, 1, 1] weights)."""
+        return cls(cross_attention_dim=768, num_heads=(8, 8, 8, 8), head_dim=None)
 
     def __init__(self, in_channels=4, out_channels=4, block_out_channels: Sequence[int] = (320, 640, 1280, 1280), layers_per_block=2,
                  cross_attention_dim=1024, num_heads: Sequence[int] = (5, 10, 20, 20), head_dim=64,
@@ -479,17 +488,23 @@ def load_diffusers_state_dict(model: nn.Module, weight_dir: str) -> nn.Module:
             path = os.path.join(weight_dir, cand)
             break
     sd = load_file(path)
+    own = dict(model.named_parameters())
+    for k, v in list(sd.items()):               # SD 1.x: proj_in / proj_out stored as 1x1 convolutions
+        if k in own and v.dim() == 4 and own[k].dim() == 2 and v.shape[2:] == (1, 1):
+            sd[k] = v[:, :, 0, 0]
     missing, unexpected = model.load_state_dict(sd, strict=False)
     if missing or unexpected:
         raise RuntimeError(f"state dict mismatch: missing {missing[:5]}..., unexpected {unexpected[:5]}...")
     return model
 
 
-def count_flops_per_image(model: nn.Module, h: int = 64, w: int = 64, ctx_len: int = 77, ctx_dim: int = 1024) -> int:
+def count_flops_per_image(model: nn.Module, h: int = 64, w: int = 64, ctx_len: int = 77, ctx_dim: Optional[int] = None) -> int:
     """Forward FLOPs for one image (2 x MACs of conv / linear / attention), via torch's FlopCounterMode on meta tensors."""
     from torch.utils.flop_counter import FlopCounterMode
     import copy
     m = copy.deepcopy(model).to("meta")
+    if ctx_dim is None:
+        ctx_dim = next(mod for n, mod in m.named_modules() if n.endswith("attn2")).to_k.in_features
     dt = next(m.parameters()).dtype
     x = torch.empty(1, 4, h, w, device="meta", dtype=dt)
     t = torch.empty(1, device="meta")

@@ -161,6 +161,12 @@ def img_to_latents(x: torch.Tensor, vae: AutoencoderKL) -> torch.Tensor:
 
 
 @torch.no_grad()
+def normalised_img_to_latents(xn: torch.Tensor, vae: AutoencoderKL) -> torch.Tensor:
+    """img_to_latents for an input that already is 2x-1 (imaging.resize_lanczos / jpeg_roundtrip with out='f16' fuse it)."""
+    return (vae.encode_mean(xn) * SCALING_FACTOR).contiguous()
+
+
+@torch.no_grad()
 def latents_to_img(latents: torch.Tensor, vae: AutoencoderKL) -> torch.Tensor:
     """`decode_image` + `torch_to_numpy` prefix of the bytecode pipelines: vae.decode(latents / 0.18215) -> (x/2+0.5).clamp(0,1)."""
     return (vae.decode(latents / SCALING_FACTOR) / 2 + 0.5).clamp(0, 1)

@@ -163,6 +163,14 @@ int gsw_add_layernorm(const void* x_dev, const void* delta_dev, const void* gamm
 int gsw_linear(const void* x_dev, const void* w_dev, const void* bias_dev, const void* resid_dev, void* y_dev, int64_t M, int K, int N,
                int geglu, int dtype, void* stream);
 
+/* E4, bit-parity mode -- gs_insert.py:62 `np.random.uniform(0, 1)` / nodes.py:52-53,114-117 `RandomState(seed).uniform(0, 1)`:
+ * NumPy's legacy MT19937 `random_sample` stream continued on the device.  key/pos: the generator state as
+ * np.random.get_state()[1:3] gives it (pos == 624: block exhausted).  Writes n float64 uniforms to u_dev and, when
+ * state_out_dev != NULL, the advanced state ([624] key words + [1] pos) so that the host generator can be moved past the draws.
+ * gsw_mt19937_seed: NumPy's legacy integer seeding (init_genrand); use pos = 624 with it. */
+void gsw_mt19937_seed(uint32_t seed, uint32_t key[624]);
+int gsw_mt19937_uniform(const uint32_t key[624], int pos, double* u_dev, int64_t n, uint32_t* state_out_dev, void* stream);
+
 /* =====================================================================================================================
  * Image-side stages either side of the latent loops.  Images are uint8 [B, H, W, 3]
  * (what np.asarray(PIL image) gives); every function restates, bit for bit, what Pillow / libjpeg compute for the call the

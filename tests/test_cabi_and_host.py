@@ -147,3 +147,15 @@ def test_shard_range_and_param_packing():
     assert gdist.broadcast_params(p) == p                                       # no process group: identity
     with pytest.raises(ValueError):
         gdist.pack_params(dict(p, message=b"x" * 5000))
+
+
+@pytest.mark.parametrize("seed", [0, 1, 42, 2**32 - 1])
+def test_mt19937_seed_equals_numpy_legacy_seeding(seed):
+    """gsw_mt19937_seed (pure host) == the key np.random.RandomState(seed) starts from (nodes.py:52-53)."""
+    import numpy as np
+    import gswm_amd
+    from gswm_amd import codec
+    st = np.random.RandomState(seed).get_state()
+    assert st[2] == 624 and np.array_equal(codec.mt19937_seed(seed), st[1])
+    with pytest.raises(ValueError):
+        codec.mt19937_seed(2**32)

@@ -407,3 +407,41 @@ def test_roundtrip_lossless_full_size(G, keys, B, shape, ml, fast, dtype):
     # oracle spot check on two images of the big batch
     for b in (0, B - 1):
         assert O.recover_bits(z[b].float().cpu().numpy(), key, nonce, ml) == "".join(format(x, "08b") for x in k)
+
+
+@pytest.mark.parametrize("n,skip_words", [(1, 0), (311, 0), (312, 0), (313, 0), (16384, 0), (16384, 1), (5000, 3), (36864, 0), (3 * 16384 + 7, 1)])
+def test_mt19937_device_stream_equals_numpy(n, skip_words):
+    """E4 bit-parity mode: the device continues NumPy's legacy MT19937 exactly (values AND the generator state it leaves),
+    from even and odd word positions (a 4-byte `bytes()` draw moves the position by one word)."""
+    import gswm_amd
+    from gswm_amd import codec
+    a, b = np.random.RandomState(1234), np.random.RandomState(1234)
+    for r in (a, b):
+        r.uniform(0, 1, 100)
+        for _ in range(skip_words):
+            r.bytes(4)
+    ref = a.uniform(0, 1, n)
+    got = codec.mt19937_uniform(n, b).cpu().numpy()
+    assert np.array_equal(got, ref)
+    sa, sb = a.get_state(), b.get_state()
+    assert sa[2] == sb[2] and np.array_equal(sa[1], sb[1])
+    assert np.array_equal(a.uniform(0, 1, 700), b.uniform(0, 1, 700))          # and the host generator carries on identically
+
+
+def test_mt19937_global_generator_and_twin_parity():
+    """gs_watermark_init_noise draws from the GLOBAL numpy generator like gs_insert.py:62 and leaves it where the reference does."""
+    import types
+    import gswm_amd
+    from gswm_amd import codec, gs_insert
+    np.random.seed(7)
+    ref_u = np.random.uniform(0, 1, 16384)
+    ref_next = np.random.uniform(0, 1, 5)
+    np.random.seed(7)
+    got_u = codec.mt19937_uniform(16384).cpu().numpy()
+    assert np.array_equal(got_u, ref_u) and np.array_equal(np.random.uniform(0, 1, 5), ref_next)
+    opt = types.SimpleNamespace(key_hex=README_KEY, nonce_hex=README_NONCE)
+    np.random.seed(0)
+    z = gs_insert.gs_watermark_init_noise(opt, "lthero", log_path=None)
+    np.random.seed(0)
+    want = O.gs_watermark_init_noise(opt, "lthero")
+    assert np.abs(z - want).max() < 1e-12

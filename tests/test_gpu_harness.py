@@ -101,3 +101,28 @@ def test_image_level_roundtrip_runs(E, keys):
     assert lat.shape == x0.shape and torch.isfinite(lat).all()
     bits, flags = pipe.invert_and_extract(lat)
     assert bits.shape == (B, 32) and flags.shape == (B,)
+
+
+def test_device_jpeg_equals_pil_checker(E):
+    from gswm_amd import pipeline as P
+    g = torch.Generator().manual_seed(4)
+    x = torch.rand(3, 3, 96, 80, generator=g).cuda().half()
+    assert torch.equal(P.jpeg_roundtrip(x, 10), P.jpeg_roundtrip_pil(x, 10))
+
+
+def test_load_images_device_equals_reference_chain(E, tmp_path):
+    """PNG files -> device Lanczos resize + ToTensor + fp16 + 2x-1 == the reference's load_image(...).to(fp16); 2.*x-1. (extract.py:31-48)."""
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    paths = []
+    for i in range(3):
+        a = rng.integers(0, 256, (72, 88, 3), dtype=np.uint8)
+        p = tmp_path / f"im{i}.png"
+        Image.fromarray(a).save(p)
+        paths.append(str(p))
+    got = E.load_images_device(paths, [64, 48])
+    ref = torch.cat([E.load_image(p, [64, 48]) for p in paths]).to(torch.float16)
+    ref = 2.0 * ref - 1.0
+    assert got.shape == (3, 3, 48, 64) and torch.equal(got.cpu(), ref)
+    same = E.load_images_device(paths, None, out="f32")
+    assert torch.equal(same.cpu(), torch.cat([E.load_image(p) for p in paths]))

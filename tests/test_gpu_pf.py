@@ -139,3 +139,24 @@ def test_unet_pf_path_equals_torch_path(G, chs, heads):
     e1 = (y1.float() - yref).abs().max().item()
     e0 = (y0.float() - yref).abs().max().item()
     assert y1.shape == y0.shape and e1 <= max(2 * e0, 2e-2), (e1, e0)
+
+
+def test_sd15_shape_unet_on_96x96_lattice(G):
+    """BASELINE config 5's eps-model: SD 1.5 UNet (8 heads, head_dim 40/80/160, ctx 768) on the 4x96x96 lattice -- the PF path
+    (96-wide rows fall back from the halo kernel to the plain implicit-GEMM kernel where the halo tile exceeds LDS) against the
+    torch path of the same module."""
+    U = G.unet
+    m = U.synthetic_init_(U.UNet2DCondition.sd15(), 0).cuda().half().eval()
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1, 4, 96, 96, generator=g).cuda().half()
+    c = torch.randn(1, 77, 768, generator=g).cuda().half()
+    t = torch.tensor([500]).cuda()
+    with torch.no_grad():
+        assert m._pf_ok(x)
+        y1 = m(x, t, c)
+        U.USE_PF = False
+        y0 = m(x, t, c)
+        U.USE_PF = True
+    assert y1.shape == (1, 4, 96, 96) and torch.isfinite(y1).all()
+    scale = y0.float().abs().max().item()
+    assert (y1.float() - y0.float()).abs().max().item() <= 3e-2 * max(1.0, scale)

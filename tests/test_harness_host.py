@@ -51,6 +51,11 @@ def test_vae_and_unet_shapes_and_parameter_counts():
         v, u = V.AutoencoderKL(), U.UNet2DCondition()
     assert sum(p.numel() for p in v.parameters()) == 83_653_863           # SD AutoencoderKL
     assert sum(p.numel() for p in u.parameters()) == 865_910_724           # SD 2.1 UNet2DConditionModel
+    with torch.device("meta"):
+        u15 = U.UNet2DCondition.sd15()
+    assert sum(p.numel() for p in u15.parameters()) == 859_520_964         # SD 1.5 UNet2DConditionModel (BASELINE config 5)
+    assert [b.attentions[0].transformer_blocks[0].attn1.heads for b in u15.down_blocks[:3]] == [8, 8, 8]
+    assert u15.down_blocks[0].attentions[0].transformer_blocks[0].attn2.to_k.in_features == 768
     small = V.synthetic_init_(V.AutoencoderKL(block_out_channels=(32, 32, 64, 64)), 0)
     x = torch.rand(2, 3, 64, 48)
     z = V.img_to_latents(x, small)
@@ -62,7 +67,7 @@ def test_vae_and_unet_shapes_and_parameter_counts():
 def test_jpeg_roundtrip_is_pil_quality_save():
     from PIL import Image
     x = torch.rand(2, 3, 32, 32)
-    y = P.jpeg_roundtrip(x, 10)
+    y = P.jpeg_roundtrip_pil(x, 10)            # the host-side checker; the device path is tested in test_gpu_harness.py
     assert y.shape == x.shape
     buf = io.BytesIO()
     Image.fromarray(((x[0].clamp(0, 1) * 255).round().to(torch.uint8)).permute(1, 2, 0).numpy()).save(buf, format="JPEG", quality=10)
