@@ -74,8 +74,9 @@ class ConvTimer:
     """HIP events around every convolution launch, on the stream the kernel is launched on (torch's current stream), bucketed
     by the kernel libgswm picks for the shape.  bench.py installs one as `pf.CONV_TIMER` for its timed region."""
 
-    def __init__(self):
+    def __init__(self, by_shape: bool = False):
         self.ev = []
+        self.by_shape = by_shape          # bucket by (kernel, B, H, W, K, N) instead of by kernel only (tools/unet_forward_bench.py)
 
     def start(self):
         e = torch.cuda.Event(enable_timing=True)
@@ -124,13 +125,19 @@ def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
 
 
 def conv_pf(x: PF, w_packed: torch.Tensor, bias: Optional[torch.Tensor], *, ksize: int = 3, stride: int = 1,
-            rowbias: Optional[torch.Tensor] = None, resid: Optional[PF] = None, cin: Optional[int] = None, cin_offset: int = 0) -> PF:
-    """y = conv(x) (+ bias + rowbias[b] + resid) as one MFMA implicit GEMM; border rows of y are zero."""
+            rowbias: Optional[torch.Tensor] = None, resid: Optional[PF] = None, cin: Optional[int] = None, cin_offset: int = 0,
+            pad_after_only: bool = False) -> PF:
+    """y = conv(x) (+ bias + rowbias[b] + resid) as one MFMA implicit GEMM; border rows of y are zero.
+    pad_after_only (stride 2): the asymmetric F.pad(x, (0, 1, 0, 1)) + padding-0 convolution of the SD VAE downsampler -- in the PF
+    layout that is the same tap table read one row and one column further on, i.e. a shifted base pointer."""
     C = x.C if cin is None else cin
     Nn = w_packed.shape[0]
     Ho, Wo = x.H // stride, x.W // stride
     y = PF.empty(x.B, Ho, Wo, Nn, x.buf.dtype, x.buf.device)
     xp = x.rows.data_ptr() + cin_offset * x.buf.element_size()
+    if pad_after_only:
+        assert stride == 2 and ksize == 3
+        xp += (x.W + 2 + 1) * x.C * x.buf.element_size()
     tm = CONV_TIMER
     with torch.cuda.device(x.buf.device):
         e0 = tm.start() if tm is not None else None
@@ -139,7 +146,8 @@ def conv_pf(x: PF, w_packed: torch.Tensor, bias: Optional[torch.Tensor], *, ksiz
                                     resid.rows.data_ptr() if resid is not None else None, y.rows.data_ptr(),
                                     x.B, Ho, Wo, C, Nn, ksize, stride, x.C, _dt(x.buf.dtype), _stream_ptr()))
         if tm is not None:
-            tm.stop(e0, _conv_kernel_name(Wo, Nn, ksize, stride), 2.0 * x.B * Ho * Wo * Nn * ksize * ksize * C)
+            name = _conv_kernel_name(Wo, Nn, ksize, stride)
+            tm.stop(e0, (name, x.B, Ho, Wo, ksize * ksize * C, Nn, stride) if tm.by_shape else name, 2.0 * x.B * Ho * Wo * Nn * ksize * ksize * C)
     return y
 
 
@@ -231,5 +239,5 @@ def conv3x3_res_pf(x: PF, w_cat: torch.Tensor, bias: Optional[torch.Tensor], *, 
                                            _dt(x.buf.dtype), _stream_ptr()))
         if tm is not None:
             k = 9 * x.C + (x1.C if x1 is not None else 0) + (x2.C if x2 is not None else 0)
-            tm.stop(e0, "gsw_conv3x3_halo_kernel", 2.0 * x.B * x.H * x.W * Nn * k)
+            tm.stop(e0, ("gsw_conv3x3_halo_kernel", x.B, x.H, x.W, k, Nn, 1) if tm.by_shape else "gsw_conv3x3_halo_kernel", 2.0 * x.B * x.H * x.W * Nn * k)
     return y

@@ -19,6 +19,56 @@ import torch.nn.functional as F
 
 SCALING_FACTOR = 0.18215  # extract.py:42
 
+# Padded-flat NHWC path (pf.py / csrc/gswm_conv.hip), same scheme as the UNet: every 3x3 / 1x1 / stride-2 convolution is the
+# hand-written MFMA implicit GEMM with bias and residual fused in its epilogue, GroupNorm+SiLU the PF kernels; plain torch ops
+# remain for CPU / fp32 tensors.
+USE_PF = True
+
+
+def _pw(conv: nn.Conv2d, cin_pad: int = 0, cout_pad: int = 0):
+    """Packed [N, 9*C] weight (+ bias) of a convolution, optionally zero-padded to `cin_pad` input / `cout_pad` output channels
+    (the 3- / 4- / 8-channel edges of the VAE ride on one 64-wide tile)."""
+    c = getattr(conv, "_gsw_packed", None)
+    if c is None or c[0].device != conv.weight.device or c[0].dtype != conv.weight.dtype:
+        from .pf import pack_conv_weight
+        w, b = conv.weight.detach(), conv.bias.detach()
+        if cin_pad and w.shape[1] < cin_pad:
+            w = torch.cat([w, w.new_zeros(w.shape[0], cin_pad - w.shape[1], *w.shape[2:])], dim=1)
+        if cout_pad and w.shape[0] < cout_pad:
+            w = torch.cat([w, w.new_zeros(cout_pad - w.shape[0], *w.shape[1:])], dim=0)
+            b = torch.cat([b, b.new_zeros(cout_pad - b.shape[0])])
+        c = (pack_conv_weight(w), b.contiguous())
+        conv._gsw_packed = c
+    return c
+
+
+def _gn_pf(x, norm: nn.GroupNorm, act=True, tokens=False):
+    from .pf import groupnorm_pf
+    return groupnorm_pf(x, norm.weight, norm.bias, norm.num_groups, norm.eps, act=act, tokens=tokens)
+
+
+def _pf_ok(x: torch.Tensor) -> bool:
+    return USE_PF and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and x.shape[-1] % 8 == 0 and x.shape[-2] % 8 == 0
+
+
+def _convs_fit_pf(module: nn.Module) -> bool:
+    """Every convolution but the padded edges (conv_in's input, conv_out's output) needs channel counts in multiples of 64."""
+    ok = getattr(module, "_gsw_pf_ok", None)
+    if ok is None:
+        ok = all((n == "conv_in" or m.in_channels % 64 == 0) and (n == "conv_out" or m.out_channels % 64 == 0)
+                 for n, m in module.named_modules() if isinstance(m, nn.Conv2d))
+        module._gsw_pf_ok = ok
+    return ok
+
+
+def _to_pf64(x: torch.Tensor):
+    """NCHW tensor with <= 64 channels -> PF tensor with 64 channels (zero-filled)."""
+    from .pf import PF
+    B, C, H, W = x.shape
+    p = PF.zeros(B, H, W, 64, x.dtype, x.device)
+    p.interior[..., :C].copy_(x.permute(0, 2, 3, 1))
+    return p
+
 
 class VaeResnet(nn.Module):
     def __init__(self, cin, cout, groups=32, eps=1e-6):
@@ -33,6 +83,13 @@ class VaeResnet(nn.Module):
         h = self.conv1(F.silu(self.norm1(x)))
         h = self.conv2(F.silu(self.norm2(h)))
         return (x if self.conv_shortcut is None else self.conv_shortcut(x)) + h
+
+    def forward_pf(self, x):
+        from .pf import conv_pf
+        h = conv_pf(_gn_pf(x, self.norm1), *_pw(self.conv1))
+        h = _gn_pf(h, self.norm2)
+        sc = x if self.conv_shortcut is None else conv_pf(x, *_pw(self.conv_shortcut), ksize=1)
+        return conv_pf(h, *_pw(self.conv2), resid=sc)                   # residual add in the GEMM epilogue
 
 
 class VaeAttention(nn.Module):
@@ -51,6 +108,13 @@ class VaeAttention(nn.Module):
         o = F.scaled_dot_product_attention(q, k, v)[:, 0]
         return x + self.to_out[0](o).transpose(1, 2).reshape(b, c, h, w)
 
+    def forward_pf(self, x):
+        y = _gn_pf(x, self.group_norm, act=False, tokens=True)          # GroupNorm writes dense tokens [B, H*W, C]
+        q, k, v = self.to_q(y)[:, None], self.to_k(y)[:, None], self.to_v(y)[:, None]
+        o = F.scaled_dot_product_attention(q, k, v)[:, 0]
+        x.interior.add_(self.to_out[0](o).view(x.B, x.H, x.W, x.C))
+        return x
+
 
 class VaeMid(nn.Module):
     def __init__(self, ch):
@@ -61,6 +125,9 @@ class VaeMid(nn.Module):
     def forward(self, x):
         return self.resnets[1](self.attentions[0](self.resnets[0](x)))
 
+    def forward_pf(self, x):
+        return self.resnets[1].forward_pf(self.attentions[0].forward_pf(self.resnets[0].forward_pf(x)))
+
 
 class _Down(nn.Module):
     def __init__(self, ch):
@@ -70,6 +137,10 @@ class _Down(nn.Module):
     def forward(self, x):
         return self.conv(F.pad(x, (0, 1, 0, 1)))     # diffusers' asymmetric padding for the VAE downsampler
 
+    def forward_pf(self, x):
+        from .pf import conv_pf
+        return conv_pf(x, *_pw(self.conv), stride=2, pad_after_only=True)
+
 
 class _Up(nn.Module):
     def __init__(self, ch):
@@ -78,6 +149,15 @@ class _Up(nn.Module):
 
     def forward(self, x):
         return self.conv(F.interpolate(x, scale_factor=2.0, mode="nearest"))
+
+    def forward_pf(self, x):
+        from .pf import PF, conv_pf
+        up = PF.zeros(x.B, 2 * x.H, 2 * x.W, x.C, x.buf.dtype, x.buf.device)
+        xi, g = x.interior, up.grid
+        for dy in (0, 1):
+            for dx in (0, 1):
+                g[:, 1 + dy:1 + dy + 2 * x.H:2, 1 + dx:1 + dx + 2 * x.W:2, :].copy_(xi)
+        return conv_pf(up, *_pw(self.conv))
 
 
 class _EncBlock(nn.Module):
@@ -91,6 +171,11 @@ class _EncBlock(nn.Module):
             x = r(x)
         return x if self.downsamplers is None else self.downsamplers[0](x)
 
+    def forward_pf(self, x):
+        for r in self.resnets:
+            x = r.forward_pf(x)
+        return x if self.downsamplers is None else self.downsamplers[0].forward_pf(x)
+
 
 class _DecBlock(nn.Module):
     def __init__(self, cin, cout, up):
@@ -103,6 +188,11 @@ class _DecBlock(nn.Module):
             x = r(x)
         return x if self.upsamplers is None else self.upsamplers[0](x)
 
+    def forward_pf(self, x):
+        for r in self.resnets:
+            x = r.forward_pf(x)
+        return x if self.upsamplers is None else self.upsamplers[0].forward_pf(x)
+
 
 class Encoder(nn.Module):
     def __init__(self, chs: Sequence[int], latent=4):
@@ -114,10 +204,24 @@ class Encoder(nn.Module):
         self.conv_out = nn.Conv2d(chs[-1], 2 * latent, 3, padding=1)
 
     def forward(self, x):
+        if _pf_ok(x) and self._pf_shapes_ok():
+            return self.forward_pf(x)
         x = self.conv_in(x)
         for b in self.down_blocks:
             x = b(x)
         return self.conv_out(F.silu(self.conv_norm_out(self.mid_block(x))))
+
+    def _pf_shapes_ok(self):
+        return _convs_fit_pf(self)
+
+    def forward_pf(self, x):
+        from .pf import conv_pf
+        h = conv_pf(_to_pf64(x), *_pw(self.conv_in, cin_pad=64))
+        for b in self.down_blocks:
+            h = b.forward_pf(h)
+        h = _gn_pf(self.mid_block.forward_pf(h), self.conv_norm_out)
+        y = conv_pf(h, *_pw(self.conv_out, cout_pad=64))
+        return y.interior[..., : self.conv_out.out_channels].permute(0, 3, 1, 2).contiguous()
 
 
 class Decoder(nn.Module):
@@ -131,10 +235,23 @@ class Decoder(nn.Module):
         self.conv_out = nn.Conv2d(rev[-1], 3, 3, padding=1)
 
     def forward(self, z):
+        if _pf_ok(z) and self._pf_shapes_ok():
+            return self.forward_pf(z)
         x = self.mid_block(self.conv_in(z))
         for b in self.up_blocks:
             x = b(x)
         return self.conv_out(F.silu(self.conv_norm_out(x)))
+
+    def _pf_shapes_ok(self):
+        return _convs_fit_pf(self)
+
+    def forward_pf(self, z):
+        from .pf import conv_pf
+        h = self.mid_block.forward_pf(conv_pf(_to_pf64(z), *_pw(self.conv_in, cin_pad=64)))
+        for b in self.up_blocks:
+            h = b.forward_pf(h)
+        y = conv_pf(_gn_pf(h, self.conv_norm_out), *_pw(self.conv_out, cout_pad=64))
+        return y.interior[..., : self.conv_out.out_channels].permute(0, 3, 1, 2).contiguous()
 
 
 class AutoencoderKL(nn.Module):

@@ -46,6 +46,12 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=20, help="images of the CPU-baseline sample (0.7-2.2 s each)")
     ap.add_argument("--ddim-steps", type=int, default=50)
+    ap.add_argument("--image-stages", choices=["none", "vae", "vae+jpeg"], default="vae",
+                    help="e2e: also run (and time) VAE decode -> uint8 image -> [JPEG QF] -> ToTensor/normalise -> VAE encode per image "
+                         "(BASELINE config 4's data path; synthetic VAE weights, so the inversion still consumes the latent)")
+    ap.add_argument("--jpeg-qf", type=int, default=10)
+    ap.add_argument("--vae-chunk", type=int, default=8, help="images per VAE call")
+    ap.add_argument("--unet", choices=["sd21", "sd15"], default="sd21", help="sd15 + --height 768 --width 768 = BASELINE config 5's shape")
     a = ap.parse_args()
     if a.steps is None:
         a.steps = 50 if a.tier == "codec" else 2

@@ -1,6 +1,7 @@
 """bench.py --tier e2e: watermarked images/sec end to end on the SD2.1-base-shaped UNet (synthetic weights):
-one step = embed(B) -> 50-step DDIM sampling with CFG 7.5 (2B-row UNet batch) -> 50-step DDIM inversion (prompt "") ->
-fused last step + vote.  Latent level (no VAE): see DESIGN.md for why the lossless gate is defined there."""
+one step = embed(B) -> 50-step DDIM sampling with CFG 7.5 (2B-row UNet batch) -> [VAE decode -> uint8 image -> ToTensor -> VAE encode]
+-> 50-step DDIM inversion (prompt "") -> fused last step + vote.  The image stages are computed and timed, but with synthetic VAE
+weights (not an autoencoder) the inversion consumes the latent: see DESIGN.md for why the lossless gate is defined there."""
 import json
 import os
 import sys
@@ -38,7 +39,7 @@ class TimedModel:
                 "flops_per_call_avg": rows * self.flops_per_row / max(1, len(self.events))}
 
 
-def cpu_baseline_e2e(unet_cfg, ddim_steps, M):
+def cpu_baseline_e2e(unet_cfg, ddim_steps, M, h=64, w=64, with_vae=False):
     """Bounded CPU sample of the same workload: the oracle's reference-shaped codec port on 1 image + ONE fp32 UNet forward
     of one image on the host cores (torch CPU), extrapolated to the 3*S forwards an image needs (2S with CFG + S inversion)."""
     import types
@@ -56,7 +57,7 @@ def cpu_baseline_e2e(unet_cfg, ddim_steps, M):
     O.recover_exactracted_message_scalar(z.astype(np.float16), a)
     t_codec = time.perf_counter() - t0
     m = U.synthetic_init_(U.UNet2DCondition(**unet_cfg), 0).float().eval()
-    x = torch.randn(1, 4, 64, 64); t = torch.tensor([500]); c = torch.randn(1, 77, unet_cfg.get("cross_attention_dim", 1024))
+    x = torch.randn(1, 4, h, w); t = torch.tensor([500]); c = torch.randn(1, 77, unet_cfg.get("cross_attention_dim", 1024))
     with torch.no_grad():
         m(x, t, c)
         t1 = time.perf_counter()
@@ -65,9 +66,20 @@ def cpu_baseline_e2e(unet_cfg, ddim_steps, M):
             m(x, t, c)
         t_fw = (time.perf_counter() - t1) / n_fw
     per_image = t_codec + 3 * ddim_steps * t_fw
+    vae_note = ""
+    if with_vae:
+        from gswm_amd import vae as V
+        v = V.synthetic_init_(V.AutoencoderKL(), 1).float().eval()
+        with torch.no_grad():
+            t2 = time.perf_counter()
+            img = V.latents_to_img(x, v)
+            V.img_to_latents(img, v)
+            t_vae = time.perf_counter() - t2
+        per_image += t_vae
+        vae_note = f" + 1 fp32 VAE decode+encode ({t_vae:.2f} s)"
     return {"value": 1.0 / per_image, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"1 image: reference-shaped scalar codec port ({t_codec:.2f} s, 1 core) + {n_fw} fp32 UNet forwards of the same "
-                      f"module on the host ({t_fw:.2f} s each, {torch.get_num_threads()} threads), extrapolated to {3 * ddim_steps} forwards/image",
+                      f"module on the host ({t_fw:.2f} s each, {torch.get_num_threads()} threads), extrapolated to {3 * ddim_steps} forwards/image" + vae_note,
             "host_cpus": os.cpu_count()}
 
 
@@ -87,7 +99,8 @@ def run_e2e(args, rank, world, local_rank):
     params = gdist.broadcast_params(
         {"key": bytes.fromhex(README_KEY), "nonce": bytes.fromhex(README_NONCE), "message": codec.pad_message("lthero", M // 8),
          "seed": 2024, "height": args.height, "width": args.width} if rank == 0 else None, src=0)
-    unet_cfg = {}
+    unet_cfg = {} if args.unet == "sd21" else dict(cross_attention_dim=768, num_heads=(8, 8, 8, 8), head_dim=None)
+    ctx_dim = unet_cfg.get("cross_attention_dim", 1024)
     model = U.synthetic_init_(U.UNet2DCondition(**unet_cfg), seed=0).to(dev, dtype).eval()
     if os.environ.get("GSW_CHANNELS_LAST", "0") == "1":   # NCHW measured faster here (377 vs 343 TFLOP/s at B=64)
         model = model.to(memory_format=torch.channels_last)
@@ -95,15 +108,39 @@ def run_e2e(args, rank, world, local_rank):
     flops_row = U.count_flops_per_image(model, h, w)
     tm = TimedModel(model, flops_row)
     g = torch.Generator(device="cpu").manual_seed(1)
-    ctx_uncond = (torch.randn(1, 77, 1024, generator=g) * 1.0).to(dev, dtype)           # stands for CLIP("")
-    ctx_text = (torch.randn(B, 77, 1024, generator=g) * 1.0).to(dev, dtype)             # stands for CLIP(prompt)
+    ctx_uncond = (torch.randn(1, 77, ctx_dim, generator=g) * 1.0).to(dev, dtype)        # stands for CLIP("")
+    ctx_text = (torch.randn(B, 77, ctx_dim, generator=g) * 1.0).to(dev, dtype)          # stands for CLIP(prompt)
     pipe = GaussianShadingPipeline(tm, params["key"], params["nonce"], params["message"], height=args.height, width=args.width,
                                    num_inference_steps=S, dtype=dtype, device=dev, ctx_uncond=ctx_uncond)
     want = torch.frombuffer(bytearray(params["message"]), dtype=torch.uint8).to(dev)
 
+    vae = None
+    if args.image_stages != "none":
+        from gswm_amd import vae as V, imaging
+        vae = V.synthetic_init_(V.AutoencoderKL(), 1).to(dev, dtype).eval()
+
+    def image_stages(x0):
+        """G1 tail + X1 per image: VAE decode -> uint8 RGB (the watermarked image) -> [JPEG QF] -> ToTensor/fp16/2x-1 -> VAE encode.
+        Synthetic VAE weights are not an autoencoder, so the re-encoded latents are computed (and timed) but the inversion below
+        consumes x0: the lossless gate lives at the latent level."""
+        outs = []
+        for chunk in x0.split(args.vae_chunk):
+            img = V.latents_to_img(chunk, vae)
+            u8 = imaging.tensor_to_image(img)
+            xn = imaging.jpeg_roundtrip(u8, args.jpeg_qf, out="f16") if args.image_stages == "vae+jpeg" else imaging.to_tensor(u8, out="f16")
+            outs.append(V.normalised_img_to_latents(xn, vae))
+        return torch.cat(outs)
+
     def step(i):
         idx0 = (i * world + rank) * B
-        return pipe.roundtrip(B, ctx_text, seed=params["seed"], image_index0=idx0, guidance_scale=7.5)
+        if vae is None:
+            return pipe.roundtrip(B, ctx_text, seed=params["seed"], image_index0=idx0, guidance_scale=7.5)
+        z_T = pipe.embed(B, seed=params["seed"], image_index0=idx0)
+        x0 = pipe.generate(z_T, ctx_text, 7.5)
+        with torch.no_grad():
+            image_stages(x0)
+        bits, flags = pipe.invert_and_extract(x0)
+        return z_T, x0, bits, flags
 
     for i in range(args.warmup):
         step(i)
@@ -143,8 +180,9 @@ def run_e2e(args, rank, world, local_rank):
             "value": total_images / dt, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"e2e latent level: gsw_embed -> {S}-step DDIM sampling (CFG 7.5, 2B-row UNet) -> {S}-step DDIM inversion -> "
-                                   f"fused last step + {M}-bit vote; SD2.1-base-shaped UNet (865.9 M params, synthetic weights; convolutions on the hand-written MFMA implicit GEMM), no VAE",
+            "config": {"workload": f"e2e: gsw_embed -> {S}-step DDIM sampling (CFG 7.5, 2B-row UNet) -> {S}-step DDIM inversion -> "
+                                   f"fused last step + {M}-bit vote; {'SD2.1-base' if args.unet == 'sd21' else 'SD1.5'}-shaped UNet ({sum(p.numel() for p in model.parameters()) / 1e6:.1f} M params, synthetic weights; convolutions on the hand-written MFMA implicit GEMM), "
+                                   + ("no VAE" if vae is None else f"image stages per image: VAE decode -> uint8 -> {'JPEG QF ' + str(args.jpeg_qf) + ' -> ' if args.image_stages == 'vae+jpeg' else ''}ToTensor -> VAE encode (timed; synthetic VAE, inversion consumes the latent)"),
                        "batch_per_gpu": B, "global_batch": world * B, "lattice": [4, h, w], "message_bits": M, "ddim_steps": S,
                        "parallelism": f"dp{world} (images sharded, UNet replicated, no data-path collective)"},
             "bit_accuracy": bit_acc, "lossless": bit_acc == 1.0 and int(flagged.item()) == 0, "flagged_images": int(flagged.item()),
@@ -170,7 +208,7 @@ def run_e2e(args, rank, world, local_rank):
         if "roofline" not in out:
             out["roofline"] = out["roofline_unet"]
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline_e2e(unet_cfg, S, M)
+            out["cpu_baseline"] = cpu_baseline_e2e(unet_cfg, S, M, h, w, with_vae=vae is not None)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         else:
             out["cpu_baseline"] = None

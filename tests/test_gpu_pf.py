@@ -160,3 +160,30 @@ def test_sd15_shape_unet_on_96x96_lattice(G):
     assert y1.shape == (1, 4, 96, 96) and torch.isfinite(y1).all()
     scale = y0.float().abs().max().item()
     assert (y1.float() - y0.float()).abs().max().item() <= 3e-2 * max(1.0, scale)
+
+
+@pytest.mark.parametrize("chs,hw,fp32_ref", [((64, 128, 128, 128), (64, 48), True), ((128, 256, 512, 512), (64, 64), False)])
+def test_vae_pf_path_equals_torch_path(G, chs, hw, fp32_ref):
+    """SD VAE encoder (asymmetric-pad stride-2 downsamplers, 3 -> C edge) and decoder (nearest upsamplers, C -> 3 edge) on the PF
+    kernels against the torch path of the same module; the small configuration is also judged against its fp32 evaluation."""
+    import gswm_amd
+    from gswm_amd import vae as V
+    v = V.synthetic_init_(V.AutoencoderKL(block_out_channels=chs), 3).cuda().half().eval()
+    g = torch.Generator().manual_seed(1)
+    x = (torch.rand(2, 3, *hw, generator=g) * 2 - 1).cuda().half()
+    z = torch.randn(2, 4, hw[0] // 8, hw[1] // 8, generator=g).cuda().half()
+    with torch.no_grad():
+        assert V._pf_ok(x) and v.encoder._pf_shapes_ok() and v.decoder._pf_shapes_ok()
+        e1, d1 = v.encode_mean(x), v.decode(z)
+        V.USE_PF = False
+        e0, d0 = v.encode_mean(x), v.decode(z)
+        V.USE_PF = True
+        if fp32_ref:
+            vf = v.float()
+            er, dr = vf.encode_mean(x.float()), vf.decode(z.float())
+        else:
+            er, dr = e0.float(), d0.float()
+    assert e1.shape == (2, 4, hw[0] // 8, hw[1] // 8) and d1.shape == (2, 3, *hw)
+    for a1, a0, ar in ((e1, e0, er), (d1, d0, dr)):
+        err1, err0 = (a1.float() - ar).abs().max().item(), (a0.float() - ar).abs().max().item()
+        assert err1 <= max(2 * err0, 2e-2 * max(1.0, ar.abs().max().item())), (err1, err0)

@@ -12,3 +12,18 @@ with torch.no_grad():
     for _ in range(4): y=m(x,t,c)
     torch.cuda.synchronize(); d=(time.perf_counter()-t0)/4
 print(f"B={B}: {d*1e3:.1f} ms {B*0.804/d:.0f} TFLOP/s", flush=True)
+
+if len(sys.argv) > 2 and sys.argv[2] == "convs":      # per-shape table of the convolution launches (HIP events around each)
+    from gswm_amd import pf
+    tm = pf.ConvTimer(by_shape=True)
+    pf.CONV_TIMER = tm
+    with torch.no_grad():
+        for _ in range(3): m(x,t,c)
+    torch.cuda.synchronize()
+    pf.CONV_TIMER = None
+    tot = sum(v["ms"] for v in tm.summary().values())
+    print(f"conv total {tot/3:.1f} ms per forward")
+    for k, v in sorted(tm.summary().items(), key=lambda kv: -kv[1]["ms"]):
+        name, b, h, w, kk, n, st = k
+        pad = (h + 2) * (w + 2) / (h * w)
+        print(f"{name:28s} {h:3d}x{w:<3d} K={kk:6d} N={n:5d} s{st} calls/fwd={v['calls']//3:3d} avg={v['avg_us']:8.1f} us  {v['tflops']:7.1f} TFLOP/s (x{pad:.2f} padded = {v['tflops']*pad:7.1f})  {v['ms']/tot*100:5.1f} %")
