@@ -60,24 +60,49 @@ __device__ __forceinline__ int clip8(int32_t v) { return v < 0 ? 0 : (v > 255 ? 
 // ---------------------------------------------------------------------------------------------------------------------------
 // Pillow resampler
 // ---------------------------------------------------------------------------------------------------------------------------
-// horizontal pass: in [rows, Win, nch] u8 -> out [rows, Wout, nch] u8; one workgroup per row
+// horizontal pass: in [rows, Win, nch] u8 -> out [rows, Wout, nch] u8; one workgroup per R consecutive rows (staged once in LDS), so
+// that a thread's coefficient row k[0..xmax) is fetched once and applied to R pixels
+constexpr int RESAMPLE_ROWS = 8;
 __global__ __launch_bounds__(256) void gsw_resample_h_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
                                                              const int32_t* __restrict__ bounds, const int32_t* __restrict__ kk, int ksize,
-                                                             int Win, int Wout, int nch) {
+                                                             int Win, int Wout, int nch, int64_t rows, int R) {
     extern __shared__ uint8_t row[];
-    const int64_t r = blockIdx.x;
-    const uint8_t* src = in + r * (int64_t)Win * nch;
-    const int nb = Win * nch;
-    for (int i = threadIdx.x; i < nb; i += blockDim.x) row[i] = src[i];
+    const int64_t r0 = (int64_t)blockIdx.x * R;
+    const int nr = (int)min((int64_t)R, rows - r0);
+    const int nb = Win * nch;                       // bytes per row; LDS pitch rounded up to 4
+    const int pitch = (nb + 3) & ~3;
+    const uint8_t* src = in + r0 * (int64_t)nb;
+    if (((nb & 3) == 0) && ((reinterpret_cast<uintptr_t>(src) & 3) == 0)) {
+        const int nw = nb >> 2;
+        for (int i = threadIdx.x; i < nw * nr; i += blockDim.x) {
+            const int rr = i / nw, w = i - rr * nw;
+            reinterpret_cast<uint32_t*>(row + rr * pitch)[w] = reinterpret_cast<const uint32_t*>(src + (int64_t)rr * nb)[w];
+        }
+    } else {
+        for (int i = threadIdx.x; i < nb * nr; i += blockDim.x) {
+            const int rr = i / nb, w = i - rr * nb;
+            row[rr * pitch + w] = src[(int64_t)rr * nb + w];
+        }
+    }
     __syncthreads();
-    uint8_t* dst = out + r * (int64_t)Wout * nch;
+    uint8_t* dst = out + r0 * (int64_t)Wout * nch;
     for (int o = threadIdx.x; o < Wout * nch; o += blockDim.x) {
         const int xx = o / nch, c = o - xx * nch;
         const int xmin = bounds[2 * xx], xmax = bounds[2 * xx + 1];
         const int32_t* k = kk + (int64_t)xx * ksize;
-        int32_t ss = 1 << (PRECISION_BITS - 1);
-        for (int x = 0; x < xmax; ++x) ss += (int32_t)row[(x + xmin) * nch + c] * k[x];
-        dst[o] = (uint8_t)clip8(ss >> PRECISION_BITS);
+        int32_t ss[RESAMPLE_ROWS];
+#pragma unroll
+        for (int rr = 0; rr < RESAMPLE_ROWS; ++rr) ss[rr] = 1 << (PRECISION_BITS - 1);
+        const uint8_t* p = row + xmin * nch + c;
+        for (int x = 0; x < xmax; ++x) {
+            const int32_t kv = k[x];
+#pragma unroll
+            for (int rr = 0; rr < RESAMPLE_ROWS; ++rr)
+                if (rr < R) ss[rr] += (int32_t)p[rr * pitch + x * nch] * kv;        // rows in [nr, R) read stale LDS, never stored
+        }
+#pragma unroll
+        for (int rr = 0; rr < RESAMPLE_ROWS; ++rr)
+            if (rr < nr) dst[(int64_t)rr * Wout * nch + o] = (uint8_t)clip8(ss[rr] >> PRECISION_BITS);
     }
 }
 
@@ -334,15 +359,37 @@ __global__ __launch_bounds__(256) void gsw_jpeg_finish_kernel(const uint8_t* __r
 // ---------------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t rgb2l(uint32_t r, uint32_t g, uint32_t b) { return (r * 19595u + g * 38470u + b * 7471u + 0x8000u) >> 16; }   // Convert.c
 
-// per-image sum of L over all pixels (exact, uint64 atomics): ImageStat.Stat(image.convert("L")).mean[0] = sum / count
+// per-image sum of L over all pixels (exact, uint64): ImageStat.Stat(image.convert("L")).mean[0] = sum / count.
+// 16 pixels (48 bytes = three 16-byte loads) per thread and iteration; one atomic per workgroup.
 __global__ __launch_bounds__(256) void gsw_image_lsum_kernel(const uint8_t* __restrict__ in, unsigned long long* __restrict__ sums, int64_t npix) {
+    __shared__ unsigned long long part[4];
     const int64_t b = blockIdx.y;
     const uint8_t* img = in + b * npix * 3;
     unsigned long long s = 0;
-    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < npix; p += (int64_t)gridDim.x * blockDim.x)
+    const int64_t ngrp = ((reinterpret_cast<uintptr_t>(img) & 15) == 0) ? npix / 16 : 0;      // aligned groups of 16 pixels
+    for (int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; g < ngrp; g += (int64_t)gridDim.x * blockDim.x) {
+        const uint4* q = reinterpret_cast<const uint4*>(img + g * 48);
+        const uint4 a = q[0], c = q[1], d = q[2];
+        const uint32_t w[12] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+        uint32_t acc = 0;
+#pragma unroll
+        for (int px = 0; px < 16; ++px) {
+            const int o = px * 3;
+            const uint32_t r = (w[o >> 2] >> ((o & 3) * 8)) & 255u, gg = (w[(o + 1) >> 2] >> (((o + 1) & 3) * 8)) & 255u,
+                           bl = (w[(o + 2) >> 2] >> (((o + 2) & 3) * 8)) & 255u;
+            acc += rgb2l(r, gg, bl);
+        }
+        s += acc;
+    }
+    for (int64_t p = ngrp * 16 + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < npix; p += (int64_t)gridDim.x * blockDim.x)
         s += rgb2l(img[p * 3], img[p * 3 + 1], img[p * 3 + 2]);
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
-    if ((threadIdx.x & 63) == 0 && s) atomicAdd(&sums[b], s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long t = part[0] + part[1] + part[2] + part[3];
+        if (t) atomicAdd(&sums[b], t);
+    }
 }
 
 // Blend.c ImagingBlend(in1 = degenerate, in2 = image, alpha): float arithmetic, truncation; clipped outside [0, 1]
@@ -476,12 +523,14 @@ int gsw_resize_lanczos(const uint8_t* in_dev, int B, int Hin, int Win, void* out
     if (need_h) {
         // straight into out_dev when nothing follows; else into tmp_dev [B, Hin, Wout, 3]
         uint8_t* dst = (!need_v && out_mode == GSW_IMG_U8_HWC) ? (uint8_t*)out_dev : tmp_dev;
-        const size_t lds = (size_t)Win * 3;
+        const int R = (int)std::max<int64_t>(1, std::min<int64_t>(RESAMPLE_ROWS, (48 * 1024) / (((int64_t)Win * 3 + 3) & ~3)));
+        const size_t lds = (size_t)R * (((size_t)Win * 3 + 3) & ~(size_t)3);
+        const int64_t rows = (int64_t)B * Hin;
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute((const void*)gsw_resample_h_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) { g_img_hip_error = (int)e; return GSW_ERR_HIP; }
         }
-        hipLaunchKernelGGL(gsw_resample_h_kernel, dim3((uint32_t)((int64_t)B * Hin)), dim3(256), lds, st, in_dev, dst, hbounds_dev, hkk_dev, hksize, Win, Wout, 3);
+        hipLaunchKernelGGL(gsw_resample_h_kernel, dim3((uint32_t)((rows + R - 1) / R)), dim3(256), lds, st, in_dev, dst, hbounds_dev, hkk_dev, hksize, Win, Wout, 3, rows, R);
         GSW_IMG_LAUNCH_CHECK();
         if (dst == (uint8_t*)out_dev) return GSW_OK;
         src = tmp_dev;
@@ -556,7 +605,7 @@ int gsw_image_pointwise(const uint8_t* rgb_dev, int B, int H, int W, int op, flo
         hipError_t e = hipMemsetAsync(workspace_dev, 0, (size_t)B * sizeof(uint64_t), st);
         if (e != hipSuccess) { g_img_hip_error = (int)e; return GSW_ERR_HIP; }
         const int64_t npix = (int64_t)H * W;
-        const int nb = (int)std::min<int64_t>(256, (npix + 255) / 256);
+        const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(64, (npix / 16 + 255) / 256));
         hipLaunchKernelGGL(gsw_image_lsum_kernel, dim3(nb, B), dim3(256), 0, st, rgb_dev, (unsigned long long*)workspace_dev, npix);
         GSW_IMG_LAUNCH_CHECK();
     }
