@@ -1,0 +1,225 @@
+// gswm_attn.hip -- self-attention of the eps-model (rows X2 / G1 of SURVEY.md section 8a) as a hand-written flash-attention
+// forward for gfx950: softmax(Q K^T / sqrt(d)) V with head_dim 64, fp16 / bf16 operands, fp32 accumulation, non-causal.
+//
+// Reference call site: extract.py:66-69 / the generation loop run diffusers' UNet2DConditionModel, whose BasicTransformerBlock
+// self-attention (attn1) at 64x64 / 32x32 / 16x16 latent resolution is sequence length 4096 / 1024 / 256 with 5 / 10 / 20 heads of
+// width 64 (SD 2.1-base).  ~16 % of the UNet forward.
+//
+// Design (wave64, v_mfma_f32_32x32x16):
+//   * one workgroup = 128 queries of one (batch, head): 4 waves x 32 queries; K and V tiles of 64 keys are staged once per
+//     workgroup in LDS (double-buffered, register-prefetched) and shared by the 4 waves
+//   * scores are computed TRANSPOSED, S^T = K Q^T (A = K tile rows, B = Q^T held in 16 VGPRs for the whole kernel): the accumulator
+//     layout then puts one QUERY per lane column, so the softmax row reductions are lane-local plus one cross-half exchange, and the
+//     probabilities are already in the B-operand layout of the second product O^T = V^T P^T -- no LDS round trip for P
+//   * V is consumed as V^T [head_dim][keys] (the host computes the value projection transposed: it is one GEMM either way), so the
+//     A operand of the second product is two 8-byte LDS reads per MFMA instead of a transposing gather
+//   * the key order inside a 16-wide MFMA k-slice is the permutation the S^T accumulator layout dictates (slots 0-3 | 4-7 | 8-11 |
+//     12-15 <-> keys 0-3 | 8-11 | 4-7 | 12-15); contraction order is free as long as V^T uses the same one
+//   * LDS row pitches 144 B (K, ds_read_b128) and 136 B (V^T, ds_read_b64) are conflict-free for those access widths
+//   * blockIdx -> (batch*head, query tile) is XCD-aware: the query tiles of one (batch, head) land on one XCD and share its L2 copy of K / V
+// Roofline: MFMA; at head_dim 64 the 32 v_exp_f32 per lane and 64 keys (quarter rate) cost as much issue time as the 16 MFMAs.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "../../include/gswm.h"
+
+extern __attribute__((visibility("hidden"))) thread_local int g_last_hip_error;   // gswm_kernels.hip
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <typename T> struct AT;
+template <> struct AT<_Float16> {
+    using v8 = f16x8;
+    using v4 = f16x4;
+    static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+template <> struct AT<__bf16> {
+    using v8 = bf16x8;
+    using v4 = bf16x4;
+    static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+
+struct AttnArgs {
+    const void* q;      // [B, Sq, ...] row stride ldq elements; head h at column h*64
+    const void* k;      // [B, Sk, ...] row stride ldk
+    const void* vt;     // [B, H*64, Sk]: V transposed
+    void* o;            // [B, Sq, ...] row stride ldo
+    int32_t H, Sq, Sk, ldq, ldk, ldo;
+    float scale_log2;   // softmax scale * log2(e)
+    uint32_t nqt;       // Sq / 128
+    uint32_t total;     // nqt * B * H
+};
+
+constexpr uint32_t KP = 144, VP = 136;                     // LDS row pitches in bytes
+constexpr uint32_t STAGE = 64 * KP + 64 * VP;              // one K tile + one V^T tile
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void gsw_attn_fwd_kernel(AttnArgs p) {
+    using v8 = typename AT<T>::v8;
+    using v4 = typename AT<T>::v4;
+    __shared__ __attribute__((aligned(16))) uint8_t lds[2 * STAGE];
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u, h = lane >> 5, c32 = lane & 31u;
+
+    // XCD-aware placement: hardware sends workgroup b to XCD b % 8; give each XCD a contiguous range of logical ids, whose
+    // consecutive members are the query tiles of one (batch, head)
+    uint32_t logical = blockIdx.x;
+    if ((p.total & 7u) == 0) logical = (blockIdx.x & 7u) * (p.total >> 3) + (blockIdx.x >> 3);
+    const uint32_t bh = logical / p.nqt, qt = logical - bh * p.nqt;
+    const uint32_t b = bh / (uint32_t)p.H, hh = bh - b * (uint32_t)p.H;
+
+    const T* Q = reinterpret_cast<const T*>(p.q) + ((int64_t)b * p.Sq + qt * 128u + wave * 32u + c32) * p.ldq + hh * 64u;
+    const T* K = reinterpret_cast<const T*>(p.k) + (int64_t)b * p.Sk * p.ldk + hh * 64u;
+    const T* VT = reinterpret_cast<const T*>(p.vt) + ((int64_t)b * p.H + hh) * 64 * (int64_t)p.Sk;
+
+    v8 qreg[4];
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) qreg[kc] = *reinterpret_cast<const v8*>(Q + kc * 16 + h * 8);
+
+    // staging roles: 512 16-byte chunks per tile and operand, two per thread
+    const uint32_t r0 = tid >> 3, c16 = tid & 7u;          // rows r0 and r0 + 32, 16-byte column c16
+    // (kept as named scalars + macros: lambdas capturing the prefetch registers by reference made the compiler keep them in scratch)
+    uint4 kreg0, kreg1, vreg0, vreg1;
+    const T* Kg = K + (int64_t)r0 * p.ldk + c16 * 8u;
+    const T* Vg = VT + (int64_t)r0 * p.Sk + c16 * 8u;
+    const int64_t k32 = (int64_t)32 * p.ldk, v32 = (int64_t)32 * p.Sk;
+    const uint32_t kst = r0 * KP + c16 * 16u, vst = 64u * KP + r0 * VP + c16 * 16u;
+#define GSW_ATTN_GLOAD(key0)                                                                  \
+    do {                                                                                      \
+        kreg0 = *reinterpret_cast<const uint4*>(Kg + (int64_t)(key0) * p.ldk);                \
+        kreg1 = *reinterpret_cast<const uint4*>(Kg + (int64_t)(key0) * p.ldk + k32);          \
+        vreg0 = *reinterpret_cast<const uint4*>(Vg + (key0));                                 \
+        vreg1 = *reinterpret_cast<const uint4*>(Vg + (key0) + v32);                           \
+    } while (0)
+#define GSW_ATTN_LSTORE(st)                                                                               \
+    do {                                                                                                  \
+        uint8_t* base_ = lds + (st) * STAGE;                                                              \
+        *reinterpret_cast<uint4*>(base_ + kst) = kreg0;                                                   \
+        *reinterpret_cast<uint4*>(base_ + kst + 32u * KP) = kreg1;                                        \
+        *reinterpret_cast<uint2*>(base_ + vst) = make_uint2(vreg0.x, vreg0.y);          /* V^T rows are */ \
+        *reinterpret_cast<uint2*>(base_ + vst + 8u) = make_uint2(vreg0.z, vreg0.w);     /* 136 B apart: */ \
+        *reinterpret_cast<uint2*>(base_ + vst + 32u * VP) = make_uint2(vreg1.x, vreg1.y);  /* 8-byte    */ \
+        *reinterpret_cast<uint2*>(base_ + vst + 32u * VP + 8u) = make_uint2(vreg1.z, vreg1.w); /* aligned */ \
+    } while (0)
+
+    f32x16 o[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
+    float m_i = -INFINITY, l_i = 0.f;
+    const float cs = p.scale_log2;
+
+    const int32_t nt = p.Sk >> 6;
+    GSW_ATTN_GLOAD(0);
+    GSW_ATTN_LSTORE(0u);
+    __syncthreads();
+    for (int32_t t = 0; t < nt; ++t) {
+        const bool more = t + 1 < nt;
+        if (more) GSW_ATTN_GLOAD((t + 1) << 6);
+        const uint8_t* Kl = lds + (uint32_t)(t & 1) * STAGE;
+        const uint8_t* Vl = Kl + 64u * KP;
+
+        // ---- S^T = K Q^T : two 32-key blocks
+        f32x16 s[2];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { s[0][i] = 0.f; s[1][i] = 0.f; }
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {        // two independent accumulator chains, interleaved
+                const v8 a = *reinterpret_cast<const v8*>(Kl + (uint32_t)(kb * 32 + (int)c32) * KP + (uint32_t)kc * 32u + h * 16u);
+                s[kb] = AT<T>::mfma(a, qreg[kc], s[kb]);
+            }
+        }
+
+        // ---- online softmax (base-2 domain); a query lives in lanes c32 and c32 + 32
+        float mx = s[0][0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) mx = fmaxf(mx, s[0][i]);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[1][i]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_i, mx * cs);
+        const float alpha = __builtin_amdgcn_exp2f(m_i - m_new);      // raw v_exp_f32: arguments are <= 0, underflow to 0 is the intent
+        m_i = m_new;
+        float rs = 0.f;
+        v8 pb[2][2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float e = __builtin_amdgcn_exp2f(fmaf(s[kb][i], cs, -m_new));
+                rs += e;
+                pb[kb][i >> 3][i & 7] = (T)e;
+            }
+        }
+        l_i = fmaf(l_i, alpha, rs);
+        if (__any(alpha != 1.0f)) {                 // once the running maxima have settled the whole wave skips the rescale
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+        }
+
+        // ---- O^T += V^T P^T
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const uint8_t* vp = Vl + (uint32_t)(db * 32 + (int)c32) * VP + (uint32_t)(kb * 32 + tt * 16 + (int)h * 4) * 2u;
+                    const v4 lo = *reinterpret_cast<const v4*>(vp);
+                    const v4 hi = *reinterpret_cast<const v4*>(vp + 16);
+                    const v8 a = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    o[db] = AT<T>::mfma(a, pb[kb][tt], o[db]);
+                }
+            }
+        }
+
+        if (more) GSW_ATTN_LSTORE((uint32_t)((t + 1) & 1));
+        __syncthreads();
+    }
+
+    // ---- normalise and store: lane holds O^T[d][query c32] for d = db*32 + (i/4)*8 + h*4 + (i%4)
+    const float l = l_i + __shfl_xor(l_i, 32);
+    const float inv = 1.0f / l;
+    T* O = reinterpret_cast<T*>(p.o) + ((int64_t)b * p.Sq + qt * 128u + wave * 32u + c32) * p.ldo + hh * 64u;
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            v4 w;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[j] = (T)(o[db][g * 4 + j] * inv);
+            *reinterpret_cast<v4*>(O + db * 32 + g * 8 + (int)h * 4) = w;
+        }
+    }
+}
+
+}  // namespace
+
+int gsw_attention_hd64(const void* q_dev, const void* k_dev, const void* vt_dev, void* out_dev, int B, int H, int Sq, int Sk, int ldq, int ldk, int ldo,
+                       float scale, int dtype, void* stream) {
+    // q: [B, Sq, >= H*64] (row stride ldq), k: [B, Sk, >= H*64] (row stride ldk), vt: [B, H*64, Sk] contiguous (V transposed),
+    // out: [B, Sq, >= H*64] (row stride ldo).  Sq % 128 == 0, Sk % 64 == 0; row strides multiples of 8 elements.
+    if (!q_dev || !k_dev || !vt_dev || !out_dev || B <= 0 || H <= 0 || Sq <= 0 || Sk <= 0) return GSW_ERR_BAD_ARG;
+    if (dtype != GSW_F16 && dtype != GSW_BF16) return GSW_ERR_BAD_ARG;
+    if ((Sq & 127) || (Sk & 63) || ldq < H * 64 || ldk < H * 64 || ldo < H * 64 || ((ldq | ldk | ldo) & 7)) return GSW_ERR_UNSUPPORTED;
+    const int64_t total = (int64_t)(Sq / 128) * B * H;
+    if (total > 0x7FFFFFFF) return GSW_ERR_UNSUPPORTED;
+    AttnArgs a;
+    a.q = q_dev; a.k = k_dev; a.vt = vt_dev; a.o = out_dev;
+    a.H = H; a.Sq = Sq; a.Sk = Sk; a.ldq = ldq; a.ldk = ldk; a.ldo = ldo;
+    a.scale_log2 = scale * 1.4426950408889634f;
+    a.nqt = (uint32_t)(Sq / 128);
+    a.total = (uint32_t)total;
+    if (dtype == GSW_F16) hipLaunchKernelGGL(gsw_attn_fwd_kernel<_Float16>, dim3((uint32_t)total), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(gsw_attn_fwd_kernel<__bf16>, dim3((uint32_t)total), dim3(256), 0, (hipStream_t)stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { g_last_hip_error = (int)e; return GSW_ERR_HIP; }
+    return GSW_OK;
+}

@@ -241,3 +241,21 @@ def conv3x3_res_pf(x: PF, w_cat: torch.Tensor, bias: Optional[torch.Tensor], *, 
             k = 9 * x.C + (x1.C if x1 is not None else 0) + (x2.C if x2 is not None else 0)
             tm.stop(e0, ("gsw_conv3x3_halo_kernel", x.B, x.H, x.W, k, Nn, 1) if tm.by_shape else "gsw_conv3x3_halo_kernel", 2.0 * x.B * x.H * x.W * Nn * k)
     return y
+
+
+def attention_hd64_ok(x: torch.Tensor, heads: int, head_dim: int, n_q: int, n_k: int) -> bool:
+    return x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and head_dim == 64 and n_q % 128 == 0 and n_k % 64 == 0
+
+
+def attention_hd64(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, scale: Optional[float] = None) -> torch.Tensor:
+    """softmax(q k^T * scale) v for head_dim 64 on the hand-written flash-attention kernel (csrc/gswm_attn.hip).
+    q [B, Sq, heads*64], k [B, Sk, heads*64], vt [B, heads*64, Sk] (V transposed) -> [B, Sq, heads*64]."""
+    B, Sq, inner = q.shape
+    Sk = k.shape[1]
+    assert inner == heads * 64 and vt.shape == (B, inner, Sk) and k.shape[2] == inner
+    q, k, vt = q.contiguous(), k.contiguous(), vt.contiguous()
+    out = torch.empty_like(q)
+    with torch.cuda.device(q.device):
+        N.check(N.lib().gsw_attention_hd64(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), B, heads, Sq, Sk, inner, inner, inner,
+                                           float(scale if scale is not None else 64 ** -0.5), _dt(q.dtype), _stream_ptr()))
+    return out

@@ -57,6 +57,8 @@ def _pw(conv: nn.Conv2d) -> torch.Tensor:
     return w
 
 
+OWN_ATTENTION = True  # self-attention (head_dim 64, sequence % 128 == 0) on gsw_attention_hd64 instead of torch SDPA
+
 GEMM_MAX_K = 0        # linear layers with K <= this would run on the hand-written GEMM (gsw_linear).  Measured on MI355X: it only
                       # beats hipBLASLt on [524288,320]x[320,320] (398 vs 343 TFLOP/s) and loses elsewhere, incl. the fused GEGLU
                       # form (output-bound epilogue), so the transformer linears stay on the library GEMM; set > 0 to experiment.
@@ -151,8 +153,15 @@ class Attention(nn.Module):
         self.to_out = nn.ModuleList([nn.Linear(inner, dim)])
 
     def forward(self, x, ctx=None):
-        ctx = x if ctx is None else ctx
         b, n, _ = x.shape
+        if ctx is None and OWN_ATTENTION and FUSED_KERNELS:
+            from .pf import attention_hd64, attention_hd64_ok
+            if attention_hd64_ok(x, self.heads, self.to_q.out_features // self.heads, n, n):
+                # self-attention on the hand-written flash-attention kernel; the value projection is computed transposed
+                # (V^T = W_v x^T, one GEMM either way) because the kernel consumes V^T tiles
+                vt = torch.bmm(self.to_v.weight.unsqueeze(0).expand(b, -1, -1), x.transpose(1, 2))
+                return _lin(attention_hd64(_lin(x, self.to_q), _lin(x, self.to_k), vt, self.heads), self.to_out[0])
+        ctx = x if ctx is None else ctx
         q = _lin(x, self.to_q).view(b, n, self.heads, -1).transpose(1, 2)
         k = _lin(ctx, self.to_k).view(b, ctx.shape[1], self.heads, -1).transpose(1, 2)
         v = _lin(ctx, self.to_v).view(b, ctx.shape[1], self.heads, -1).transpose(1, 2)

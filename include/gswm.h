@@ -163,6 +163,16 @@ int gsw_add_layernorm(const void* x_dev, const void* delta_dev, const void* gamm
 int gsw_linear(const void* x_dev, const void* w_dev, const void* bias_dev, const void* resid_dev, void* y_dev, int64_t M, int K, int N,
                int geglu, int dtype, void* stream);
 
+/* Self-attention of the eps-model (diffusers BasicTransformerBlock.attn1 inside the UNet the reference runs at extract.py:66-69):
+ * out = softmax(q k^T * scale) v per (batch, head), head_dim 64, fp16 / bf16, fp32 accumulation -- a flash-attention forward.
+ *   q   : [B, Sq, >= H*64] row stride ldq elements, head h in columns [h*64, h*64+64)
+ *   k   : [B, Sk, >= H*64] row stride ldk
+ *   vt  : [B, H*64, Sk] contiguous -- the value projection TRANSPOSED (compute it as W_v x^T)
+ *   out : [B, Sq, >= H*64] row stride ldo
+ * Sq % 128 == 0, Sk % 64 == 0, strides % 8 == 0; else GSW_ERR_UNSUPPORTED. */
+int gsw_attention_hd64(const void* q_dev, const void* k_dev, const void* vt_dev, void* out_dev, int B, int H, int Sq, int Sk, int ldq, int ldk,
+                       int ldo, float scale, int dtype, void* stream);
+
 /* E4, bit-parity mode -- gs_insert.py:62 `np.random.uniform(0, 1)` / nodes.py:52-53,114-117 `RandomState(seed).uniform(0, 1)`:
  * NumPy's legacy MT19937 `random_sample` stream continued on the device.  key/pos: the generator state as
  * np.random.get_state()[1:3] gives it (pos == 624: block exhausted).  Writes n float64 uniforms to u_dev and, when

@@ -187,3 +187,43 @@ def test_vae_pf_path_equals_torch_path(G, chs, hw, fp32_ref):
     for a1, a0, ar in ((e1, e0, er), (d1, d0, dr)):
         err1, err0 = (a1.float() - ar).abs().max().item(), (a0.float() - ar).abs().max().item()
         assert err1 <= max(2 * err0, 2e-2 * max(1.0, ar.abs().max().item())), (err1, err0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("B,H,S", [(2, 5, 256), (1, 3, 1024), (3, 2, 128), (1, 1, 4096)])
+def test_attention_hd64_vs_fp32_reference(G, dtype, B, H, S):
+    """Hand-written flash-attention forward (head_dim 64) against softmax(QK^T/8)V evaluated in fp32 on the same rounded inputs;
+    tolerance = a few ulp of the output dtype at the output's scale (documented: 4e-3 fp16, 2e-2 bf16)."""
+    g = torch.Generator().manual_seed(S + H)
+    q, k, v = (torch.randn(B, S, H * 64, generator=g).to(dtype).cuda() for _ in range(3))
+    q = q * 2.0                                                   # sharper softmax than N(0,1) scores
+    got = G.pf.attention_hd64(q, k, v.transpose(1, 2).contiguous(), H)
+    qf, kf, vf = (a.float().view(B, S, H, 64).transpose(1, 2) for a in (q, k, v))
+    ref = torch.softmax(qf @ kf.transpose(-1, -2) / 8.0, dim=-1) @ vf
+    ref = ref.transpose(1, 2).reshape(B, S, H * 64)
+    tol = 4e-3 if dtype == torch.float16 else 2e-2
+    assert got.shape == ref.shape and got.dtype == dtype
+    assert (got.float() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+
+
+def test_attention_hd64_rejects_unsupported_shapes(G):
+    q = torch.zeros(1, 100, 64, dtype=torch.float16, device="cuda")
+    with pytest.raises(Exception):
+        G.pf.attention_hd64(q, q, q.transpose(1, 2).contiguous(), 1)          # Sq % 128 != 0 -> GSW_ERR_UNSUPPORTED
+
+
+def test_unet_own_attention_equals_sdpa_path(G):
+    U = G.unet
+    m = U.synthetic_init_(U.UNet2DCondition(block_out_channels=(64, 128, 128, 128), cross_attention_dim=64, num_heads=(1, 2, 2, 2), head_dim=64), 0)
+    m = m.cuda().half().eval()
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 4, 64, 64, generator=g).cuda().half()          # 64x64 lattice: sequences 4096 / 1024 / 256 -> all on the own kernel
+    c = torch.randn(2, 77, 64, generator=g).cuda().half()
+    t = torch.tensor([981, 1]).cuda()
+    with torch.no_grad():
+        U.OWN_ATTENTION = True
+        y1 = m(x, t, c)
+        U.OWN_ATTENTION = False
+        y0 = m(x, t, c)
+        U.OWN_ATTENTION = True
+    assert (y1.float() - y0.float()).abs().max().item() <= 2e-2 * max(1.0, y0.float().abs().max().item())
