@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 
 #include "../../include/gswm.h"
 
@@ -52,20 +53,24 @@ struct AttnArgs {
     const void* vt;     // [B, H*64, Sk]: V transposed
     void* o;            // [B, Sq, ...] row stride ldo
     int32_t H, Sq, Sk, ldq, ldk, ldo;
+    int32_t Sk_valid;   // keys >= Sk_valid are padding (masked out); == Sk when there is none
     float scale_log2;   // softmax scale * log2(e)
-    uint32_t nqt;       // Sq / 128
+    uint32_t nqt;       // query tiles per (batch, head)
     uint32_t total;     // nqt * B * H
 };
 
 constexpr uint32_t KP = 144, VP = 136;                     // LDS row pitches in bytes
 constexpr uint32_t STAGE = 64 * KP + 64 * VP;              // one K tile + one V^T tile
 
-template <typename T>
+// QB = 32-query blocks per wave (1: 128 queries per workgroup; 2: 256 -- every K / V^T fragment read from LDS feeds two MFMAs and
+// the two blocks' softmax / MFMA chains are independent instruction streams the scheduler can interleave inside one wave)
+template <typename T, int QB>
 __global__ __launch_bounds__(256, 2) void gsw_attn_fwd_kernel(AttnArgs p) {
     using v8 = typename AT<T>::v8;
     using v4 = typename AT<T>::v4;
     __shared__ __attribute__((aligned(16))) uint8_t lds[2 * STAGE];
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u, h = lane >> 5, c32 = lane & 31u;
+    constexpr uint32_t QW = 32u * QB, QWG = 4u * QW;          // queries per wave / per workgroup
 
     // XCD-aware placement: hardware sends workgroup b to XCD b % 8; give each XCD a contiguous range of logical ids, whose
     // consecutive members are the query tiles of one (batch, head)
@@ -74,13 +79,15 @@ __global__ __launch_bounds__(256, 2) void gsw_attn_fwd_kernel(AttnArgs p) {
     const uint32_t bh = logical / p.nqt, qt = logical - bh * p.nqt;
     const uint32_t b = bh / (uint32_t)p.H, hh = bh - b * (uint32_t)p.H;
 
-    const T* Q = reinterpret_cast<const T*>(p.q) + ((int64_t)b * p.Sq + qt * 128u + wave * 32u + c32) * p.ldq + hh * 64u;
+    const T* Q = reinterpret_cast<const T*>(p.q) + ((int64_t)b * p.Sq + qt * QWG + wave * QW + c32) * p.ldq + hh * 64u;
     const T* K = reinterpret_cast<const T*>(p.k) + (int64_t)b * p.Sk * p.ldk + hh * 64u;
     const T* VT = reinterpret_cast<const T*>(p.vt) + ((int64_t)b * p.H + hh) * 64 * (int64_t)p.Sk;
 
-    v8 qreg[4];
+    v8 qreg[QB][4];
 #pragma unroll
-    for (int kc = 0; kc < 4; ++kc) qreg[kc] = *reinterpret_cast<const v8*>(Q + kc * 16 + h * 8);
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) qreg[qb][kc] = *reinterpret_cast<const v8*>(Q + (int64_t)qb * 32 * p.ldq + kc * 16 + h * 8);
 
     // staging roles: 512 16-byte chunks per tile and operand, two per thread
     const uint32_t r0 = tid >> 3, c16 = tid & 7u;          // rows r0 and r0 + 32, 16-byte column c16
@@ -108,10 +115,15 @@ __global__ __launch_bounds__(256, 2) void gsw_attn_fwd_kernel(AttnArgs p) {
         *reinterpret_cast<uint2*>(base_ + vst + 32u * VP + 8u) = make_uint2(vreg1.z, vreg1.w); /* aligned */ \
     } while (0)
 
-    f32x16 o[2];
+    f32x16 o[QB][2];
+    float m_i[QB], l_i[QB];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
-    float m_i = -INFINITY, l_i = 0.f;
+    for (int qb = 0; qb < QB; ++qb) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { o[qb][0][i] = 0.f; o[qb][1][i] = 0.f; }
+        m_i[qb] = -INFINITY;
+        l_i[qb] = 0.f;
+    }
     const float cs = p.scale_log2;
 
     const int32_t nt = p.Sk >> 6;
@@ -124,44 +136,62 @@ __global__ __launch_bounds__(256, 2) void gsw_attn_fwd_kernel(AttnArgs p) {
         const uint8_t* Kl = lds + (uint32_t)(t & 1) * STAGE;
         const uint8_t* Vl = Kl + 64u * KP;
 
-        // ---- S^T = K Q^T : two 32-key blocks
-        f32x16 s[2];
+        // ---- S^T = K Q^T : two 32-key blocks per query block; 2 * QB independent accumulator chains, interleaved
+        f32x16 s[QB][2];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { s[0][i] = 0.f; s[1][i] = 0.f; }
+        for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { s[qb][0][i] = 0.f; s[qb][1][i] = 0.f; }
 #pragma unroll
         for (int kc = 0; kc < 4; ++kc) {
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {        // two independent accumulator chains, interleaved
+            for (int kb = 0; kb < 2; ++kb) {
                 const v8 a = *reinterpret_cast<const v8*>(Kl + (uint32_t)(kb * 32 + (int)c32) * KP + (uint32_t)kc * 32u + h * 16u);
-                s[kb] = AT<T>::mfma(a, qreg[kc], s[kb]);
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) s[qb][kb] = AT<T>::mfma(a, qreg[qb][kc], s[qb][kb]);
             }
+        }
+        if ((t + 1) * 64 > p.Sk_valid) {            // padded keys of the last tile(s) (cross-attention, 77 context tokens): score -inf
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int32_t key = t * 64 + kb * 32 + (i >> 2) * 8 + (int32_t)h * 4 + (i & 3);
+                    if (key >= p.Sk_valid) {
+#pragma unroll
+                        for (int qb = 0; qb < QB; ++qb) s[qb][kb][i] = -INFINITY;
+                    }
+                }
         }
 
         // ---- online softmax (base-2 domain); a query lives in lanes c32 and c32 + 32
-        float mx = s[0][0];
+        v8 pb[QB][2][2];
 #pragma unroll
-        for (int i = 1; i < 16; ++i) mx = fmaxf(mx, s[0][i]);
+        for (int qb = 0; qb < QB; ++qb) {
+            float mx = s[qb][0][0];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[1][i]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float m_new = fmaxf(m_i, mx * cs);
-        const float alpha = __builtin_amdgcn_exp2f(m_i - m_new);      // raw v_exp_f32: arguments are <= 0, underflow to 0 is the intent
-        m_i = m_new;
-        float rs = 0.f;
-        v8 pb[2][2];
+            for (int i = 1; i < 16; ++i) mx = fmaxf(mx, s[qb][0][i]);
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+            for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[qb][1][i]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m_i[qb], mx * cs);
+            const float alpha = __builtin_amdgcn_exp2f(m_i[qb] - m_new);      // raw v_exp_f32: arguments are <= 0, underflow to 0 is the intent
+            m_i[qb] = m_new;
+            float rs = 0.f;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float e = __builtin_amdgcn_exp2f(fmaf(s[kb][i], cs, -m_new));
-                rs += e;
-                pb[kb][i >> 3][i & 7] = (T)e;
+            for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float e = __builtin_amdgcn_exp2f(fmaf(s[qb][kb][i], cs, -m_new));
+                    rs += e;
+                    pb[qb][kb][i >> 3][i & 7] = (T)e;
+                }
             }
-        }
-        l_i = fmaf(l_i, alpha, rs);
-        if (__any(alpha != 1.0f)) {                 // once the running maxima have settled the whole wave skips the rescale
+            l_i[qb] = fmaf(l_i[qb], alpha, rs);
+            if (__any(alpha != 1.0f)) {                 // once the running maxima have settled the whole wave skips the rescale
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+                for (int i = 0; i < 16; ++i) { o[qb][0][i] *= alpha; o[qb][1][i] *= alpha; }
+            }
         }
 
         // ---- O^T += V^T P^T
@@ -175,7 +205,8 @@ __global__ __launch_bounds__(256, 2) void gsw_attn_fwd_kernel(AttnArgs p) {
                     const v4 lo = *reinterpret_cast<const v4*>(vp);
                     const v4 hi = *reinterpret_cast<const v4*>(vp + 16);
                     const v8 a = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                    o[db] = AT<T>::mfma(a, pb[kb][tt], o[db]);
+#pragma unroll
+                    for (int qb = 0; qb < QB; ++qb) o[qb][db] = AT<T>::mfma(a, pb[qb][kb][tt], o[qb][db]);
                 }
             }
         }
@@ -185,40 +216,52 @@ __global__ __launch_bounds__(256, 2) void gsw_attn_fwd_kernel(AttnArgs p) {
     }
 
     // ---- normalise and store: lane holds O^T[d][query c32] for d = db*32 + (i/4)*8 + h*4 + (i%4)
-    const float l = l_i + __shfl_xor(l_i, 32);
-    const float inv = 1.0f / l;
-    T* O = reinterpret_cast<T*>(p.o) + ((int64_t)b * p.Sq + qt * 128u + wave * 32u + c32) * p.ldo + hh * 64u;
 #pragma unroll
-    for (int db = 0; db < 2; ++db) {
+    for (int qb = 0; qb < QB; ++qb) {
+        const float l = l_i[qb] + __shfl_xor(l_i[qb], 32);
+        const float inv = 1.0f / l;
+        T* O = reinterpret_cast<T*>(p.o) + ((int64_t)b * p.Sq + qt * QWG + wave * QW + (uint32_t)qb * 32u + c32) * p.ldo + hh * 64u;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            v4 w;
+        for (int db = 0; db < 2; ++db) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) w[j] = (T)(o[db][g * 4 + j] * inv);
-            *reinterpret_cast<v4*>(O + db * 32 + g * 8 + (int)h * 4) = w;
+            for (int g = 0; g < 4; ++g) {
+                v4 w;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w[j] = (T)(o[qb][db][g * 4 + j] * inv);
+                *reinterpret_cast<v4*>(O + db * 32 + g * 8 + (int)h * 4) = w;
+            }
         }
     }
 }
 
 }  // namespace
 
-int gsw_attention_hd64(const void* q_dev, const void* k_dev, const void* vt_dev, void* out_dev, int B, int H, int Sq, int Sk, int ldq, int ldk, int ldo,
-                       float scale, int dtype, void* stream) {
+int gsw_attention_hd64(const void* q_dev, const void* k_dev, const void* vt_dev, void* out_dev, int B, int H, int Sq, int Sk, int Sk_valid, int ldq,
+                       int ldk, int ldo, float scale, int dtype, void* stream) {
     // q: [B, Sq, >= H*64] (row stride ldq), k: [B, Sk, >= H*64] (row stride ldk), vt: [B, H*64, Sk] contiguous (V transposed),
-    // out: [B, Sq, >= H*64] (row stride ldo).  Sq % 128 == 0, Sk % 64 == 0; row strides multiples of 8 elements.
-    if (!q_dev || !k_dev || !vt_dev || !out_dev || B <= 0 || H <= 0 || Sq <= 0 || Sk <= 0) return GSW_ERR_BAD_ARG;
+    // out: [B, Sq, >= H*64] (row stride ldo).  Sq % 128 == 0, Sk % 64 == 0; row strides multiples of 8 elements; keys in
+    // [Sk_valid, Sk) are padding and get zero weight.
+    if (!q_dev || !k_dev || !vt_dev || !out_dev || B <= 0 || H <= 0 || Sq <= 0 || Sk <= 0 || Sk_valid <= 0 || Sk_valid > Sk) return GSW_ERR_BAD_ARG;
     if (dtype != GSW_F16 && dtype != GSW_BF16) return GSW_ERR_BAD_ARG;
     if ((Sq & 127) || (Sk & 63) || ldq < H * 64 || ldk < H * 64 || ldo < H * 64 || ((ldq | ldk | ldo) & 7)) return GSW_ERR_UNSUPPORTED;
-    const int64_t total = (int64_t)(Sq / 128) * B * H;
+    static const int qb_env = getenv("GSW_ATTN_QB") ? atoi(getenv("GSW_ATTN_QB")) : 2;      // A/B switch for profiling
+    const int QB = ((Sq & 255) == 0 && Sq >= 512 && qb_env == 2) ? 2 : 1;      // 256-query workgroups once there are plenty of them
+    const int64_t total = (int64_t)(Sq / (128 * QB)) * B * H;
     if (total > 0x7FFFFFFF) return GSW_ERR_UNSUPPORTED;
     AttnArgs a;
     a.q = q_dev; a.k = k_dev; a.vt = vt_dev; a.o = out_dev;
-    a.H = H; a.Sq = Sq; a.Sk = Sk; a.ldq = ldq; a.ldk = ldk; a.ldo = ldo;
+    a.H = H; a.Sq = Sq; a.Sk = Sk; a.ldq = ldq; a.ldk = ldk; a.ldo = ldo; a.Sk_valid = Sk_valid;
     a.scale_log2 = scale * 1.4426950408889634f;
-    a.nqt = (uint32_t)(Sq / 128);
+    a.nqt = (uint32_t)(Sq / (128 * QB));
     a.total = (uint32_t)total;
-    if (dtype == GSW_F16) hipLaunchKernelGGL(gsw_attn_fwd_kernel<_Float16>, dim3((uint32_t)total), dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(gsw_attn_fwd_kernel<__bf16>, dim3((uint32_t)total), dim3(256), 0, (hipStream_t)stream, a);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == GSW_F16) {
+        if (QB == 2) hipLaunchKernelGGL((gsw_attn_fwd_kernel<_Float16, 2>), dim3((uint32_t)total), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((gsw_attn_fwd_kernel<_Float16, 1>), dim3((uint32_t)total), dim3(256), 0, st, a);
+    } else {
+        if (QB == 2) hipLaunchKernelGGL((gsw_attn_fwd_kernel<__bf16, 2>), dim3((uint32_t)total), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((gsw_attn_fwd_kernel<__bf16, 1>), dim3((uint32_t)total), dim3(256), 0, st, a);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g_last_hip_error = (int)e; return GSW_ERR_HIP; }
     return GSW_OK;

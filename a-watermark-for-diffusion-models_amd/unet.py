@@ -57,7 +57,7 @@ def _pw(conv: nn.Conv2d) -> torch.Tensor:
     return w
 
 
-OWN_ATTENTION = True  # self-attention (head_dim 64, sequence % 128 == 0) on gsw_attention_hd64 instead of torch SDPA
+OWN_ATTENTION = True  # attention with head_dim 64 and a query count % 128 == 0 runs on gsw_attention_hd64 instead of torch SDPA
 
 GEMM_MAX_K = 0        # linear layers with K <= this would run on the hand-written GEMM (gsw_linear).  Measured on MI355X: it only
                       # beats hipBLASLt on [524288,320]x[320,320] (398 vs 343 TFLOP/s) and loses elsewhere, incl. the fused GEGLU
@@ -140,6 +140,19 @@ class ResnetBlock2D(nn.Module):
         return conv3x3_res_pf(h, c[0], c[1], x1=x, x2=x2)                                # conv2 + conv_shortcut in one GEMM
 
 
+def _padded_ctx(ctx: torch.Tensor):
+    """Context tokens zero-padded to a multiple of 64 keys for the attention kernel (77 -> 128), computed once per context tensor:
+    every cross-attention layer of every step receives the same object."""
+    n = ctx.shape[1]
+    if n % 64 == 0:
+        return ctx, n
+    pad = getattr(ctx, "_gsw_pad", None)
+    if pad is None or pad.device != ctx.device or pad.dtype != ctx.dtype:
+        pad = F.pad(ctx, (0, 0, 0, (-n) % 64)).contiguous()
+        ctx._gsw_pad = pad
+    return pad, n
+
+
 class Attention(nn.Module):
     def __init__(self, dim, ctx_dim, heads, head_dim):
         super().__init__()
@@ -154,13 +167,16 @@ class Attention(nn.Module):
 
     def forward(self, x, ctx=None):
         b, n, _ = x.shape
-        if ctx is None and OWN_ATTENTION and FUSED_KERNELS:
+        if OWN_ATTENTION and FUSED_KERNELS:
             from .pf import attention_hd64, attention_hd64_ok
-            if attention_hd64_ok(x, self.heads, self.to_q.out_features // self.heads, n, n):
-                # self-attention on the hand-written flash-attention kernel; the value projection is computed transposed
-                # (V^T = W_v x^T, one GEMM either way) because the kernel consumes V^T tiles
-                vt = torch.bmm(self.to_v.weight.unsqueeze(0).expand(b, -1, -1), x.transpose(1, 2))
-                return _lin(attention_hd64(_lin(x, self.to_q), _lin(x, self.to_k), vt, self.heads), self.to_out[0])
+            src, valid = (x, n) if ctx is None else _padded_ctx(ctx)
+            if attention_hd64_ok(x, self.heads, self.to_q.out_features // self.heads, n, src.shape[1]):
+                # hand-written flash-attention kernel (self- and cross-attention); the value projection is computed transposed
+                # (V^T = W_v src^T, one GEMM either way) because the kernel consumes V^T tiles.  Padded context rows are zero and
+                # masked by `valid`.
+                vt = torch.bmm(self.to_v.weight.unsqueeze(0).expand(b, -1, -1), src.transpose(1, 2))
+                o = attention_hd64(_lin(x, self.to_q), _lin(src, self.to_k), vt, self.heads, valid_keys=valid)
+                return _lin(o, self.to_out[0])
         ctx = x if ctx is None else ctx
         q = _lin(x, self.to_q).view(b, n, self.heads, -1).transpose(1, 2)
         k = _lin(ctx, self.to_k).view(b, ctx.shape[1], self.heads, -1).transpose(1, 2)

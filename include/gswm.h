@@ -169,9 +169,10 @@ int gsw_linear(const void* x_dev, const void* w_dev, const void* bias_dev, const
  *   k   : [B, Sk, >= H*64] row stride ldk
  *   vt  : [B, H*64, Sk] contiguous -- the value projection TRANSPOSED (compute it as W_v x^T)
  *   out : [B, Sq, >= H*64] row stride ldo
+ *   Sk_valid : keys in [Sk_valid, Sk) are padding and get zero weight (cross-attention: 77 context tokens padded to 128)
  * Sq % 128 == 0, Sk % 64 == 0, strides % 8 == 0; else GSW_ERR_UNSUPPORTED. */
-int gsw_attention_hd64(const void* q_dev, const void* k_dev, const void* vt_dev, void* out_dev, int B, int H, int Sq, int Sk, int ldq, int ldk,
-                       int ldo, float scale, int dtype, void* stream);
+int gsw_attention_hd64(const void* q_dev, const void* k_dev, const void* vt_dev, void* out_dev, int B, int H, int Sq, int Sk, int Sk_valid,
+                       int ldq, int ldk, int ldo, float scale, int dtype, void* stream);
 
 /* E4, bit-parity mode -- gs_insert.py:62 `np.random.uniform(0, 1)` / nodes.py:52-53,114-117 `RandomState(seed).uniform(0, 1)`:
  * NumPy's legacy MT19937 `random_sample` stream continued on the device.  key/pos: the generator state as

@@ -206,6 +206,22 @@ def test_attention_hd64_vs_fp32_reference(G, dtype, B, H, S):
     assert (got.float() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("Sk_valid", [77, 64, 1, 128])
+def test_attention_hd64_masked_keys(G, Sk_valid):
+    """Cross-attention shape: context padded to 128 keys, keys >= Sk_valid carry zero weight whatever they hold."""
+    g = torch.Generator().manual_seed(Sk_valid)
+    B, H, S = 2, 3, 256
+    q = torch.randn(B, S, H * 64, generator=g).half().cuda()
+    k = torch.randn(B, 128, H * 64, generator=g).half().cuda()
+    v = torch.randn(B, 128, H * 64, generator=g).half().cuda()
+    k[:, Sk_valid:] = 50.0                                        # would dominate the softmax if it leaked
+    v[:, Sk_valid:] = 1000.0
+    got = G.pf.attention_hd64(q, k, v.transpose(1, 2).contiguous(), H, valid_keys=Sk_valid)
+    qf, kf, vf = (a.float().view(B, a.shape[1], H, 64).transpose(1, 2) for a in (q, k[:, :Sk_valid], v[:, :Sk_valid]))
+    ref = (torch.softmax(qf @ kf.transpose(-1, -2) / 8.0, dim=-1) @ vf).transpose(1, 2).reshape(B, S, H * 64)
+    assert (got.float() - ref).abs().max().item() <= 4e-3 * max(1.0, ref.abs().max().item())
+
+
 def test_attention_hd64_rejects_unsupported_shapes(G):
     q = torch.zeros(1, 100, 64, dtype=torch.float16, device="cuda")
     with pytest.raises(Exception):
