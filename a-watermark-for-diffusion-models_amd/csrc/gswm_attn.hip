@@ -17,7 +17,12 @@
 //     12-15 <-> keys 0-3 | 8-11 | 4-7 | 12-15); contraction order is free as long as V^T uses the same one
 //   * LDS row pitches 144 B (K, ds_read_b128) and 136 B (V^T, ds_read_b64) are conflict-free for those access widths
 //   * blockIdx -> (batch*head, query tile) is XCD-aware: the query tiles of one (batch, head) land on one XCD and share its L2 copy of K / V
-// Roofline: MFMA; at head_dim 64 the 32 v_exp_f32 per lane and 64 keys (quarter rate) cost as much issue time as the 16 MFMAs.
+// Roofline: MFMA.  Measured (B=128, 5 heads, S=4096, fp16): 825-832 TFLOP/s = 33 % of the 2.5 PF nominal peak, MFMA pipe busy 40-42 % of
+// the cycles the chip actually runs (PMC: effective clock 1.87 GHz under this load); torch SDPA (aotriton) does 630-690 on the same shape.
+// At head_dim 64 every 16 MFMAs come with ~170 VALU instructions (32 v_exp_f32, max / sum / convert / rescale) per wave.
+// Tried and dropped: software pipelining over 32-key blocks (S^T of block u+1 issued before the softmax of block u, 3 LDS stages,
+// one barrier per tile): 790 vs 831 TFLOP/s -- the per-block max / exchange / rescale overhead doubles and hipcc does not interleave
+// the two streams any better than the wave scheduler already does across the 2-4 resident waves.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -88,6 +93,18 @@ __global__ __launch_bounds__(256, 2) void gsw_attn_fwd_kernel(AttnArgs p) {
     for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
         for (int kc = 0; kc < 4; ++kc) qreg[qb][kc] = *reinterpret_cast<const v8*>(Q + (int64_t)qb * 32 * p.ldq + kc * 16 + h * 8);
+    // Pass Q through a VALU move before the loop: the loop's MFMAs then read ALU results, not load results, so the waitcnt pass does
+    // not place `s_waitcnt vmcnt` (which would drain the in-flight K / V prefetch) in front of them.
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            u32x4 w = __builtin_bit_cast(u32x4, qreg[qb][kc]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { uint32_t e = w[j]; asm volatile("v_mov_b32 %0, %0" : "+v"(e)); w[j] = e; }
+            qreg[qb][kc] = __builtin_bit_cast(v8, w);
+        }
 
     // staging roles: 512 16-byte chunks per tile and operand, two per thread
     const uint32_t r0 = tid >> 3, c16 = tid & 7u;          // rows r0 and r0 + 32, 16-byte column c16
@@ -131,8 +148,11 @@ __global__ __launch_bounds__(256, 2) void gsw_attn_fwd_kernel(AttnArgs p) {
     GSW_ATTN_LSTORE(0u);
     __syncthreads();
     for (int32_t t = 0; t < nt; ++t) {
-        const bool more = t + 1 < nt;
-        if (more) GSW_ATTN_GLOAD((t + 1) << 6);
+        // prefetch the next tile into registers -- unconditionally (the last iteration re-fetches its own tile into the idle stage):
+        // a conditional load made the compiler merge the registers right after the branch, i.e. wait for HBM inside the MFMA phase
+        const int32_t tn = t + 1 < nt ? t + 1 : t;
+        GSW_ATTN_GLOAD(tn << 6);
+        __builtin_amdgcn_sched_barrier(0);          // keep the prefetch at the top of the iteration (the scheduler sinks it otherwise)
         const uint8_t* Kl = lds + (uint32_t)(t & 1) * STAGE;
         const uint8_t* Vl = Kl + 64u * KP;
 
@@ -211,7 +231,7 @@ __global__ __launch_bounds__(256, 2) void gsw_attn_fwd_kernel(AttnArgs p) {
             }
         }
 
-        if (more) GSW_ATTN_LSTORE((uint32_t)((t + 1) & 1));
+        GSW_ATTN_LSTORE((uint32_t)((t + 1) & 1));
         __syncthreads();
     }
 
@@ -233,6 +253,7 @@ __global__ __launch_bounds__(256, 2) void gsw_attn_fwd_kernel(AttnArgs p) {
         }
     }
 }
+
 
 }  // namespace
 
