@@ -83,16 +83,16 @@ class ConvTimer:
         e.record()
         return e
 
-    def stop(self, e0, kernel: str, flops: float):
+    def stop(self, e0, kernel: str, flops: float, launches: int = 1):
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        self.ev.append((kernel, flops, e0, e1))
+        self.ev.append((kernel, flops, e0, e1, launches))
 
     def summary(self):
         out = {}
-        for k, f, a, b in self.ev:
+        for k, f, a, b, nl in self.ev:
             d = out.setdefault(k, {"calls": 0, "flops": 0.0, "ms": 0.0})
-            d["calls"] += 1
+            d["calls"] += nl                     # kernel launches (the sub-pixel upsampling call is four launches)
             d["flops"] += f
             d["ms"] += a.elapsed_time(b)
         for d in out.values():
@@ -261,3 +261,40 @@ def attention_hd64(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: in
         N.check(N.lib().gsw_attention_hd64(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), B, heads, Sq, Sk, Sk if valid_keys is None else int(valid_keys), inner, inner, inner,
                                            float(scale if scale is not None else 64 ** -0.5), _dt(q.dtype), _stream_ptr()))
     return out
+
+
+def pack_upsample_weight(w: torch.Tensor) -> torch.Tensor:
+    """3x3 weights [N, C, 3, 3] of a convolution that follows a nearest-neighbour 2x upsampling -> [4, N, 4*C]: for output parity
+    (dy, dx) the 2x2 kernel over the low-resolution input, tap (a, b) = sum of the 3x3 taps that read source pixel (i+a+dy-1, j+b+dx-1)."""
+    rows = {(0, 0): (0,), (0, 1): (1, 2), (1, 0): (0, 1), (1, 1): (2,)}          # (parity, tap) -> 3x3 indices merged into it
+    wf = w.detach().float()
+    out = []
+    for dy in (0, 1):
+        for dx in (0, 1):
+            taps = []
+            for a in (0, 1):
+                for b in (0, 1):
+                    taps.append(sum(wf[:, :, kh, kw] for kh in rows[(dy, a)] for kw in rows[(dx, b)]))       # [N, C]
+            out.append(torch.stack(taps, dim=1).reshape(w.shape[0], -1))                                     # [N, 4*C]
+    return torch.stack(out).to(w.dtype).contiguous()
+
+
+def conv_up2x_fusable(x: PF, n_out: int) -> bool:
+    return n_out % 160 == 0 and x.C % 64 == 0 and _halo_lds_bytes(x.W) <= 80 * 1024
+
+
+def conv_up2x_pf(x: PF, w4: torch.Tensor, bias: Optional[torch.Tensor]) -> PF:
+    """conv3x3(nearest_upsample_2x(x)) without materialising the upsampled tensor (gsw_conv_up2x_pf)."""
+    Nn = w4.shape[1]
+    y = PF.empty(x.B, 2 * x.H, 2 * x.W, Nn, x.buf.dtype, x.buf.device)
+    g = y.grid
+    g[:, 0].zero_(); g[:, -1].zero_(); g[:, :, 0].zero_(); g[:, :, -1].zero_()        # the kernel writes interior rows only
+    tm = CONV_TIMER
+    with torch.cuda.device(x.buf.device):
+        e0 = tm.start() if tm is not None else None
+        N.check(N.lib().gsw_conv_up2x_pf(x.rows.data_ptr(), w4.data_ptr(), bias.data_ptr() if bias is not None else None, y.rows.data_ptr(),
+                                         x.B, x.H, x.W, x.C, Nn, _dt(x.buf.dtype), _stream_ptr()))
+        if tm is not None:      # algorithmic FLOPs = the convolution it replaces (9 taps at high resolution); 16*C MACs per output are executed
+            tm.stop(e0, ("gsw_conv3x3_halo_kernel(up2x)", x.B, 2 * x.H, 2 * x.W, 9 * x.C, Nn, 1) if tm.by_shape else "gsw_conv3x3_halo_kernel",
+                    2.0 * x.B * 4 * x.H * x.W * Nn * 9 * x.C, launches=4)
+    return y

@@ -57,6 +57,8 @@ def _pw(conv: nn.Conv2d) -> torch.Tensor:
     return w
 
 
+UPSAMPLE_SUBPIXEL = True   # Upsample2D = four 2x2 convolutions of the low-resolution tensor (gsw_conv_up2x_pf) instead of upsample + 3x3
+
 OWN_ATTENTION = True  # attention with head_dim 64 and a query count % 128 == 0 runs on gsw_attention_hd64 instead of torch SDPA
 
 GEMM_MAX_K = 0        # linear layers with K <= this would run on the hand-written GEMM (gsw_linear).  Measured on MI355X: it only
@@ -286,7 +288,13 @@ class Upsample2D(nn.Module):
         return self.conv(F.interpolate(x, scale_factor=2.0, mode="nearest"))
 
     def forward_pf(self, x):
-        from .pf import PF, conv_pf
+        from .pf import PF, conv_pf, conv_up2x_pf, conv_up2x_fusable, pack_upsample_weight
+        if UPSAMPLE_SUBPIXEL and conv_up2x_fusable(x, self.conv.out_channels):
+            w4 = getattr(self, "_gsw_up4", None)
+            if w4 is None or w4.device != self.conv.weight.device or w4.dtype != self.conv.weight.dtype:
+                w4 = pack_upsample_weight(self.conv.weight)
+                self._gsw_up4 = w4
+            return conv_up2x_pf(x, w4, self.conv.bias)            # 2.25x fewer FLOPs, no upsampled intermediate
         up = PF.zeros(x.B, 2 * x.H, 2 * x.W, x.C, x.buf.dtype, x.buf.device)
         xi, g = x.interior, up.grid
         for dy in (0, 1):

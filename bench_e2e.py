@@ -191,8 +191,9 @@ def run_e2e(args, rank, world, local_rank):
         dom = cs.get("gsw_conv3x3_halo_kernel")
         if dom is not None:
             # the dominant kernel of the step (largest share of GPU time in profiles/*_e2e_*_kernel_stats.csv): the 3x3 implicit-GEMM
-            # convolution.  achieved = algorithmic conv FLOPs (2 * real output pixels * N * K; padded border rows not counted) / the
-            # HIP-event time of its launches in the timed region.
+            # convolution.  achieved = algorithmic conv FLOPs (2 * real output pixels * N * K of the convolution the model defines; padded
+            # border rows not counted; the upsampler's sub-pixel form executes 2.25x fewer) / the HIP-event time of its launches in the
+            # timed region.
             out["roofline"] = {"bound": "mfma", "kernel": "gsw_conv3x3_halo_kernel", "achieved": dom["tflops"], "peak": MFMA_PEAK_TFLOPS,
                                "unit": "TFLOP/s", "frac": dom["tflops"] / MFMA_PEAK_TFLOPS, "traffic": None,
                                "algorithmic_flops_per_launch": dom["flops_per_launch"], "avg_launch_us": dom["avg_us"], "calls": dom["calls"],

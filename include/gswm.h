@@ -163,6 +163,12 @@ int gsw_add_layernorm(const void* x_dev, const void* delta_dev, const void* gamm
 int gsw_linear(const void* x_dev, const void* w_dev, const void* bias_dev, const void* resid_dev, void* y_dev, int64_t M, int K, int N,
                int geglu, int dtype, void* stream);
 
+/* diffusers Upsample2D (nearest 2x + 3x3 convolution) from the low-resolution PF input, by sub-pixel decomposition: w4 =
+ * [4 output parities (dy*2+dx)][N][4 taps (a*2+b)][C], the 3x3 weights pre-summed over the taps that read the same source pixel
+ * (pf.pack_upsample_weight).  y: PF [B, 2H, 2W, N] whose border rows the caller has zeroed; only interior rows are written. */
+int gsw_conv_up2x_pf(const void* x_dev, const void* w4_dev, const void* bias_dev, void* y_dev, int B, int H, int W, int C, int N, int dtype,
+                     void* stream);
+
 /* Self-attention of the eps-model (diffusers BasicTransformerBlock.attn1 inside the UNet the reference runs at extract.py:66-69):
  * out = softmax(q k^T * scale) v per (batch, head), head_dim 64, fp16 / bf16, fp32 accumulation -- a flash-attention forward.
  *   q   : [B, Sq, >= H*64] row stride ldq elements, head h in columns [h*64, h*64+64)

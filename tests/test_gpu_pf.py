@@ -243,3 +243,20 @@ def test_unet_own_attention_equals_sdpa_path(G):
         y0 = m(x, t, c)
         U.OWN_ATTENTION = True
     assert (y1.float() - y0.float()).abs().max().item() <= 2e-2 * max(1.0, y0.float().abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("B,H,W,C,N", [(2, 8, 8, 64, 160), (1, 16, 12, 128, 320), (3, 5, 7, 64, 160)])
+def test_conv_up2x_vs_torch_fp32(G, dtype, B, H, W, C, N):
+    """Sub-pixel form of nearest-upsample-2x + 3x3 convolution against F.conv2d(F.interpolate(x)) in fp32 (tolerance: the pre-summed
+    weights are rounded once more to the storage dtype: 4e-3 fp16 / 3e-2 bf16 relative to the output scale)."""
+    g = torch.Generator().manual_seed(B * 100 + H)
+    x = torch.randn(B, C, H, W, generator=g).to(dtype).cuda()
+    w = (torch.randn(N, C, 3, 3, generator=g) * (1.0 / (9 * C)) ** 0.5).to(dtype).cuda()
+    b = (0.1 * torch.randn(N, generator=g)).to(dtype).cuda()
+    ref = F.conv2d(F.interpolate(x.float(), scale_factor=2.0, mode="nearest"), w.float(), b.float(), padding=1)
+    y = G.pf.conv_up2x_pf(G.pf.PF.from_nchw(x), G.pf.pack_upsample_weight(w), b)
+    tol = 4e-3 if dtype == torch.float16 else 3e-2
+    assert (y.to_nchw().float() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+    gr = y.grid
+    assert gr[:, 0].abs().max() == 0 and gr[:, -1].abs().max() == 0 and gr[:, :, 0].abs().max() == 0 and gr[:, :, -1].abs().max() == 0

@@ -13,9 +13,10 @@ def run(n=4):
         for _ in range(n): m(x, t, c)
         torch.cuda.synchronize()
     return (time.perf_counter() - t0) / n
-variants = {"own attention": dict(OWN_ATTENTION=True), "sdpa": dict(OWN_ATTENTION=False)}
+variants = {"default": dict(UPSAMPLE_SUBPIXEL=True, OWN_ATTENTION=True), "no subpixel upsample": dict(UPSAMPLE_SUBPIXEL=False, OWN_ATTENTION=True),
+            "sdpa": dict(UPSAMPLE_SUBPIXEL=True, OWN_ATTENTION=False)}
 for rep in range(3):
     for name, flags in variants.items():
         for k, v in flags.items(): setattr(U, k, v)
         d = run()
-        print(f"rep {rep} {name:16s}: {d*1e3:7.1f} ms  {B*0.804/d:6.0f} TFLOP/s", flush=True)
+        print(f"rep {rep} {name:22s}: {d*1e3:7.1f} ms  {B*0.804/d:6.0f} TFLOP/s", flush=True)
