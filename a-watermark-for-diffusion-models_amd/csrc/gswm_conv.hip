@@ -942,6 +942,36 @@ __global__ __launch_bounds__(256) void gsw_add_layernorm_kernel(const uint16_t* 
 extern __attribute__((visibility("hidden"))) thread_local int g_last_hip_error;   // gswm_kernels.hip; read by gsw_last_hip_error()
 #define g_conv_hip_error g_last_hip_error
 #define GSW_CONV_HIP(call) do { hipError_t _e = (call); if (_e != hipSuccess) { g_conv_hip_error = (int)_e; return GSW_ERR_HIP; } } while (0)
+// Launch the halo kernel for a prepared ConvArgs: double-buffered weights when the LDS image (halo'd activation tile + 2 weight tiles)
+// fits two workgroups per CU (<= 80 KiB), single-buffered weights for wider rows (e.g. the 96-wide lattice of BASELINE config 5),
+// GSW_ERR_UNSUPPORTED beyond that.  GSW_CONV_WDB=0 forces the single-buffered variant (profiling A/B).
+static int launch_halo(const ConvArgs& a, int64_t M, int N, int dtype, void* stream) {
+    static const int wdb_env = getenv("GSW_CONV_WDB") ? atoi(getenv("GSW_CONV_WDB")) : 1;
+    const int32_t HP = ((a.Wp + 1) + 7) & ~7;
+    const size_t xbytes = (size_t)std::max(CW_BM + 2 * HP, 2 * CW_BM) * 128u, wbytes = (size_t)CW_BN * 128u;
+    const bool wdb = wdb_env && xbytes + 2 * wbytes <= 80u * 1024u;
+    const size_t lds = xbytes + (wdb ? 2 : 1) * wbytes;
+    if (lds > 80u * 1024u) return GSW_ERR_UNSUPPORTED;
+    const uint32_t grid = (uint32_t)(((M + 127) / 128) * (N / CW_BN));
+    hipStream_t st = (hipStream_t)stream;
+#define GSW_HALO_LAUNCH(TT, DB)                                                                                                              \
+    do {                                                                                                                                     \
+        if (lds > 48u * 1024u)                                                                                                               \
+            GSW_CONV_HIP(hipFuncSetAttribute((const void*)gsw_conv3x3_halo_kernel<TT, DB>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)); \
+        hipLaunchKernelGGL((gsw_conv3x3_halo_kernel<TT, DB>), dim3(grid), dim3(256), lds, st, a, HP);                                        \
+    } while (0)
+    if (dtype == GSW_F16) { if (wdb) GSW_HALO_LAUNCH(_Float16, true); else GSW_HALO_LAUNCH(_Float16, false); }
+    else { if (wdb) GSW_HALO_LAUNCH(__bf16, true); else GSW_HALO_LAUNCH(__bf16, false); }
+#undef GSW_HALO_LAUNCH
+    GSW_CONV_HIP(hipGetLastError());
+    return GSW_OK;
+}
+
+static bool halo_fits(int Wp) {
+    const int32_t HP = ((Wp + 1) + 7) & ~7;
+    return (size_t)std::max(CW_BM + 2 * HP, 2 * CW_BM) * 128u + (size_t)CW_BN * 128u <= 80u * 1024u;
+}
+
 static int launch_conv_gemm(ConvArgs& a, int64_t M, int N, int dtype, void* stream);
 
 int gsw_conv_pf(const void* x_dev, const void* w_dev, const void* bias_dev, const void* rowbias_dev, const void* resid_dev, void* y_dev,
@@ -977,26 +1007,8 @@ static int launch_conv_gemm(ConvArgs& a, int64_t M, int N, int dtype, void* stre
     hipStream_t st = (hipStream_t)stream;
     if (N % CW_BN == 0 && !narrow_only) {
         static const bool no_halo = getenv("GSW_CONV_NOHALO") != nullptr;
-        const int32_t HP = ((a.Wp + 1) + 7) & ~7;
-        static const int wdb_env = getenv("GSW_CONV_WDB") ? atoi(getenv("GSW_CONV_WDB")) : 1;
-        const size_t halo_lds = (size_t)std::max(CW_BM + 2 * HP, 2 * CW_BM) * 128u + (size_t)CW_BN * 128u * (wdb_env ? 2u : 1u);
-        if (!a.dense && a.ntaps == 9 && a.stride == 1 && !no_halo && halo_lds <= 80u * 1024u) {
-            const uint32_t grid = (uint32_t)(((M + 127) / 128) * (N / CW_BN));
-            if (wdb_env) {
-                if (halo_lds > 48u * 1024u) {
-                    GSW_CONV_HIP(hipFuncSetAttribute((const void*)gsw_conv3x3_halo_kernel<_Float16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-                    GSW_CONV_HIP(hipFuncSetAttribute((const void*)gsw_conv3x3_halo_kernel<__bf16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-                }
-                if (dtype == GSW_F16) hipLaunchKernelGGL((gsw_conv3x3_halo_kernel<_Float16, true>), dim3(grid), dim3(256), halo_lds, st, a, HP);
-                else hipLaunchKernelGGL((gsw_conv3x3_halo_kernel<__bf16, true>), dim3(grid), dim3(256), halo_lds, st, a, HP);
-            } else {
-                if (halo_lds > 48u * 1024u) {
-                    GSW_CONV_HIP(hipFuncSetAttribute((const void*)gsw_conv3x3_halo_kernel<_Float16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-                    GSW_CONV_HIP(hipFuncSetAttribute((const void*)gsw_conv3x3_halo_kernel<__bf16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-                }
-                if (dtype == GSW_F16) hipLaunchKernelGGL((gsw_conv3x3_halo_kernel<_Float16, false>), dim3(grid), dim3(256), halo_lds, st, a, HP);
-                else hipLaunchKernelGGL((gsw_conv3x3_halo_kernel<__bf16, false>), dim3(grid), dim3(256), halo_lds, st, a, HP);
-            }
+        if (!a.dense && a.ntaps == 9 && a.stride == 1 && !no_halo && halo_fits(a.Wp)) {
+            return launch_halo(a, M, N, dtype, stream);
         } else if (a.dense) {
             const uint32_t grid = (uint32_t)(((M + 127) / 128) * (N / CW_BN));
             if (dtype == GSW_F16) hipLaunchKernelGGL((gsw_conv_gemm_wide_kernel<_Float16, 2, false, true>), dim3(grid), dim3(256), 0, st, a);
@@ -1101,18 +1113,7 @@ int gsw_conv3x3_res_pf(const void* x_dev, const void* w_dev, const void* bias_de
         for (int kw = 0; kw < 3; ++kw) a.tap_off[kh * 3 + kw] = (kh - 1) * a.Wp + (kw - 1);
     a.dense = 0; a.geglu = 0; a.ldy = N;
     a.x1 = x1_dev; a.x2 = x2_dev; a.C1 = x1_dev ? C1 : 0; a.C2 = x2_dev ? C2 : 0; a.up = 0;
-    const int32_t HP = ((a.Wp + 1) + 7) & ~7;
-    const size_t halo_lds = (size_t)std::max(CW_BM + 2 * HP, 2 * CW_BM) * 128u + (size_t)CW_BN * 128u * 2u;
-    if (halo_lds > 80u * 1024u) return GSW_ERR_UNSUPPORTED;
-    const uint32_t grid = (uint32_t)(((M + 127) / 128) * (N / CW_BN));
-    if (halo_lds > 48u * 1024u) {
-        GSW_CONV_HIP(hipFuncSetAttribute((const void*)gsw_conv3x3_halo_kernel<_Float16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-        GSW_CONV_HIP(hipFuncSetAttribute((const void*)gsw_conv3x3_halo_kernel<__bf16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-    }
-    if (dtype == GSW_F16) hipLaunchKernelGGL((gsw_conv3x3_halo_kernel<_Float16, true>), dim3(grid), dim3(256), halo_lds, (hipStream_t)stream, a, HP);
-    else hipLaunchKernelGGL((gsw_conv3x3_halo_kernel<__bf16, true>), dim3(grid), dim3(256), halo_lds, (hipStream_t)stream, a, HP);
-    GSW_CONV_HIP(hipGetLastError());
-    return GSW_OK;
+    return launch_halo(a, M, N, dtype, stream);
 }
 
 int gsw_conv_up2x_pf(const void* x_dev, const void* w4_dev, const void* bias_dev, void* y_dev, int B, int H, int W, int C, int N, int dtype, void* stream) {
@@ -1134,14 +1135,7 @@ int gsw_conv_up2x_pf(const void* x_dev, const void* w4_dev, const void* bias_dev
     a.M = (int32_t)M; a.ntaps = 4;
     a.dense = 0; a.geglu = 0; a.ldy = N;
     a.x1 = nullptr; a.x2 = nullptr; a.C1 = 0; a.C2 = 0;
-    const int32_t HP = ((a.Wp + 1) + 7) & ~7;
-    const size_t halo_lds = (size_t)std::max(CW_BM + 2 * HP, 2 * CW_BM) * 128u + (size_t)CW_BN * 128u * 2u;
-    if (halo_lds > 80u * 1024u) return GSW_ERR_UNSUPPORTED;
-    const uint32_t grid = (uint32_t)(((M + 127) / 128) * (N / CW_BN));
-    if (halo_lds > 48u * 1024u) {
-        GSW_CONV_HIP(hipFuncSetAttribute((const void*)gsw_conv3x3_halo_kernel<_Float16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-        GSW_CONV_HIP(hipFuncSetAttribute((const void*)gsw_conv3x3_halo_kernel<__bf16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-    }
+    if (!halo_fits(a.Wp)) return GSW_ERR_UNSUPPORTED;
     const size_t esz = 2;
     for (int par = 0; par < 4; ++par) {
         const int dy = par >> 1, dx = par & 1;
@@ -1150,9 +1144,7 @@ int gsw_conv_up2x_pf(const void* x_dev, const void* w4_dev, const void* bias_dev
             for (int tb = 0; tb < 2; ++tb) a.tap_off[ta * 2 + tb] = (ta + dy - 1) * a.Wp + (tb + dx - 1);
         a.w = (const uint8_t*)w4_dev + (size_t)par * N * 4 * C * esz;
         a.up = 1 + par;
-        if (dtype == GSW_F16) hipLaunchKernelGGL((gsw_conv3x3_halo_kernel<_Float16, true>), dim3(grid), dim3(256), halo_lds, (hipStream_t)stream, a, HP);
-        else hipLaunchKernelGGL((gsw_conv3x3_halo_kernel<__bf16, true>), dim3(grid), dim3(256), halo_lds, (hipStream_t)stream, a, HP);
-        GSW_CONV_HIP(hipGetLastError());
+        { const int rc = launch_halo(a, M, N, dtype, stream); if (rc != GSW_OK) return rc; }
     }
     return GSW_OK;
 }

@@ -107,7 +107,7 @@ CONV_TIMER: Optional[ConvTimer] = None
 
 def _halo_lds_bytes(W: int) -> int:
     hp = ((W + 3) + 7) & ~7
-    return max(128 + 2 * hp, 256) * 128 + 2 * 160 * 128
+    return max(128 + 2 * hp, 256) * 128 + 160 * 128        # single-buffered weights: what the widest supported rows need
 
 
 def _conv_kernel_name(W: int, n_out: int, ksize: int, stride: int) -> str:

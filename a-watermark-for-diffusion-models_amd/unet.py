@@ -66,6 +66,14 @@ GEMM_MAX_K = 0        # linear layers with K <= this would run on the hand-writt
                       # form (output-bound epilogue), so the transformer linears stay on the library GEMM; set > 0 to experiment.
 
 
+GEGLU_GEMM_MAX_K = 0  # feed-forward projection + GEGLU as ONE own GEMM (value * gelu(gate) in the epilogue) when K <= this
+
+
+def _own_geglu_ok(x: torch.Tensor, K: int, N: int) -> bool:
+    return USE_PF and FUSED_KERNELS and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and x.is_contiguous() \
+        and K % 64 == 0 and N % 160 == 0 and K <= GEGLU_GEMM_MAX_K
+
+
 def _own_gemm_ok(x: torch.Tensor, K: int, N: int) -> bool:
     return USE_PF and FUSED_KERNELS and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and x.is_contiguous() \
         and K % 64 == 0 and N % 160 == 0 and K <= GEMM_MAX_K
@@ -194,7 +202,8 @@ class GEGLU(nn.Module):
 
     def forward(self, x):
         inner = self.proj.out_features // 2
-        if _own_gemm_ok(x, self.proj.in_features, self.proj.out_features) and inner % 80 == 0:
+        if (_own_gemm_ok(x, self.proj.in_features, self.proj.out_features) or _own_geglu_ok(x, self.proj.in_features, self.proj.out_features)) \
+                and inner % 80 == 0:
             from .pf import linear, pack_geglu_weight     # value * gelu(gate) in the GEMM epilogue: no [M, 2I] intermediate
             c = getattr(self, "_gsw_geglu", None)
             if c is None or c[0].device != x.device or c[0].dtype != x.dtype:

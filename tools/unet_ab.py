@@ -13,8 +13,10 @@ def run(n=4):
         for _ in range(n): m(x, t, c)
         torch.cuda.synchronize()
     return (time.perf_counter() - t0) / n
-variants = {"default": dict(UPSAMPLE_SUBPIXEL=True, OWN_ATTENTION=True), "no subpixel upsample": dict(UPSAMPLE_SUBPIXEL=False, OWN_ATTENTION=True),
-            "sdpa": dict(UPSAMPLE_SUBPIXEL=True, OWN_ATTENTION=False)}
+variants = {"default": dict(GEGLU_GEMM_MAX_K=0), "geglu fused K<=320": dict(GEGLU_GEMM_MAX_K=320), "geglu fused K<=640": dict(GEGLU_GEMM_MAX_K=640),
+            "geglu fused all": dict(GEGLU_GEMM_MAX_K=1280)}
+if len(sys.argv) > 2:
+    variants = eval(sys.argv[2])
 for rep in range(3):
     for name, flags in variants.items():
         for k, v in flags.items(): setattr(U, k, v)
