@@ -15,7 +15,9 @@
 //     A operand of the second product is two 8-byte LDS reads per MFMA instead of a transposing gather
 //   * the key order inside a 16-wide MFMA k-slice is the permutation the S^T accumulator layout dictates (slots 0-3 | 4-7 | 8-11 |
 //     12-15 <-> keys 0-3 | 8-11 | 4-7 | 12-15); contraction order is free as long as V^T uses the same one
-//   * LDS row pitches 144 B (K, ds_read_b128) and 136 B (V^T, ds_read_b64) are conflict-free for those access widths
+//   * LDS row pitches 144 B (K, ds_read_b128; 112 / 176 B for head_dim 40 / 80) and 136 B (V^T, ds_read_b64) are conflict-free for those
+//     access widths
+//   * head_dim 40 and 80 (the SD 1.5 shape: 8 heads at every level) run the same code with zero-padded k-slices / output row blocks
 //   * blockIdx -> (batch*head, query tile) is XCD-aware: the query tiles of one (batch, head) land on one XCD and share its L2 copy of K / V
 // Roofline: MFMA.  Measured (B=128, 5 heads, S=4096, fp16): 825-832 TFLOP/s = 33 % of the 2.5 PF nominal peak, MFMA pipe busy 40-42 % of
 // the cycles the chip actually runs (PMC: effective clock 1.87 GHz under this load); torch SDPA (aotriton) does 630-690 on the same shape.
@@ -64,15 +66,20 @@ struct AttnArgs {
     uint32_t total;     // nqt * B * H
 };
 
-constexpr uint32_t KP = 144, VP = 136;                     // LDS row pitches in bytes
-constexpr uint32_t STAGE = 64 * KP + 64 * VP;              // one K tile + one V^T tile
+constexpr uint32_t VP = 136;                               // V^T LDS row pitch in bytes (64 keys + 8 B: conflict-free ds_read_b64)
 
 // QB = 32-query blocks per wave (1: 128 queries per workgroup; 2: 256 -- every K / V^T fragment read from LDS feeds two MFMAs and
-// the two blocks' softmax / MFMA chains are independent instruction streams the scheduler can interleave inside one wave)
-template <typename T, int QB>
+// the two blocks' softmax / MFMA chains are independent instruction streams the scheduler can interleave inside one wave).
+// DU = head_dim / 8 (5, 8, 10 <-> head_dim 40, 64, 80): the contraction over head_dim runs in KC = ceil(DU/2) MFMA k-slices and the
+// output in DB = ceil(head_dim/32) row blocks; the padding lanes of Q are zero registers and the padding rows of V^T zero LDS rows.
+template <typename T, int QB, int DU>
 __global__ __launch_bounds__(256, 2) void gsw_attn_fwd_kernel(AttnArgs p) {
     using v8 = typename AT<T>::v8;
     using v4 = typename AT<T>::v4;
+    constexpr int D = DU * 8, KC = (DU + 1) / 2, DB = (D + 31) / 32;
+    constexpr uint32_t KP = KC * 32 + 16;                         // K LDS row pitch: odd number of 16-byte slots -> conflict-free ds_read_b128
+    constexpr uint32_t STAGE = 64 * KP + DB * 32 * VP;            // one 64-key K tile + one V^T tile
+    constexpr int NU = (64 * DU + 255) / 256;                     // 16-byte staging units per thread, tile and operand
     __shared__ __attribute__((aligned(16))) uint8_t lds[2 * STAGE];
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u, h = lane >> 5, c32 = lane & 31u;
     constexpr uint32_t QW = 32u * QB, QWG = 4u * QW;          // queries per wave / per workgroup
@@ -84,74 +91,85 @@ __global__ __launch_bounds__(256, 2) void gsw_attn_fwd_kernel(AttnArgs p) {
     const uint32_t bh = logical / p.nqt, qt = logical - bh * p.nqt;
     const uint32_t b = bh / (uint32_t)p.H, hh = bh - b * (uint32_t)p.H;
 
-    const T* Q = reinterpret_cast<const T*>(p.q) + ((int64_t)b * p.Sq + qt * QWG + wave * QW + c32) * p.ldq + hh * 64u;
-    const T* K = reinterpret_cast<const T*>(p.k) + (int64_t)b * p.Sk * p.ldk + hh * 64u;
-    const T* VT = reinterpret_cast<const T*>(p.vt) + ((int64_t)b * p.H + hh) * 64 * (int64_t)p.Sk;
+    const T* Q = reinterpret_cast<const T*>(p.q) + ((int64_t)b * p.Sq + qt * QWG + wave * QW + c32) * p.ldq + hh * (uint32_t)D;
+    const T* K = reinterpret_cast<const T*>(p.k) + (int64_t)b * p.Sk * p.ldk + hh * (uint32_t)D;
+    const T* VT = reinterpret_cast<const T*>(p.vt) + ((int64_t)b * p.H + hh) * D * (int64_t)p.Sk;
 
-    v8 qreg[QB][4];
+    if (DU & 1 || D & 31) {      // zero the LDS once: padding units of K rows / padding rows of V^T are never written by the staging
+        for (uint32_t i = tid; i < 2 * STAGE / 16; i += 256) reinterpret_cast<uint4*>(lds)[i] = make_uint4(0, 0, 0, 0);
+        __syncthreads();
+    }
+
+    v8 qreg[QB][KC];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
-        for (int kc = 0; kc < 4; ++kc) qreg[qb][kc] = *reinterpret_cast<const v8*>(Q + (int64_t)qb * 32 * p.ldq + kc * 16 + h * 8);
-    // Pass Q through a VALU move before the loop: the loop's MFMAs then read ALU results, not load results, so the waitcnt pass does
-    // not place `s_waitcnt vmcnt` (which would drain the in-flight K / V prefetch) in front of them.
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb)
-#pragma unroll
-        for (int kc = 0; kc < 4; ++kc) {
+        for (int kc = 0; kc < KC; ++kc) {
             typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-            u32x4 w = __builtin_bit_cast(u32x4, qreg[qb][kc]);
+            u32x4 w = u32x4{0u, 0u, 0u, 0u};
+            if (2 * kc + 1 < DU || h == 0) w = *reinterpret_cast<const u32x4*>(Q + (int64_t)qb * 32 * p.ldq + kc * 16 + h * 8);   // unit 2kc+h < DU
+            // Pass Q through a VALU move before the loop: the loop's MFMAs then read ALU results, not load results, so the waitcnt pass
+            // does not place `s_waitcnt vmcnt` (which would drain the in-flight K / V prefetch) in front of them.
 #pragma unroll
             for (int j = 0; j < 4; ++j) { uint32_t e = w[j]; asm volatile("v_mov_b32 %0, %0" : "+v"(e)); w[j] = e; }
             qreg[qb][kc] = __builtin_bit_cast(v8, w);
         }
 
-    // staging roles: 512 16-byte chunks per tile and operand, two per thread
-    const uint32_t r0 = tid >> 3, c16 = tid & 7u;          // rows r0 and r0 + 32, 16-byte column c16
-    // (kept as named scalars + macros: lambdas capturing the prefetch registers by reference made the compiler keep them in scratch)
-    uint4 kreg0, kreg1, vreg0, vreg1;
-    const T* Kg = K + (int64_t)r0 * p.ldk + c16 * 8u;
-    const T* Vg = VT + (int64_t)r0 * p.Sk + c16 * 8u;
-    const int64_t k32 = (int64_t)32 * p.ldk, v32 = (int64_t)32 * p.Sk;
-    const uint32_t kst = r0 * KP + c16 * 16u, vst = 64u * KP + r0 * VP + c16 * 16u;
-#define GSW_ATTN_GLOAD(key0)                                                                  \
-    do {                                                                                      \
-        kreg0 = *reinterpret_cast<const uint4*>(Kg + (int64_t)(key0) * p.ldk);                \
-        kreg1 = *reinterpret_cast<const uint4*>(Kg + (int64_t)(key0) * p.ldk + k32);          \
-        vreg0 = *reinterpret_cast<const uint4*>(Vg + (key0));                                 \
-        vreg1 = *reinterpret_cast<const uint4*>(Vg + (key0) + v32);                           \
-    } while (0)
-#define GSW_ATTN_LSTORE(st)                                                                               \
-    do {                                                                                                  \
-        uint8_t* base_ = lds + (st) * STAGE;                                                              \
-        *reinterpret_cast<uint4*>(base_ + kst) = kreg0;                                                   \
-        *reinterpret_cast<uint4*>(base_ + kst + 32u * KP) = kreg1;                                        \
-        *reinterpret_cast<uint2*>(base_ + vst) = make_uint2(vreg0.x, vreg0.y);          /* V^T rows are */ \
-        *reinterpret_cast<uint2*>(base_ + vst + 8u) = make_uint2(vreg0.z, vreg0.w);     /* 136 B apart: */ \
-        *reinterpret_cast<uint2*>(base_ + vst + 32u * VP) = make_uint2(vreg1.x, vreg1.y);  /* 8-byte    */ \
-        *reinterpret_cast<uint2*>(base_ + vst + 32u * VP + 8u) = make_uint2(vreg1.z, vreg1.w); /* aligned */ \
-    } while (0)
+    // staging roles: 64*DU 16-byte units per tile and operand.  K unit u: key row u / DU, column u % DU; V^T unit u: row u / 8 (< D),
+    // key column u % 8.  (Named scalars + macros: arrays or lambdas holding the prefetch registers end up in scratch.)
+    // NU <= 3; unit i of this thread is u = tid + 256 i
+    constexpr bool ALLV = NU * 256 == 64 * DU;                 // every unit slot of every thread is a real unit
+#define GSW_ATTN_UNIT_DECL(i)                                                                           \
+    uint4 kreg##i = make_uint4(0, 0, 0, 0), vreg##i = make_uint4(0, 0, 0, 0);                           \
+    const uint32_t u##i = tid + 256u * i;                                                               \
+    const bool uv##i = u##i < 64u * DU;                                                                 \
+    const uint32_t uu##i = uv##i ? u##i : 0u;                                                           \
+    const uint32_t kr##i = uu##i / (uint32_t)DU, kcol##i = uu##i - kr##i * (uint32_t)DU;                \
+    const T* kg##i = K + (int64_t)kr##i * p.ldk + kcol##i * 8u;                                         \
+    const uint32_t kst##i = kr##i * KP + kcol##i * 16u;                                                 \
+    const T* vg##i = VT + (int64_t)(uu##i >> 3) * p.Sk + (uu##i & 7u) * 8u;                             \
+    const uint32_t vst##i = 64u * KP + (uu##i >> 3) * VP + (uu##i & 7u) * 16u;
+    GSW_ATTN_UNIT_DECL(0)
+    GSW_ATTN_UNIT_DECL(1)
+    GSW_ATTN_UNIT_DECL(2)
+#define GSW_ATTN_GLOAD1(i, key0)                                                                        \
+    if (NU > i && (ALLV || uv##i)) {                                                                    \
+        kreg##i = *reinterpret_cast<const uint4*>(kg##i + (int64_t)(key0) * p.ldk);                     \
+        vreg##i = *reinterpret_cast<const uint4*>(vg##i + (key0));                                      \
+    }
+#define GSW_ATTN_GLOAD(key0) GSW_ATTN_GLOAD1(0, key0) GSW_ATTN_GLOAD1(1, key0) GSW_ATTN_GLOAD1(2, key0)
+#define GSW_ATTN_LSTORE1(i, st)                                                                         \
+    if (NU > i && (ALLV || uv##i)) {                                                                    \
+        uint8_t* base_ = lds + (st) * STAGE;                                                            \
+        *reinterpret_cast<uint4*>(base_ + kst##i) = kreg##i;                                            \
+        *reinterpret_cast<uint2*>(base_ + vst##i) = make_uint2(vreg##i.x, vreg##i.y);      /* V^T rows are 136 B apart: */ \
+        *reinterpret_cast<uint2*>(base_ + vst##i + 8u) = make_uint2(vreg##i.z, vreg##i.w); /* 8-byte aligned only      */ \
+    }
+#define GSW_ATTN_LSTORE(st) GSW_ATTN_LSTORE1(0, st) GSW_ATTN_LSTORE1(1, st) GSW_ATTN_LSTORE1(2, st)
+    static_assert(NU <= 3, "staging code covers up to 3 units per thread");
 
-    f32x16 o[QB][2];
+    f32x16 o[QB][DB];
     float m_i[QB], l_i[QB];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { o[qb][0][i] = 0.f; o[qb][1][i] = 0.f; }
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o[qb][db][i] = 0.f;
         m_i[qb] = -INFINITY;
         l_i[qb] = 0.f;
     }
     const float cs = p.scale_log2;
 
     const int32_t nt = p.Sk >> 6;
-    GSW_ATTN_GLOAD(0);
-    GSW_ATTN_LSTORE(0u);
+    GSW_ATTN_GLOAD(0)
+    GSW_ATTN_LSTORE(0u)
     __syncthreads();
     for (int32_t t = 0; t < nt; ++t) {
         // prefetch the next tile into registers -- unconditionally (the last iteration re-fetches its own tile into the idle stage):
         // a conditional load made the compiler merge the registers right after the branch, i.e. wait for HBM inside the MFMA phase
         const int32_t tn = t + 1 < nt ? t + 1 : t;
-        GSW_ATTN_GLOAD(tn << 6);
+        GSW_ATTN_GLOAD(tn << 6)
         __builtin_amdgcn_sched_barrier(0);          // keep the prefetch at the top of the iteration (the scheduler sinks it otherwise)
         const uint8_t* Kl = lds + (uint32_t)(t & 1) * STAGE;
         const uint8_t* Vl = Kl + 64u * KP;
@@ -163,7 +181,7 @@ __global__ __launch_bounds__(256, 2) void gsw_attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) { s[qb][0][i] = 0.f; s[qb][1][i] = 0.f; }
 #pragma unroll
-        for (int kc = 0; kc < 4; ++kc) {
+        for (int kc = 0; kc < KC; ++kc) {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
                 const v8 a = *reinterpret_cast<const v8*>(Kl + (uint32_t)(kb * 32 + (int)c32) * KP + (uint32_t)kc * 32u + h * 16u);
@@ -210,7 +228,9 @@ __global__ __launch_bounds__(256, 2) void gsw_attn_fwd_kernel(AttnArgs p) {
             l_i[qb] = fmaf(l_i[qb], alpha, rs);
             if (__any(alpha != 1.0f)) {                 // once the running maxima have settled the whole wave skips the rescale
 #pragma unroll
-                for (int i = 0; i < 16; ++i) { o[qb][0][i] *= alpha; o[qb][1][i] *= alpha; }
+                for (int db = 0; db < DB; ++db)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) o[qb][db][i] *= alpha;
             }
         }
 
@@ -220,7 +240,7 @@ __global__ __launch_bounds__(256, 2) void gsw_attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
 #pragma unroll
-                for (int db = 0; db < 2; ++db) {
+                for (int db = 0; db < DB; ++db) {
                     const uint8_t* vp = Vl + (uint32_t)(db * 32 + (int)c32) * VP + (uint32_t)(kb * 32 + tt * 16 + (int)h * 4) * 2u;
                     const v4 lo = *reinterpret_cast<const v4*>(vp);
                     const v4 hi = *reinterpret_cast<const v4*>(vp + 16);
@@ -231,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void gsw_attn_fwd_kernel(AttnArgs p) {
             }
         }
 
-        GSW_ATTN_LSTORE((uint32_t)((t + 1) & 1));
+        GSW_ATTN_LSTORE((uint32_t)((t + 1) & 1))
         __syncthreads();
     }
 
@@ -240,33 +260,55 @@ __global__ __launch_bounds__(256, 2) void gsw_attn_fwd_kernel(AttnArgs p) {
     for (int qb = 0; qb < QB; ++qb) {
         const float l = l_i[qb] + __shfl_xor(l_i[qb], 32);
         const float inv = 1.0f / l;
-        T* O = reinterpret_cast<T*>(p.o) + ((int64_t)b * p.Sq + qt * QWG + wave * QW + (uint32_t)qb * 32u + c32) * p.ldo + hh * 64u;
+        T* O = reinterpret_cast<T*>(p.o) + ((int64_t)b * p.Sq + qt * QWG + wave * QW + (uint32_t)qb * 32u + c32) * p.ldo + hh * (uint32_t)D;
 #pragma unroll
-        for (int db = 0; db < 2; ++db) {
+        for (int db = 0; db < DB; ++db) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                v4 w;
+                const int d0 = db * 32 + g * 8 + (int)h * 4;
+                if (db * 32 + g * 8 + 8 <= D || d0 < D) {          // rows >= head_dim are padding
+                    v4 w;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) w[j] = (T)(o[qb][db][g * 4 + j] * inv);
-                *reinterpret_cast<v4*>(O + db * 32 + g * 8 + (int)h * 4) = w;
+                    for (int j = 0; j < 4; ++j) w[j] = (T)(o[qb][db][g * 4 + j] * inv);
+                    *reinterpret_cast<v4*>(O + d0) = w;
+                }
             }
         }
     }
+#undef GSW_ATTN_GLOAD
+#undef GSW_ATTN_LSTORE
+#undef GSW_ATTN_GLOAD1
+#undef GSW_ATTN_LSTORE1
+#undef GSW_ATTN_UNIT_DECL
 }
-
 
 }  // namespace
 
-int gsw_attention_hd64(const void* q_dev, const void* k_dev, const void* vt_dev, void* out_dev, int B, int H, int Sq, int Sk, int Sk_valid, int ldq,
-                       int ldk, int ldo, float scale, int dtype, void* stream) {
-    // q: [B, Sq, >= H*64] (row stride ldq), k: [B, Sk, >= H*64] (row stride ldk), vt: [B, H*64, Sk] contiguous (V transposed),
-    // out: [B, Sq, >= H*64] (row stride ldo).  Sq % 128 == 0, Sk % 64 == 0; row strides multiples of 8 elements; keys in
-    // [Sk_valid, Sk) are padding and get zero weight.
+template <typename T>
+static void launch_attn(const AttnArgs& a, int head_dim, int QB, uint32_t grid, hipStream_t st) {
+    if (head_dim == 64) {
+        if (QB == 2) hipLaunchKernelGGL((gsw_attn_fwd_kernel<T, 2, 8>), dim3(grid), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((gsw_attn_fwd_kernel<T, 1, 8>), dim3(grid), dim3(256), 0, st, a);
+    } else if (head_dim == 40) {
+        if (QB == 2) hipLaunchKernelGGL((gsw_attn_fwd_kernel<T, 2, 5>), dim3(grid), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((gsw_attn_fwd_kernel<T, 1, 5>), dim3(grid), dim3(256), 0, st, a);
+    } else {
+        hipLaunchKernelGGL((gsw_attn_fwd_kernel<T, 1, 10>), dim3(grid), dim3(256), 0, st, a);
+    }
+}
+
+int gsw_attention(const void* q_dev, const void* k_dev, const void* vt_dev, void* out_dev, int B, int H, int head_dim, int Sq, int Sk, int Sk_valid,
+                  int ldq, int ldk, int ldo, float scale, int dtype, void* stream) {
+    // q: [B, Sq, >= H*head_dim] (row stride ldq), k: [B, Sk, >= H*head_dim] (row stride ldk), vt: [B, H*head_dim, Sk] contiguous (V
+    // transposed), out: [B, Sq, >= H*head_dim] (row stride ldo).  head_dim 40 / 64 / 80; Sq % 128 == 0, Sk % 64 == 0; row strides
+    // multiples of 8 elements; keys in [Sk_valid, Sk) are padding and get zero weight.
     if (!q_dev || !k_dev || !vt_dev || !out_dev || B <= 0 || H <= 0 || Sq <= 0 || Sk <= 0 || Sk_valid <= 0 || Sk_valid > Sk) return GSW_ERR_BAD_ARG;
     if (dtype != GSW_F16 && dtype != GSW_BF16) return GSW_ERR_BAD_ARG;
-    if ((Sq & 127) || (Sk & 63) || ldq < H * 64 || ldk < H * 64 || ldo < H * 64 || ((ldq | ldk | ldo) & 7)) return GSW_ERR_UNSUPPORTED;
+    if (head_dim != 40 && head_dim != 64 && head_dim != 80) return GSW_ERR_UNSUPPORTED;
+    const int inner = H * head_dim;
+    if ((Sq & 127) || (Sk & 63) || ldq < inner || ldk < inner || ldo < inner || ((ldq | ldk | ldo) & 7)) return GSW_ERR_UNSUPPORTED;
     static const int qb_env = getenv("GSW_ATTN_QB") ? atoi(getenv("GSW_ATTN_QB")) : 2;      // A/B switch for profiling
-    const int QB = ((Sq & 255) == 0 && Sq >= 512 && qb_env == 2) ? 2 : 1;      // 256-query workgroups once there are plenty of them
+    const int QB = ((Sq & 255) == 0 && Sq >= 512 && qb_env == 2 && head_dim != 80) ? 2 : 1;      // 256-query workgroups once there are plenty of them
     const int64_t total = (int64_t)(Sq / (128 * QB)) * B * H;
     if (total > 0x7FFFFFFF) return GSW_ERR_UNSUPPORTED;
     AttnArgs a;
@@ -275,15 +317,14 @@ int gsw_attention_hd64(const void* q_dev, const void* k_dev, const void* vt_dev,
     a.scale_log2 = scale * 1.4426950408889634f;
     a.nqt = (uint32_t)(Sq / (128 * QB));
     a.total = (uint32_t)total;
-    hipStream_t st = (hipStream_t)stream;
-    if (dtype == GSW_F16) {
-        if (QB == 2) hipLaunchKernelGGL((gsw_attn_fwd_kernel<_Float16, 2>), dim3((uint32_t)total), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((gsw_attn_fwd_kernel<_Float16, 1>), dim3((uint32_t)total), dim3(256), 0, st, a);
-    } else {
-        if (QB == 2) hipLaunchKernelGGL((gsw_attn_fwd_kernel<__bf16, 2>), dim3((uint32_t)total), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((gsw_attn_fwd_kernel<__bf16, 1>), dim3((uint32_t)total), dim3(256), 0, st, a);
-    }
+    if (dtype == GSW_F16) launch_attn<_Float16>(a, head_dim, QB, (uint32_t)total, (hipStream_t)stream);
+    else launch_attn<__bf16>(a, head_dim, QB, (uint32_t)total, (hipStream_t)stream);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g_last_hip_error = (int)e; return GSW_ERR_HIP; }
     return GSW_OK;
+}
+
+int gsw_attention_hd64(const void* q_dev, const void* k_dev, const void* vt_dev, void* out_dev, int B, int H, int Sq, int Sk, int Sk_valid, int ldq,
+                       int ldk, int ldo, float scale, int dtype, void* stream) {
+    return gsw_attention(q_dev, k_dev, vt_dev, out_dev, B, H, 64, Sq, Sk, Sk_valid, ldq, ldk, ldo, scale, dtype, stream);
 }

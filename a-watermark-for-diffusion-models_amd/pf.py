@@ -243,24 +243,35 @@ def conv3x3_res_pf(x: PF, w_cat: torch.Tensor, bias: Optional[torch.Tensor], *, 
     return y
 
 
-def attention_hd64_ok(x: torch.Tensor, heads: int, head_dim: int, n_q: int, n_k: int) -> bool:
-    return x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and head_dim == 64 and n_q % 128 == 0 and n_k % 64 == 0
+ATTN_HEAD_DIMS = (40, 64, 80)
 
 
-def attention_hd64(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, scale: Optional[float] = None,
-                   valid_keys: Optional[int] = None) -> torch.Tensor:
-    """softmax(q k^T * scale) v for head_dim 64 on the hand-written flash-attention kernel (csrc/gswm_attn.hip).
-    q [B, Sq, heads*64], k [B, Sk, heads*64], vt [B, heads*64, Sk] (V transposed) -> [B, Sq, heads*64]; keys >= valid_keys are
+def attention_ok(x: torch.Tensor, heads: int, head_dim: int, n_q: int, n_k: int) -> bool:
+    return x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and head_dim in ATTN_HEAD_DIMS and n_q % 128 == 0 and n_k % 64 == 0
+
+
+attention_hd64_ok = attention_ok
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, scale: Optional[float] = None,
+              valid_keys: Optional[int] = None) -> torch.Tensor:
+    """softmax(q k^T * scale) v on the hand-written flash-attention kernel (csrc/gswm_attn.hip), head_dim 40 / 64 / 80.
+    q [B, Sq, heads*d], k [B, Sk, heads*d], vt [B, heads*d, Sk] (V transposed) -> [B, Sq, heads*d]; keys >= valid_keys are
     padding (zero weight)."""
     B, Sq, inner = q.shape
     Sk = k.shape[1]
-    assert inner == heads * 64 and vt.shape == (B, inner, Sk) and k.shape[2] == inner
+    d = inner // heads
+    assert inner == heads * d and vt.shape == (B, inner, Sk) and k.shape[2] == inner
     q, k, vt = q.contiguous(), k.contiguous(), vt.contiguous()
     out = torch.empty_like(q)
     with torch.cuda.device(q.device):
-        N.check(N.lib().gsw_attention_hd64(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), B, heads, Sq, Sk, Sk if valid_keys is None else int(valid_keys), inner, inner, inner,
-                                           float(scale if scale is not None else 64 ** -0.5), _dt(q.dtype), _stream_ptr()))
+        N.check(N.lib().gsw_attention(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), B, heads, d, Sq, Sk,
+                                      Sk if valid_keys is None else int(valid_keys), inner, inner, inner,
+                                      float(scale if scale is not None else d ** -0.5), _dt(q.dtype), _stream_ptr()))
     return out
+
+
+attention_hd64 = attention
 
 
 def pack_upsample_weight(w: torch.Tensor) -> torch.Tensor:

@@ -59,7 +59,7 @@ def _pw(conv: nn.Conv2d) -> torch.Tensor:
 
 UPSAMPLE_SUBPIXEL = True   # Upsample2D = four 2x2 convolutions of the low-resolution tensor (gsw_conv_up2x_pf) instead of upsample + 3x3
 
-OWN_ATTENTION = True  # attention with head_dim 64 and a query count % 128 == 0 runs on gsw_attention_hd64 instead of torch SDPA
+OWN_ATTENTION = True  # attention with head_dim 40 / 64 / 80 and a query count % 128 == 0 runs on gsw_attention instead of torch SDPA
 
 GEMM_MAX_K = 0        # linear layers with K <= this would run on the hand-written GEMM (gsw_linear).  Measured on MI355X: it only
                       # beats hipBLASLt on [524288,320]x[320,320] (398 vs 343 TFLOP/s) and loses elsewhere, incl. the fused GEGLU
@@ -178,14 +178,14 @@ class Attention(nn.Module):
     def forward(self, x, ctx=None):
         b, n, _ = x.shape
         if OWN_ATTENTION and FUSED_KERNELS:
-            from .pf import attention_hd64, attention_hd64_ok
+            from .pf import attention, attention_ok
             src, valid = (x, n) if ctx is None else _padded_ctx(ctx)
-            if attention_hd64_ok(x, self.heads, self.to_q.out_features // self.heads, n, src.shape[1]):
+            if attention_ok(x, self.heads, self.to_q.out_features // self.heads, n, src.shape[1]):
                 # hand-written flash-attention kernel (self- and cross-attention); the value projection is computed transposed
                 # (V^T = W_v src^T, one GEMM either way) because the kernel consumes V^T tiles.  Padded context rows are zero and
                 # masked by `valid`.
                 vt = torch.bmm(self.to_v.weight.unsqueeze(0).expand(b, -1, -1), src.transpose(1, 2))
-                o = attention_hd64(_lin(x, self.to_q), _lin(src, self.to_k), vt, self.heads, valid_keys=valid)
+                o = attention(_lin(x, self.to_q), _lin(src, self.to_k), vt, self.heads, valid_keys=valid)
                 return _lin(o, self.to_out[0])
         ctx = x if ctx is None else ctx
         q = _lin(x, self.to_q).view(b, n, self.heads, -1).transpose(1, 2)

@@ -169,14 +169,17 @@ int gsw_linear(const void* x_dev, const void* w_dev, const void* bias_dev, const
 int gsw_conv_up2x_pf(const void* x_dev, const void* w4_dev, const void* bias_dev, void* y_dev, int B, int H, int W, int C, int N, int dtype,
                      void* stream);
 
-/* Self-attention of the eps-model (diffusers BasicTransformerBlock.attn1 inside the UNet the reference runs at extract.py:66-69):
- * out = softmax(q k^T * scale) v per (batch, head), head_dim 64, fp16 / bf16, fp32 accumulation -- a flash-attention forward.
- *   q   : [B, Sq, >= H*64] row stride ldq elements, head h in columns [h*64, h*64+64)
- *   k   : [B, Sk, >= H*64] row stride ldk
- *   vt  : [B, H*64, Sk] contiguous -- the value projection TRANSPOSED (compute it as W_v x^T)
- *   out : [B, Sq, >= H*64] row stride ldo
+/* Attention of the eps-model (diffusers BasicTransformerBlock.attn1 / attn2 inside the UNet the reference runs at extract.py:66-69):
+ * out = softmax(q k^T * scale) v per (batch, head), fp16 / bf16, fp32 accumulation -- a flash-attention forward.
+ *   head_dim : 64 (SD 2.x), 40 or 80 (SD 1.x levels with 8 heads); other widths return GSW_ERR_UNSUPPORTED
+ *   q   : [B, Sq, >= H*head_dim] row stride ldq elements, head h in columns [h*head_dim, (h+1)*head_dim)
+ *   k   : [B, Sk, >= H*head_dim] row stride ldk
+ *   vt  : [B, H*head_dim, Sk] contiguous -- the value projection TRANSPOSED (compute it as W_v x^T)
+ *   out : [B, Sq, >= H*head_dim] row stride ldo
  *   Sk_valid : keys in [Sk_valid, Sk) are padding and get zero weight (cross-attention: 77 context tokens padded to 128)
- * Sq % 128 == 0, Sk % 64 == 0, strides % 8 == 0; else GSW_ERR_UNSUPPORTED. */
+ * Sq % 128 == 0, Sk % 64 == 0, strides % 8 == 0; else GSW_ERR_UNSUPPORTED.  gsw_attention_hd64 == gsw_attention(head_dim = 64). */
+int gsw_attention(const void* q_dev, const void* k_dev, const void* vt_dev, void* out_dev, int B, int H, int head_dim, int Sq, int Sk,
+                  int Sk_valid, int ldq, int ldk, int ldo, float scale, int dtype, void* stream);
 int gsw_attention_hd64(const void* q_dev, const void* k_dev, const void* vt_dev, void* out_dev, int B, int H, int Sq, int Sk, int Sk_valid,
                        int ldq, int ldk, int ldo, float scale, int dtype, void* stream);
 

@@ -261,3 +261,31 @@ def test_conv_up2x_vs_torch_fp32(G, dtype, B, H, W, C, N):
     assert (y.to_nchw().float() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
     gr = y.grid
     assert gr[:, 0].abs().max() == 0 and gr[:, -1].abs().max() == 0 and gr[:, :, 0].abs().max() == 0 and gr[:, :, -1].abs().max() == 0
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("B,H,S,D", [(2, 8, 256, 40), (1, 8, 1024, 40), (2, 8, 128, 80), (1, 4, 768, 80), (1, 2, 2304, 40)])
+def test_attention_head_dim_40_80_vs_fp32_reference(G, dtype, B, H, S, D):
+    """The SD 1.5 head widths (8 heads at 320 / 640 channels): zero-padded k-slices and output row blocks of the same kernel."""
+    g = torch.Generator().manual_seed(S + D)
+    q, k, v = (torch.randn(B, S, H * D, generator=g).to(dtype).cuda() for _ in range(3))
+    q = q * 2.0
+    got = G.pf.attention(q, k, v.transpose(1, 2).contiguous(), H)
+    qf, kf, vf = (a.float().view(B, S, H, D).transpose(1, 2) for a in (q, k, v))
+    ref = (torch.softmax(qf @ kf.transpose(-1, -2) * D ** -0.5, dim=-1) @ vf).transpose(1, 2).reshape(B, S, H * D)
+    tol = 4e-3 if dtype == torch.float16 else 2e-2
+    assert (got.float() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+
+
+def test_attention_head_dim_40_masked_cross(G):
+    g = torch.Generator().manual_seed(5)
+    B, H, S, D = 2, 8, 256, 40
+    q = torch.randn(B, S, H * D, generator=g).half().cuda()
+    k = torch.randn(B, 128, H * D, generator=g).half().cuda()
+    v = torch.randn(B, 128, H * D, generator=g).half().cuda()
+    k[:, 77:] = 30.0
+    v[:, 77:] = 1000.0
+    got = G.pf.attention(q, k, v.transpose(1, 2).contiguous(), H, valid_keys=77)
+    qf, kf, vf = (a.float().view(B, a.shape[1], H, D).transpose(1, 2) for a in (q, k[:, :77], v[:, :77]))
+    ref = (torch.softmax(qf @ kf.transpose(-1, -2) * D ** -0.5, dim=-1) @ vf).transpose(1, 2).reshape(B, S, H * D)
+    assert (got.float() - ref).abs().max().item() <= 4e-3 * max(1.0, ref.abs().max().item())
