@@ -14,8 +14,8 @@
 //   gsw_resample_h_kernel / _v_kernel : Pillow's two-pass fixed-point resampler (22 fractional bits, uint8 between the passes);
 //                                       one workgroup per image row, the source row staged once in LDS (horizontal pass),
 //                                       coalesced column-parallel accumulation (vertical pass) with the output conversion fused.
-//   gsw_jpeg_blocks_kernel            : one thread per 8x8 block, the whole RGB->YCbCr(+2x2 box) -> FDCT -> quantise -> dequantise ->
-//                                       IDCT chain in registers (64 int32), waves homogeneous in component kind.
+//   gsw_jpeg_blocks_kernel            : one wave per 16x256 RGB tile staged in LDS (coalesced 16-byte loads); one thread per 8x8 block runs
+//                                       the whole RGB->YCbCr(+2x2 box) -> FDCT -> quantise -> dequantise -> IDCT chain in 64 registers.
 //   gsw_jpeg_finish_kernel            : triangle ("fancy") chroma upsampling + YCbCr->RGB + output conversion, one thread per pixel.
 //   gsw_image_pointwise_kernel        : the point-wise attacks; contrast's mean grey level comes from gsw_image_lsum_kernel.
 #include <hip/hip_runtime.h>
@@ -160,6 +160,7 @@ __global__ __launch_bounds__(256) void gsw_tensor_to_image_kernel(const T* __res
 // ---------------------------------------------------------------------------------------------------------------------------
 struct JpegTables {
     uint8_t q[2][64];      // luma, chroma quantisation tables in natural (row-major) order
+    uint32_t magic[2][64]; // ceil(2^32 / (8 q)): n / (8 q) == umulhi(n, magic) exactly for n < 2^21 (8 q <= 2040)
 };
 
 constexpr int CONST_BITS = 13, PASS1_BITS = 2;
@@ -221,7 +222,7 @@ __device__ __forceinline__ void idct8(int32_t& i0, int32_t& i1, int32_t& i2, int
 #define COL8(F, d, c) F(d[0 * 8 + (c)], d[1 * 8 + (c)], d[2 * 8 + (c)], d[3 * 8 + (c)], d[4 * 8 + (c)], d[5 * 8 + (c)], d[6 * 8 + (c)], d[7 * 8 + (c)])
 
 // FDCT -> quantise -> dequantise -> IDCT of one block held in registers; d: level-shifted samples in, reconstructed samples (0..255) out
-__device__ __forceinline__ void jpeg_block_codec(int32_t (&d)[64], const uint8_t* __restrict__ q) {
+__device__ __forceinline__ void jpeg_block_codec(int32_t (&d)[64], const uint8_t* __restrict__ q, const uint32_t* __restrict__ magic) {
 #pragma unroll
     for (int r = 0; r < 8; ++r) ROW8(fdct8<true>, d, r);
 #pragma unroll
@@ -232,7 +233,7 @@ __device__ __forceinline__ void jpeg_block_codec(int32_t (&d)[64], const uint8_t
         const int32_t qq = (int32_t)q[i];
         const int32_t qv = qq << 3;
         const int32_t a = (d[i] < 0 ? -d[i] : d[i]) + (qv >> 1);
-        const int32_t m = (int32_t)((uint32_t)a / (uint32_t)qv);
+        const int32_t m = (int32_t)__umulhi((uint32_t)a, magic[i]);          // == a / qv (a < 2^18), without the ~40-instruction integer divide
         d[i] = (d[i] < 0 ? -m : m) * qq;
     }
 #pragma unroll
@@ -248,69 +249,89 @@ __device__ __forceinline__ int32_t ycc_y(int32_t r, int32_t g, int32_t b) { retu
 __device__ __forceinline__ int32_t ycc_cb(int32_t r, int32_t g, int32_t b) { return (-11059 * r - 21709 * g + 32768 * b + (128 << 16) + 32767) >> 16; }
 __device__ __forceinline__ int32_t ycc_cr(int32_t r, int32_t g, int32_t b) { return (32768 * r - 27439 * g - 5329 * b + (128 << 16) + 32767) >> 16; }
 
-// One thread per 8x8 block.  Thread index space per image: [0, nby*nbx) luma blocks, then [.., + ncy*ncx) Cb blocks, then Cr blocks;
-// blockIdx.y = image.  Planes: yplane [B][nby*8][nbx*8], cplane [B][2][ncy*8][ncx*8].
+// One wave per 16-row x 256-column tile of the image (one MCU row x 16 MCUs): the RGB tile is staged in LDS with coalesced 16-byte
+// loads (byte loads with clamping for tiles that touch the right edge of an image whose width is not a multiple of 16, or an
+// unaligned base), replicated at the image edges as libjpeg pads (last column / last row).  Then one thread per 8x8 block runs the
+// whole chain in registers: all 64 lanes a luma block, lanes 0-31 then a Cb / Cr block.  grid = (tiles_x, tiles_y, B).
+// Planes: yplane [B][nby*8][nbx*8], cplane [B][2][ncy*8][ncx*8].
+constexpr int JT_W = 256, JT_H = 16, JT_PITCH = JT_W * 3 + 16;      // +16: rows start 16-byte aligned, bank-shifted by 4 words
 __global__ __launch_bounds__(64) void gsw_jpeg_blocks_kernel(const uint8_t* __restrict__ rgb, uint8_t* __restrict__ yplane, uint8_t* __restrict__ cplane,
                                                              JpegTables tb, int H, int W, int nby, int nbx, int ncy, int ncx) {
-    const int64_t b = blockIdx.y;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int nY = nby * nbx, nC = ncy * ncx;
-    if (t >= nY + 2 * nC) return;
+    __shared__ __attribute__((aligned(16))) uint8_t tile[JT_H * JT_PITCH];
+    const int64_t b = blockIdx.z;
+    const int tx = blockIdx.x, ty = blockIdx.y, lane = threadIdx.x;
+    const int x0 = tx * JT_W, y0 = ty * JT_H;
     const uint8_t* img = rgb + b * (int64_t)H * W * 3;
-    int32_t d[64];
-    if (t < nY) {
-        const int by = t / nbx, bx = t - by * nbx;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int y = min(by * 8 + r, H - 1);                       // bottom / right edges replicate the last row / column
-            const uint8_t* p = img + (int64_t)y * W * 3;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const int x = min(bx * 8 + c, W - 1);
-                d[r * 8 + c] = ycc_y(p[x * 3], p[x * 3 + 1], p[x * 3 + 2]) - 128;
-            }
-        }
-        jpeg_block_codec(d, tb.q[0]);
-        uint8_t* o = yplane + (b * nby * 8 + by * 8) * (int64_t)(nbx * 8) + bx * 8;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            uint32_t lo = d[r * 8] | (d[r * 8 + 1] << 8) | (d[r * 8 + 2] << 16) | (d[r * 8 + 3] << 24);
-            uint32_t hi = d[r * 8 + 4] | (d[r * 8 + 5] << 8) | (d[r * 8 + 6] << 16) | (d[r * 8 + 7] << 24);
-            *(uint2*)(o + (int64_t)r * nbx * 8) = make_uint2(lo, hi);
+    const bool fast = (x0 + JT_W <= W) && ((W & 15) == 0) && ((reinterpret_cast<uintptr_t>(img) & 15) == 0);
+    if (fast) {
+        for (int i = lane; i < JT_H * (JT_W * 3 / 16); i += 64) {                // 16 rows x 48 chunks
+            const int r = i / 48, c = i - r * 48;
+            const int y = min(y0 + r, H - 1);                                     // bottom edge: replicate the last row
+            *reinterpret_cast<uint4*>(tile + r * JT_PITCH + c * 16) = *reinterpret_cast<const uint4*>(img + ((int64_t)y * W + x0) * 3 + c * 16);
         }
     } else {
-        const int comp = (t - nY) >= nC;
-        const int tc = t - nY - comp * nC;
-        const int by = tc / ncx, bx = tc - by * ncx;
-        const int hc = (H + 1) >> 1;
+        for (int i = lane; i < JT_H * JT_W; i += 64) {
+            const int r = i / JT_W, c = i - r * JT_W;
+            const int y = min(y0 + r, H - 1), x = min(x0 + c, W - 1);             // right edge: replicate the last column
+            const uint8_t* q = img + ((int64_t)y * W + x) * 3;
+            uint8_t* o = tile + r * JT_PITCH + c * 3;
+            o[0] = q[0]; o[1] = q[1]; o[2] = q[2];
+        }
+    }
+    __syncthreads();
+    int32_t d[64];
+    {   // luma: lane -> block (2 ty + lane / 32, 32 tx + lane % 32)
+        const int byl = lane >> 5, bxl = lane & 31;
+        const int by = ty * 2 + byl, bx = tx * 32 + bxl;
+        if (by < nby && bx < nbx) {
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            // rows past the downsampled image replicate ITS last row (jcprepct.c expand_bottom_edge on the output buffer);
-            // the full-resolution rows are only padded to a pair (one row group)
-            const int j = min(by * 8 + r, hc - 1);
-            const uint8_t* p0 = img + (int64_t)(2 * j) * W * 3;
-            const uint8_t* p1 = img + (int64_t)min(2 * j + 1, H - 1) * W * 3;
+            for (int r = 0; r < 8; ++r) {
+                const uint8_t* p = tile + (byl * 8 + r) * JT_PITCH + bxl * 24;
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const int i = bx * 8 + c;
-                const int x0 = min(2 * i, W - 1), x1 = min(2 * i + 1, W - 1);     // jcsample.c expand_right_edge
-                int32_t s;
-                if (comp == 0)
-                    s = ycc_cb(p0[x0 * 3], p0[x0 * 3 + 1], p0[x0 * 3 + 2]) + ycc_cb(p0[x1 * 3], p0[x1 * 3 + 1], p0[x1 * 3 + 2]) +
-                        ycc_cb(p1[x0 * 3], p1[x0 * 3 + 1], p1[x0 * 3 + 2]) + ycc_cb(p1[x1 * 3], p1[x1 * 3 + 1], p1[x1 * 3 + 2]);
-                else
-                    s = ycc_cr(p0[x0 * 3], p0[x0 * 3 + 1], p0[x0 * 3 + 2]) + ycc_cr(p0[x1 * 3], p0[x1 * 3 + 1], p0[x1 * 3 + 2]) +
-                        ycc_cr(p1[x0 * 3], p1[x0 * 3 + 1], p1[x0 * 3 + 2]) + ycc_cr(p1[x1 * 3], p1[x1 * 3 + 1], p1[x1 * 3 + 2]);
-                d[r * 8 + c] = ((s + 1 + (c & 1)) >> 2) - 128;                    // h2v2_downsample: bias 1, 2, 1, 2 ...
+                for (int c = 0; c < 8; ++c) d[r * 8 + c] = ycc_y(p[c * 3], p[c * 3 + 1], p[c * 3 + 2]) - 128;
+            }
+            jpeg_block_codec(d, tb.q[0], tb.magic[0]);
+            uint8_t* o = yplane + (b * nby * 8 + by * 8) * (int64_t)(nbx * 8) + bx * 8;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                uint32_t lo = d[r * 8] | (d[r * 8 + 1] << 8) | (d[r * 8 + 2] << 16) | (d[r * 8 + 3] << 24);
+                uint32_t hi = d[r * 8 + 4] | (d[r * 8 + 5] << 8) | (d[r * 8 + 6] << 16) | (d[r * 8 + 7] << 24);
+                *(uint2*)(o + (int64_t)r * nbx * 8) = make_uint2(lo, hi);
             }
         }
-        jpeg_block_codec(d, tb.q[1]);
-        uint8_t* o = cplane + ((b * 2 + comp) * ncy * 8 + by * 8) * (int64_t)(ncx * 8) + bx * 8;
+    }
+    if (lane < 32) {   // chroma: lane -> component lane / 16, block (ty, 16 tx + lane % 16)
+        const int comp = lane >> 4, bxl = lane & 15;
+        const int by = ty, bx = tx * 16 + bxl;
+        const int hc = (H + 1) >> 1;
+        if (by < ncy && bx < ncx) {
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            uint32_t lo = d[r * 8] | (d[r * 8 + 1] << 8) | (d[r * 8 + 2] << 16) | (d[r * 8 + 3] << 24);
-            uint32_t hi = d[r * 8 + 4] | (d[r * 8 + 5] << 8) | (d[r * 8 + 6] << 16) | (d[r * 8 + 7] << 24);
-            *(uint2*)(o + (int64_t)r * ncx * 8) = make_uint2(lo, hi);
+            for (int r = 0; r < 8; ++r) {
+                // rows past the downsampled image replicate ITS last row (jcprepct.c expand_bottom_edge on the output buffer);
+                // the full-resolution rows are only padded to a pair (one row group) -- the tile already replicates row H-1
+                const int j = min(by * 8 + r, hc - 1);
+                const uint8_t* p0 = tile + (2 * j - y0) * JT_PITCH + bxl * 48;
+                const uint8_t* p1 = p0 + JT_PITCH;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const uint8_t* a0 = p0 + c * 6;                               // pixels 2i, 2i+1 of both rows (right edge replicated in the tile)
+                    const uint8_t* a1 = p1 + c * 6;
+                    int32_t sum;
+                    if (comp == 0)
+                        sum = ycc_cb(a0[0], a0[1], a0[2]) + ycc_cb(a0[3], a0[4], a0[5]) + ycc_cb(a1[0], a1[1], a1[2]) + ycc_cb(a1[3], a1[4], a1[5]);
+                    else
+                        sum = ycc_cr(a0[0], a0[1], a0[2]) + ycc_cr(a0[3], a0[4], a0[5]) + ycc_cr(a1[0], a1[1], a1[2]) + ycc_cr(a1[3], a1[4], a1[5]);
+                    d[r * 8 + c] = ((sum + 1 + (c & 1)) >> 2) - 128;              // h2v2_downsample: bias 1, 2, 1, 2 ...
+                }
+            }
+            jpeg_block_codec(d, tb.q[1], tb.magic[1]);
+            uint8_t* o = cplane + ((b * 2 + comp) * ncy * 8 + by * 8) * (int64_t)(ncx * 8) + bx * 8;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                uint32_t lo = d[r * 8] | (d[r * 8 + 1] << 8) | (d[r * 8 + 2] << 16) | (d[r * 8 + 3] << 24);
+                uint32_t hi = d[r * 8 + 4] | (d[r * 8 + 5] << 8) | (d[r * 8 + 6] << 16) | (d[r * 8 + 7] << 24);
+                *(uint2*)(o + (int64_t)r * ncx * 8) = make_uint2(lo, hi);
+            }
         }
     }
 }
@@ -583,12 +604,17 @@ int gsw_jpeg_roundtrip(const uint8_t* rgb_dev, int B, int H, int W, int quality,
     if (B > 65535 || H > 65500 || W > 65500) return GSW_ERR_UNSUPPORTED;         // JPEG's own dimension limit
     JpegTables tb;
     gsw_jpeg_quant_tables(quality, tb.q[0], tb.q[1]);
+    for (int t = 0; t < 2; ++t)
+        for (int i = 0; i < 64; ++i) {
+            const uint64_t dv = (uint64_t)tb.q[t][i] * 8u;
+            tb.magic[t][i] = (uint32_t)((((uint64_t)1 << 32) + dv - 1) / dv);
+        }
     const int nby = (H + 7) / 8, nbx = (W + 7) / 8, ncy = ((H + 1) / 2 + 7) / 8, ncx = ((W + 1) / 2 + 7) / 8;
     uint8_t* yplane = workspace_dev;
     uint8_t* cplane = workspace_dev + (size_t)B * nby * nbx * 64;
     hipStream_t st = (hipStream_t)stream;
-    const int nthreads = nby * nbx + 2 * ncy * ncx;
-    hipLaunchKernelGGL(gsw_jpeg_blocks_kernel, dim3((nthreads + 63) / 64, B), dim3(64), 0, st, rgb_dev, yplane, cplane, tb, H, W, nby, nbx, ncy, ncx);
+    hipLaunchKernelGGL(gsw_jpeg_blocks_kernel, dim3((W + JT_W - 1) / JT_W, (H + JT_H - 1) / JT_H, B), dim3(64), 0, st, rgb_dev, yplane, cplane, tb, H, W, nby, nbx,
+                       ncy, ncx);
     GSW_IMG_LAUNCH_CHECK();
     hipLaunchKernelGGL(gsw_jpeg_finish_kernel, dim3(H, B), dim3(256), 0, st, (const uint8_t*)yplane, (const uint8_t*)cplane, out_dev, H, W, nby, nbx, ncy, ncx, out_mode);
     GSW_IMG_LAUNCH_CHECK();
