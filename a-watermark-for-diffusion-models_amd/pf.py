@@ -70,6 +70,17 @@ class PF:
         return self.interior.reshape(self.B, self.H * self.W, self.C)
 
 
+def cached(owner, name: str, params, build):
+    """Derived-weight cache on a module attribute, keyed by the source parameters' storage, version counter, device and dtype, so
+    that `.to()`, `load_state_dict` or any in-place edit of the weights rebuilds the packed copy."""
+    key = tuple((q.data_ptr(), q._version, str(q.device), q.dtype) for q in params)
+    c = getattr(owner, name, None)
+    if c is None or c[0] != key:
+        c = (key, build())
+        setattr(owner, name, c)
+    return c[1]
+
+
 class ConvTimer:
     """HIP events around every convolution launch, on the stream the kernel is launched on (torch's current stream), bucketed
     by the kernel libgswm picks for the shape.  bench.py installs one as `pf.CONV_TIMER` for its timed region."""

@@ -49,12 +49,8 @@ USE_PF = True
 
 
 def _pw(conv: nn.Conv2d) -> torch.Tensor:
-    w = getattr(conv, "_gsw_packed", None)
-    if w is None or w.device != conv.weight.device or w.dtype != conv.weight.dtype:
-        from .pf import pack_conv_weight
-        w = pack_conv_weight(conv.weight.detach())
-        conv._gsw_packed = w
-    return w
+    from .pf import cached, pack_conv_weight
+    return cached(conv, "_gsw_packed", (conv.weight,), lambda: pack_conv_weight(conv.weight.detach()))
 
 
 UPSAMPLE_SUBPIXEL = True   # Upsample2D = four 2x2 convolutions of the low-resolution tensor (gsw_conv_up2x_pf) instead of upsample + 3x3
@@ -142,11 +138,10 @@ class ResnetBlock2D(nn.Module):
         if not fuse:
             sc = conv_pf(x, _pw(self.conv_shortcut), self.conv_shortcut.bias, ksize=1)
             return conv_pf(h, _pw(self.conv2), self.conv2.bias, resid=sc)
-        c = getattr(self, "_gsw_res", None)                                              # [N, 9*C | C_shortcut], summed biases
-        if c is None or c[0].device != h.buf.device or c[0].dtype != h.buf.dtype:
-            w = torch.cat([_pw(self.conv2), self.conv_shortcut.weight.detach()[:, :, 0, 0]], dim=1).contiguous()
-            c = (w, (self.conv2.bias.detach() + self.conv_shortcut.bias.detach()).contiguous())
-            self._gsw_res = c
+        from .pf import cached
+        c = cached(self, "_gsw_res", (self.conv2.weight, self.conv2.bias, self.conv_shortcut.weight, self.conv_shortcut.bias),
+                   lambda: (torch.cat([_pw(self.conv2), self.conv_shortcut.weight.detach()[:, :, 0, 0]], dim=1).contiguous(),      # [N, 9*C | C_shortcut]
+                            (self.conv2.bias.detach() + self.conv_shortcut.bias.detach()).contiguous()))                           # summed biases
         return conv3x3_res_pf(h, c[0], c[1], x1=x, x2=x2)                                # conv2 + conv_shortcut in one GEMM
 
 
@@ -156,10 +151,11 @@ def _padded_ctx(ctx: torch.Tensor):
     n = ctx.shape[1]
     if n % 64 == 0:
         return ctx, n
-    pad = getattr(ctx, "_gsw_pad", None)
-    if pad is None or pad.device != ctx.device or pad.dtype != ctx.dtype:
-        pad = F.pad(ctx, (0, 0, 0, (-n) % 64)).contiguous()
-        ctx._gsw_pad = pad
+    cached = getattr(ctx, "_gsw_pad", None)              # (tensor version at padding time, padded copy)
+    if cached is not None and cached[0] == ctx._version and cached[1].device == ctx.device and cached[1].dtype == ctx.dtype:
+        return cached[1], n
+    pad = F.pad(ctx, (0, 0, 0, (-n) % 64)).contiguous()
+    ctx._gsw_pad = (ctx._version, pad)                   # in-place edits of ctx bump _version and invalidate the copy
     return pad, n
 
 
@@ -205,10 +201,8 @@ class GEGLU(nn.Module):
         if (_own_gemm_ok(x, self.proj.in_features, self.proj.out_features) or _own_geglu_ok(x, self.proj.in_features, self.proj.out_features)) \
                 and inner % 80 == 0:
             from .pf import linear, pack_geglu_weight     # value * gelu(gate) in the GEMM epilogue: no [M, 2I] intermediate
-            c = getattr(self, "_gsw_geglu", None)
-            if c is None or c[0].device != x.device or c[0].dtype != x.dtype:
-                c = pack_geglu_weight(self.proj.weight.detach(), self.proj.bias.detach())
-                self._gsw_geglu = c
+            from .pf import cached
+            c = cached(self, "_gsw_geglu", (self.proj.weight, self.proj.bias), lambda: pack_geglu_weight(self.proj.weight.detach(), self.proj.bias.detach()))
             return linear(x, c[0], c[1], geglu=True)
         y = self.proj(x)
         if FUSED_KERNELS and y.is_cuda and y.is_contiguous() and (y.shape[-1] // 2) % 8 == 0:
@@ -299,10 +293,8 @@ class Upsample2D(nn.Module):
     def forward_pf(self, x):
         from .pf import PF, conv_pf, conv_up2x_pf, conv_up2x_fusable, pack_upsample_weight
         if UPSAMPLE_SUBPIXEL and conv_up2x_fusable(x, self.conv.out_channels):
-            w4 = getattr(self, "_gsw_up4", None)
-            if w4 is None or w4.device != self.conv.weight.device or w4.dtype != self.conv.weight.dtype:
-                w4 = pack_upsample_weight(self.conv.weight)
-                self._gsw_up4 = w4
+            from .pf import cached
+            w4 = cached(self, "_gsw_up4", (self.conv.weight,), lambda: pack_upsample_weight(self.conv.weight))
             return conv_up2x_pf(x, w4, self.conv.bias)            # 2.25x fewer FLOPs, no upsampled intermediate
         up = PF.zeros(x.B, 2 * x.H, 2 * x.W, x.C, x.buf.dtype, x.buf.device)
         xi, g = x.interior, up.grid
@@ -461,19 +453,19 @@ def _unet_pf_ok(self, x: torch.Tensor) -> bool:
 
 def _edge_conv_weights(self):
     """conv_in (4 -> 320) and conv_out (320 -> 4) for the PF GEMM: the 4-channel side is zero-padded to one 64-wide tile."""
-    cache = getattr(self, "_gsw_edge", None)
+    from .pf import cached, pack_conv_weight
     w_in, w_out = self.conv_in.weight, self.conv_out.weight
-    if cache is None or cache[0].device != w_in.device or cache[0].dtype != w_in.dtype:
-        from .pf import pack_conv_weight
+
+    def build():
         wi = torch.zeros((w_in.shape[0], 64, 3, 3), dtype=w_in.dtype, device=w_in.device)
         wi[:, : w_in.shape[1]] = w_in.detach()
         wo = torch.zeros((64, w_out.shape[1], 3, 3), dtype=w_out.dtype, device=w_out.device)
         wo[: w_out.shape[0]] = w_out.detach()
         bo = torch.zeros(64, dtype=w_out.dtype, device=w_out.device)
         bo[: w_out.shape[0]] = self.conv_out.bias.detach()
-        cache = (pack_conv_weight(wi), pack_conv_weight(wo), bo)
-        self._gsw_edge = cache
-    return cache
+        return pack_conv_weight(wi), pack_conv_weight(wo), bo
+
+    return cached(self, "_gsw_edge", (w_in, w_out, self.conv_out.bias), build)
 
 
 def _unet_forward_pf(self, x: torch.Tensor, temb: torch.Tensor, ctx: torch.Tensor) -> torch.Tensor:

@@ -28,18 +28,18 @@ USE_PF = True
 def _pw(conv: nn.Conv2d, cin_pad: int = 0, cout_pad: int = 0):
     """Packed [N, 9*C] weight (+ bias) of a convolution, optionally zero-padded to `cin_pad` input / `cout_pad` output channels
     (the 3- / 4- / 8-channel edges of the VAE ride on one 64-wide tile)."""
-    c = getattr(conv, "_gsw_packed", None)
-    if c is None or c[0].device != conv.weight.device or c[0].dtype != conv.weight.dtype:
-        from .pf import pack_conv_weight
+    from .pf import cached, pack_conv_weight
+
+    def build():
         w, b = conv.weight.detach(), conv.bias.detach()
         if cin_pad and w.shape[1] < cin_pad:
             w = torch.cat([w, w.new_zeros(w.shape[0], cin_pad - w.shape[1], *w.shape[2:])], dim=1)
         if cout_pad and w.shape[0] < cout_pad:
             w = torch.cat([w, w.new_zeros(cout_pad - w.shape[0], *w.shape[1:])], dim=0)
             b = torch.cat([b, b.new_zeros(cout_pad - b.shape[0])])
-        c = (pack_conv_weight(w), b.contiguous())
-        conv._gsw_packed = c
-    return c
+        return pack_conv_weight(w), b.contiguous()
+
+    return cached(conv, "_gsw_packed", (conv.weight, conv.bias), build)
 
 
 def _gn_pf(x, norm: nn.GroupNorm, act=True, tokens=False):

@@ -289,3 +289,27 @@ def test_attention_head_dim_40_masked_cross(G):
     qf, kf, vf = (a.float().view(B, a.shape[1], H, D).transpose(1, 2) for a in (q, k[:, :77], v[:, :77]))
     ref = (torch.softmax(qf @ kf.transpose(-1, -2) * D ** -0.5, dim=-1) @ vf).transpose(1, 2).reshape(B, S, H * D)
     assert (got.float() - ref).abs().max().item() <= 4e-3 * max(1.0, ref.abs().max().item())
+
+
+def test_packed_weight_caches_follow_weight_updates(G):
+    """Derived weights (packed / fused / sub-pixel) are rebuilt when the parameters change in place (load_state_dict after a forward)."""
+    U = G.unet
+    m = U.synthetic_init_(U.UNet2DCondition(block_out_channels=(320, 640, 640, 640), cross_attention_dim=64, num_heads=(5, 10, 10, 10), head_dim=64), 0)
+    m = m.cuda().half().eval()
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1, 4, 16, 16, generator=g).cuda().half()
+    c = torch.randn(1, 77, 64, generator=g).cuda().half()
+    t = torch.tensor([500]).cuda()
+    with torch.no_grad():
+        y_a = m(x, t, c)
+        sd = {k: v.clone() for k, v in m.state_dict().items()}
+        U.synthetic_init_(m, 1)                                   # in-place re-initialisation: every cache must notice
+        y_b = m(x, t, c)
+        U.USE_PF = False
+        y_b_ref = m(x, t, c)
+        U.USE_PF = True
+        m.load_state_dict(sd)
+        y_a2 = m(x, t, c)
+    assert (y_b.float() - y_b_ref.float()).abs().max().item() <= 2e-2 * max(1.0, y_b_ref.float().abs().max().item())
+    assert (y_a.float() - y_a2.float()).abs().max().item() <= 2e-3 * max(1.0, y_a.float().abs().max().item())
+    assert (y_a.float() - y_b.float()).abs().max().item() > 1e-2
