@@ -42,6 +42,19 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// value of the lane 32 positions away, combined: v_permlane32_swap_b32 exchanges the upper half of one register with the lower half of
+// another in the VALU (no LDS round trip like ds_bpermute, which sits on the critical path between the S^T MFMAs and the exponentials)
+__device__ __forceinline__ float xhalf_max(float v) {
+    const uint32_t u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xhalf_sum(float v) {
+    const uint32_t u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 template <typename T> struct AT;
 template <> struct AT<_Float16> {
     using v8 = f16x8;
@@ -211,7 +224,7 @@ __global__ __launch_bounds__(256, 2) void gsw_attn_fwd_kernel(AttnArgs p) {
             for (int i = 1; i < 16; ++i) mx = fmaxf(mx, s[qb][0][i]);
 #pragma unroll
             for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[qb][1][i]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            mx = xhalf_max(mx);
             const float m_new = fmaxf(m_i[qb], mx * cs);
             const float alpha = __builtin_amdgcn_exp2f(m_i[qb] - m_new);      // raw v_exp_f32: arguments are <= 0, underflow to 0 is the intent
             m_i[qb] = m_new;
@@ -258,7 +271,7 @@ __global__ __launch_bounds__(256, 2) void gsw_attn_fwd_kernel(AttnArgs p) {
     // ---- normalise and store: lane holds O^T[d][query c32] for d = db*32 + (i/4)*8 + h*4 + (i%4)
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
-        const float l = l_i[qb] + __shfl_xor(l_i[qb], 32);
+        const float l = xhalf_sum(l_i[qb]);
         const float inv = 1.0f / l;
         T* O = reinterpret_cast<T*>(p.o) + ((int64_t)b * p.Sq + qt * QWG + wave * QW + (uint32_t)qb * 32u + c32) * p.ldo + hh * (uint32_t)D;
 #pragma unroll
