@@ -268,16 +268,25 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, sc
               valid_keys: Optional[int] = None) -> torch.Tensor:
     """softmax(q k^T * scale) v on the hand-written flash-attention kernel (csrc/gswm_attn.hip), head_dim 40 / 64 / 80.
     q [B, Sq, heads*d], k [B, Sk, heads*d], vt [B, heads*d, Sk] (V transposed) -> [B, Sq, heads*d]; keys >= valid_keys are
-    padding (zero weight)."""
+    padding (zero weight).  q and k may be column slices of a wider row-major tensor (a fused QK projection): only their last
+    dimension has to be contiguous and the batch stride has to equal rows * row stride."""
     B, Sq, inner = q.shape
     Sk = k.shape[1]
     d = inner // heads
     assert inner == heads * d and vt.shape == (B, inner, Sk) and k.shape[2] == inner
-    q, k, vt = q.contiguous(), k.contiguous(), vt.contiguous()
-    out = torch.empty_like(q)
+
+    def rows(t):          # (tensor, row stride) of a [B, S, inner] operand the kernel can address directly
+        if t.stride(2) == 1 and t.stride(0) == t.shape[1] * t.stride(1) and t.stride(1) % 8 == 0 and t.data_ptr() % 16 == 0:
+            return t, t.stride(1)
+        t = t.contiguous()
+        return t, inner
+
+    (q, ldq), (k, ldk) = rows(q), rows(k)
+    vt = vt.contiguous()
+    out = torch.empty((B, Sq, inner), dtype=q.dtype, device=q.device)
     with torch.cuda.device(q.device):
         N.check(N.lib().gsw_attention(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), B, heads, d, Sq, Sk,
-                                      Sk if valid_keys is None else int(valid_keys), inner, inner, inner,
+                                      Sk if valid_keys is None else int(valid_keys), ldq, ldk, inner,
                                       float(scale if scale is not None else d ** -0.5), _dt(q.dtype), _stream_ptr()))
     return out
 

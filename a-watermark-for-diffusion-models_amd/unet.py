@@ -55,6 +55,8 @@ def _pw(conv: nn.Conv2d) -> torch.Tensor:
 
 UPSAMPLE_SUBPIXEL = True   # Upsample2D = four 2x2 convolutions of the low-resolution tensor (gsw_conv_up2x_pf) instead of upsample + 3x3
 
+FUSED_QK = True       # self-attention: q and k projections as one GEMM (own attention kernel reads them as column slices)
+
 OWN_ATTENTION = True  # attention with head_dim 40 / 64 / 80 and a query count % 128 == 0 runs on gsw_attention instead of torch SDPA
 
 GEMM_MAX_K = 0        # linear layers with K <= this would run on the hand-written GEMM (gsw_linear).  Measured on MI355X: it only
@@ -181,7 +183,15 @@ class Attention(nn.Module):
                 # (V^T = W_v src^T, one GEMM either way) because the kernel consumes V^T tiles.  Padded context rows are zero and
                 # masked by `valid`.
                 vt = torch.bmm(self.to_v.weight.unsqueeze(0).expand(b, -1, -1), src.transpose(1, 2))
-                o = attention(_lin(x, self.to_q), _lin(src, self.to_k), vt, self.heads, valid_keys=valid)
+                if ctx is None and FUSED_QK:
+                    # self-attention: q and k from ONE GEMM over x (x is read once); the kernel takes them as column slices
+                    from .pf import cached
+                    wqk = cached(self, "_gsw_wqk", (self.to_q.weight, self.to_k.weight), lambda: torch.cat([self.to_q.weight.detach(), self.to_k.weight.detach()], dim=0).contiguous())
+                    qk = F.linear(x, wqk)
+                    inner = self.to_q.out_features
+                    o = attention(qk[..., :inner], qk[..., inner:], vt, self.heads, valid_keys=valid)
+                else:
+                    o = attention(_lin(x, self.to_q), _lin(src, self.to_k), vt, self.heads, valid_keys=valid)
                 return _lin(o, self.to_out[0])
         ctx = x if ctx is None else ctx
         q = _lin(x, self.to_q).view(b, n, self.heads, -1).transpose(1, 2)
