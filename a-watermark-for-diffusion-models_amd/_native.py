@@ -64,6 +64,8 @@ _PROTOTYPES = {
     "gsw_jpeg_quant_tables": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p]),
     "gsw_jpeg_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "gsw_jpeg_roundtrip": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "gsw_gaussian_blur_params": (C.c_int, [C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gsw_gaussian_blur": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gsw_image_pointwise": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_uint64, C.c_void_p, C.c_int,
                                       C.c_void_p, C.c_void_p]),
     "gsw_linear": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -476,6 +476,46 @@ __global__ __launch_bounds__(256) void gsw_image_pointwise_kernel(const uint8_t*
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Gaussian blur: PIL's ImageFilter.GaussianBlur = three passes per axis of an "extended box" filter (BoxBlur.c): out = (ww * sum of the
+// 2r+1 window + fw * (the two pixels just outside it) + 2^23) >> 24 in uint32 arithmetic, edges replicated, uint8 between passes.
+// Pillow slides an accumulator along each line; the sum is exact integer arithmetic, so evaluating the window per output pixel gives
+// the same bytes and parallelises over every pixel.
+// ---------------------------------------------------------------------------------------------------------------------------
+// horizontal pass: one workgroup per row (staged in LDS), thread per output byte
+__global__ __launch_bounds__(256) void gsw_boxblur_h_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int W, int radius, uint32_t ww, uint32_t fw) {
+    extern __shared__ uint8_t row[];
+    const int64_t r = blockIdx.x;
+    const int nb = W * 3;
+    const uint8_t* src = in + r * nb;
+    for (int i = threadIdx.x; i < nb; i += blockDim.x) row[i] = src[i];
+    __syncthreads();
+    uint8_t* dst = out + r * nb;
+    for (int o = threadIdx.x; o < nb; o += blockDim.x) {
+        const int x = o / 3, c = o - x * 3;
+        uint32_t acc = 0;
+        for (int d = -radius; d <= radius; ++d) acc += row[min(max(x + d, 0), W - 1) * 3 + c];
+        const uint32_t far = (uint32_t)row[min(max(x - radius - 1, 0), W - 1) * 3 + c] + (uint32_t)row[min(max(x + radius + 1, 0), W - 1) * 3 + c];
+        dst[o] = (uint8_t)((acc * ww + far * fw + (1u << 23)) >> 24);
+    }
+}
+
+// vertical pass: grid (H, B), thread per output byte of the row; window rows are read from global (coalesced along the row, L2-resident)
+__global__ __launch_bounds__(256) void gsw_boxblur_v_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int H, int W, int radius, uint32_t ww,
+                                                            uint32_t fw) {
+    const int y = blockIdx.x;
+    const int64_t b = blockIdx.y;
+    const int nb = W * 3;
+    const uint8_t* img = in + b * (int64_t)H * nb;
+    uint8_t* dst = out + (b * H + y) * (int64_t)nb;
+    for (int o = threadIdx.x; o < nb; o += blockDim.x) {
+        uint32_t acc = 0;
+        for (int d = -radius; d <= radius; ++d) acc += img[(int64_t)min(max(y + d, 0), H - 1) * nb + o];
+        const uint32_t far = (uint32_t)img[(int64_t)min(max(y - radius - 1, 0), H - 1) * nb + o] + (uint32_t)img[(int64_t)min(max(y + radius + 1, 0), H - 1) * nb + o];
+        dst[o] = (uint8_t)((acc * ww + far * fw + (1u << 23)) >> 24);
+    }
+}
+
 double sinc_filter(double x) {
     if (x == 0.0) return 1.0;
     x = x * M_PI;
@@ -637,6 +677,55 @@ int gsw_image_pointwise(const uint8_t* rgb_dev, int B, int H, int W, int op, flo
     }
     hipLaunchKernelGGL(gsw_image_pointwise_kernel, dim3(H, B), dim3(256), 0, st, rgb_dev, out_dev, H, W, op, strength, (const unsigned long long*)workspace_dev,
                        seed, image_index0, out_mode);
+    GSW_IMG_LAUNCH_CHECK();
+    return GSW_OK;
+}
+
+int gsw_gaussian_blur_params(float radius, int passes, int* box_radius, uint32_t* ww, uint32_t* fw) {
+    // BoxBlur.c _gaussian_blur_radius + the weights of ImagingHorizontalBoxBlur, with the C expression's float / double mix
+    if (!box_radius || !ww || !fw || radius < 0 || passes < 1) return GSW_ERR_BAD_ARG;
+    float sigma2, L, l, a;
+    sigma2 = radius * radius / passes;
+    L = sqrt(12.0 * sigma2 + 1.0);
+    l = floor((L - 1.0) / 2.0);
+    a = (2 * l + 1) * (l * (l + 1) - 3 * sigma2);
+    a /= 6 * (sigma2 - (l + 1) * (l + 1));
+    const float floatRadius = l + a;
+    const int r = (int)floatRadius;
+    const uint32_t w = (uint32_t)((uint32_t)(1 << 24) / (floatRadius * 2 + 1));
+    *box_radius = r;
+    *ww = w;
+    *fw = ((1u << 24) - (uint32_t)(r * 2 + 1) * w) / 2;
+    return GSW_OK;
+}
+
+int gsw_gaussian_blur(const uint8_t* rgb_dev, int B, int H, int W, float radius, uint8_t* out_dev, uint8_t* tmp_dev, void* stream) {
+    // distortions:157-164 `image.filter(ImageFilter.GaussianBlur(radius))`: uint8 [B, H, W, 3] -> out_dev; tmp_dev: same size scratch
+    if (!rgb_dev || !out_dev || !tmp_dev || B <= 0 || H <= 0 || W <= 0 || radius < 0) return GSW_ERR_BAD_ARG;
+    if (B > 65535 || (int64_t)W * 3 > 160 * 1024 || (int64_t)B * H > 0x7FFFFFFF) return GSW_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t bytes = (size_t)B * H * W * 3;
+    if (radius == 0.0f) {                                   // ImageFilter.GaussianBlur(0): a copy
+        hipError_t e = hipMemcpyAsync(out_dev, rgb_dev, bytes, hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) { g_img_hip_error = (int)e; return GSW_ERR_HIP; }
+        return GSW_OK;
+    }
+    int r;
+    uint32_t ww, fw;
+    gsw_gaussian_blur_params(radius, 3, &r, &ww, &fw);
+    const size_t lds = (size_t)W * 3;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)gsw_boxblur_h_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) { g_img_hip_error = (int)e; return GSW_ERR_HIP; }
+    }
+    const dim3 gh((uint32_t)((int64_t)B * H)), gv(H, B);
+    // ImagingBoxBlur: three horizontal passes, then three vertical ones; ping-pong so that the last pass lands in out_dev
+    hipLaunchKernelGGL(gsw_boxblur_h_kernel, gh, dim3(256), lds, st, rgb_dev, tmp_dev, W, r, ww, fw);
+    hipLaunchKernelGGL(gsw_boxblur_h_kernel, gh, dim3(256), lds, st, (const uint8_t*)tmp_dev, out_dev, W, r, ww, fw);
+    hipLaunchKernelGGL(gsw_boxblur_h_kernel, gh, dim3(256), lds, st, (const uint8_t*)out_dev, tmp_dev, W, r, ww, fw);
+    hipLaunchKernelGGL(gsw_boxblur_v_kernel, gv, dim3(256), 0, st, (const uint8_t*)tmp_dev, out_dev, H, W, r, ww, fw);
+    hipLaunchKernelGGL(gsw_boxblur_v_kernel, gv, dim3(256), 0, st, (const uint8_t*)out_dev, tmp_dev, H, W, r, ww, fw);
+    hipLaunchKernelGGL(gsw_boxblur_v_kernel, gv, dim3(256), 0, st, (const uint8_t*)tmp_dev, out_dev, H, W, r, ww, fw);
     GSW_IMG_LAUNCH_CHECK();
     return GSW_OK;
 }

@@ -5,8 +5,8 @@ Host-side mirror of what the reference does with PIL / torchvision on the CPU, o
 * `load_image` of extract.py:31-37 (Lanczos resize -> ToTensor) plus the `.to(float16)` / `2.*x - 1.` that follow (extract.py:48,40)
   -> `resize_lanczos(..., out="f16")`: the fp16 CHW batch the VAE encoder consumes, bit-identical to the reference's tensor.
 * `decode_image` / numpy_to_pil of the generation pipeline -> `tensor_to_image`.
-* the `distortions` tool (apply_single_distortion): "compression" (JPEG QF), "scaling", "brightness", "contrast", "noise", "togray",
-  "invert", "horizontal_flip", "vertical_flip" -> `apply_distortion`, same strength conventions (`relative_strength_to_absolute`).
+* the `distortions` tool (apply_single_distortion): "compression" (JPEG QF), "scaling", "blurring", "brightness", "contrast", "noise",
+  "togray", "invert", "horizontal_flip", "vertical_flip" -> `apply_distortion`, same strength conventions (`relative_strength_to_absolute`).
 
 Images are uint8 [B, H, W, 3] device tensors (np.asarray(PIL image) stacked).  There is no CPU fallback: every function launches the
 HIP kernels of libgswm through the C ABI.
@@ -127,6 +127,23 @@ def jpeg_roundtrip(images: torch.Tensor, quality: int, *, out: str = "u8") -> to
     return res
 
 
+def gaussian_blur_params(radius: float, passes: int = 3) -> Tuple[int, int, int]:
+    """(box radius, ww, fw) Pillow derives from a Gaussian radius (BoxBlur.c), computed by libgswm on the host."""
+    r, ww, fw = C.c_int(), C.c_uint32(), C.c_uint32()
+    N.check(N.lib().gsw_gaussian_blur_params(float(radius), int(passes), C.byref(r), C.byref(ww), C.byref(fw)))
+    return r.value, ww.value, fw.value
+
+
+def gaussian_blur(images: torch.Tensor, radius: float) -> torch.Tensor:
+    """distortions:157-164: `image.filter(ImageFilter.GaussianBlur(radius))` for a batch, bit-exact, on the device."""
+    images = _check_images(images)
+    B, H, W, _ = images.shape
+    out, tmp = torch.empty_like(images), torch.empty_like(images)
+    with torch.cuda.device(images.device):
+        N.check(N.lib().gsw_gaussian_blur(images.data_ptr(), B, H, W, float(radius), out.data_ptr(), tmp.data_ptr(), _stream_ptr()))
+    return out
+
+
 _OPS = {"brightness": N.GSW_PW_BRIGHTNESS, "contrast": N.GSW_PW_CONTRAST, "invert": N.GSW_PW_INVERT, "togray": N.GSW_PW_GRAY,
         "horizontal_flip": N.GSW_PW_HFLIP, "vertical_flip": N.GSW_PW_VFLIP, "noise": N.GSW_PW_NOISE}
 
@@ -144,7 +161,7 @@ def pointwise(images: torch.Tensor, op: str, strength: float = 0.0, *, seed: int
 
 
 # the strength ranges of the reference's tool (distortions:17-34), for the distortion types this module runs on the device
-distortion_strength_paras = dict(scaling=(0, 1), brightness=(1, 16), contrast=(1, 6), noise=(0, 0.5), compression=(100, 0),
+distortion_strength_paras = dict(scaling=(0, 1), brightness=(1, 16), contrast=(1, 6), blurring=(0, 20), noise=(0, 0.5), compression=(100, 0),
                                  horizontal_flip=(0, 0), vertical_flip=(0, 0), togray=(0, 0), invert=(0, 0))
 
 
@@ -171,6 +188,9 @@ def apply_distortion(images: torch.Tensor, distortion_type: str, strength: Optio
         assert min(lo, hi) <= strength <= max(lo, hi)
     if distortion_type == "compression":
         return jpeg_roundtrip(images, int(strength), out=out)
+    if distortion_type == "blurring":
+        blurred = gaussian_blur(images, int(strength))                  # distortions:158-164: kernel_size = int(strength)
+        return blurred if out == "u8" else to_tensor(blurred, out=out)
     if distortion_type == "scaling":
         _, H, W, _ = images.shape
         return resize_lanczos(images, (int(W * strength), int(H * strength)), out=out)

@@ -229,6 +229,12 @@ size_t gsw_jpeg_workspace_bytes(int B, int H, int W);
 int gsw_jpeg_roundtrip(const uint8_t* rgb_dev, int B, int H, int W, int quality, void* out_dev, int out_mode, uint8_t* workspace_dev,
                        void* stream);
 
+/* distortions:157-164 "blurring": `image.filter(ImageFilter.GaussianBlur(radius))` = Pillow's three extended-box passes per axis
+ * (BoxBlur.c), bit-exact.  tmp_dev: uint8 scratch of the image batch's size.  gsw_gaussian_blur_params exposes the integer box
+ * radius and the two 8.24 weights Pillow derives from `radius` (pure host). */
+int gsw_gaussian_blur_params(float radius, int passes, int* box_radius, uint32_t* ww, uint32_t* fw);
+int gsw_gaussian_blur(const uint8_t* rgb_dev, int B, int H, int W, float radius, uint8_t* out_dev, uint8_t* tmp_dev, void* stream);
+
 /* Point-wise attacks of distortions:131-224. */
 typedef enum gsw_pointwise_op {
     GSW_PW_BRIGHTNESS = 0, /* ImageEnhance.Brightness(image).enhance(strength)  (distortions:131-139)                  */

@@ -347,3 +347,52 @@ def enhance_contrast(rgb: np.ndarray, factor: float) -> np.ndarray:
     hist_mean = rgb_to_l(rgb).astype(np.float64).mean()
     mean = int(hist_mean + 0.5)
     return blend_u8(np.full_like(rgb, mean), rgb, factor)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Gaussian blur (PIL ImageFilter.GaussianBlur = three passes of an extended box blur per axis; BoxBlur.c)
+# ---------------------------------------------------------------------------------------------------------------------
+def gaussian_box_radius(radius: float, passes: int = 3) -> np.float32:
+    """BoxBlur.c _gaussian_blur_radius: float / double mix exactly as the C expression evaluates."""
+    f32 = np.float32
+    sigma2 = f32(f32(f32(radius) * f32(radius)) / f32(passes))
+    L = f32(np.sqrt(12.0 * float(sigma2) + 1.0))
+    l = f32(np.floor((float(L) - 1.0) / 2.0))
+    a = f32(f32(f32(2) * l + f32(1)) * f32(f32(l * f32(l + f32(1))) - f32(f32(3) * sigma2)))
+    a = f32(a / f32(f32(6) * f32(sigma2 - f32(f32(l + f32(1)) * f32(l + f32(1))))))
+    return f32(l + a)
+
+
+def box_blur_params(float_radius) -> Tuple[int, int, int]:
+    """ImagingHorizontalBoxBlur: integer radius and the 8.24 fixed-point weights of the window body (ww) and its two fractional ends (fw)."""
+    fr = np.float32(float_radius)
+    radius = int(fr)
+    ww = int(np.float32(16777216.0) / np.float32(fr * np.float32(2) + np.float32(1)))
+    fw = ((1 << 24) - (radius * 2 + 1) * ww) // 2
+    return radius, ww, fw
+
+
+def _box_blur_axis(img: np.ndarray, radius: int, ww: int, fw: int, axis: int) -> np.ndarray:
+    """One extended-box pass along `axis` of [H, W, C] uint8: (ww * sum(window) + fw * (left + right) + 2^23) >> 24, edges replicated."""
+    src = np.moveaxis(img, axis, 0).astype(np.int64)
+    n = src.shape[0]
+    idx = np.arange(n)
+    acc = np.zeros_like(src)
+    for d in range(-radius, radius + 1):
+        acc += src[np.clip(idx + d, 0, n - 1)]
+    far = src[np.clip(idx - radius - 1, 0, n - 1)] + src[np.clip(idx + radius + 1, 0, n - 1)]
+    out = ((acc * ww + far * fw + (1 << 23)) & 0xFFFFFFFF) >> 24
+    return np.moveaxis(out.astype(np.uint8), 0, axis)
+
+
+def gaussian_blur(img: np.ndarray, radius: float, passes: int = 3) -> np.ndarray:
+    """`PIL.Image.fromarray(img).filter(ImageFilter.GaussianBlur(radius))` (distortions:157-164) for [H, W, 3] uint8."""
+    if radius == 0:
+        return img.copy()
+    r, ww, fw = box_blur_params(gaussian_box_radius(radius, passes))
+    out = img
+    for _ in range(passes):
+        out = _box_blur_axis(out, r, ww, fw, 1)
+    for _ in range(passes):
+        out = _box_blur_axis(out, r, ww, fw, 0)
+    return out

@@ -173,3 +173,21 @@ def test_bad_arguments(im):
         im.resize_lanczos(torch.zeros(1, 8, 8, 3), (4, 4))                   # host tensor
     with pytest.raises(ValueError):
         im.jpeg_roundtrip(torch.zeros(1, 8, 8, 4, dtype=torch.uint8).cuda(), 10)
+
+
+@pytest.mark.parametrize("hw", [(64, 64), (33, 47), (5, 9), (1, 7), (20, 3), (512, 512)])
+@pytest.mark.parametrize("radius", [0, 1, 3, 10, 20, 1.7])
+def test_gaussian_blur_equals_oracle_and_pil(im, hw, radius):
+    imgs = np.random.default_rng(int(radius * 10) + hw[0]).integers(0, 256, (2, *hw, 3), dtype=np.uint8)
+    got = im.gaussian_blur(torch.from_numpy(imgs).cuda(), radius).cpu().numpy()
+    for i in range(2):
+        assert np.array_equal(got[i], IO.gaussian_blur(imgs[i], radius))
+    PILImage = pytest.importorskip("PIL.Image")
+    from PIL import ImageFilter
+    assert np.array_equal(got[0], np.asarray(PILImage.fromarray(imgs[0]).filter(ImageFilter.GaussianBlur(radius))))
+
+
+def test_apply_distortion_blurring(im):
+    imgs = batch(48, 64, 2, seed=31)
+    got = im.apply_distortion(torch.from_numpy(imgs).cuda(), "blurring", 0.25).cpu().numpy()       # relative 0.25 -> radius int(5.0)
+    assert np.array_equal(got[1], IO.gaussian_blur(imgs[1], 5))

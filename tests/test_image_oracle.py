@@ -113,3 +113,19 @@ def test_relative_strength_table():
     assert imaging.relative_strength_to_absolute(0.0, "compression") == 100
     assert imaging.relative_strength_to_absolute(0.5, "scaling") == 0.5
     assert imaging.relative_strength_to_absolute(1.0, "brightness") == 16
+
+
+@pytest.mark.parametrize("hw", [(64, 64), (33, 47), (5, 9), (1, 7), (20, 3)])
+@pytest.mark.parametrize("radius", [0, 1, 2, 3, 5, 10, 20, 0.5, 1.7])
+def test_gaussian_blur_matches_pil(hw, radius):
+    from PIL import ImageFilter
+    img = np.random.default_rng(int(radius * 10) + hw[0]).integers(0, 256, (*hw, 3), dtype=np.uint8)
+    ref = np.asarray(Image.fromarray(img).filter(ImageFilter.GaussianBlur(radius)))
+    assert np.array_equal(IO.gaussian_blur(img, radius), ref)
+
+
+@pytest.mark.parametrize("radius", [1, 2, 3, 5, 7, 10, 13, 20, 0.5, 1.7, 30])
+def test_cabi_gaussian_blur_params_equal_oracle(radius):
+    import gswm_amd
+    from gswm_amd import imaging
+    assert imaging.gaussian_blur_params(radius) == IO.box_blur_params(IO.gaussian_box_radius(radius))
