@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgswm.so")
+LIB_PATH = os.environ.get("GSWM_LIB", os.path.join(_HERE, "libgswm.so"))     # GSWM_LIB: an alternative build of the same ABI (kernel A/Bs)
 
 GSW_F32, GSW_F16, GSW_BF16, GSW_F64 = 0, 1, 2, 3
 GSW_OK, GSW_ERR_BAD_ARG, GSW_ERR_UNSUPPORTED, GSW_ERR_RAGGED, GSW_ERR_HIP = 0, 1, 2, 3, 4

@@ -557,24 +557,38 @@ __global__ __launch_bounds__(256, 2) void gsw_conv3x3_halo_kernel(ConvArgs p, in
                                              (__attribute__((address_space(3))) void*)(wbuf + (wave * 5u + i) * 1024u), 16, 0, 0);
     };
     auto compute = [&](int32_t t, const uint8_t* wbuf) {
+        // all 18 fragment reads of the tap step are issued up front (both 32-channel halves), so the second half's LDS latency is
+        // covered by the first half's 20 MFMAs instead of a wait in front of every few MFMAs
         const int32_t toff = p.tap_off[t];
+        typename Mfma<T>::frag xf[2][4], wf[2][5];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const uint32_t lc = (uint32_t)ks * 4u + (lane >> 4);
-            typename Mfma<T>::frag xf[4];
 #pragma unroll
             for (int im = 0; im < 4; ++im) {
                 const uint32_t r = (uint32_t)(lrow[im] + toff);
-                xf[im] = *reinterpret_cast<const typename Mfma<T>::frag*>(ldsX + r * 128u + ((lc ^ ((r >> 1) & 7u)) << 4));
+                xf[ks][im] = *reinterpret_cast<const typename Mfma<T>::frag*>(ldsX + r * 128u + ((lc ^ ((r >> 1) & 7u)) << 4));
             }
 #pragma unroll
             for (int in = 0; in < 5; ++in) {
                 const uint32_t r = wn * 80u + (uint32_t)in * 16u + (lane & 15u);
-                const typename Mfma<T>::frag wf = *reinterpret_cast<const typename Mfma<T>::frag*>(wbuf + r * 128u + ((lc ^ ((r >> 1) & 7u)) << 4));
-#pragma unroll
-                for (int im = 0; im < 4; ++im) acc[in][im] = Mfma16<T>::mma(wf, xf[im], acc[in][im]);
+                wf[ks][in] = *reinterpret_cast<const typename Mfma<T>::frag*>(wbuf + r * 128u + ((lc ^ ((r >> 1) & 7u)) << 4));
             }
         }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int in = 0; in < 5; ++in)
+#pragma unroll
+                for (int im = 0; im < 4; ++im) acc[in][im] = Mfma16<T>::mma(wf[ks][in], xf[ks][im], acc[in][im]);
+        // issue order: the first half's 9 reads, then one read of the second half per two MFMAs of the first, then the rest
+        __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 22, 0);
     };
     for (int32_t kc = 0; kc < kc_blocks; ++kc) {
         stage_x(X, p.ldx, kc);
