@@ -47,7 +47,7 @@ def test_geglu_vs_torch_fp32(G, dtype, shape):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("rows,C", [(4096 * 3, 320), (1024, 640), (257, 1280), (5, 64), (77, 1536)])
+@pytest.mark.parametrize("rows,C", [(4096 * 3, 320), (1024, 640), (257, 1280), (5, 64), (77, 1536), (33, 328), (9, 8), (130, 1288), (3, 648)])
 @pytest.mark.parametrize("with_delta", [True, False])
 def test_add_layernorm_vs_torch_fp32(G, dtype, rows, C, with_delta):
     g = torch.Generator().manual_seed(C + rows)
