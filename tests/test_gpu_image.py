@@ -191,3 +191,37 @@ def test_apply_distortion_blurring(im):
     imgs = batch(48, 64, 2, seed=31)
     got = im.apply_distortion(torch.from_numpy(imgs).cuda(), "blurring", 0.25).cpu().numpy()       # relative 0.25 -> radius int(5.0)
     assert np.array_equal(got[1], IO.gaussian_blur(imgs[1], 5))
+
+
+@pytest.mark.parametrize("hw", [(20, 257), (40, 300), (16, 272), (33, 513), (17, 255), (48, 768)])
+def test_jpeg_tile_boundaries_against_pil(im, hw):
+    """Widths around the 256-pixel tile of gsw_jpeg_blocks_kernel: fast (16-byte) and clamped (byte) staging paths in one image."""
+    PILImage = pytest.importorskip("PIL.Image")
+    imgs = np.random.default_rng(hw[1]).integers(0, 256, (2, *hw, 3), dtype=np.uint8)
+    got = im.jpeg_roundtrip(torch.from_numpy(imgs).cuda(), 35).cpu().numpy()
+    for i in range(2):
+        buf = io.BytesIO()
+        PILImage.fromarray(imgs[i]).save(buf, format="JPEG", quality=35)
+        buf.seek(0)
+        assert np.array_equal(got[i], np.asarray(PILImage.open(buf).convert("RGB")))
+
+
+def test_random_sizes_resize_blur_jpeg_against_pil(im):
+    """A seeded sweep of odd geometries through the three bit-exact image kernels."""
+    PILImage = pytest.importorskip("PIL.Image")
+    from PIL import ImageFilter
+    rng = np.random.default_rng(2024)
+    for _ in range(12):
+        h, w = int(rng.integers(1, 90)), int(rng.integers(1, 400))
+        img = rng.integers(0, 256, (1, h, w, 3), dtype=np.uint8)
+        dev = torch.from_numpy(img).cuda()
+        pil = PILImage.fromarray(img[0])
+        size = (int(rng.integers(1, 300)), int(rng.integers(1, 120)))
+        assert np.array_equal(im.resize_lanczos(dev, size).cpu().numpy()[0], np.asarray(pil.resize(size, PILImage.Resampling.LANCZOS))), (h, w, size)
+        r = int(rng.integers(0, 21))
+        assert np.array_equal(im.gaussian_blur(dev, r).cpu().numpy()[0], np.asarray(pil.filter(ImageFilter.GaussianBlur(r)))), (h, w, r)
+        q = int(rng.integers(1, 101))
+        buf = io.BytesIO()
+        pil.save(buf, format="JPEG", quality=q)
+        buf.seek(0)
+        assert np.array_equal(im.jpeg_roundtrip(dev, q).cpu().numpy()[0], np.asarray(PILImage.open(buf).convert("RGB"))), (h, w, q)
