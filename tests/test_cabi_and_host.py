@@ -159,3 +159,45 @@ def test_mt19937_seed_equals_numpy_legacy_seeding(seed):
     assert st[2] == 624 and np.array_equal(codec.mt19937_seed(seed), st[1])
     with pytest.raises(ValueError):
         codec.mt19937_seed(2**32)
+
+
+def test_argument_validation_of_eps_model_and_image_entry_points():
+    """Status codes of the UNet / VAE / image entry points that are decided before any HIP call."""
+    lib = N.lib()
+    p = ctypes.c_void_p(64)
+    BAD, UNS = N.GSW_ERR_BAD_ARG, N.GSW_ERR_UNSUPPORTED
+    # attention: null operand, head width, tile divisibility, strides
+    assert lib.gsw_attention(None, p, p, p, 1, 5, 64, 256, 256, 256, 320, 320, 320, 0.125, 1, None) == BAD
+    assert lib.gsw_attention(p, p, p, p, 1, 5, 48, 256, 256, 256, 240, 240, 240, 0.125, 1, None) == UNS          # head_dim 48
+    assert lib.gsw_attention(p, p, p, p, 1, 5, 64, 200, 256, 256, 320, 320, 320, 0.125, 1, None) == UNS          # Sq % 128
+    assert lib.gsw_attention(p, p, p, p, 1, 5, 64, 256, 100, 77, 320, 320, 320, 0.125, 1, None) == UNS           # Sk % 64
+    assert lib.gsw_attention(p, p, p, p, 1, 5, 64, 256, 128, 129, 320, 320, 320, 0.125, 1, None) == BAD          # valid keys > keys
+    assert lib.gsw_attention(p, p, p, p, 1, 5, 64, 256, 128, 77, 316, 320, 320, 0.125, 1, None) == UNS           # row stride < H * d
+    assert lib.gsw_attention(p, p, p, p, 1, 5, 64, 256, 128, 77, 320, 320, 320, 0.125, 0, None) == BAD           # fp32
+    # convolutions on padded-flat activations
+    assert lib.gsw_conv_pf(p, p, None, None, None, p, 1, 8, 8, 60, 64, 3, 1, 60, 1, None) == UNS                 # C % 64
+    assert lib.gsw_conv_pf(p, p, None, None, None, p, 1, 8, 8, 64, 64, 5, 1, 64, 1, None) == BAD                 # 5x5
+    assert lib.gsw_conv3x3_res_pf(p, p, None, None, None, p, 1, 8, 8, 64, 64, p, 64, None, 0, 1, None) == UNS    # N % 160
+    assert lib.gsw_conv_up2x_pf(p, p, None, p, 1, 8, 8, 64, 64, 1, None) == UNS                                  # N % 160
+    assert lib.gsw_conv_up2x_pf(None, p, None, p, 1, 8, 8, 64, 160, 1, None) == BAD
+    assert lib.gsw_conv_up2x_pf(p, p, None, p, 1, 8, 400, 64, 160, 1, None) == UNS                               # halo tile beyond LDS
+    assert lib.gsw_add_layernorm(p, None, p, p, None, p, 4, 1544, 1e-5, 1, None) == UNS                          # C > 1536
+    assert lib.gsw_add_layernorm(p, p, p, p, None, p, 4, 320, 1e-5, 1, None) == BAD                              # delta without x_new
+    # image stages
+    assert lib.gsw_resize_lanczos(None, 1, 8, 8, p, 4, 4, 0, None, None, None, 0, None, None, 0, None) == BAD
+    assert lib.gsw_resize_lanczos(p, 1, 8, 8, p, 4, 4, 7, None, None, None, 0, None, None, 0, None) == BAD       # output mode
+    assert lib.gsw_resize_lanczos(p, 1, 8, 8, p, 4, 4, 0, None, None, None, 0, None, None, 0, None) == BAD       # resampling without a plan
+    assert lib.gsw_lanczos_plan(0, 4, None, None, 0) == -BAD
+    assert lib.gsw_lanczos_plan(512, 256, None, None, 0) == 13                                                   # ceil(3 * 2) * 2 + 1
+    assert lib.gsw_jpeg_roundtrip(p, 1, 8, 8, 10, p, 0, None, None) == BAD                                       # no workspace
+    assert lib.gsw_jpeg_roundtrip(p, 1, 70000, 8, 10, p, 0, p, None) == UNS                                      # JPEG's size limit
+    assert lib.gsw_jpeg_workspace_bytes(2, 16, 16) == 2 * (4 + 2) * 64
+    assert lib.gsw_gaussian_blur(p, 1, 8, 8, -1.0, p, p, None) == BAD
+    assert lib.gsw_gaussian_blur(p, 1, 8, 8, 2.0, p, None, None) == BAD
+    assert lib.gsw_image_pointwise(p, 1, 8, 8, 9, 1.0, 0, 0, p, 0, None, None) == BAD                            # unknown op
+    assert lib.gsw_image_pointwise(p, 1, 8, 8, N.GSW_PW_CONTRAST, 1.0, 0, 0, p, 0, None, None) == BAD            # contrast needs a workspace
+    assert lib.gsw_tensor_to_image(p, 3, 1, 8, 8, 0, p, None) == BAD                                             # fp64
+    assert lib.gsw_mt19937_uniform(None, 0, p, 4, None, None) == BAD
+    key = (ctypes.c_uint32 * 624)()
+    assert lib.gsw_mt19937_uniform(key, 625, p, 4, None, None) == BAD
+    assert lib.gsw_mt19937_uniform(key, 624, p, 0, None, None) == N.GSW_OK
