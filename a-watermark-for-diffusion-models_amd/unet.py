@@ -55,6 +55,8 @@ def _pw(conv: nn.Conv2d) -> torch.Tensor:
 
 UPSAMPLE_SUBPIXEL = True   # Upsample2D = four 2x2 convolutions of the low-resolution tensor (gsw_conv_up2x_pf) instead of upsample + 3x3
 
+CACHE_CONTEXT_KV = True   # cross-attention K / V^T of a context tensor are computed once and reused across the steps of a loop
+
 FUSED_QK = True       # self-attention: q and k projections as one GEMM (own attention kernel reads them as column slices)
 
 OWN_ATTENTION = True  # attention with head_dim 40 / 64 / 80 and a query count % 128 == 0 runs on gsw_attention instead of torch SDPA
@@ -182,6 +184,21 @@ class Attention(nn.Module):
                 # hand-written flash-attention kernel (self- and cross-attention); the value projection is computed transposed
                 # (V^T = W_v src^T, one GEMM either way) because the kernel consumes V^T tiles.  Padded context rows are zero and
                 # masked by `valid`.
+                if ctx is not None and CACHE_CONTEXT_KV:
+                    # cross-attention keys / values depend on the context only: computed once per (context tensor, layer) and reused by
+                    # every step of a sampling / inversion loop.  The cache lives ON the context tensor (it dies with it) and is keyed
+                    # by the tensor's and the weights' version counters, so in-place edits recompute it.
+                    store = getattr(src, "_gsw_kv", None)
+                    if store is None:
+                        store = {}
+                        src._gsw_kv = store
+                    ver = (src._version, self.to_k.weight._version, self.to_v.weight._version, self.to_k.weight.data_ptr(), self.to_v.weight.data_ptr())
+                    ent = store.get(id(self))
+                    if ent is None or ent[0] != ver:
+                        ent = (ver, _lin(src, self.to_k), torch.bmm(self.to_v.weight.unsqueeze(0).expand(b, -1, -1), src.transpose(1, 2)))
+                        store[id(self)] = ent
+                    o = attention(_lin(x, self.to_q), ent[1], ent[2], self.heads, valid_keys=valid)
+                    return _lin(o, self.to_out[0])
                 vt = torch.bmm(self.to_v.weight.unsqueeze(0).expand(b, -1, -1), src.transpose(1, 2))
                 if ctx is None and FUSED_QK:
                     # self-attention: q and k from ONE GEMM over x (x is read once); the kernel takes them as column slices

@@ -313,3 +313,45 @@ def test_packed_weight_caches_follow_weight_updates(G):
     assert (y_b.float() - y_b_ref.float()).abs().max().item() <= 2e-2 * max(1.0, y_b_ref.float().abs().max().item())
     assert (y_a.float() - y_a2.float()).abs().max().item() <= 2e-3 * max(1.0, y_a.float().abs().max().item())
     assert (y_a.float() - y_b.float()).abs().max().item() > 1e-2
+
+
+def test_context_kv_cache_is_tied_to_the_context_tensor(G):
+    """Cross-attention K / V^T are cached per context tensor: a second context (even one that reuses the freed storage), an in-place
+    edit of the context and a weight update must all be noticed.  (Forwards are not bit-reproducible run to run -- float atomics in the
+    GroupNorm statistics, stream-K GEMMs -- so "same" means within 1 % of the output scale and "different" well outside it.)"""
+    U = G.unet
+    m = U.synthetic_init_(U.UNet2DCondition(block_out_channels=(64, 128, 128, 128), cross_attention_dim=64, num_heads=(1, 2, 2, 2), head_dim=64), 0)
+    m = m.cuda().half().eval()
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1, 4, 32, 32, generator=g).cuda().half()
+    t = torch.tensor([500]).cuda()
+
+    def ref(c):
+        U.CACHE_CONTEXT_KV = False
+        try:
+            return m(x, t, c)
+        finally:
+            U.CACHE_CONTEXT_KV = True
+
+    def dist(a, b):
+        return (a.float() - b.float()).abs().max().item() / max(1.0, b.float().abs().max().item())
+
+    with torch.no_grad():
+        prev = None
+        for seed in (1, 2, 3):                                    # fresh contexts, the allocator is free to hand back the same block
+            c = (3 * torch.randn(1, 77, 64, generator=torch.Generator().manual_seed(seed))).cuda().half()
+            y1, y2 = m(x, t, c), m(x, t, c)                       # second call: served from the cache
+            assert dist(y1, y2) < 1e-2 and dist(y1, ref(c)) < 1e-2
+            if prev is not None:
+                assert dist(y1, prev) > 3e-2                      # a stale cache would reproduce the previous context's output
+            prev = y1
+            del c
+        c = (3 * torch.randn(1, 77, 64, generator=g)).cuda().half()
+        ya = m(x, t, c)
+        c.mul_(0.25)                                              # in-place edit of a cached context
+        yb = m(x, t, c)
+        assert dist(yb, ref(c)) < 1e-2 and dist(ya, yb) > 3e-2
+        for blk in m.modules():
+            if isinstance(blk, U.Attention):
+                blk.to_k.weight.mul_(2.0)                         # weight update
+        assert dist(m(x, t, c), ref(c)) < 1e-2
