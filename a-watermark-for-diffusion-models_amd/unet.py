@@ -69,6 +69,9 @@ GEMM_MAX_K = 0        # linear layers with K <= this would run on the hand-writt
 GEGLU_GEMM_MAX_K = 0  # feed-forward projection + GEGLU as ONE own GEMM (value * gelu(gate) in the epilogue) when K <= this
 
 
+GEMM_MAX_N = 320      # ... and only for outputs this narrow (the [.., 320] x [320, 320] projections of the 64x64 level)
+
+
 def _own_geglu_ok(x: torch.Tensor, K: int, N: int) -> bool:
     return USE_PF and FUSED_KERNELS and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and x.is_contiguous() \
         and K % 64 == 0 and N % 160 == 0 and K <= GEGLU_GEMM_MAX_K
@@ -76,7 +79,7 @@ def _own_geglu_ok(x: torch.Tensor, K: int, N: int) -> bool:
 
 def _own_gemm_ok(x: torch.Tensor, K: int, N: int) -> bool:
     return USE_PF and FUSED_KERNELS and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and x.is_contiguous() \
-        and K % 64 == 0 and N % 160 == 0 and K <= GEMM_MAX_K
+        and K % 64 == 0 and N % 160 == 0 and K <= GEMM_MAX_K and N <= GEMM_MAX_N
 
 
 def _lin(x: torch.Tensor, lin: nn.Linear, resid: Optional[torch.Tensor] = None) -> torch.Tensor:
