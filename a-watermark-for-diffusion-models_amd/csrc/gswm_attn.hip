@@ -85,7 +85,8 @@ constexpr uint32_t VP = 136;                               // V^T LDS row pitch 
 // the two blocks' softmax / MFMA chains are independent instruction streams the scheduler can interleave inside one wave).
 // DU = head_dim / 8 (5, 8, 10 <-> head_dim 40, 64, 80): the contraction over head_dim runs in KC = ceil(DU/2) MFMA k-slices and the
 // output in DB = ceil(head_dim/32) row blocks; the padding lanes of Q are zero registers and the padding rows of V^T zero LDS rows.
-template <typename T, int QB, int DU>
+// PAIR: four LDS stages and ONE barrier per two 64-key tiles (half the barriers; 4 x 17.5 KiB of dynamic LDS at head_dim 64).
+template <typename T, int QB, int DU, bool PAIR>
 __global__ __launch_bounds__(256, 2) void gsw_attn_fwd_kernel(AttnArgs p) {
     using v8 = typename AT<T>::v8;
     using v4 = typename AT<T>::v4;
@@ -93,7 +94,8 @@ __global__ __launch_bounds__(256, 2) void gsw_attn_fwd_kernel(AttnArgs p) {
     constexpr uint32_t KP = KC * 32 + 16;                         // K LDS row pitch: odd number of 16-byte slots -> conflict-free ds_read_b128
     constexpr uint32_t STAGE = 64 * KP + DB * 32 * VP;            // one 64-key K tile + one V^T tile
     constexpr int NU = (64 * DU + 255) / 256;                     // 16-byte staging units per thread, tile and operand
-    __shared__ __attribute__((aligned(16))) uint8_t lds[2 * STAGE];
+    constexpr uint32_t NSTG = PAIR ? 4 : 2;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];          // NSTG * STAGE bytes
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u, h = lane >> 5, c32 = lane & 31u;
     constexpr uint32_t QW = 32u * QB, QWG = 4u * QW;          // queries per wave / per workgroup
 
@@ -109,7 +111,7 @@ __global__ __launch_bounds__(256, 2) void gsw_attn_fwd_kernel(AttnArgs p) {
     const T* VT = reinterpret_cast<const T*>(p.vt) + ((int64_t)b * p.H + hh) * D * (int64_t)p.Sk;
 
     if (DU & 1 || D & 31) {      // zero the LDS once: padding units of K rows / padding rows of V^T are never written by the staging
-        for (uint32_t i = tid; i < 2 * STAGE / 16; i += 256) reinterpret_cast<uint4*>(lds)[i] = make_uint4(0, 0, 0, 0);
+        for (uint32_t i = tid; i < NSTG * STAGE / 16; i += 256) reinterpret_cast<uint4*>(lds)[i] = make_uint4(0, 0, 0, 0);
         __syncthreads();
     }
 
@@ -175,16 +177,9 @@ __global__ __launch_bounds__(256, 2) void gsw_attn_fwd_kernel(AttnArgs p) {
     const float cs = p.scale_log2;
 
     const int32_t nt = p.Sk >> 6;
-    GSW_ATTN_GLOAD(0)
-    GSW_ATTN_LSTORE(0u)
-    __syncthreads();
-    for (int32_t t = 0; t < nt; ++t) {
-        // prefetch the next tile into registers -- unconditionally (the last iteration re-fetches its own tile into the idle stage):
-        // a conditional load made the compiler merge the registers right after the branch, i.e. wait for HBM inside the MFMA phase
-        const int32_t tn = t + 1 < nt ? t + 1 : t;
-        GSW_ATTN_GLOAD(tn << 6)
-        __builtin_amdgcn_sched_barrier(0);          // keep the prefetch at the top of the iteration (the scheduler sinks it otherwise)
-        const uint8_t* Kl = lds + (uint32_t)(t & 1) * STAGE;
+    // one 64-key tile: S^T, online softmax, O^T accumulation
+    auto tile = [&](uint32_t stage, int32_t t) {
+        const uint8_t* Kl = lds + stage * STAGE;
         const uint8_t* Vl = Kl + 64u * KP;
 
         // ---- S^T = K Q^T : two 32-key blocks per query block; 2 * QB independent accumulator chains, interleaved
@@ -264,8 +259,41 @@ __global__ __launch_bounds__(256, 2) void gsw_attn_fwd_kernel(AttnArgs p) {
             }
         }
 
-        GSW_ATTN_LSTORE((uint32_t)((t + 1) & 1))
+    };
+    if (PAIR) {
+        GSW_ATTN_GLOAD(0)
+        GSW_ATTN_LSTORE(0u)
+        GSW_ATTN_GLOAD((nt > 1 ? 1 : 0) << 6)
+        GSW_ATTN_LSTORE(1u)
         __syncthreads();
+        for (int32_t t = 0; t < nt; t += 2) {
+            // tiles t and t+1 are visible; t+2 and t+3 are fetched, written into the two idle stages, and published by ONE barrier
+            GSW_ATTN_GLOAD((t + 2 < nt ? t + 2 : nt - 1) << 6)
+            __builtin_amdgcn_sched_barrier(0);
+            tile((uint32_t)(t & 3), t);
+            GSW_ATTN_LSTORE((uint32_t)((t + 2) & 3))
+            if (t + 1 < nt) {
+                GSW_ATTN_GLOAD((t + 3 < nt ? t + 3 : nt - 1) << 6)
+                __builtin_amdgcn_sched_barrier(0);
+                tile((uint32_t)((t + 1) & 3), t + 1);
+                GSW_ATTN_LSTORE((uint32_t)((t + 3) & 3))
+            }
+            __syncthreads();
+        }
+    } else {
+        GSW_ATTN_GLOAD(0)
+        GSW_ATTN_LSTORE(0u)
+        __syncthreads();
+        for (int32_t t = 0; t < nt; ++t) {
+            // prefetch the next tile into registers -- unconditionally (the last iteration re-fetches its own tile into the idle stage):
+            // a conditional load made the compiler merge the registers right after the branch, i.e. wait for HBM inside the MFMA phase
+            const int32_t tn = t + 1 < nt ? t + 1 : t;
+            GSW_ATTN_GLOAD(tn << 6)
+            __builtin_amdgcn_sched_barrier(0);          // keep the prefetch at the top of the iteration (the scheduler sinks it otherwise)
+            tile((uint32_t)(t & 1), t);
+            GSW_ATTN_LSTORE((uint32_t)((t + 1) & 1))
+            __syncthreads();
+        }
     }
 
     // ---- normalise and store: lane holds O^T[d][query c32] for d = db*32 + (i/4)*8 + h*4 + (i%4)
@@ -297,17 +325,30 @@ __global__ __launch_bounds__(256, 2) void gsw_attn_fwd_kernel(AttnArgs p) {
 
 }  // namespace
 
-template <typename T>
-static void launch_attn(const AttnArgs& a, int head_dim, int QB, uint32_t grid, hipStream_t st) {
-    if (head_dim == 64) {
-        if (QB == 2) hipLaunchKernelGGL((gsw_attn_fwd_kernel<T, 2, 8>), dim3(grid), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((gsw_attn_fwd_kernel<T, 1, 8>), dim3(grid), dim3(256), 0, st, a);
-    } else if (head_dim == 40) {
-        if (QB == 2) hipLaunchKernelGGL((gsw_attn_fwd_kernel<T, 2, 5>), dim3(grid), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((gsw_attn_fwd_kernel<T, 1, 5>), dim3(grid), dim3(256), 0, st, a);
+template <typename T, int QB, int DU>
+static int launch_attn_cfg(const AttnArgs& a, uint32_t grid, hipStream_t st) {
+    constexpr int KC = (DU + 1) / 2, DB = (DU * 8 + 31) / 32;
+    constexpr uint32_t stage = 64 * (KC * 32 + 16) + DB * 32 * 136;
+    static const int pair_env = getenv("GSW_ATTN_PAIR") ? atoi(getenv("GSW_ATTN_PAIR")) : 1;      // A/B switch for profiling
+    const bool pair = pair_env && 4 * stage <= 80 * 1024 && (a.Sk >> 6) >= 16;      // long key sequences only: +2 % at 4096 keys, a loss at 256
+    const uint32_t lds = (pair ? 4 : 2) * stage;
+    if (pair) {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void*)gsw_attn_fwd_kernel<T, QB, DU, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            if (e != hipSuccess) { g_last_hip_error = (int)e; return GSW_ERR_HIP; }
+        }
+        hipLaunchKernelGGL((gsw_attn_fwd_kernel<T, QB, DU, true>), dim3(grid), dim3(256), lds, st, a);
     } else {
-        hipLaunchKernelGGL((gsw_attn_fwd_kernel<T, 1, 10>), dim3(grid), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((gsw_attn_fwd_kernel<T, QB, DU, false>), dim3(grid), dim3(256), lds, st, a);
     }
+    return GSW_OK;
+}
+
+template <typename T>
+static int launch_attn(const AttnArgs& a, int head_dim, int QB, uint32_t grid, hipStream_t st) {
+    if (head_dim == 64) return QB == 2 ? launch_attn_cfg<T, 2, 8>(a, grid, st) : launch_attn_cfg<T, 1, 8>(a, grid, st);
+    if (head_dim == 40) return QB == 2 ? launch_attn_cfg<T, 2, 5>(a, grid, st) : launch_attn_cfg<T, 1, 5>(a, grid, st);
+    return launch_attn_cfg<T, 1, 10>(a, grid, st);
 }
 
 int gsw_attention(const void* q_dev, const void* k_dev, const void* vt_dev, void* out_dev, int B, int H, int head_dim, int Sq, int Sk, int Sk_valid,
@@ -330,8 +371,9 @@ int gsw_attention(const void* q_dev, const void* k_dev, const void* vt_dev, void
     a.scale_log2 = scale * 1.4426950408889634f;
     a.nqt = (uint32_t)(Sq / (128 * QB));
     a.total = (uint32_t)total;
-    if (dtype == GSW_F16) launch_attn<_Float16>(a, head_dim, QB, (uint32_t)total, (hipStream_t)stream);
-    else launch_attn<__bf16>(a, head_dim, QB, (uint32_t)total, (hipStream_t)stream);
+    const int rc = dtype == GSW_F16 ? launch_attn<_Float16>(a, head_dim, QB, (uint32_t)total, (hipStream_t)stream)
+                                    : launch_attn<__bf16>(a, head_dim, QB, (uint32_t)total, (hipStream_t)stream);
+    if (rc != GSW_OK) return rc;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g_last_hip_error = (int)e; return GSW_ERR_HIP; }
     return GSW_OK;
