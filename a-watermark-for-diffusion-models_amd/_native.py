@@ -68,6 +68,8 @@ _PROTOTYPES = {
     "gsw_gaussian_blur": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gsw_image_pointwise": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_uint64, C.c_void_p, C.c_int,
                                       C.c_void_p, C.c_void_p]),
+    "gsw_gemm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                           C.c_int, C.c_void_p]),
     "gsw_linear": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
                              C.c_void_p]),
 }

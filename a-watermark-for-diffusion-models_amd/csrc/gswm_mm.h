@@ -1,0 +1,42 @@
+// gswm_mm.h -- internal interface of the matmul engine (csrc/gswm_mm.hip), shared with the convolution front end (csrc/gswm_conv.hip).
+#ifndef GSWM_MM_H
+#define GSWM_MM_H
+#include <stdint.h>
+
+struct MMSeg {
+    const void* x;       // A-operand rows of this K segment (row 0; PF tensors have guard rows at negative indices)
+    int32_t ld;          // row stride in elements
+    int32_t kblocks;     // channels / 64
+    int32_t ntaps;       // 1, 4 (2 x 2) or 9 (3 x 3)
+    int32_t tw;          // taps per tap row (1, 2, 3)
+    int32_t tap_row;     // row offset between tap rows (= padded input width)
+    int32_t tap_base;    // row offset of tap 0
+    int32_t wk0;         // offset of this segment inside a weight row; inside it K runs tap-major, channel-minor
+};
+
+enum { MM_MODE_DENSE = 0, MM_MODE_PF = 1, MM_MODE_TOK2PF = 2, MM_MODE_UP2X = 3, MM_MODE_GEGLU = 4, MM_MODE_TRANS = 5 };
+enum { MM_FLAG_NONE = 0 };
+
+struct MMArgs {
+    MMSeg seg[3];
+    int32_t nseg;
+    int32_t P;            // stages (K / 64 summed over segments and taps) per tile
+    const void* w;        // [N][ldw]
+    int32_t ldw;
+    int32_t M, N;
+    int32_t tiles_n, ntiles;      // filled by gsw_mm_launch
+    const void* bias;     // [N] or null
+    const void* rowbias;  // [images][N] or null (MM_MODE_PF)
+    const void* resid;    // [rows][ldr] or null, addressed like the output
+    void* y;
+    int32_t ldy, ldr;
+    int32_t mode;
+    int32_t Hp, Wp;       // padded geometry of the output row space (PF / UP2X) or of the target PF tensor (TOK2PF)
+    int32_t S, Wimg;      // tokens per image (TRANS, TOK2PF), image width (TOK2PF)
+    int32_t up;           // UP2X: 1 + dy * 2 + dx
+    int32_t flags;        // filled by gsw_mm_launch
+};
+
+int gsw_mm_launch(MMArgs& a, int dtype, void* stream);
+
+#endif

@@ -1,0 +1,514 @@
+// gswm_mm.hip -- the matmul engine of the eps model (rows X2 / G1 of SURVEY.md section 8a): every transformer linear of the UNet
+// (diffusers BasicTransformerBlock / Transformer2DModel behind extract.py:66-69) and, through a tap table, the PF convolutions.
+// gfx950 only.
+//
+//   Y[m, n] = sum_k A[m, k] * W[n, k]  (+ bias[n] + rowbias[image(m), n] + resid[m, n]),   fp16 / bf16 in, fp32 accumulate
+//
+// Structure (one workgroup per CU, persistent over output tiles):
+//   * 512 threads = 8 waves = two GROUPS of four (one wave of each group per SIMD).  A tile is BM x BN = 256 x 160 (waves 4 x 2) or
+//     128 x 320 (2 x 4); a wave owns 64 x 80 outputs as 4 x 5 v_mfma_f32_16x16x32 tiles; group g owns columns [g*BN/2, (g+1)*BN/2).
+//   * K is consumed in PHASES of 32.  Operands of a phase are one STAGE of an LDS ring (4 stages x (BM + BN) rows x 64 B) filled by
+//     LDS-DMA (global_load_lds, 16 B per lane) three phases ahead; waits are COUNTED (s_waitcnt vmcnt(2n): the two newest stages stay in
+//     flight across the barrier), barriers are raw s_barrier.  The producer walks tiles independently of the consumer, so the next
+//     tile's first three stages stream in while the current tile's epilogue runs (HBM-bound shapes, K = 320, live off that).
+//   * The two groups run PING-PONG, offset by one slot: while group 0 multiplies phase p (20 MFMAs per wave, the SIMD's matrix pipe
+//     busy), group 1 -- the other wave on the same SIMD -- issues its DMA pieces and reads its 9 operand fragments for phase p, then
+//     they swap.  Every slot ends in one s_barrier, so a SIMD always has exactly one wave feeding MFMAs and one wave loading.
+//   * LDS rows are 64 B (32 k-values); 16-byte chunks are XOR-swizzled with (-(row >> 2)) & 3 on the DMA SOURCE address, which makes
+//     every ds_read_b128 fragment read conflict-free (the four 16-lane groups of a b128 read cover all sixteen 16-byte slots).
+//   * A-operand rows come from up to three K SEGMENTS (pointer, row stride, channel count, tap table): a dense matrix is one segment
+//     with one tap; a 3x3 convolution on a padded-flat NHWC tensor is one segment with nine taps (a tap = a constant row offset, see
+//     gswm_conv.hip); the resnet's conv2 + 1x1 shortcut of cat(x, skip) is three segments.
+//   * Epilogue through an LDS image (16-byte coalesced stores): bias, per-image row bias, residual, GEGLU (value * gelu(gate) of a
+//     tile-interleaved projection), transposed output ([B, N, S] for the attention kernel's V^T operand; MFMA operands swapped so a lane
+//     holds 4 consecutive rows), PF border zeroing, tokens -> PF interior scatter (proj_out's residual add in place), sub-pixel scatter.
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <algorithm>
+
+#include "../../include/gswm.h"
+#include "gswm_mm.h"
+
+namespace {
+
+typedef _Float16 mm_h8 __attribute__((ext_vector_type(8)));
+typedef __bf16 mm_b8 __attribute__((ext_vector_type(8)));
+typedef float mm_f4 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct MM;
+template <> struct MM<_Float16> {
+    typedef mm_h8 frag;
+    static __device__ __forceinline__ mm_f4 mma(frag a, frag b, mm_f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ uint16_t cvt(float f) { return __half_as_ushort(__float2half_rn(f)); }
+    static __device__ __forceinline__ float up(uint16_t h) { return __half2float(__ushort_as_half(h)); }
+};
+template <> struct MM<__bf16> {
+    typedef mm_b8 frag;
+    static __device__ __forceinline__ mm_f4 mma(frag a, frag b, mm_f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ uint16_t cvt(float f) {
+        union { __hip_bfloat16 h; uint16_t u; } c; c.h = __float2bfloat16(f); return c.u;
+    }
+    static __device__ __forceinline__ float up(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+};
+
+#define MM_BARRIER() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+// epilogue barrier: LDS image traffic only -- the DMA prefetch of the next tile stays in flight (no vmcnt wait)
+#define MM_LDS_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); MM_BARRIER(); } while (0)
+
+template <typename T, bool SWAP>
+__global__ __launch_bounds__(512, 2) void gsw_mm_kernel(const MMArgs p) {
+    constexpr int WM = 4;                            // waves along M; 2 groups of 4 waves along N
+    constexpr int BM = 256, BN = 160;
+    constexpr int NPA = BM / 8 / 8;                  // A pieces (8 rows x 128 B = 1 KiB) per wave per stage: 4
+    constexpr int NPW = BN / 8 / 8;                  // full rounds of W pieces per wave: 2
+    constexpr int NEXTRA = BN / 8 - 8 * NPW;         // waves that issue one more W piece: 4
+    constexpr int NDMA = NPA + NPW;                  // pieces per stage of a wave without the extra one: 6
+    constexpr uint32_t STAGE = (uint32_t)(BM + BN) * 128u;     // one stage = 64 k-values of every tile row: 52 KiB
+    constexpr uint32_t RING = 3u * STAGE;
+    constexpr int HC = BN / 2;                       // columns owned by a group
+    constexpr uint32_t PITCH = SWAP ? (uint32_t)BM * 2u + 8u : (uint32_t)HC * 2u + 8u;
+    typedef typename MM<T>::frag frag;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const uint32_t grp = wave >> 2, wm = wave & 3u;
+    constexpr uint32_t wnl = 0u;
+    const bool extra = wave < (uint32_t)NEXTRA;
+
+    // LDS rows are 128 B (64 k-values); 16-byte chunks are XOR-swizzled with (row >> 1) & 7.
+    // fragment read of k-half h: row = lane & 15 of a 16-row block, logical chunk = 4h + (lane >> 4); (row >> 1) & 7 = (lane >> 1) & 7
+    const uint32_t lane_rd0 = (lane & 15u) * 128u + ((((lane >> 4)) ^ ((lane >> 1) & 7u)) << 4);
+    const uint32_t a_rd0 = wm * 64u * 128u + lane_rd0, a_rd1 = a_rd0 ^ 64u;            // k-half 1 = chunk + 4 = byte offset ^ 64
+    const uint32_t w_rd0 = (uint32_t)BM * 128u + (grp * (uint32_t)HC) * 128u + lane_rd0, w_rd1 = w_rd0 ^ 64u;
+    // DMA source: lane -> row lane >> 3 of an 8-row piece, physical chunk lane & 7 holds logical chunk (lane & 7) ^ ((row >> 1) & 7);
+    // a wave's pieces are wave, wave + 8, ...: (row >> 1) & 7 = (4 (wave & 1) + (lane >> 4)) & 7
+    const uint32_t prow = lane >> 3;
+    const uint32_t chunk8 = ((lane & 7u) ^ ((4u * (wave & 1u) + (lane >> 4)) & 7u)) * 8u;
+
+    // tile schedule: hardware block b runs on XCD b % 8; consecutive logical tiles (N tiles fastest) go to ONE XCD, so the
+    // workgroups sharing an activation tile find it in that XCD's L2
+    const uint32_t G = gridDim.x;
+    const uint32_t slotx = (blockIdx.x & 7u) * (G >> 3) + (blockIdx.x >> 3);
+    const uint32_t ntiles = (uint32_t)p.ntiles;
+    const uint32_t nt_mine = ntiles > slotx ? (ntiles - slotx + G - 1u) / G : 0u;
+    if (nt_mine == 0u) return;
+    const T* Wbase = reinterpret_cast<const T*>(p.w);
+    // logical tile -> (tile_m, tile_n): N is walked in PANELS of 8 tiles (M fastest across panels' rows), so the 32 tiles an XCD works on
+    // at a time are a 4 x 8 block: 4 activation tiles + 8 weight tiles in its L2 instead of 1 + 32 for a wide projection
+    auto decode_tile = [&](uint32_t L, int32_t& tm, int32_t& tn) {
+        const uint32_t tiles_m = ntiles / (uint32_t)p.tiles_n;
+        const uint32_t full = tiles_m * 8u;
+        const uint32_t pn = L / full, rem = L - pn * full;
+        const uint32_t width = min(8u, (uint32_t)p.tiles_n - pn * 8u);
+        tm = (int32_t)(rem / width);
+        tn = (int32_t)(pn * 8u + rem - (rem / width) * width);
+    };
+
+    // ---------------------------------------------------------------- producer: per-lane source pointers advanced by uniform steps.
+    // A RUN is a sequence of stages with constant steps: a dense segment is one run over its K blocks; a convolution segment visits
+    // channel block kc (outer) x tap row kh x tap column kw (inner, the run: next pixel, next tap's weights).
+    uint32_t pr_it = 0, pr_slot = 0;
+    int32_t pr_seg = 0, pr_kc = 0, pr_kh = 0, pr_run = 0, a_step = 0, w_step = 0;
+    int32_t pr_arow[NPA], pr_wrow[NPW + 1];
+    const T* pa[NPA];
+    const T* pw[NPW + 1];
+    auto setup_tile = [&](uint32_t it) {
+        int32_t tm, tn;
+        decode_tile(it * G + slotx, tm, tn);
+        const int32_t m0 = tm * BM, n0 = tn * BN;
+#pragma unroll
+        for (int i = 0; i < NPA; ++i) {
+            const int32_t m = m0 + 8 * (int32_t)(wave + 8u * i) + (int32_t)prow;
+            pr_arow[i] = m < p.M ? m : p.M - 1;
+        }
+#pragma unroll
+        for (int i = 0; i <= NPW; ++i) {
+            const int32_t n = n0 + 8 * (int32_t)(wave + 8u * i) + (int32_t)prow;
+            pr_wrow[i] = n < p.N ? n : p.N - 1;              // (only the unused extra piece of waves >= NEXTRA can exceed the tile)
+        }
+    };
+    auto begin_run = [&]() {
+        const MMSeg& s0 = p.seg[0]; const MMSeg& s1 = p.seg[1]; const MMSeg& s2 = p.seg[2];
+        const int32_t s = pr_seg;
+        const T* x = reinterpret_cast<const T*>(s == 0 ? s0.x : s == 1 ? s1.x : s2.x);
+        const int32_t ld = s == 0 ? s0.ld : s == 1 ? s1.ld : s2.ld;
+        const int32_t kb = s == 0 ? s0.kblocks : s == 1 ? s1.kblocks : s2.kblocks;
+        const int32_t nt = s == 0 ? s0.ntaps : s == 1 ? s1.ntaps : s2.ntaps;
+        const int32_t tw = s == 0 ? s0.tw : s == 1 ? s1.tw : s2.tw;
+        const int32_t trow = s == 0 ? s0.tap_row : s == 1 ? s1.tap_row : s2.tap_row;
+        const int32_t tbase = s == 0 ? s0.tap_base : s == 1 ? s1.tap_base : s2.tap_base;
+        const int32_t wk0 = s == 0 ? s0.wk0 : s == 1 ? s1.wk0 : s2.wk0;
+        const int32_t tapoff = tbase + pr_kh * trow;
+        const int32_t wk = wk0 + pr_kh * tw * (kb * 64) + pr_kc * 64 + (int32_t)chunk8;
+        if (nt == 1) { pr_run = kb; a_step = 64; w_step = 64; }
+        else { pr_run = tw; a_step = ld; w_step = kb * 64; }
+#pragma unroll
+        for (int i = 0; i < NPA; ++i) pa[i] = x + ((int64_t)(pr_arow[i] + tapoff) * ld + pr_kc * 64 + (int32_t)chunk8);
+#pragma unroll
+        for (int i = 0; i <= NPW; ++i) pw[i] = Wbase + (pr_wrow[i] * p.ldw + wk);
+    };
+    auto end_run = [&]() {                                   // slow path: next tap row / channel block / segment / tile
+        const MMSeg& s0 = p.seg[0]; const MMSeg& s1 = p.seg[1]; const MMSeg& s2 = p.seg[2];
+        const int32_t s = pr_seg;
+        const int32_t kb = s == 0 ? s0.kblocks : s == 1 ? s1.kblocks : s2.kblocks;
+        const int32_t nt = s == 0 ? s0.ntaps : s == 1 ? s1.ntaps : s2.ntaps;
+        const int32_t tw = s == 0 ? s0.tw : s == 1 ? s1.tw : s2.tw;
+        bool seg_done = nt == 1;
+        if (!seg_done && ++pr_kh * tw == nt) { pr_kh = 0; seg_done = ++pr_kc == kb; }
+        if (seg_done) {
+            pr_kc = 0; pr_kh = 0;
+            if (++pr_seg == p.nseg) {
+                pr_seg = 0;
+                if (++pr_it == nt_mine) {
+                    // no stage left: the (unconditional) DMA of the remaining steps re-reads one valid, cached location into ring slots
+                    // that are never read again, so the loop body needs no "is there a stage" branch and the wait counts stay exact
+                    pr_run = 0x7FFFFFFF; a_step = 0; w_step = 0;
+#pragma unroll
+                    for (int i = 0; i < NPA; ++i) pa[i] = Wbase + chunk8;
+#pragma unroll
+                    for (int i = 0; i <= NPW; ++i) pw[i] = Wbase + chunk8;
+                    return;
+                }
+                setup_tile(pr_it);
+            }
+        }
+        begin_run();
+    };
+    auto dma_extra = [&]() {                                 // the W piece only waves < NEXTRA carry (wave-uniform branch, kept out of the main block)
+        if (extra) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pw[NPW],
+                                             (__attribute__((address_space(3))) void*)(lds + pr_slot + (uint32_t)BM * 128u + (wave + 8u * NPW) * 1024u), 16, 0, 0);
+            pw[NPW] += w_step;
+        }
+    };
+    auto dma_stage = [&]() {                                 // this wave's NDMA pieces of the next stage: straight-line code
+        uint8_t* sb = lds + pr_slot;
+#pragma unroll
+        for (int i = 0; i < NPA; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pa[i],
+                                             (__attribute__((address_space(3))) void*)(sb + (wave + 8u * i) * 1024u), 16, 0, 0);
+            pa[i] += a_step;
+        }
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pw[i],
+                                             (__attribute__((address_space(3))) void*)(sb + (uint32_t)BM * 128u + (wave + 8u * i) * 1024u), 16, 0, 0);
+            pw[i] += w_step;
+        }
+        pr_slot = pr_slot + STAGE == RING ? 0u : pr_slot + STAGE;
+    };
+    setup_tile(0);
+    begin_run();
+    for (int i = 0; i < 2; ++i) { dma_extra(); dma_stage(); if (--pr_run == 0) end_run(); }
+    // this wave's pieces of stage 0 have landed: at most the newest stage is in flight.  The count is exact for waves without the
+    // extra piece and conservative for the others; any other VMEM operation in flight only makes a wait longer.
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NDMA) : "memory");
+    MM_BARRIER();
+
+    // ---------------------------------------------------------------- consumer: a STEP = one stage = two phases of 32 k-values; every wave:
+    //   even phase: DMA(stage s+2) | fragment reads (s, k-half 1) into the other register set | 20 MFMAs of (s, k-half 0) | counted wait | barrier
+    //   odd phase :                  fragment reads (s+1, k-half 0)                            | 20 MFMAs of (s, k-half 1)                | barrier
+    const uint16_t* bias = reinterpret_cast<const uint16_t*>(p.bias);
+    const uint16_t* rowbias = reinterpret_cast<const uint16_t*>(p.rowbias);
+    const uint16_t* resid = reinterpret_cast<const uint16_t*>(p.resid);
+    uint16_t* Y = reinterpret_cast<uint16_t*>(p.y);
+    const int32_t HpWp = p.Hp * p.Wp;
+    mm_f4 acc[5][4];
+#pragma unroll
+    for (int a = 0; a < 5; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = mm_f4{0.f, 0.f, 0.f, 0.f};
+    uint32_t c_it = 0, rd_slot = 0;                           // rd_slot: ring offset of the stage being multiplied
+
+    auto read_frags = [&](frag (&xf)[4], frag (&wf)[5], uint32_t slot, uint32_t khalf) {
+        const uint8_t* ap = lds + ((khalf ? a_rd1 : a_rd0) + slot);
+        const uint8_t* wp = lds + ((khalf ? w_rd1 : w_rd0) + slot);
+#pragma unroll
+        for (int im = 0; im < 4; ++im) xf[im] = *reinterpret_cast<const frag*>(ap + im * 2048);
+#pragma unroll
+        for (int in = 0; in < 5; ++in) wf[in] = *reinterpret_cast<const frag*>(wp + in * 2048);
+    };
+
+    auto epilogue = [&]() {
+        // the LDS image lives in the ring slot of the tile's last stage (just consumed; its refill is issued after the closing barrier)
+        uint8_t* img = lds + (rd_slot == 0u ? RING - STAGE : rd_slot - STAGE);
+        int32_t tile_m, tile_n;
+        decode_tile(c_it * G + slotx, tile_m, tile_n);
+        const int32_t m0 = tile_m * BM, n0 = tile_n * BN;
+        // non-SWAP accumulator layout: m = lane & 15 (+16 im), n = (lane >> 4) * 4 + reg (+16 in); SWAP: n = lane & 15, m = (lane >> 4) * 4 + reg
+        auto put = [&](bool gelu_it) {                        // this wave's 64 x 80 accumulators (+bias) -> LDS image
+#pragma unroll
+            for (int in = 0; in < 5; ++in) {
+                if (!SWAP) {
+                    const uint32_t nc = wnl * 80u + (uint32_t)in * 16u + (lane >> 4) * 4u;          // column inside the group
+                    uint2 bw = make_uint2(0, 0);
+                    if (bias) bw = *reinterpret_cast<const uint2*>(bias + n0 + (int32_t)(grp * HC + nc));
+                    const uint16_t bh[4] = {(uint16_t)bw.x, (uint16_t)(bw.x >> 16), (uint16_t)bw.y, (uint16_t)(bw.y >> 16)};
+#pragma unroll
+                    for (int im = 0; im < 4; ++im) {
+                        const uint32_t m = wm * 64u + (uint32_t)im * 16u + (lane & 15u);
+                        uint16_t h[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            float v = acc[in][im][j] + (bias ? MM<T>::up(bh[j]) : 0.f);
+                            if (gelu_it) {                   // torch: F.gelu(gate) on the stored (rounded) gate, result rounded again
+                                v = MM<T>::up(MM<T>::cvt(v));
+                                v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+                            }
+                            h[j] = MM<T>::cvt(v);
+                        }
+                        *reinterpret_cast<uint2*>(img + m * PITCH + nc * 2u) =
+                            make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+                    }
+                } else {
+                    const uint32_t nr = wnl * 80u + (uint32_t)in * 16u + (lane & 15u);              // output row (= column of the GEMM) inside the group
+                    const float bv = bias ? MM<T>::up(bias[n0 + (int32_t)(grp * HC + nr)]) : 0.f;
+#pragma unroll
+                    for (int im = 0; im < 4; ++im) {
+                        const uint32_t m = wm * 64u + (uint32_t)im * 16u + (lane >> 4) * 4u;
+                        uint16_t h[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) h[j] = MM<T>::cvt(acc[in][im][j] + bv);
+                        *reinterpret_cast<uint2*>(img + nr * PITCH + m * 2u) =
+                            make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+                    }
+                }
+            }
+        };
+        auto store = [&](uint32_t sel) {                      // LDS image of group `sel` -> global, 16 bytes per thread per round
+            if (!SWAP) {
+                constexpr uint32_t CPR = HC / 8;              // 16-byte chunks per image row
+                const bool glu = p.mode == MM_MODE_GEGLU;
+                const int32_t ld = p.ldy;
+#pragma unroll
+                for (int i = 0; i < (BM * (int)CPR) / 512; ++i) {
+                    const uint32_t qq = tid + 512u * i;
+                    const uint32_t r = qq / CPR, cc = qq - r * CPR;
+                    const int32_t m = m0 + (int32_t)r;
+                    if (m >= p.M) continue;
+                    const int64_t col = glu ? (int64_t)tile_n * (BN / 2) + cc * 8u : (int64_t)n0 + sel * (uint32_t)HC + cc * 8u;
+                    int64_t orow = m;
+                    int32_t b = 0;
+                    bool border = false, skip = false;
+                    if (p.mode == MM_MODE_PF || p.mode == MM_MODE_UP2X) {
+                        b = m / HpWp;
+                        const int32_t rr = m - b * HpWp;
+                        const int32_t yy = rr / p.Wp, xx = rr - yy * p.Wp;
+                        border = (yy == 0) | (yy == p.Hp - 1) | (xx == 0) | (xx == p.Wp - 1);
+                        if (p.mode == MM_MODE_UP2X) {         // low-resolution pixel (yy-1, xx-1) -> pixel (2(yy-1)+dy, 2(xx-1)+dx) of a [B, 2H+2, 2W+2] PF tensor
+                            const int32_t dy = (p.up - 1) >> 1, dx = (p.up - 1) & 1;
+                            orow = ((int64_t)b * (2 * p.Hp - 2) + (2 * (yy - 1) + dy + 1)) * (2 * p.Wp - 2) + (2 * (xx - 1) + dx + 1);
+                            skip = border;
+                        }
+                    } else if (p.mode == MM_MODE_TOK2PF) {    // token (b, y, x) -> interior row of the PF tensor [B, H+2, W+2]
+                        b = m / p.S;
+                        const int32_t ii = m - b * p.S;
+                        const int32_t yy = ii / p.Wimg, xx = ii - yy * p.Wimg;
+                        orow = (int64_t)b * HpWp + (int64_t)(yy + 1) * p.Wp + (xx + 1);
+                    }
+                    if (skip) continue;
+                    uint4 o = make_uint4(0, 0, 0, 0);
+                    if (!border) {
+                        const uint2 lo = *reinterpret_cast<const uint2*>(img + r * PITCH + cc * 16u);
+                        const uint2 hi = *reinterpret_cast<const uint2*>(img + r * PITCH + cc * 16u + 8u);
+                        uint32_t w4[4] = {lo.x, lo.y, hi.x, hi.y};
+                        if (rowbias || resid) {
+                            uint4 rb = make_uint4(0, 0, 0, 0), rs = make_uint4(0, 0, 0, 0);
+                            if (rowbias) rb = *reinterpret_cast<const uint4*>(rowbias + (int64_t)b * p.N + col);
+                            if (resid) rs = *reinterpret_cast<const uint4*>(resid + orow * p.ldr + col);
+                            const uint32_t rbw[4] = {rb.x, rb.y, rb.z, rb.w}, rsw[4] = {rs.x, rs.y, rs.z, rs.w};
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const float a0 = MM<T>::up((uint16_t)w4[k]) + MM<T>::up((uint16_t)rbw[k]) + MM<T>::up((uint16_t)rsw[k]);
+                                const float a1 = MM<T>::up((uint16_t)(w4[k] >> 16)) + MM<T>::up((uint16_t)(rbw[k] >> 16)) + MM<T>::up((uint16_t)(rsw[k] >> 16));
+                                w4[k] = (uint32_t)MM<T>::cvt(a0) | ((uint32_t)MM<T>::cvt(a1) << 16);
+                            }
+                        }
+                        o = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+                    }
+                    *reinterpret_cast<uint4*>(Y + orow * ld + col) = o;
+                }
+            } else {
+                constexpr uint32_t CPR = BM / 8;              // image rows are GEMM columns, 8 consecutive tokens per chunk
+#pragma unroll
+                for (int i = 0; i < (HC * (int)CPR) / 512; ++i) {
+                    const uint32_t qq = tid + 512u * i;
+                    const uint32_t r = qq / CPR, cc = qq - r * CPR;
+                    const int32_t m = m0 + (int32_t)cc * 8;
+                    if (m >= p.M) continue;
+                    const int32_t b = m / p.S, s = m - b * p.S;
+                    const uint2 lo = *reinterpret_cast<const uint2*>(img + r * PITCH + cc * 16u);
+                    const uint2 hi = *reinterpret_cast<const uint2*>(img + r * PITCH + cc * 16u + 8u);
+                    *reinterpret_cast<uint4*>(Y + ((int64_t)b * p.N + n0 + (int32_t)(sel * HC + r)) * p.S + s) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                }
+            }
+        };
+        if (!SWAP && WM == 4 && p.mode == MM_MODE_GEGLU) {
+            // tile columns are [80 value | 80 gate] of the same 80 outputs: group 1 holds the gates, group 0 the values, with identical
+            // lane mapping: gate -> gelu -> image; group 0 multiplies in place; one 80-column store
+            if (grp == 1u) put(true);
+            MM_LDS_BARRIER();
+            if (grp == 0u) {
+#pragma unroll
+                for (int in = 0; in < 5; ++in) {
+                    const uint32_t nc = (uint32_t)in * 16u + (lane >> 4) * 4u;
+                    uint2 bw = make_uint2(0, 0);
+                    if (bias) bw = *reinterpret_cast<const uint2*>(bias + n0 + (int32_t)nc);
+                    const uint16_t bh[4] = {(uint16_t)bw.x, (uint16_t)(bw.x >> 16), (uint16_t)bw.y, (uint16_t)(bw.y >> 16)};
+#pragma unroll
+                    for (int im = 0; im < 4; ++im) {
+                        const uint32_t m = wm * 64u + (uint32_t)im * 16u + (lane & 15u);
+                        uint2* cell = reinterpret_cast<uint2*>(img + m * PITCH + nc * 2u);
+                        const uint2 g = *cell;
+                        const uint16_t gh[4] = {(uint16_t)g.x, (uint16_t)(g.x >> 16), (uint16_t)g.y, (uint16_t)(g.y >> 16)};
+                        uint16_t h[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float v = MM<T>::up(MM<T>::cvt(acc[in][im][j] + (bias ? MM<T>::up(bh[j]) : 0.f)));
+                            h[j] = MM<T>::cvt(v * MM<T>::up(gh[j]));
+                        }
+                        *cell = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+                    }
+                }
+            }
+            MM_LDS_BARRIER();
+            store(0u);
+        } else {
+            if (grp == 0u) put(false);
+            MM_LDS_BARRIER();
+            store(0u);
+            MM_LDS_BARRIER();
+            if (grp == 1u) put(false);
+            MM_LDS_BARRIER();
+            store(1u);
+        }
+        MM_LDS_BARRIER();                                     // the image slot is refilled by the next even phase's DMA
+#pragma unroll
+        for (int a = 0; a < 5; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = mm_f4{0.f, 0.f, 0.f, 0.f};
+        ++c_it;
+    };
+
+    auto mfma20 = [&](frag (&xc)[4], frag (&wc)[5]) {
+#pragma unroll
+        for (int in = 0; in < 5; ++in)
+#pragma unroll
+            for (int im = 0; im < 4; ++im)
+                acc[in][im] = SWAP ? MM<T>::mma(xc[im], wc[in], acc[in][im]) : MM<T>::mma(wc[in], xc[im], acc[in][im]);
+    };
+    // X holds the fragments of (stage s, k-half 0) on entry; Y is filled with (s, k-half 1), then X with (s+1, k-half 0)
+    auto step = [&](frag (&xX)[4], frag (&wX)[5], frag (&xY)[4], frag (&wY)[5]) {
+        const uint32_t nx_slot = rd_slot + STAGE == RING ? 0u : rd_slot + STAGE;
+        // ---- even phase (one basic block; issue order pinned so that the matrix pipe never waits for the DMA issue or the LDS)
+        dma_extra();
+        dma_stage();                                          // stage s+2 -> the slot stage s-1 was read from
+        read_frags(xY, wY, rd_slot, 1u);
+        mfma20(xX, wX);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#pragma unroll
+        for (int i = 0; i < NDMA; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);    // one LDS-DMA piece
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // one fragment read
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 20 - 1 - NDMA - 9, 0);
+        if (--pr_run == 0) end_run();
+        // stage s+1 is read in the odd phase: everything but the newest stage (s+2) must have landed
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NDMA) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        MM_BARRIER();
+        // ---- odd phase
+        read_frags(xX, wX, nx_slot, 0u);
+        mfma20(xY, wY);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's reads of stage s are complete: its slot may be refilled after the barrier
+        MM_BARRIER();
+        rd_slot = nx_slot;
+    };
+
+    // The step loop is a loop of its own (not one flat loop with the epilogue inside): hipcc then places the wait for the epilogue's
+    // loads / stores once in front of it instead of inside the steady state.
+    frag xa[4], wa[5], xb[4], wb[5];
+    read_frags(xa, wa, 0u, 0u);                               // (stage 0, k-half 0)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (uint32_t it = 0; it < nt_mine; ++it) {
+        for (int32_t i = 0; i < p.P; ++i) step(xa, wa, xb, wb);
+        epilogue();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the filler DMA of the last steps
+}
+
+// host ---------------------------------------------------------------------------------------------
+template <typename T, bool SWAP>
+int mm_launch_t(const MMArgs& a, uint32_t grid, size_t ldsb, hipStream_t st) {
+    static bool attr_done = false;          // benign race: setting the attribute twice is harmless
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)gsw_mm_kernel<T, SWAP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((gsw_mm_kernel<T, SWAP>), dim3(grid), dim3(512), ldsb, st, a);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern __attribute__((visibility("hidden"))) thread_local int g_last_hip_error;   // gswm_kernels.hip
+
+// Launch the engine for a prepared MMArgs (segments, weights, epilogue); fills the tiling fields.
+int gsw_mm_launch(MMArgs& a, int dtype, void* stream) {
+    if (dtype != GSW_F16 && dtype != GSW_BF16) return GSW_ERR_BAD_ARG;
+    if (a.N % 160 || a.M <= 0 || a.P <= 0) return GSW_ERR_UNSUPPORTED;
+    const bool swap = a.mode == MM_MODE_TRANS;
+    constexpr int BM = 256, BN = 160;
+    const int64_t tiles_m = ((int64_t)a.M + BM - 1) / BM, tiles_n = a.N / BN;
+    if (tiles_m * tiles_n > 0x7FFFFFFF) return GSW_ERR_UNSUPPORTED;
+    a.tiles_n = (int32_t)tiles_n;
+    a.ntiles = (int32_t)(tiles_m * tiles_n);
+    a.flags = 0;
+    const uint32_t grid = (uint32_t)std::min<int64_t>(256, (a.ntiles + 7) / 8 * 8);
+    const size_t ldsb = 3u * (size_t)(BM + BN) * 128u;        // the epilogue image lives in a ring slot
+    hipStream_t st = (hipStream_t)stream;
+    int e;
+    if (dtype == GSW_F16) e = swap ? mm_launch_t<_Float16, true>(a, grid, ldsb, st) : mm_launch_t<_Float16, false>(a, grid, ldsb, st);
+    else e = swap ? mm_launch_t<__bf16, true>(a, grid, ldsb, st) : mm_launch_t<__bf16, false>(a, grid, ldsb, st);
+    if (e != 0) { g_last_hip_error = e; return GSW_ERR_HIP; }
+    return GSW_OK;
+}
+
+int gsw_gemm(const void* x_dev, const void* w_dev, const void* bias_dev, const void* resid_dev, void* y_dev, int64_t M, int K, int N,
+             int mode, int S, int Wimg, int dtype, void* stream) {
+    if (!x_dev || !w_dev || !y_dev || M <= 0 || K <= 0 || N <= 0) return GSW_ERR_BAD_ARG;
+    if (mode != GSW_GEMM_PLAIN && mode != GSW_GEMM_GEGLU && mode != GSW_GEMM_TRANS && mode != GSW_GEMM_TOK2PF) return GSW_ERR_BAD_ARG;
+    if (K % 64 || N % 160 || M > 0x7FFFFF00 || M * (int64_t)K >= ((int64_t)1 << 40) || (int64_t)N * K >= ((int64_t)1 << 31)) return GSW_ERR_UNSUPPORTED;
+    if (mode == GSW_GEMM_GEGLU && resid_dev) return GSW_ERR_UNSUPPORTED;
+    if (mode == GSW_GEMM_TRANS && (resid_dev || S <= 0 || (S & 7) || M % S)) return GSW_ERR_UNSUPPORTED;
+    if (mode == GSW_GEMM_TOK2PF && (S <= 0 || Wimg <= 0 || S % Wimg || M % S)) return GSW_ERR_BAD_ARG;
+    MMArgs a;
+    for (int i = 0; i < 3; ++i) a.seg[i] = MMSeg{x_dev, K, K / 64, 1, 1, 0, 0, 0};
+    a.nseg = 1; a.P = K / 64;
+    a.w = w_dev; a.ldw = K;
+    a.M = (int32_t)M; a.N = N;
+    a.bias = bias_dev; a.rowbias = nullptr; a.resid = resid_dev; a.y = y_dev;
+    a.ldy = mode == GSW_GEMM_GEGLU ? N / 2 : N; a.ldr = N;
+    a.Hp = 1; a.Wp = 1; a.S = S > 0 ? S : 1; a.Wimg = Wimg > 0 ? Wimg : 1; a.up = 0;
+    a.mode = MM_MODE_DENSE;
+    if (mode == GSW_GEMM_GEGLU) a.mode = MM_MODE_GEGLU;
+    else if (mode == GSW_GEMM_TRANS) a.mode = MM_MODE_TRANS;
+    else if (mode == GSW_GEMM_TOK2PF) { a.mode = MM_MODE_TOK2PF; a.Wp = Wimg + 2; a.Hp = S / Wimg + 2; }
+    return gsw_mm_launch(a, dtype, stream);
+}

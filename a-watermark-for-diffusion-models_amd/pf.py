@@ -214,6 +214,66 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], *, re
     return out
 
 
+GEMM_MODES = {"plain": 0, "geglu": 1, "trans": 2, "tok2pf": 3}
+
+
+def _same(t: Optional[torch.Tensor], like: torch.Tensor, name: str, numel: Optional[int] = None):
+    """A companion operand whose raw pointer crosses the C ABI: same device and dtype as `like`, contiguous, 16-byte aligned."""
+    if t is None:
+        return
+    if not t.is_cuda or t.device != like.device:
+        raise RuntimeError(f"{name} must live on {like.device} (got {t.device}); there is no CPU fallback")
+    if t.dtype != like.dtype:
+        raise ValueError(f"{name} must be {like.dtype} like the activations (got {t.dtype})")
+    if not t.is_contiguous() or t.data_ptr() % 16:
+        raise ValueError(f"{name} must be contiguous and 16-byte aligned")
+    if numel is not None and t.numel() != numel:
+        raise ValueError(f"{name} has {t.numel()} elements, expected {numel}")
+
+
+def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, resid: Optional[torch.Tensor] = None, mode: str = "plain",
+         tokens: int = 0, width: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x[..., K] @ w[N, K]^T + bias on the matmul engine (csrc/gswm_mm.hip).
+    mode "plain":  -> [..., N] (+ resid[..., N]);  "geglu": pf.pack_geglu_weight operands -> [..., N/2] = value * gelu(gate);
+    "trans": x is [B, S, K] -> [B, N, S] (tokens = S);  "tok2pf": rows are tokens of `tokens`-pixel images of width `width`, `out` is the
+    `.rows` view of a PF tensor [B, H, W, N]: its interior rows receive x w^T + bias (+ resid, which may be `out` itself)."""
+    if x.dtype not in (torch.float16, torch.bfloat16):
+        raise ValueError(f"gemm: fp16 / bf16 only (got {x.dtype})")
+    _same(x, x, "x")
+    K = x.shape[-1]
+    M = x.numel() // K
+    Nn = w.shape[0]
+    _same(w, x, "w", Nn * K)
+    _same(bias, x, "bias", Nn)
+    m = GEMM_MODES[mode]
+    if mode == "plain":
+        _same(resid, x, "resid", M * Nn)
+        y = torch.empty((*x.shape[:-1], Nn), dtype=x.dtype, device=x.device) if out is None else out
+        _same(y, x, "out", M * Nn)
+    elif mode == "geglu":
+        if resid is not None:
+            raise ValueError("gemm: geglu takes no residual")
+        y = torch.empty((*x.shape[:-1], Nn // 2), dtype=x.dtype, device=x.device) if out is None else out
+        _same(y, x, "out", M * Nn // 2)
+    elif mode == "trans":
+        if resid is not None or tokens <= 0 or M % tokens:
+            raise ValueError("gemm: trans needs tokens = rows per image and no residual")
+        y = torch.empty((M // tokens, Nn, tokens), dtype=x.dtype, device=x.device) if out is None else out
+        _same(y, x, "out", M * Nn)
+    else:
+        if out is None or tokens <= 0 or width <= 0 or tokens % width or M % tokens:
+            raise ValueError("gemm: tok2pf needs out (PF rows), tokens = H*W and width = W")
+        y = out
+        rows = (M // tokens) * (tokens // width + 2) * (width + 2)
+        _same(y, x, "out", rows * Nn)
+        _same(resid, x, "resid", rows * Nn)
+    with torch.cuda.device(x.device):
+        N.check(N.lib().gsw_gemm(x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                 resid.data_ptr() if resid is not None else None, y.data_ptr(), M, K, Nn, m, tokens, width,
+                                 _dt(x.dtype), _stream_ptr()))
+    return y
+
+
 def groupnorm_pf2(x: PF, x2: Optional[PF], gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float, *, act: bool = True) -> PF:
     """act(GroupNorm(cat([x, x2], channels))) -> one PF tensor, without materialising the concatenation."""
     if x2 is None:

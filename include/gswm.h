@@ -163,6 +163,24 @@ int gsw_add_layernorm(const void* x_dev, const void* delta_dev, const void* gamm
 int gsw_linear(const void* x_dev, const void* w_dev, const void* bias_dev, const void* resid_dev, void* y_dev, int64_t M, int K, int N,
                int geglu, int dtype, void* stream);
 
+/* X2 / G1 -- every dense linear layer of the eps model (diffusers BasicTransformerBlock / Transformer2DModel / TimestepEmbedding /
+ * ResnetBlock2D.time_emb_proj, which the reference reaches through `pipe(...)` at extract.py:66-69) on the hand-written matmul engine
+ * (csrc/gswm_mm.hip: persistent 256 x 160 / 128 x 320 tiles, 4-stage LDS-DMA ring, two wave groups in ping-pong on each SIMD):
+ *   x: [M, K] row-major, w: [N, K] (nn.Linear layout), bias: [N] or NULL; K % 32 == 0, N % 160 == 0; GSW_F16 / GSW_BF16.
+ *   mode GSW_GEMM_PLAIN : y[M, N] = x w^T + bias (+ resid[M, N])
+ *        GSW_GEMM_GEGLU : rows of w / bias interleaved per 160-wide tile as [80 value | 80 gate] (pf.pack_geglu_weight);
+ *                         y[M, N/2] = value * gelu(gate) -- diffusers' GEGLU without the [M, N] intermediate
+ *        GSW_GEMM_TRANS : y[M/S][N][S] = per-image transpose of x w^T + bias (the attention kernel's V^T operand); S % 8 == 0
+ *        GSW_GEMM_TOK2PF: rows are tokens (b, y, x) of S = H*W-token images of width Wimg; y_dev is row 0 of a padded-flat NHWC tensor
+ *                         [B, H+2, W+2, N] and token rows land on its interior rows: y[pf(m)] = x w^T + bias (+ resid[pf(m)], which may
+ *                         alias y: Transformer2DModel's `proj_out(...) + residual` in place) */
+#define GSW_GEMM_PLAIN 0
+#define GSW_GEMM_GEGLU 1
+#define GSW_GEMM_TRANS 2
+#define GSW_GEMM_TOK2PF 3
+int gsw_gemm(const void* x_dev, const void* w_dev, const void* bias_dev, const void* resid_dev, void* y_dev, int64_t M, int K, int N,
+             int mode, int S, int Wimg, int dtype, void* stream);
+
 /* diffusers Upsample2D (nearest 2x + 3x3 convolution) from the low-resolution PF input, by sub-pixel decomposition: w4 =
  * [4 output parities (dy*2+dx)][N][4 taps (a*2+b)][C], the 3x3 weights pre-summed over the taps that read the same source pixel
  * (pf.pack_upsample_weight).  y: PF [B, 2H, 2W, N] whose border rows the caller has zeroed; only interior rows are written. */
