@@ -32,6 +32,18 @@ def _need_gpu(t: torch.Tensor, name: str):
         raise ValueError(f"{name} must be 16-byte aligned (got a view at an odd storage offset; .clone() it)")
 
 
+def _like(t: torch.Tensor, ref: torch.Tensor, name: str, numel: Optional[int] = None):
+    """A companion operand whose raw pointer crosses the C ABI next to `ref`: same device and dtype, contiguous, aligned, expected size.
+    (A dtype mismatch would be read as the wrong bytes, a short tensor is an out-of-bounds device read: both are silent otherwise.)"""
+    _need_gpu(t, name)
+    if t.device != ref.device:
+        raise RuntimeError(f"{name} lives on {t.device}, expected {ref.device}")
+    if t.dtype != ref.dtype:
+        raise ValueError(f"{name} is {t.dtype}, expected {ref.dtype}")
+    if numel is not None and t.numel() != numel:
+        raise ValueError(f"{name} has {t.numel()} elements, expected {numel}")
+
+
 def _dt(t: torch.dtype) -> int:
     try:
         return _DTYPES[t]
@@ -196,7 +208,7 @@ def ddim_step(x: torch.Tensor, model_out: torch.Tensor, a: float, b: float, out:
         raise ValueError("x / model_out mismatch")
     if out is None:
         out = torch.empty_like(x)
-    _need_gpu(out, "out")
+    _like(out, x, "out", x.numel())
     with torch.cuda.device(x.device):
         N.check(N.lib().gsw_ddim_step(x.data_ptr(), model_out.data_ptr(), out.data_ptr(), a, b, _dt(x.dtype), x.numel(), _stream_ptr()))
     return out
@@ -205,11 +217,11 @@ def ddim_step(x: torch.Tensor, model_out: torch.Tensor, a: float, b: float, out:
 def ddim_step_cfg(x: torch.Tensor, e_uncond: torch.Tensor, e_text: torch.Tensor, a: float, b: float, guidance: float,
                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out = a*x + b*(e_uncond + guidance*(e_text - e_uncond))."""
-    for t, nm in ((x, "x"), (e_uncond, "e_uncond"), (e_text, "e_text")):
-        _need_gpu(t, nm)
+    _need_gpu(x, "x")
+    _like(e_uncond, x, "e_uncond", x.numel()); _like(e_text, x, "e_text", x.numel())
     if out is None:
         out = torch.empty_like(x)
-    _need_gpu(out, "out")
+    _like(out, x, "out", x.numel())
     with torch.cuda.device(x.device):
         N.check(N.lib().gsw_ddim_step_cfg(x.data_ptr(), e_uncond.data_ptr(), e_text.data_ptr(), out.data_ptr(), a, b, guidance,
                                           _dt(x.dtype), x.numel(), _stream_ptr()))
@@ -220,7 +232,10 @@ def ddim_step_extract(x: torch.Tensor, model_out: torch.Tensor, a: float, b: flo
                       message_length: int, *, z_out: Optional[torch.Tensor] = None, return_counts: bool = False):
     """Last inversion step fused with the vote: z = a*x + b*model_out is quantised and voted without a round trip to HBM."""
     _check_key_nonce(key, nonce)
-    _need_gpu(x, "x"); _need_gpu(model_out, "model_out")
+    _need_gpu(x, "x")
+    _like(model_out, x, "model_out", x.numel())
+    if z_out is not None:
+        _like(z_out, x, "z_out", x.numel())
     B = x.shape[0]
     n = x.numel() // max(B, 1)
     M = int(message_length)
@@ -243,10 +258,12 @@ def groupnorm_silu(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, gro
     HW = x.numel() // max(B * C, 1)
     if out is None:
         out = torch.empty_like(x)
+    _like(out, x, "out", x.numel())
+    _like(gamma, x, "gamma", C); _like(beta, x, "beta", C)
     pb = None
     if pre_bias is not None:
         pre_bias = pre_bias.to(x.dtype).contiguous()
-        _need_gpu(pre_bias, "pre_bias")
+        _like(pre_bias, x, "pre_bias", B * C)
         pb = pre_bias.data_ptr()
     with torch.cuda.device(x.device):
         N.check(N.lib().gsw_groupnorm_silu(x.data_ptr(), pb, gamma.data_ptr(), beta.data_ptr(), out.data_ptr(), B, C, HW, groups, eps,
@@ -270,11 +287,12 @@ def add_layernorm(x: torch.Tensor, delta: Optional[torch.Tensor], weight: torch.
     _need_gpu(x, "x")
     C = x.shape[-1]
     rows = x.numel() // C
+    _like(weight, x, "weight", C); _like(bias, x, "bias", C)
     y = torch.empty_like(x)
     xnew = x
     dptr = None
     if delta is not None:
-        _need_gpu(delta, "delta")
+        _like(delta, x, "delta", x.numel())
         xnew = torch.empty_like(x)
         dptr = delta.data_ptr()
     with torch.cuda.device(x.device):

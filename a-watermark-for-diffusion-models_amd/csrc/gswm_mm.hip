@@ -54,9 +54,42 @@ template <> struct MM<__bf16> {
     static __device__ __forceinline__ float up(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
 };
 
+// MM_TRACE (tools/ubench/mm_trace.hip only): cycles between consecutive stamps, summed per interval kind in scalar registers (no memory
+// traffic inside the loop); workgroup 0's waves write their sums when the kernel ends
+#ifdef MM_TRACE
+__device__ unsigned long long* g_mm_trace_buf;
+#define MM_STAMP(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tr_acc[k] += t_ - tr_last; tr_last = t_; } while (0)
+#else
+#define MM_STAMP(k) do { } while (0)
+#endif
+
 #define MM_BARRIER() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
 // epilogue barrier: LDS image traffic only -- the DMA prefetch of the next tile stays in flight (no vmcnt wait)
 #define MM_LDS_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); MM_BARRIER(); } while (0)
+
+// LDS image traffic of the epilogue as inline asm: hipcc puts s_waitcnt vmcnt(0) in front of every LDS access it can see while an LDS-DMA
+// may be in flight (it cannot prove the image and the DMA destinations disjoint), which serialises the epilogue behind the prefetch of
+// the next tile and behind every one of its own stores (measured: 1800 cycles per put, 3600 per 5-chunk store, tools/ubench/mm_trace).
+__device__ __forceinline__ void mm_lds_write_b64(uint32_t addr, uint32_t lo, uint32_t hi) {
+    const uint2 v = make_uint2(lo, hi);
+    asm volatile("ds_write_b64 %0, %1" :: "v"(addr), "v"(v) : "memory");
+}
+// five 16-byte chunks (ten ds_read_b64) and their wait in ONE statement: the outputs are valid when it ends
+__device__ __forceinline__ void mm_lds_read5(const uint32_t (&a)[5], uint4 (&v)[5]) {
+    uint2 l0, h0, l1, h1, l2, h2, l3, h3, l4, h4;
+    asm volatile("ds_read_b64 %0, %10\n\tds_read_b64 %1, %10 offset:8\n\tds_read_b64 %2, %11\n\tds_read_b64 %3, %11 offset:8\n\t"
+                 "ds_read_b64 %4, %12\n\tds_read_b64 %5, %12 offset:8\n\tds_read_b64 %6, %13\n\tds_read_b64 %7, %13 offset:8\n\t"
+                 "ds_read_b64 %8, %14\n\tds_read_b64 %9, %14 offset:8\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(l0), "=&v"(h0), "=&v"(l1), "=&v"(h1), "=&v"(l2), "=&v"(h2), "=&v"(l3), "=&v"(h3), "=&v"(l4), "=&v"(h4)
+                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]) : "memory");
+    v[0] = make_uint4(l0.x, l0.y, h0.x, h0.y); v[1] = make_uint4(l1.x, l1.y, h1.x, h1.y); v[2] = make_uint4(l2.x, l2.y, h2.x, h2.y);
+    v[3] = make_uint4(l3.x, l3.y, h3.x, h3.y); v[4] = make_uint4(l4.x, l4.y, h4.x, h4.y);
+}
+// four 8-byte cells and their wait in one statement (GEGLU: the value waves pick up the gate cells they multiply into)
+__device__ __forceinline__ void mm_lds_read4x8(const uint32_t (&a)[4], uint2 (&v)[4]) {
+    asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %5\n\tds_read_b64 %2, %6\n\tds_read_b64 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]) : "memory");
+}
 
 template <typename T, bool SWAP>
 __global__ __launch_bounds__(512, 2) void gsw_mm_kernel(const MMArgs p) {
@@ -223,6 +256,9 @@ __global__ __launch_bounds__(512, 2) void gsw_mm_kernel(const MMArgs p) {
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = mm_f4{0.f, 0.f, 0.f, 0.f};
     uint32_t c_it = 0, rd_slot = 0;                           // rd_slot: ring offset of the stage being multiplied
+#ifdef MM_TRACE
+    unsigned long long tr_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tr_last = __builtin_amdgcn_s_memtime();
+#endif
 
     auto read_frags = [&](frag (&xf)[4], frag (&wf)[5], uint32_t slot, uint32_t khalf) {
         const uint8_t* ap = lds + ((khalf ? a_rd1 : a_rd0) + slot);
@@ -235,7 +271,7 @@ __global__ __launch_bounds__(512, 2) void gsw_mm_kernel(const MMArgs p) {
 
     auto epilogue = [&]() {
         // the LDS image lives in the ring slot of the tile's last stage (just consumed; its refill is issued after the closing barrier)
-        uint8_t* img = lds + (rd_slot == 0u ? RING - STAGE : rd_slot - STAGE);
+        const uint32_t img = (uint32_t)(uintptr_t)lds + (rd_slot == 0u ? RING - STAGE : rd_slot - STAGE);     // LDS byte address
         int32_t tile_m, tile_n;
         decode_tile(c_it * G + slotx, tile_m, tile_n);
         const int32_t m0 = tile_m * BM, n0 = tile_n * BN;
@@ -261,8 +297,7 @@ __global__ __launch_bounds__(512, 2) void gsw_mm_kernel(const MMArgs p) {
                             }
                             h[j] = MM<T>::cvt(v);
                         }
-                        *reinterpret_cast<uint2*>(img + m * PITCH + nc * 2u) =
-                            make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+                        mm_lds_write_b64(img + m * PITCH + nc * 2u, (uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
                     }
                 } else {
                     const uint32_t nr = wnl * 80u + (uint32_t)in * 16u + (lane & 15u);              // output row (= column of the GEMM) inside the group
@@ -273,31 +308,37 @@ __global__ __launch_bounds__(512, 2) void gsw_mm_kernel(const MMArgs p) {
                         uint16_t h[4];
 #pragma unroll
                         for (int j = 0; j < 4; ++j) h[j] = MM<T>::cvt(acc[in][im][j] + bv);
-                        *reinterpret_cast<uint2*>(img + nr * PITCH + m * 2u) =
-                            make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+                        mm_lds_write_b64(img + nr * PITCH + m * 2u, (uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
                     }
                 }
             }
         };
-        auto store = [&](uint32_t sel) {                      // LDS image of group `sel` -> global, 16 bytes per thread per round
+        auto store = [&](uint32_t sel) {                      // LDS image of group `sel` -> global, five 16-byte chunks per thread
+            constexpr uint32_t CPR = SWAP ? BM / 8 : HC / 8;  // 16-byte chunks per image row
+            uint32_t rr[5], cc[5], ad[5];
+            uint4 v[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const uint32_t qq = tid + 512u * i;
+                rr[i] = qq / CPR; cc[i] = qq - rr[i] * CPR;
+                ad[i] = img + rr[i] * PITCH + cc[i] * 16u;
+            }
+            mm_lds_read5(ad, v);                              // all image reads first: the stores below then go out back to back
             if (!SWAP) {
-                constexpr uint32_t CPR = HC / 8;              // 16-byte chunks per image row
                 const bool glu = p.mode == MM_MODE_GEGLU;
                 const int32_t ld = p.ldy;
 #pragma unroll
-                for (int i = 0; i < (BM * (int)CPR) / 512; ++i) {
-                    const uint32_t qq = tid + 512u * i;
-                    const uint32_t r = qq / CPR, cc = qq - r * CPR;
-                    const int32_t m = m0 + (int32_t)r;
+                for (int i = 0; i < 5; ++i) {
+                    const int32_t m = m0 + (int32_t)rr[i];
                     if (m >= p.M) continue;
-                    const int64_t col = glu ? (int64_t)tile_n * (BN / 2) + cc * 8u : (int64_t)n0 + sel * (uint32_t)HC + cc * 8u;
+                    const int64_t col = glu ? (int64_t)tile_n * (BN / 2) + cc[i] * 8u : (int64_t)n0 + sel * (uint32_t)HC + cc[i] * 8u;
                     int64_t orow = m;
                     int32_t b = 0;
                     bool border = false, skip = false;
                     if (p.mode == MM_MODE_PF || p.mode == MM_MODE_UP2X) {
                         b = m / HpWp;
-                        const int32_t rr = m - b * HpWp;
-                        const int32_t yy = rr / p.Wp, xx = rr - yy * p.Wp;
+                        const int32_t q = m - b * HpWp;
+                        const int32_t yy = q / p.Wp, xx = q - yy * p.Wp;
                         border = (yy == 0) | (yy == p.Hp - 1) | (xx == 0) | (xx == p.Wp - 1);
                         if (p.mode == MM_MODE_UP2X) {         // low-resolution pixel (yy-1, xx-1) -> pixel (2(yy-1)+dy, 2(xx-1)+dx) of a [B, 2H+2, 2W+2] PF tensor
                             const int32_t dy = (p.up - 1) >> 1, dx = (p.up - 1) & 1;
@@ -313,9 +354,7 @@ __global__ __launch_bounds__(512, 2) void gsw_mm_kernel(const MMArgs p) {
                     if (skip) continue;
                     uint4 o = make_uint4(0, 0, 0, 0);
                     if (!border) {
-                        const uint2 lo = *reinterpret_cast<const uint2*>(img + r * PITCH + cc * 16u);
-                        const uint2 hi = *reinterpret_cast<const uint2*>(img + r * PITCH + cc * 16u + 8u);
-                        uint32_t w4[4] = {lo.x, lo.y, hi.x, hi.y};
+                        uint32_t w4[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
                         if (rowbias || resid) {
                             uint4 rb = make_uint4(0, 0, 0, 0), rs = make_uint4(0, 0, 0, 0);
                             if (rowbias) rb = *reinterpret_cast<const uint4*>(rowbias + (int64_t)b * p.N + col);
@@ -333,17 +372,13 @@ __global__ __launch_bounds__(512, 2) void gsw_mm_kernel(const MMArgs p) {
                     *reinterpret_cast<uint4*>(Y + orow * ld + col) = o;
                 }
             } else {
-                constexpr uint32_t CPR = BM / 8;              // image rows are GEMM columns, 8 consecutive tokens per chunk
+                // image rows are GEMM columns, 8 consecutive tokens per chunk: Y[b][n][s]
 #pragma unroll
-                for (int i = 0; i < (HC * (int)CPR) / 512; ++i) {
-                    const uint32_t qq = tid + 512u * i;
-                    const uint32_t r = qq / CPR, cc = qq - r * CPR;
-                    const int32_t m = m0 + (int32_t)cc * 8;
+                for (int i = 0; i < 5; ++i) {
+                    const int32_t m = m0 + (int32_t)cc[i] * 8;
                     if (m >= p.M) continue;
-                    const int32_t b = m / p.S, s = m - b * p.S;
-                    const uint2 lo = *reinterpret_cast<const uint2*>(img + r * PITCH + cc * 16u);
-                    const uint2 hi = *reinterpret_cast<const uint2*>(img + r * PITCH + cc * 16u + 8u);
-                    *reinterpret_cast<uint4*>(Y + ((int64_t)b * p.N + n0 + (int32_t)(sel * HC + r)) * p.S + s) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                    const int32_t b = m / p.S, sidx = m - b * p.S;
+                    *reinterpret_cast<uint4*>(Y + ((int64_t)b * p.N + n0 + (int32_t)(sel * HC + rr[i])) * p.S + sidx) = v[i];
                 }
             }
         };
@@ -359,11 +394,14 @@ __global__ __launch_bounds__(512, 2) void gsw_mm_kernel(const MMArgs p) {
                     uint2 bw = make_uint2(0, 0);
                     if (bias) bw = *reinterpret_cast<const uint2*>(bias + n0 + (int32_t)nc);
                     const uint16_t bh[4] = {(uint16_t)bw.x, (uint16_t)(bw.x >> 16), (uint16_t)bw.y, (uint16_t)(bw.y >> 16)};
+                    uint32_t cell[4];
+                    uint2 g4[4];
+#pragma unroll
+                    for (int im = 0; im < 4; ++im) cell[im] = img + (wm * 64u + (uint32_t)im * 16u + (lane & 15u)) * PITCH + nc * 2u;
+                    mm_lds_read4x8(cell, g4);
 #pragma unroll
                     for (int im = 0; im < 4; ++im) {
-                        const uint32_t m = wm * 64u + (uint32_t)im * 16u + (lane & 15u);
-                        uint2* cell = reinterpret_cast<uint2*>(img + m * PITCH + nc * 2u);
-                        const uint2 g = *cell;
+                        const uint2 g = g4[im];
                         const uint16_t gh[4] = {(uint16_t)g.x, (uint16_t)(g.x >> 16), (uint16_t)g.y, (uint16_t)(g.y >> 16)};
                         uint16_t h[4];
 #pragma unroll
@@ -371,20 +409,26 @@ __global__ __launch_bounds__(512, 2) void gsw_mm_kernel(const MMArgs p) {
                             const float v = MM<T>::up(MM<T>::cvt(acc[in][im][j] + (bias ? MM<T>::up(bh[j]) : 0.f)));
                             h[j] = MM<T>::cvt(v * MM<T>::up(gh[j]));
                         }
-                        *cell = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+                        mm_lds_write_b64(cell[im], (uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
                     }
                 }
             }
             MM_LDS_BARRIER();
             store(0u);
         } else {
+            MM_STAMP(8);
             if (grp == 0u) put(false);
+            MM_STAMP(9);
             MM_LDS_BARRIER();
+            MM_STAMP(10);
             store(0u);
+            MM_STAMP(11);
             MM_LDS_BARRIER();
             if (grp == 1u) put(false);
             MM_LDS_BARRIER();
+            MM_STAMP(12);
             store(1u);
+            MM_STAMP(13);
         }
         MM_LDS_BARRIER();                                     // the image slot is refilled by the next even phase's DMA
 #pragma unroll
@@ -405,6 +449,7 @@ __global__ __launch_bounds__(512, 2) void gsw_mm_kernel(const MMArgs p) {
     auto step = [&](frag (&xX)[4], frag (&wX)[5], frag (&xY)[4], frag (&wY)[5]) {
         const uint32_t nx_slot = rd_slot + STAGE == RING ? 0u : rd_slot + STAGE;
         // ---- even phase (one basic block; issue order pinned so that the matrix pipe never waits for the DMA issue or the LDS)
+        MM_STAMP(0);
         dma_extra();
         dma_stage();                                          // stage s+2 -> the slot stage s-1 was read from
         read_frags(xY, wY, rd_slot, 1u);
@@ -422,10 +467,13 @@ __global__ __launch_bounds__(512, 2) void gsw_mm_kernel(const MMArgs p) {
         }
         __builtin_amdgcn_sched_group_barrier(0x008, 20 - 1 - NDMA - 9, 0);
         if (--pr_run == 0) end_run();
+        MM_STAMP(1);
         // stage s+1 is read in the odd phase: everything but the newest stage (s+2) must have landed
         asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NDMA) : "memory");
+        MM_STAMP(2);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         MM_BARRIER();
+        MM_STAMP(3);
         // ---- odd phase
         read_frags(xX, wX, nx_slot, 0u);
         mfma20(xY, wY);
@@ -435,8 +483,10 @@ __global__ __launch_bounds__(512, 2) void gsw_mm_kernel(const MMArgs p) {
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
         }
+        MM_STAMP(4);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's reads of stage s are complete: its slot may be refilled after the barrier
         MM_BARRIER();
+        MM_STAMP(5);
         rd_slot = nx_slot;
     };
 
@@ -448,7 +498,13 @@ __global__ __launch_bounds__(512, 2) void gsw_mm_kernel(const MMArgs p) {
     for (uint32_t it = 0; it < nt_mine; ++it) {
         for (int32_t i = 0; i < p.P; ++i) step(xa, wa, xb, wb);
         epilogue();
+        MM_STAMP(6);
     }
+#ifdef MM_TRACE
+    if (blockIdx.x == 0 && lane == 0) {
+        for (int k = 0; k < 16; ++k) g_mm_trace_buf[wave * 16 + k] = tr_acc[k];
+    }
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the filler DMA of the last steps
 }
 

@@ -144,6 +144,13 @@ def conv_pf(x: PF, w_packed: torch.Tensor, bias: Optional[torch.Tensor], *, ksiz
     C = x.C if cin is None else cin
     Nn = w_packed.shape[0]
     Ho, Wo = x.H // stride, x.W // stride
+    _same(w_packed, x.buf, "conv weight", Nn * ksize * ksize * C)
+    _same(bias, x.buf, "conv bias", Nn)
+    _same(rowbias, x.buf, "rowbias", x.B * Nn)
+    if resid is not None:
+        _same(resid.buf, x.buf, "resid")
+        if (resid.B, resid.H, resid.W, resid.C) != (x.B, Ho, Wo, Nn):
+            raise ValueError("resid geometry does not match the convolution output")
     y = PF.empty(x.B, Ho, Wo, Nn, x.buf.dtype, x.buf.device)
     xp = x.rows.data_ptr() + cin_offset * x.buf.element_size()
     if pad_after_only:
@@ -175,6 +182,8 @@ def _gn_workspace(device, B, groups):
 def groupnorm_pf(x: PF, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float, *, act: bool = True, tokens: bool = False):
     """act(GroupNorm(x)) on a PF tensor -> PF (zero border) or dense tokens [B, H*W, C] (tokens=True)."""
     dev = x.buf.device
+    _same(gamma, x.buf, "gamma", x.C)
+    _same(beta, x.buf, "beta", x.C)
     ws = _gn_workspace(dev, x.B, groups)
     if tokens:
         out = torch.empty((x.B, x.H * x.W, x.C), dtype=x.buf.dtype, device=dev)
@@ -280,6 +289,9 @@ def groupnorm_pf2(x: PF, x2: Optional[PF], gamma: torch.Tensor, beta: torch.Tens
         return groupnorm_pf(x, gamma, beta, groups, eps, act=act)
     dev = x.buf.device
     C = x.C + x2.C
+    _same(x2.buf, x.buf, "x2")
+    _same(gamma, x.buf, "gamma", C)
+    _same(beta, x.buf, "beta", C)
     ws = _gn_workspace(dev, x.B, groups)
     y = PF.empty(x.B, x.H, x.W, C, x.buf.dtype, dev)
     with torch.cuda.device(dev):
@@ -297,6 +309,12 @@ def conv3x3_res_pf(x: PF, w_cat: torch.Tensor, bias: Optional[torch.Tensor], *, 
                    resid: Optional[PF] = None, x1: Optional[PF] = None, x2: Optional[PF] = None) -> PF:
     """y = conv3x3(x) + conv1x1(cat([x1, x2])) + bias (+ rowbias + resid) in one GEMM; w_cat = [N, 9*C | C1 | C2]."""
     Nn = w_cat.shape[0]
+    _same(w_cat, x.buf, "w_cat", Nn * (9 * x.C + (x1.C if x1 is not None else 0) + (x2.C if x2 is not None else 0)))
+    _same(bias, x.buf, "bias", Nn)
+    _same(rowbias, x.buf, "rowbias", x.B * Nn)
+    for t_, nm in ((resid, "resid"), (x1, "x1"), (x2, "x2")):
+        if t_ is not None:
+            _same(t_.buf, x.buf, nm)
     y = PF.empty(x.B, x.H, x.W, Nn, x.buf.dtype, x.buf.device)
     tm = CONV_TIMER
     with torch.cuda.device(x.buf.device):
@@ -343,6 +361,9 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, sc
 
     (q, ldq), (k, ldk) = rows(q), rows(k)
     vt = vt.contiguous()
+    for t_, nm in ((k, "k"), (vt, "vt")):
+        if t_.dtype != q.dtype or t_.device != q.device:
+            raise ValueError(f"attention: {nm} is {t_.dtype} on {t_.device}, q is {q.dtype} on {q.device}")
     out = torch.empty((B, Sq, inner), dtype=q.dtype, device=q.device)
     with torch.cuda.device(q.device):
         N.check(N.lib().gsw_attention(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), B, heads, d, Sq, Sk,
@@ -377,6 +398,8 @@ def conv_up2x_fusable(x: PF, n_out: int) -> bool:
 def conv_up2x_pf(x: PF, w4: torch.Tensor, bias: Optional[torch.Tensor]) -> PF:
     """conv3x3(nearest_upsample_2x(x)) without materialising the upsampled tensor (gsw_conv_up2x_pf)."""
     Nn = w4.shape[1]
+    _same(w4, x.buf, "w4", 4 * Nn * 4 * x.C)
+    _same(bias, x.buf, "bias", Nn)
     y = PF.empty(x.B, 2 * x.H, 2 * x.W, Nn, x.buf.dtype, x.buf.device)
     g = y.grid
     g[:, 0].zero_(); g[:, -1].zero_(); g[:, :, 0].zero_(); g[:, :, -1].zero_()        # the kernel writes interior rows only

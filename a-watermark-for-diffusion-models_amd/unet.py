@@ -9,7 +9,9 @@ projections, GEGLU feed-forward, 32-group GroupNorm) and keeps diffusers' parame
 safetensors state dict loads 1:1 (`load_diffusers_state_dict`).  Without a weight directory the weights are seeded
 synthetic -- throughput is representative, image content is not.
 
-GEMM / conv / attention work runs on MFMA through hipBLASLt / MIOpen / the SDPA flash kernel (fp16 or bf16).
+On the GPU (fp16 / bf16) every convolution, linear layer and attention runs on the hand-written MFMA kernels of libgswm (PF implicit-GEMM
+convolutions, the gsw_gemm matmul engine, the flash-attention kernel); the plain torch ops remain for CPU / meta tensors (FLOP counting,
+CPU baseline) and are counted in `FALLBACKS` when a GPU call has to use them.
 """
 from __future__ import annotations
 
@@ -61,34 +63,53 @@ FUSED_QK = True       # self-attention: q and k projections as one GEMM (own att
 
 OWN_ATTENTION = True  # attention with head_dim 40 / 64 / 80 and a query count % 128 == 0 runs on gsw_attention instead of torch SDPA
 
-GEMM_MAX_K = 0        # linear layers with K <= this would run on the hand-written GEMM (gsw_linear).  Measured on MI355X: it only
-                      # beats hipBLASLt on [524288,320]x[320,320] (398 vs 343 TFLOP/s) and loses elsewhere, incl. the fused GEGLU
-                      # form (output-bound epilogue), so the transformer linears stay on the library GEMM; set > 0 to experiment.
+OWN_GEMM = True       # every dense linear layer (q / k / v / out projections, proj_in / proj_out, feed-forward, time embedding) on the
+                      # hand-written matmul engine (gsw_gemm, csrc/gswm_mm.hip) with bias / residual / GEGLU / V^T epilogues fused in
+
+FALLBACKS = {}        # (reason -> count) of GPU half-precision calls that left the hand-written path; bench and the full-size tests assert it stays empty
 
 
-GEGLU_GEMM_MAX_K = 0  # feed-forward projection + GEGLU as ONE own GEMM (value * gelu(gate) in the epilogue) when K <= this
-
-
-GEMM_MAX_N = 320      # ... and only for outputs this narrow (the [.., 320] x [320, 320] projections of the 64x64 level)
-
-
-def _own_geglu_ok(x: torch.Tensor, K: int, N: int) -> bool:
-    return USE_PF and FUSED_KERNELS and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and x.is_contiguous() \
-        and K % 64 == 0 and N % 160 == 0 and K <= GEGLU_GEMM_MAX_K
+def _note_fallback(why: str):
+    FALLBACKS[why] = FALLBACKS.get(why, 0) + 1
 
 
 def _own_gemm_ok(x: torch.Tensor, K: int, N: int) -> bool:
-    return USE_PF and FUSED_KERNELS and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and x.is_contiguous() \
-        and K % 64 == 0 and N % 160 == 0 and K <= GEMM_MAX_K and N <= GEMM_MAX_N
+    """The matmul engine takes fp16 / bf16 device tensors with K % 64 == 0 and N % 160 == 0 (every SD 1.x / 2.x linear)."""
+    if not (OWN_GEMM and USE_PF and FUSED_KERNELS and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16)):
+        return False
+    if K % 64 or N % 160:
+        _note_fallback(f"linear K={K} N={N}: library GEMM")
+        return False
+    return True
+
+
+def _wb(lin: nn.Linear, x: torch.Tensor):
+    """(weight, bias) of a linear layer as the engine wants them: contiguous, the activations' dtype (a fp32 parameter under an fp16
+    activation must not be read as fp16 bytes)."""
+    if lin.weight.dtype != x.dtype or lin.weight.device != x.device or not lin.weight.is_contiguous():
+        raise ValueError(f"linear weight is {lin.weight.dtype} on {lin.weight.device}, activations are {x.dtype} on {x.device}")
+    return lin.weight, lin.bias
 
 
 def _lin(x: torch.Tensor, lin: nn.Linear, resid: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Linear (+ residual) on the own GEMM when the shape favours it, else torch."""
-    if _own_gemm_ok(x, lin.in_features, lin.out_features) and (resid is None or resid.is_contiguous()):
-        from .pf import linear
-        return linear(x, lin.weight, lin.bias, resid=resid)
+    """Linear (+ residual in the epilogue) on the matmul engine, else torch."""
+    if _own_gemm_ok(x, lin.in_features, lin.out_features):
+        from .pf import gemm
+        w, b = _wb(lin, x)
+        return gemm(x.contiguous(), w, b, resid=None if resid is None else resid.contiguous())
     y = lin(x)
     return y if resid is None else y + resid
+
+
+def _lin_t(x: torch.Tensor, lin: nn.Linear) -> torch.Tensor:
+    """[B, S, K] -> (lin(x))^T = [B, N, S]: the value projection in the layout the attention kernel consumes."""
+    b, n, _ = x.shape
+    if _own_gemm_ok(x, lin.in_features, lin.out_features) and n % 8 == 0:
+        from .pf import gemm
+        w, bias = _wb(lin, x)
+        return gemm(x.contiguous(), w, bias, mode="trans", tokens=n)
+    vt = torch.bmm(lin.weight.unsqueeze(0).expand(b, -1, -1), x.transpose(1, 2))
+    return vt if lin.bias is None else vt + lin.bias[None, :, None]
 
 
 def _gn_pf(x, norm: nn.GroupNorm, act=True, tokens=False):
@@ -111,7 +132,7 @@ class TimestepEmbedding(nn.Module):
         self.linear_2 = nn.Linear(dim, dim)
 
     def forward(self, x):
-        return self.linear_2(F.silu(self.linear_1(x)))
+        return _lin(F.silu(_lin(x, self.linear_1)), self.linear_2)
 
 
 class ResnetBlock2D(nn.Module):
@@ -138,7 +159,7 @@ class ResnetBlock2D(nn.Module):
         if x2 is not None and not fuse:
             x, x2 = PF(torch.cat([x.buf, x2.buf], dim=1), x.B, x.H, x.W, x.C + x2.C), None
         n1 = groupnorm_pf2(x, x2, self.norm1.weight, self.norm1.bias, self.norm1.num_groups, self.norm1.eps, act=True)
-        h = conv_pf(n1, _pw(self.conv1), self.conv1.bias, rowbias=self.time_emb_proj(temb_act).contiguous())
+        h = conv_pf(n1, _pw(self.conv1), self.conv1.bias, rowbias=_lin(temb_act, self.time_emb_proj).contiguous())
         h = _gn_pf(h, self.norm2)
         if self.conv_shortcut is None:
             return conv_pf(h, _pw(self.conv2), self.conv2.bias, resid=x)                 # residual add in the GEMM epilogue
@@ -178,7 +199,8 @@ class Attention(nn.Module):
         self.to_v = nn.Linear(ctx_dim, inner, bias=False)
         self.to_out = nn.ModuleList([nn.Linear(inner, dim)])
 
-    def forward(self, x, ctx=None):
+    def forward(self, x, ctx=None, resid=None):
+        """resid: added to the output projection (in its GEMM epilogue on the own path): `x + attn(norm(x))` of the transformer block"""
         b, n, _ = x.shape
         if OWN_ATTENTION and FUSED_KERNELS:
             from .pf import attention, attention_ok
@@ -198,27 +220,33 @@ class Attention(nn.Module):
                     ver = (src._version, self.to_k.weight._version, self.to_v.weight._version, self.to_k.weight.data_ptr(), self.to_v.weight.data_ptr())
                     ent = store.get(id(self))
                     if ent is None or ent[0] != ver:
-                        ent = (ver, _lin(src, self.to_k), torch.bmm(self.to_v.weight.unsqueeze(0).expand(b, -1, -1), src.transpose(1, 2)))
+                        ent = (ver, _lin(src, self.to_k), _lin_t(src, self.to_v))
                         store[id(self)] = ent
                     o = attention(_lin(x, self.to_q), ent[1], ent[2], self.heads, valid_keys=valid)
-                    return _lin(o, self.to_out[0])
-                vt = torch.bmm(self.to_v.weight.unsqueeze(0).expand(b, -1, -1), src.transpose(1, 2))
+                    return _lin(o, self.to_out[0], resid)
+                vt = _lin_t(src, self.to_v)
                 if ctx is None and FUSED_QK:
                     # self-attention: q and k from ONE GEMM over x (x is read once); the kernel takes them as column slices
                     from .pf import cached
                     wqk = cached(self, "_gsw_wqk", (self.to_q.weight, self.to_k.weight), lambda: torch.cat([self.to_q.weight.detach(), self.to_k.weight.detach()], dim=0).contiguous())
-                    qk = F.linear(x, wqk)
+                    if _own_gemm_ok(x, wqk.shape[1], wqk.shape[0]):
+                        from .pf import gemm
+                        qk = gemm(x.contiguous(), wqk, None)
+                    else:
+                        qk = F.linear(x, wqk)
                     inner = self.to_q.out_features
                     o = attention(qk[..., :inner], qk[..., inner:], vt, self.heads, valid_keys=valid)
                 else:
                     o = attention(_lin(x, self.to_q), _lin(src, self.to_k), vt, self.heads, valid_keys=valid)
-                return _lin(o, self.to_out[0])
+                return _lin(o, self.to_out[0], resid)
+            if x.is_cuda and x.dtype in (torch.float16, torch.bfloat16):
+                _note_fallback(f"attention head_dim={self.to_q.out_features // self.heads} Sq={n} Sk={src.shape[1]}: torch SDPA")
         ctx = x if ctx is None else ctx
         q = _lin(x, self.to_q).view(b, n, self.heads, -1).transpose(1, 2)
         k = _lin(ctx, self.to_k).view(b, ctx.shape[1], self.heads, -1).transpose(1, 2)
         v = _lin(ctx, self.to_v).view(b, ctx.shape[1], self.heads, -1).transpose(1, 2)
         o = F.scaled_dot_product_attention(q, k, v)
-        return _lin(o.transpose(1, 2).reshape(b, n, -1), self.to_out[0])
+        return _lin(o.transpose(1, 2).reshape(b, n, -1), self.to_out[0], resid)
 
 
 class GEGLU(nn.Module):
@@ -228,12 +256,11 @@ class GEGLU(nn.Module):
 
     def forward(self, x):
         inner = self.proj.out_features // 2
-        if (_own_gemm_ok(x, self.proj.in_features, self.proj.out_features) or _own_geglu_ok(x, self.proj.in_features, self.proj.out_features)) \
-                and inner % 80 == 0:
-            from .pf import linear, pack_geglu_weight     # value * gelu(gate) in the GEMM epilogue: no [M, 2I] intermediate
-            from .pf import cached
+        if _own_gemm_ok(x, self.proj.in_features, self.proj.out_features) and inner % 80 == 0:
+            from .pf import gemm, pack_geglu_weight, cached     # value * gelu(gate) in the GEMM epilogue: no [M, 2I] intermediate
+            _wb(self.proj, x)
             c = cached(self, "_gsw_geglu", (self.proj.weight, self.proj.bias), lambda: pack_geglu_weight(self.proj.weight.detach(), self.proj.bias.detach()))
-            return linear(x, c[0], c[1], geglu=True)
+            return gemm(x.contiguous(), c[0], c[1], mode="geglu")
         y = self.proj(x)
         if FUSED_KERNELS and y.is_cuda and y.is_contiguous() and (y.shape[-1] // 2) % 8 == 0:
             from . import codec
@@ -264,11 +291,14 @@ class BasicTransformerBlock(nn.Module):
     def forward(self, x, ctx):
         if FUSED_KERNELS and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and x.is_contiguous() and x.shape[-1] % 8 == 0 \
                 and x.shape[-1] <= 1536:
-            from .codec import add_layernorm     # residual add fused into the following LayerNorm
+            from .codec import add_layernorm
+            # the residual adds ride in the output projections' GEMM epilogues; LayerNorm is then one read + one write
             _, n = add_layernorm(x, None, self.norm1.weight, self.norm1.bias, self.norm1.eps)
-            x, n = add_layernorm(x, self.attn1(n).contiguous(), self.norm2.weight, self.norm2.bias, self.norm2.eps)
-            x, n = add_layernorm(x, self.attn2(n, ctx).contiguous(), self.norm3.weight, self.norm3.bias, self.norm3.eps)
-            return self.ff(n, resid=x)            # residual folded into the output GEMM's epilogue when it runs on the own kernel
+            x = self.attn1(n, resid=x)
+            _, n = add_layernorm(x, None, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+            x = self.attn2(n, ctx, resid=x)
+            _, n = add_layernorm(x, None, self.norm3.weight, self.norm3.bias, self.norm3.eps)
+            return self.ff(n, resid=x)
         x = x + self.attn1(self.norm1(x))
         x = x + self.attn2(self.norm2(x), ctx)
         return x + self.ff(self.norm3(x))
@@ -295,7 +325,12 @@ class Transformer2DModel(nn.Module):
         y = _lin(_gn_pf(x, self.norm, act=False, tokens=True), self.proj_in)      # GroupNorm writes dense tokens directly
         for blk in self.transformer_blocks:
             y = blk(y, ctx)
-        x.interior.add_(_lin(y, self.proj_out).view(x.B, x.H, x.W, x.C))     # residual, in place (x has no other reader)
+        if _own_gemm_ok(y, self.proj_out.in_features, self.proj_out.out_features):
+            from .pf import gemm        # proj_out + residual written straight into the PF tensor's interior rows (x has no other reader)
+            w, b = _wb(self.proj_out, y)
+            gemm(y.contiguous(), w, b, resid=x.rows, mode="tok2pf", tokens=x.H * x.W, width=x.W, out=x.rows)
+        else:
+            x.interior.add_(_lin(y, self.proj_out).view(x.B, x.H, x.W, x.C))
         return x
 
 
