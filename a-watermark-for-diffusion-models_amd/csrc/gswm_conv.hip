@@ -1064,9 +1064,7 @@ static int launch_conv_gemm(ConvArgs& a, int64_t M, int N, int dtype, void* stre
         if (!a.dense && a.ntaps == 9 && a.stride == 1 && !no_halo && halo_fits(a.Wp)) {
             return launch_halo(a, M, N, dtype, stream);
         } else if (a.dense) {
-            const uint32_t grid = (uint32_t)(((M + 127) / 128) * (N / CW_BN));
-            if (dtype == GSW_F16) hipLaunchKernelGGL((gsw_conv_gemm_wide_kernel<_Float16, 2, false, true>), dim3(grid), dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((gsw_conv_gemm_wide_kernel<__bf16, 2, false, true>), dim3(grid), dim3(256), 0, st, a);
+            return GSW_ERR_UNSUPPORTED;       // dense matrices run on the matmul engine (gsw_gemm)
         } else if (wm_env == 4) {
             const uint32_t grid = (uint32_t)(((M + 255) / 256) * (N / CW_BN));
             if (dtype == GSW_F16) hipLaunchKernelGGL((gsw_conv_gemm_wide_kernel<_Float16, 4, false, false>), dim3(grid), dim3(512), 0, st, a);
@@ -1139,19 +1137,8 @@ int gsw_add_layernorm(const void* x_dev, const void* delta_dev, const void* gamm
 
 int gsw_linear(const void* x_dev, const void* w_dev, const void* bias_dev, const void* resid_dev, void* y_dev, int64_t M, int K, int N,
                int geglu, int dtype, void* stream) {
-    // y[M, N] = x[M, K] @ w[N, K]^T + bias (+ resid); geglu: w rows are tile-interleaved [80 value | 80 gate], y is [M, N/2]
-    if (!x_dev || !w_dev || !y_dev || M <= 0 || K <= 0 || N <= 0) return GSW_ERR_BAD_ARG;
-    if (K % CV_BK || N % CW_BN || M > 0x7FFFFF00 || (geglu && resid_dev) || M * K >= ((int64_t)1 << 31) || (int64_t)N * K >= ((int64_t)1 << 31))
-        return GSW_ERR_UNSUPPORTED;
-    if (dtype != GSW_F16 && dtype != GSW_BF16) return GSW_ERR_BAD_ARG;
-    ConvArgs a;
-    a.x = x_dev; a.w = w_dev; a.bias = bias_dev; a.rowbias = nullptr; a.resid = resid_dev; a.y = y_dev;
-    a.C = K; a.N = N; a.M = (int32_t)M; a.Hp = 0; a.Wp = 1; a.in_Hp = 0; a.in_Wp = 1; a.stride = 1; a.ldx = K;
-    a.ntaps = 1;
-    for (int i = 0; i < 9; ++i) a.tap_off[i] = 0;
-    a.dense = 1; a.geglu = geglu ? 1 : 0; a.ldy = geglu ? N / 2 : N;
-    a.x1 = nullptr; a.x2 = nullptr; a.C1 = 0; a.C2 = 0; a.up = 0;
-    return launch_conv_gemm(a, M, N, dtype, stream);
+    // kept for callers of the round-1 ABI: the same function on the matmul engine (csrc/gswm_mm.hip)
+    return gsw_gemm(x_dev, w_dev, bias_dev, resid_dev, y_dev, M, K, N, geglu ? GSW_GEMM_GEGLU : GSW_GEMM_PLAIN, 0, 0, dtype, stream);
 }
 
 int gsw_conv3x3_res_pf(const void* x_dev, const void* w_dev, const void* bias_dev, const void* rowbias_dev, const void* resid_dev, void* y_dev,

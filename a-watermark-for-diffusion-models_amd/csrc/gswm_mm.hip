@@ -269,168 +269,170 @@ __global__ __launch_bounds__(512, 2) void gsw_mm_kernel(const MMArgs p) {
         for (int in = 0; in < 5; ++in) wf[in] = *reinterpret_cast<const frag*>(wp + in * 2048);
     };
 
+    // ---------------------------------------------------------------- epilogue: straight from the accumulators, no LDS image, no barrier.
+    // MFMA layout (non-SWAP): lane (q = lane >> 4, i = lane & 15) holds columns 16 in + 4 q + j (j = 0..3) of row 16 im + i.  After
+    // bias + rounding + packing (4 fp16 = 2 registers per (in, im)), ONE v_permlane16_swap per register between row tiles im = 2p and
+    // 2p + 1 leaves every lane with 8 CONSECUTIVE columns (16 bytes) of one row:
+    //     row tile 2p + (q & 1), columns 16 in + 8 (q >> 1) .. + 7
+    // so a wave stores its 64 x 80 block with 10 global_store_dwordx4 per lane (32 contiguous bytes per row per instruction; a row's five
+    // segments come from the same wave back to back and merge in L2).  Residual / row-bias operands are loaded with the same addressing.
+    // SWAP (transposed output): the same with rows and columns exchanged -- a lane ends with 8 consecutive TOKENS of one output row.
+    // GEGLU: weight rows are packed [8 value | 8 gate] per 16-row block (pf.pack_geglu_weight), so value (q < 2) and gate (q >= 2) of one
+    // output sit in lanes l and l + 32 of the SAME accumulator register: v_permlane32_swap pairs them, all 64 lanes compute value *
+    // gelu(gate), two more swap rounds collect 8 consecutive outputs per lane.
     auto epilogue = [&]() {
-        // the LDS image lives in the ring slot of the tile's last stage (just consumed; its refill is issued after the closing barrier)
-        const uint32_t img = (uint32_t)(uintptr_t)lds + (rd_slot == 0u ? RING - STAGE : rd_slot - STAGE);     // LDS byte address
         int32_t tile_m, tile_n;
         decode_tile(c_it * G + slotx, tile_m, tile_n);
         const int32_t m0 = tile_m * BM, n0 = tile_n * BN;
-        // non-SWAP accumulator layout: m = lane & 15 (+16 im), n = (lane >> 4) * 4 + reg (+16 in); SWAP: n = lane & 15, m = (lane >> 4) * 4 + reg
-        auto put = [&](bool gelu_it) {                        // this wave's 64 x 80 accumulators (+bias) -> LDS image
+        const uint32_t q = lane >> 4, li = lane & 15u;
+        auto pack4 = [&](const mm_f4& a, const float (&b)[4], uint32_t& lo, uint32_t& hi) {
+            lo = (uint32_t)MM<T>::cvt(a[0] + b[0]) | ((uint32_t)MM<T>::cvt(a[1] + b[1]) << 16);
+            hi = (uint32_t)MM<T>::cvt(a[2] + b[2]) | ((uint32_t)MM<T>::cvt(a[3] + b[3]) << 16);
+        };
+        auto swap16 = [&](uint32_t& a, uint32_t& b) {         // a's odd 16-lane rows <-> b's even rows
+            const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+            a = r[0]; b = r[1];
+        };
+        auto swap32 = [&](uint32_t& a, uint32_t& b) {         // a's lanes 32..63 <-> b's lanes 0..31
+            const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+            a = r[0]; b = r[1];
+        };
+        if (!SWAP && p.mode != MM_MODE_GEGLU) {
+            // per row pair p: this lane's output row and its addressing
+            int64_t orow[2];
+            int32_t img_b[2];
+            bool live[2], border[2];
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                const int32_t m = m0 + (int32_t)(wm * 64u + (uint32_t)(2 * pr + (int)(q & 1u)) * 16u + li);
+                live[pr] = m < p.M; border[pr] = false; img_b[pr] = 0; orow[pr] = m;
+                const int32_t mc = live[pr] ? m : 0;
+                if (p.mode == MM_MODE_PF || p.mode == MM_MODE_UP2X) {
+                    const int32_t b = mc / HpWp, r = mc - b * HpWp;
+                    const int32_t yy = r / p.Wp, xx = r - yy * p.Wp;
+                    img_b[pr] = b;
+                    border[pr] = (yy == 0) | (yy == p.Hp - 1) | (xx == 0) | (xx == p.Wp - 1);
+                    if (p.mode == MM_MODE_UP2X) {             // low-resolution pixel (yy-1, xx-1) -> pixel (2(yy-1)+dy, 2(xx-1)+dx) of a [B, 2H+2, 2W+2] PF tensor
+                        const int32_t dy = (p.up - 1) >> 1, dx = (p.up - 1) & 1;
+                        orow[pr] = ((int64_t)b * (2 * p.Hp - 2) + (2 * (yy - 1) + dy + 1)) * (2 * p.Wp - 2) + (2 * (xx - 1) + dx + 1);
+                        live[pr] = live[pr] && !border[pr];
+                    }
+                } else if (p.mode == MM_MODE_TOK2PF) {        // token (b, y, x) -> interior row of the PF tensor [B, H+2, W+2]
+                    const int32_t b = mc / p.S, ii = mc - b * p.S;
+                    const int32_t yy = ii / p.Wimg, xx = ii - yy * p.Wimg;
+                    img_b[pr] = b;
+                    orow[pr] = (int64_t)b * HpWp + (int64_t)(yy + 1) * p.Wp + (xx + 1);
+                }
+            }
 #pragma unroll
             for (int in = 0; in < 5; ++in) {
-                if (!SWAP) {
-                    const uint32_t nc = wnl * 80u + (uint32_t)in * 16u + (lane >> 4) * 4u;          // column inside the group
-                    uint2 bw = make_uint2(0, 0);
-                    if (bias) bw = *reinterpret_cast<const uint2*>(bias + n0 + (int32_t)(grp * HC + nc));
-                    const uint16_t bh[4] = {(uint16_t)bw.x, (uint16_t)(bw.x >> 16), (uint16_t)bw.y, (uint16_t)(bw.y >> 16)};
+                float bq[4] = {0.f, 0.f, 0.f, 0.f};
+                if (bias) {                                   // bias of this lane's own accumulator columns
+                    const uint2 bw = *reinterpret_cast<const uint2*>(bias + n0 + (int32_t)(grp * HC + (uint32_t)in * 16u + q * 4u));
+                    bq[0] = MM<T>::up((uint16_t)bw.x); bq[1] = MM<T>::up((uint16_t)(bw.x >> 16)); bq[2] = MM<T>::up((uint16_t)bw.y); bq[3] = MM<T>::up((uint16_t)(bw.y >> 16));
+                }
+                const int64_t col = (int64_t)n0 + grp * (uint32_t)HC + (uint32_t)in * 16u + (q >> 1) * 8u;
 #pragma unroll
-                    for (int im = 0; im < 4; ++im) {
-                        const uint32_t m = wm * 64u + (uint32_t)im * 16u + (lane & 15u);
-                        uint16_t h[4];
+                for (int pr = 0; pr < 2; ++pr) {
+                    uint32_t a0, a1, b0, b1;
+                    pack4(acc[in][2 * pr], bq, a0, a1);
+                    pack4(acc[in][2 * pr + 1], bq, b0, b1);
+                    swap16(a0, b0);
+                    swap16(a1, b1);
+                    if (!live[pr]) continue;
+                    uint32_t w4[4] = {a0, a1, b0, b1};
+                    if (border[pr]) { w4[0] = w4[1] = w4[2] = w4[3] = 0u; }
+                    else if (rowbias || resid) {
+                        uint4 rb = make_uint4(0, 0, 0, 0), rs = make_uint4(0, 0, 0, 0);
+                        if (rowbias) rb = *reinterpret_cast<const uint4*>(rowbias + (int64_t)img_b[pr] * p.N + col);
+                        if (resid) rs = *reinterpret_cast<const uint4*>(resid + orow[pr] * p.ldr + col);
+                        const uint32_t rbw[4] = {rb.x, rb.y, rb.z, rb.w}, rsw[4] = {rs.x, rs.y, rs.z, rs.w};
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            float v = acc[in][im][j] + (bias ? MM<T>::up(bh[j]) : 0.f);
-                            if (gelu_it) {                   // torch: F.gelu(gate) on the stored (rounded) gate, result rounded again
-                                v = MM<T>::up(MM<T>::cvt(v));
-                                v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
-                            }
-                            h[j] = MM<T>::cvt(v);
+                        for (int k = 0; k < 4; ++k) {
+                            const float f0 = MM<T>::up((uint16_t)w4[k]) + MM<T>::up((uint16_t)rbw[k]) + MM<T>::up((uint16_t)rsw[k]);
+                            const float f1 = MM<T>::up((uint16_t)(w4[k] >> 16)) + MM<T>::up((uint16_t)(rbw[k] >> 16)) + MM<T>::up((uint16_t)(rsw[k] >> 16));
+                            w4[k] = (uint32_t)MM<T>::cvt(f0) | ((uint32_t)MM<T>::cvt(f1) << 16);
                         }
-                        mm_lds_write_b64(img + m * PITCH + nc * 2u, (uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
                     }
-                } else {
-                    const uint32_t nr = wnl * 80u + (uint32_t)in * 16u + (lane & 15u);              // output row (= column of the GEMM) inside the group
-                    const float bv = bias ? MM<T>::up(bias[n0 + (int32_t)(grp * HC + nr)]) : 0.f;
-#pragma unroll
-                    for (int im = 0; im < 4; ++im) {
-                        const uint32_t m = wm * 64u + (uint32_t)im * 16u + (lane >> 4) * 4u;
-                        uint16_t h[4];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) h[j] = MM<T>::cvt(acc[in][im][j] + bv);
-                        mm_lds_write_b64(img + nr * PITCH + m * 2u, (uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
-                    }
+                    *reinterpret_cast<uint4*>(Y + orow[pr] * p.ldy + col) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
                 }
             }
-        };
-        auto store = [&](uint32_t sel) {                      // LDS image of group `sel` -> global, five 16-byte chunks per thread
-            constexpr uint32_t CPR = SWAP ? BM / 8 : HC / 8;  // 16-byte chunks per image row
-            uint32_t rr[5], cc[5], ad[5];
-            uint4 v[5];
+        } else if (!SWAP) {
+            // GEGLU: accumulator columns of an n-tile are [8 value | 8 gate] of outputs 8 in .. 8 in + 7 (within the group's 40 outputs)
+            const uint32_t qv = q & 1u;
+            uint32_t D[5][2][2];                              // [in][row pair][2 registers]: 4 consecutive outputs 4 qv .. of row tile 2p + (lane >> 5)
 #pragma unroll
-            for (int i = 0; i < 5; ++i) {
-                const uint32_t qq = tid + 512u * i;
-                rr[i] = qq / CPR; cc[i] = qq - rr[i] * CPR;
-                ad[i] = img + rr[i] * PITCH + cc[i] * 16u;
-            }
-            mm_lds_read5(ad, v);                              // all image reads first: the stores below then go out back to back
-            if (!SWAP) {
-                const bool glu = p.mode == MM_MODE_GEGLU;
-                const int32_t ld = p.ldy;
-#pragma unroll
-                for (int i = 0; i < 5; ++i) {
-                    const int32_t m = m0 + (int32_t)rr[i];
-                    if (m >= p.M) continue;
-                    const int64_t col = glu ? (int64_t)tile_n * (BN / 2) + cc[i] * 8u : (int64_t)n0 + sel * (uint32_t)HC + cc[i] * 8u;
-                    int64_t orow = m;
-                    int32_t b = 0;
-                    bool border = false, skip = false;
-                    if (p.mode == MM_MODE_PF || p.mode == MM_MODE_UP2X) {
-                        b = m / HpWp;
-                        const int32_t q = m - b * HpWp;
-                        const int32_t yy = q / p.Wp, xx = q - yy * p.Wp;
-                        border = (yy == 0) | (yy == p.Hp - 1) | (xx == 0) | (xx == p.Wp - 1);
-                        if (p.mode == MM_MODE_UP2X) {         // low-resolution pixel (yy-1, xx-1) -> pixel (2(yy-1)+dy, 2(xx-1)+dx) of a [B, 2H+2, 2W+2] PF tensor
-                            const int32_t dy = (p.up - 1) >> 1, dx = (p.up - 1) & 1;
-                            orow = ((int64_t)b * (2 * p.Hp - 2) + (2 * (yy - 1) + dy + 1)) * (2 * p.Wp - 2) + (2 * (xx - 1) + dx + 1);
-                            skip = border;
-                        }
-                    } else if (p.mode == MM_MODE_TOK2PF) {    // token (b, y, x) -> interior row of the PF tensor [B, H+2, W+2]
-                        b = m / p.S;
-                        const int32_t ii = m - b * p.S;
-                        const int32_t yy = ii / p.Wimg, xx = ii - yy * p.Wimg;
-                        orow = (int64_t)b * HpWp + (int64_t)(yy + 1) * p.Wp + (xx + 1);
-                    }
-                    if (skip) continue;
-                    uint4 o = make_uint4(0, 0, 0, 0);
-                    if (!border) {
-                        uint32_t w4[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
-                        if (rowbias || resid) {
-                            uint4 rb = make_uint4(0, 0, 0, 0), rs = make_uint4(0, 0, 0, 0);
-                            if (rowbias) rb = *reinterpret_cast<const uint4*>(rowbias + (int64_t)b * p.N + col);
-                            if (resid) rs = *reinterpret_cast<const uint4*>(resid + orow * p.ldr + col);
-                            const uint32_t rbw[4] = {rb.x, rb.y, rb.z, rb.w}, rsw[4] = {rs.x, rs.y, rs.z, rs.w};
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) {
-                                const float a0 = MM<T>::up((uint16_t)w4[k]) + MM<T>::up((uint16_t)rbw[k]) + MM<T>::up((uint16_t)rsw[k]);
-                                const float a1 = MM<T>::up((uint16_t)(w4[k] >> 16)) + MM<T>::up((uint16_t)(rbw[k] >> 16)) + MM<T>::up((uint16_t)(rsw[k] >> 16));
-                                w4[k] = (uint32_t)MM<T>::cvt(a0) | ((uint32_t)MM<T>::cvt(a1) << 16);
-                            }
-                        }
-                        o = make_uint4(w4[0], w4[1], w4[2], w4[3]);
-                    }
-                    *reinterpret_cast<uint4*>(Y + orow * ld + col) = o;
+            for (int in = 0; in < 5; ++in) {
+                float bq[4] = {0.f, 0.f, 0.f, 0.f};
+                if (bias) {
+                    const uint2 bw = *reinterpret_cast<const uint2*>(bias + n0 + (int32_t)(grp * HC + (uint32_t)in * 16u + q * 4u));
+                    bq[0] = MM<T>::up((uint16_t)bw.x); bq[1] = MM<T>::up((uint16_t)(bw.x >> 16)); bq[2] = MM<T>::up((uint16_t)bw.y); bq[3] = MM<T>::up((uint16_t)(bw.y >> 16));
                 }
-            } else {
-                // image rows are GEMM columns, 8 consecutive tokens per chunk: Y[b][n][s]
+                uint32_t Wv[4];                               // per row tile im: (out j = lane >> 5 ? 1 : 0) | (out j + 2) << 16
 #pragma unroll
-                for (int i = 0; i < 5; ++i) {
-                    const int32_t m = m0 + (int32_t)cc[i] * 8;
+                for (int im = 0; im < 4; ++im) {
+                    // the projection as torch materialises it (rounded to the storage dtype), kept as fp32 bit patterns for the swaps
+                    uint32_t f[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) f[j] = __float_as_uint(MM<T>::up(MM<T>::cvt(acc[in][im][j] + bq[j])));
+                    swap32(f[0], f[1]);                       // lanes < 32: (value_0, gate_0); lanes >= 32: (value_1, gate_1)
+                    swap32(f[2], f[3]);                       // lanes < 32: (value_2, gate_2); lanes >= 32: (value_3, gate_3)
+                    uint16_t h[2];
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const float v = __uint_as_float(f[2 * k]), g = __uint_as_float(f[2 * k + 1]);
+                        const float ge = MM<T>::up(MM<T>::cvt(0.5f * g * (1.0f + erff(g * 0.70710678118654752f))));     // F.gelu(gate), rounded like torch's
+                        h[k] = MM<T>::cvt(v * ge);
+                    }
+                    Wv[im] = (uint32_t)h[0] | ((uint32_t)h[1] << 16);
+                }
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    uint32_t a = Wv[2 * pr], b = Wv[2 * pr + 1];
+                    swap32(a, b);                             // lanes < 32: outputs (0,2 | 1,3) of row tile 2p; lanes >= 32: of row tile 2p + 1
+                    D[in][pr][0] = (a & 0xFFFFu) | (b << 16);             // outputs 4 qv + 0, 1
+                    D[in][pr][1] = (a >> 16) | (b & 0xFFFF0000u);         // outputs 4 qv + 2, 3
+                }
+            }
+            const int64_t obase = (int64_t)tile_n * (BN / 2) + grp * 40u;
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                // n-tile pairs (0,1) and (2,3): one more swap round -> 8 consecutive outputs (16 bytes) per lane
+#pragma unroll
+                for (int ip = 0; ip < 2; ++ip) {
+                    uint32_t a0 = D[2 * ip][pr][0], a1 = D[2 * ip][pr][1], b0 = D[2 * ip + 1][pr][0], b1 = D[2 * ip + 1][pr][1];
+                    swap16(a0, b0);
+                    swap16(a1, b1);
+                    const int32_t m = m0 + (int32_t)(wm * 64u + (uint32_t)(2 * pr + (int)(q >> 1)) * 16u + li);
+                    if (m < p.M)
+                        *reinterpret_cast<uint4*>(Y + (int64_t)m * p.ldy + obase + (uint32_t)(2 * ip + (int)(q & 1u)) * 8u) = make_uint4(a0, a1, b0, b1);
+                }
+                // n-tile 4 has no partner: 8-byte stores (4 outputs per lane)
+                const int32_t m = m0 + (int32_t)(wm * 64u + (uint32_t)(2 * pr + (int)(lane >> 5)) * 16u + li);
+                if (m < p.M)
+                    *reinterpret_cast<uint2*>(Y + (int64_t)m * p.ldy + obase + 32u + qv * 4u) = make_uint2(D[4][pr][0], D[4][pr][1]);
+            }
+        } else {
+            // transposed output Y[image][n][token]: lane (q, i) holds tokens 16 im + 4 q + j of output row 16 in + i
+#pragma unroll
+            for (int in = 0; in < 5; ++in) {
+                const int32_t nrow = n0 + (int32_t)(grp * HC + (uint32_t)in * 16u + li);
+                const float bv = bias ? MM<T>::up(bias[nrow]) : 0.f;
+                const float bq[4] = {bv, bv, bv, bv};
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    uint32_t a0, a1, b0, b1;
+                    pack4(acc[in][2 * pr], bq, a0, a1);
+                    pack4(acc[in][2 * pr + 1], bq, b0, b1);
+                    swap16(a0, b0);
+                    swap16(a1, b1);
+                    const int32_t m = m0 + (int32_t)(wm * 64u + (uint32_t)(2 * pr + (int)(q & 1u)) * 16u + (q >> 1) * 8u);      // first of 8 consecutive tokens
                     if (m >= p.M) continue;
                     const int32_t b = m / p.S, sidx = m - b * p.S;
-                    *reinterpret_cast<uint4*>(Y + ((int64_t)b * p.N + n0 + (int32_t)(sel * HC + rr[i])) * p.S + sidx) = v[i];
+                    *reinterpret_cast<uint4*>(Y + ((int64_t)b * p.N + nrow) * p.S + sidx) = make_uint4(a0, a1, b0, b1);
                 }
             }
-        };
-        if (!SWAP && WM == 4 && p.mode == MM_MODE_GEGLU) {
-            // tile columns are [80 value | 80 gate] of the same 80 outputs: group 1 holds the gates, group 0 the values, with identical
-            // lane mapping: gate -> gelu -> image; group 0 multiplies in place; one 80-column store
-            if (grp == 1u) put(true);
-            MM_LDS_BARRIER();
-            if (grp == 0u) {
-#pragma unroll
-                for (int in = 0; in < 5; ++in) {
-                    const uint32_t nc = (uint32_t)in * 16u + (lane >> 4) * 4u;
-                    uint2 bw = make_uint2(0, 0);
-                    if (bias) bw = *reinterpret_cast<const uint2*>(bias + n0 + (int32_t)nc);
-                    const uint16_t bh[4] = {(uint16_t)bw.x, (uint16_t)(bw.x >> 16), (uint16_t)bw.y, (uint16_t)(bw.y >> 16)};
-                    uint32_t cell[4];
-                    uint2 g4[4];
-#pragma unroll
-                    for (int im = 0; im < 4; ++im) cell[im] = img + (wm * 64u + (uint32_t)im * 16u + (lane & 15u)) * PITCH + nc * 2u;
-                    mm_lds_read4x8(cell, g4);
-#pragma unroll
-                    for (int im = 0; im < 4; ++im) {
-                        const uint2 g = g4[im];
-                        const uint16_t gh[4] = {(uint16_t)g.x, (uint16_t)(g.x >> 16), (uint16_t)g.y, (uint16_t)(g.y >> 16)};
-                        uint16_t h[4];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float v = MM<T>::up(MM<T>::cvt(acc[in][im][j] + (bias ? MM<T>::up(bh[j]) : 0.f)));
-                            h[j] = MM<T>::cvt(v * MM<T>::up(gh[j]));
-                        }
-                        mm_lds_write_b64(cell[im], (uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
-                    }
-                }
-            }
-            MM_LDS_BARRIER();
-            store(0u);
-        } else {
-            MM_STAMP(8);
-            if (grp == 0u) put(false);
-            MM_STAMP(9);
-            MM_LDS_BARRIER();
-            MM_STAMP(10);
-            store(0u);
-            MM_STAMP(11);
-            MM_LDS_BARRIER();
-            if (grp == 1u) put(false);
-            MM_LDS_BARRIER();
-            MM_STAMP(12);
-            store(1u);
-            MM_STAMP(13);
         }
-        MM_LDS_BARRIER();                                     // the image slot is refilled by the next even phase's DMA
 #pragma unroll
         for (int a = 0; a < 5; ++a)
 #pragma unroll

@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--jpeg-qf", type=int, default=10)
     ap.add_argument("--vae-chunk", type=int, default=8, help="images per VAE call")
     ap.add_argument("--unet", choices=["sd21", "sd15"], default="sd21", help="sd15 + --height 768 --width 768 = BASELINE config 5's shape")
+    ap.add_argument("--launcher-selftest", action="store_true", help="only rendezvous, all-gather the ranks and print them (GSW_BENCH_BACKEND=gloo on a CPU host)")
     a = ap.parse_args()
     if a.steps is None:
         a.steps = 50 if a.tier == "codec" else 2
@@ -89,6 +90,26 @@ def cpu_baseline(n_images: int, message_length: int):
             "vectorised_numpy_images_per_s": nv / dv, "host_cpus": os.cpu_count()}
 
 
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` from a bare shell (no torch.distributed.run around it): start N rank processes -- one per GPU, RCCL over
+    127.0.0.1 -- and return the worst exit code.  The parent never touches HIP (it does not even import torch), and no process replaces
+    itself: the ranks are plain children, rank 0 prints the one JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for pr in procs:
+        rc = max(rc, abs(pr.wait()))
+    return rc
+
+
 def init_dist(args):
     import torch
     import torch.distributed as dist
@@ -98,15 +119,32 @@ def init_dist(args):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
-        if world == 1 and args.gpus > 1:
-            sys.exit(2)
-    assert torch.cuda.is_available(), "bench.py needs a GPU"
-    torch.cuda.set_device(local_rank)
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
+    backend = os.environ.get("GSW_BENCH_BACKEND", "nccl")      # "gloo": launcher self-test on a CPU-only host
+    if backend == "nccl":
+        assert torch.cuda.is_available(), "bench.py needs a GPU"
+        torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     return rank, world, local_rank
+
+
+def ranks_seen(world, local_rank):
+    """[local_rank of every rank], all-gathered: evidence in the JSON line that N distinct ranks took part"""
+    import torch
+    import torch.distributed as dist
+    if world == 1:
+        return [local_rank]
+    dev = torch.device("cuda", local_rank) if dist.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.tensor([local_rank], dtype=torch.int64, device=dev)
+    out = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(out, t)
+    return [int(v) for v in out.tolist()]
 
 
 def run_codec(args, rank, world, local_rank, steps, warmup):
@@ -193,12 +231,14 @@ def run_codec(args, rank, world, local_rank, steps, warmup):
 
     # HBM traffic per launch from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE), when it was collected on
     # this very configuration; otherwise null
-    traffic = None
+    traffic = traffic_src = None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_codec_pmc.json")))
+        pmc_file = os.path.join("profiles", "r02_codec_pmc.json")
+        pmc = json.load(open(os.path.join(ROOT, pmc_file)))
         c = pmc["config"]
         if c["batch_per_gpu"] == B and c["lattice"] == list(shape) and c["message_bits"] == M and fast:
             traffic = pmc["kernels"]["gsw_embed_kernel" if dom[0] == "gsw_embed_kernel" else "gsw_extract_wave_kernel"]["traffic_bytes"]
+            traffic_src = f"{pmc_file} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this configuration, kernel revision {pmc.get('kernel_revision')})"
     except Exception:
         pass
 
@@ -216,7 +256,7 @@ def run_codec(args, rank, world, local_rank, steps, warmup):
                        "parallelism": f"dp{world} (images sharded, no data-path collective; async all-gather of recovered bits)"},
             "bit_accuracy": bit_acc, "lossless": ok_bits,
             "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": dom[1] / dom[2] / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": dom[1] / dom[2] / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": dom[1] / dom[2] / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": dom[1], "avg_launch_us": dom[2] * 1e6,
                          "kernels": {"gsw_embed_kernel": {"bytes": bytes_embed, "avg_us": t_embed * 1e6, "GBps": bytes_embed / t_embed / 1e9},
                                      "gsw_extract_wave_kernel": {"bytes": bytes_extract, "avg_us": t_extract * 1e6, "GBps": bytes_extract / t_extract / 1e9}}},
@@ -234,8 +274,17 @@ def run_codec(args, rank, world, local_rank, steps, warmup):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     rank, world, local_rank = init_dist(args)
     import torch.distributed as dist
+    seen = ranks_seen(world, local_rank)
+    if args.launcher_selftest:
+        if rank == 0:
+            print(json.dumps({"launcher_selftest": True, "n_gpus": world, "ranks_seen": seen}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     codec_res = e2e_res = None
     if args.tier in ("both", "codec"):
         k = args.steps if args.tier == "codec" else args.codec_steps
@@ -255,6 +304,7 @@ def main():
                 out["tiers"] = {"codec": {kk: codec_res[kk] for kk in ("value", "unit", "ms_per_step", "steps", "config", "bit_accuracy",
                                                                           "lossless", "roofline", "cpu_baseline", "speedup_vs_cpu_baseline")
                                           if kk in codec_res}}
+        out["ranks_seen"] = seen
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -156,10 +156,7 @@ int gsw_conv3x3_res_pf(const void* x_dev, const void* w_dev, const void* bias_de
 int gsw_add_layernorm(const void* x_dev, const void* delta_dev, const void* gamma_dev, const void* beta_dev, void* xnew_dev, void* y_dev,
                       int64_t rows, int C, float eps, int dtype, void* stream);
 
-/* Linear layers of the eps model's transformer blocks on the same MFMA GEMM kernel (small-K shapes, where it beats the
- * library GEMM): y[M, N] = x[M, K] @ w[N, K]^T + bias[N] (+ resid[M, N]).  K % 64 == 0, N % 160 == 0.
- * geglu = 1: the rows of w (and bias) are interleaved per 160-wide tile as [80 value rows | 80 gate rows]
- * (see pf.pack_geglu_weight) and y is [M, N/2] = value * gelu(gate) -- diffusers' GEGLU without the [M, N] intermediate. */
+/* Round-1 name of the dense linear layer: gsw_gemm(mode = geglu ? GSW_GEMM_GEGLU : GSW_GEMM_PLAIN).  K % 64 == 0, N % 160 == 0. */
 int gsw_linear(const void* x_dev, const void* w_dev, const void* bias_dev, const void* resid_dev, void* y_dev, int64_t M, int K, int N,
                int geglu, int dtype, void* stream);
 
