@@ -44,6 +44,11 @@ template <> struct MM<_Float16> {
     static __device__ __forceinline__ mm_f4 mma(frag a, frag b, mm_f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
     static __device__ __forceinline__ uint16_t cvt(float f) { return __half_as_ushort(__float2half_rn(f)); }
     static __device__ __forceinline__ float up(uint16_t h) { return __half2float(__ushort_as_half(h)); }
+    static __device__ __forceinline__ uint32_t cvt2(float lo, float hi) {      // v_cvt_pk_f16_f32 (round to nearest even)
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(f2{lo, hi}, h2));
+    }
 };
 template <> struct MM<__bf16> {
     typedef mm_b8 frag;
@@ -52,6 +57,11 @@ template <> struct MM<__bf16> {
         union { __hip_bfloat16 h; uint16_t u; } c; c.h = __float2bfloat16(f); return c.u;
     }
     static __device__ __forceinline__ float up(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+    static __device__ __forceinline__ uint32_t cvt2(float lo, float hi) {      // v_cvt_pk_bf16_f32 (round to nearest even)
+        typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(f2{lo, hi}, b2));
+    }
 };
 
 // MM_TRACE (tools/ubench/mm_trace.hip only): cycles between consecutive stamps, summed per interval kind in scalar registers (no memory
@@ -91,8 +101,11 @@ __device__ __forceinline__ void mm_lds_read4x8(const uint32_t (&a)[4], uint2 (&v
                  : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]) : "memory");
 }
 
-template <typename T, bool SWAP>
+// EPI: epilogue class the kernel is compiled for -- 0 dense rows (bias, optional residual), 1 generic (PF border / row bias / token scatter /
+// sub-pixel scatter), 2 GEGLU, 3 transposed output (MFMA operands swapped)
+template <typename T, int EPI>
 __global__ __launch_bounds__(512, 2) void gsw_mm_kernel(const MMArgs p) {
+    constexpr bool SWAP = EPI == 3;
     constexpr int WM = 4;                            // waves along M; 2 groups of 4 waves along N
     constexpr int BM = 256, BN = 160;
     constexpr int NPA = BM / 8 / 8;                  // A pieces (8 rows x 128 B = 1 KiB) per wave per stage: 4
@@ -211,6 +224,11 @@ __global__ __launch_bounds__(512, 2) void gsw_mm_kernel(const MMArgs p) {
         }
         begin_run();
     };
+    // A stage's DMA is issued in two halves, half a step apart, each interleaved sparsely (one piece per three MFMAs) with a phase's MFMAs:
+    // a glds occupies the CU's address unit for ~17 cycles and the issuing wave until it is accepted, so with one MFMA per piece the
+    // matrix pipe starves (measured: the whole 52-piece burst exposed, tools/ubench/mm_trace).
+    //   H1(stage j) = activation pieces 0, 1 + weight piece 0          -- odd phase of step j-3
+    //   H2(stage j) = activation pieces 2, 3 + weight piece 1 (+ 2)    -- even phase of step j-2
     auto dma_extra = [&]() {                                 // the W piece only waves < NEXTRA carry (wave-uniform branch, kept out of the main block)
         if (extra) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pw[NPW],
@@ -218,28 +236,29 @@ __global__ __launch_bounds__(512, 2) void gsw_mm_kernel(const MMArgs p) {
             pw[NPW] += w_step;
         }
     };
-    auto dma_stage = [&]() {                                 // this wave's NDMA pieces of the next stage: straight-line code
-        uint8_t* sb = lds + pr_slot;
-#pragma unroll
-        for (int i = 0; i < NPA; ++i) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pa[i],
-                                             (__attribute__((address_space(3))) void*)(sb + (wave + 8u * i) * 1024u), 16, 0, 0);
-            pa[i] += a_step;
-        }
-#pragma unroll
-        for (int i = 0; i < NPW; ++i) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pw[i],
-                                             (__attribute__((address_space(3))) void*)(sb + (uint32_t)BM * 128u + (wave + 8u * i) * 1024u), 16, 0, 0);
-            pw[i] += w_step;
-        }
+    auto dma_piece_a = [&](int i) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pa[i],
+                                         (__attribute__((address_space(3))) void*)(lds + pr_slot + (wave + 8u * i) * 1024u), 16, 0, 0);
+        pa[i] += a_step;
+    };
+    auto dma_piece_w = [&](int i) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pw[i],
+                                         (__attribute__((address_space(3))) void*)(lds + pr_slot + (uint32_t)BM * 128u + (wave + 8u * i) * 1024u), 16, 0, 0);
+        pw[i] += w_step;
+    };
+    auto dma_h1 = [&]() { dma_piece_a(0); dma_piece_a(1); dma_piece_w(0); };
+    auto dma_h2 = [&]() {                                    // completes the stage: the ring slot advances
+        dma_piece_a(2); dma_piece_a(3); dma_piece_w(1);
         pr_slot = pr_slot + STAGE == RING ? 0u : pr_slot + STAGE;
     };
+    static_assert(NPA == 4 && NPW == 2, "the half-stage split assumes 4 + 2 (+1) pieces per wave");
+    // prologue: stages 0 and 1 and the first half of stage 2; wait for stage 0 (counted: the newer pieces stay in flight; exact for waves
+    // without the extra piece, conservative for the others; any other VMEM operation in flight only makes a wait longer)
     setup_tile(0);
     begin_run();
-    for (int i = 0; i < 2; ++i) { dma_extra(); dma_stage(); if (--pr_run == 0) end_run(); }
-    // this wave's pieces of stage 0 have landed: at most the newest stage is in flight.  The count is exact for waves without the
-    // extra piece and conservative for the others; any other VMEM operation in flight only makes a wait longer.
-    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NDMA) : "memory");
+    for (int i = 0; i < 2; ++i) { dma_h1(); dma_extra(); dma_h2(); if (--pr_run == 0) end_run(); }
+    dma_h1();
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NDMA + 3) : "memory");
     MM_BARRIER();
 
     // ---------------------------------------------------------------- consumer: a STEP = one stage = two phases of 32 k-values; every wave:
@@ -286,8 +305,19 @@ __global__ __launch_bounds__(512, 2) void gsw_mm_kernel(const MMArgs p) {
         const int32_t m0 = tile_m * BM, n0 = tile_n * BN;
         const uint32_t q = lane >> 4, li = lane & 15u;
         auto pack4 = [&](const mm_f4& a, const float (&b)[4], uint32_t& lo, uint32_t& hi) {
-            lo = (uint32_t)MM<T>::cvt(a[0] + b[0]) | ((uint32_t)MM<T>::cvt(a[1] + b[1]) << 16);
-            hi = (uint32_t)MM<T>::cvt(a[2] + b[2]) | ((uint32_t)MM<T>::cvt(a[3] + b[3]) << 16);
+            lo = MM<T>::cvt2(a[0] + b[0], a[1] + b[1]);
+            hi = MM<T>::cvt2(a[2] + b[2], a[3] + b[3]);
+        };
+        // bias of this lane's own accumulator columns, all five column blocks up front (one wait, not one per block)
+        uint2 bq_raw[5];
+#pragma unroll
+        for (int in = 0; in < 5; ++in) {
+            bq_raw[in] = make_uint2(0, 0);
+            if (!SWAP && bias) bq_raw[in] = *reinterpret_cast<const uint2*>(bias + n0 + (int32_t)(grp * HC + (uint32_t)in * 16u + q * 4u));
+        }
+        auto bias4 = [&](int in, float (&bq)[4]) {
+            bq[0] = MM<T>::up((uint16_t)bq_raw[in].x); bq[1] = MM<T>::up((uint16_t)(bq_raw[in].x >> 16));
+            bq[2] = MM<T>::up((uint16_t)bq_raw[in].y); bq[3] = MM<T>::up((uint16_t)(bq_raw[in].y >> 16));
         };
         auto swap16 = [&](uint32_t& a, uint32_t& b) {         // a's odd 16-lane rows <-> b's even rows
             const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
@@ -297,7 +327,50 @@ __global__ __launch_bounds__(512, 2) void gsw_mm_kernel(const MMArgs p) {
             const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
             a = r[0]; b = r[1];
         };
-        if (!SWAP && p.mode != MM_MODE_GEGLU) {
+        if (EPI == 0) {
+            // dense rows: out[m, n] (+ resid[m, n]); row pointers hoisted, ten 16-byte stores per lane at immediate column offsets
+            uint16_t* yrow[2];
+            const uint16_t* rrow[2];
+            bool live[2];
+            const int32_t colb = n0 + (int32_t)(grp * HC + (q >> 1) * 8u);
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                const int32_t m = m0 + (int32_t)(wm * 64u + (uint32_t)(2 * pr + (int)(q & 1u)) * 16u + li);
+                live[pr] = m < p.M;
+                const int64_t mm = live[pr] ? m : 0;
+                yrow[pr] = Y + mm * p.ldy + colb;
+                rrow[pr] = resid ? resid + mm * p.ldr + colb : nullptr;
+            }
+            uint4 rs[5][2];
+            if (resid) {                                      // all residual chunks in flight before the first is used
+#pragma unroll
+                for (int in = 0; in < 5; ++in)
+#pragma unroll
+                    for (int pr = 0; pr < 2; ++pr) rs[in][pr] = *reinterpret_cast<const uint4*>(rrow[pr] + in * 16);
+            }
+#pragma unroll
+            for (int in = 0; in < 5; ++in) {
+                float bq[4];
+                bias4(in, bq);
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    uint32_t a0, a1, b0, b1;
+                    pack4(acc[in][2 * pr], bq, a0, a1);
+                    pack4(acc[in][2 * pr + 1], bq, b0, b1);
+                    swap16(a0, b0);
+                    swap16(a1, b1);
+                    uint32_t w4[4] = {a0, a1, b0, b1};
+                    if (resid) {
+                        const uint32_t rsw[4] = {rs[in][pr].x, rs[in][pr].y, rs[in][pr].z, rs[in][pr].w};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            w4[k] = MM<T>::cvt2(MM<T>::up((uint16_t)w4[k]) + MM<T>::up((uint16_t)rsw[k]),
+                                                MM<T>::up((uint16_t)(w4[k] >> 16)) + MM<T>::up((uint16_t)(rsw[k] >> 16)));
+                    }
+                    if (live[pr]) *reinterpret_cast<uint4*>(yrow[pr] + in * 16) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+                }
+            }
+        } else if (EPI == 1) {
             // per row pair p: this lane's output row and its addressing
             int64_t orow[2];
             int32_t img_b[2];
@@ -326,11 +399,8 @@ __global__ __launch_bounds__(512, 2) void gsw_mm_kernel(const MMArgs p) {
             }
 #pragma unroll
             for (int in = 0; in < 5; ++in) {
-                float bq[4] = {0.f, 0.f, 0.f, 0.f};
-                if (bias) {                                   // bias of this lane's own accumulator columns
-                    const uint2 bw = *reinterpret_cast<const uint2*>(bias + n0 + (int32_t)(grp * HC + (uint32_t)in * 16u + q * 4u));
-                    bq[0] = MM<T>::up((uint16_t)bw.x); bq[1] = MM<T>::up((uint16_t)(bw.x >> 16)); bq[2] = MM<T>::up((uint16_t)bw.y); bq[3] = MM<T>::up((uint16_t)(bw.y >> 16));
-                }
+                float bq[4];
+                bias4(in, bq);
                 const int64_t col = (int64_t)n0 + grp * (uint32_t)HC + (uint32_t)in * 16u + (q >> 1) * 8u;
 #pragma unroll
                 for (int pr = 0; pr < 2; ++pr) {
@@ -357,17 +427,14 @@ __global__ __launch_bounds__(512, 2) void gsw_mm_kernel(const MMArgs p) {
                     *reinterpret_cast<uint4*>(Y + orow[pr] * p.ldy + col) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
                 }
             }
-        } else if (!SWAP) {
+        } else if (EPI == 2) {
             // GEGLU: accumulator columns of an n-tile are [8 value | 8 gate] of outputs 8 in .. 8 in + 7 (within the group's 40 outputs)
             const uint32_t qv = q & 1u;
             uint32_t D[5][2][2];                              // [in][row pair][2 registers]: 4 consecutive outputs 4 qv .. of row tile 2p + (lane >> 5)
 #pragma unroll
             for (int in = 0; in < 5; ++in) {
-                float bq[4] = {0.f, 0.f, 0.f, 0.f};
-                if (bias) {
-                    const uint2 bw = *reinterpret_cast<const uint2*>(bias + n0 + (int32_t)(grp * HC + (uint32_t)in * 16u + q * 4u));
-                    bq[0] = MM<T>::up((uint16_t)bw.x); bq[1] = MM<T>::up((uint16_t)(bw.x >> 16)); bq[2] = MM<T>::up((uint16_t)bw.y); bq[3] = MM<T>::up((uint16_t)(bw.y >> 16));
-                }
+                float bq[4];
+                bias4(in, bq);
                 uint32_t Wv[4];                               // per row tile im: (out j = lane >> 5 ? 1 : 0) | (out j + 2) << 16
 #pragma unroll
                 for (int im = 0; im < 4; ++im) {
@@ -447,46 +514,45 @@ __global__ __launch_bounds__(512, 2) void gsw_mm_kernel(const MMArgs p) {
             for (int im = 0; im < 4; ++im)
                 acc[in][im] = SWAP ? MM<T>::mma(xc[im], wc[in], acc[in][im]) : MM<T>::mma(wc[in], xc[im], acc[in][im]);
     };
-    // X holds the fragments of (stage s, k-half 0) on entry; Y is filled with (s, k-half 1), then X with (s+1, k-half 0)
-    auto step = [&](frag (&xX)[4], frag (&wX)[5], frag (&xY)[4], frag (&wY)[5]) {
-        const uint32_t nx_slot = rd_slot + STAGE == RING ? 0u : rd_slot + STAGE;
-        // ---- even phase (one basic block; issue order pinned so that the matrix pipe never waits for the DMA issue or the LDS)
-        MM_STAMP(0);
-        dma_extra();
-        dma_stage();                                          // stage s+2 -> the slot stage s-1 was read from
-        read_frags(xY, wY, rd_slot, 1u);
-        mfma20(xX, wX);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    // issue order of a phase's main block: three DMA pieces, each behind three MFMAs, then the nine fragment reads one per MFMA
+    auto pin_order = [&]() {
 #pragma unroll
-        for (int i = 0; i < NDMA; ++i) {
+        for (int i = 0; i < 3; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
             __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);    // one LDS-DMA piece
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         }
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // one fragment read
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // one fragment read
         }
-        __builtin_amdgcn_sched_group_barrier(0x008, 20 - 1 - NDMA - 9, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 20 - 9 - 9, 0);
+    };
+    // X holds the fragments of (stage s, k-half 0) on entry; Y is filled with (s, k-half 1), then X with (s+1, k-half 0)
+    auto step = [&](frag (&xX)[4], frag (&wX)[5], frag (&xY)[4], frag (&wY)[5]) {
+        const uint32_t nx_slot = rd_slot + STAGE == RING ? 0u : rd_slot + STAGE;
+        // ---- even phase: second half of stage s+2 (its slot held stage s-1, whose last reads completed before the previous barrier)
+        MM_STAMP(0);
+        dma_extra();
+        dma_h2();
+        read_frags(xY, wY, rd_slot, 1u);
+        mfma20(xX, wX);
+        pin_order();
         if (--pr_run == 0) end_run();
         MM_STAMP(1);
-        // stage s+1 is read in the odd phase: everything but the newest stage (s+2) must have landed
+        // stage s+1 is read in the odd phase: everything but the newest stage (s+2, both halves) must have landed
         asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NDMA) : "memory");
         MM_STAMP(2);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         MM_BARRIER();
         MM_STAMP(3);
-        // ---- odd phase
+        // ---- odd phase: first half of stage s+3, into the slot of stage s (its last reads completed before the barrier above)
+        dma_h1();
         read_frags(xX, wX, nx_slot, 0u);
         mfma20(xY, wY);
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-#pragma unroll
-        for (int i = 0; i < 9; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-        }
+        pin_order();
         MM_STAMP(4);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's reads of stage s are complete: its slot may be refilled after the barrier
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         MM_BARRIER();
         MM_STAMP(5);
         rd_slot = nx_slot;
@@ -511,16 +577,25 @@ __global__ __launch_bounds__(512, 2) void gsw_mm_kernel(const MMArgs p) {
 }
 
 // host ---------------------------------------------------------------------------------------------
-template <typename T, bool SWAP>
+template <typename T, int EPI>
 int mm_launch_t(const MMArgs& a, uint32_t grid, size_t ldsb, hipStream_t st) {
     static bool attr_done = false;          // benign race: setting the attribute twice is harmless
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)gsw_mm_kernel<T, SWAP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)gsw_mm_kernel<T, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((gsw_mm_kernel<T, SWAP>), dim3(grid), dim3(512), ldsb, st, a);
+    hipLaunchKernelGGL((gsw_mm_kernel<T, EPI>), dim3(grid), dim3(512), ldsb, st, a);
     return (int)hipGetLastError();
+}
+template <typename T>
+int mm_launch_e(const MMArgs& a, int epi, uint32_t grid, size_t ldsb, hipStream_t st) {
+    switch (epi) {
+        case 0: return mm_launch_t<T, 0>(a, grid, ldsb, st);
+        case 1: return mm_launch_t<T, 1>(a, grid, ldsb, st);
+        case 2: return mm_launch_t<T, 2>(a, grid, ldsb, st);
+        default: return mm_launch_t<T, 3>(a, grid, ldsb, st);
+    }
 }
 
 }  // namespace
@@ -541,9 +616,8 @@ int gsw_mm_launch(MMArgs& a, int dtype, void* stream) {
     const uint32_t grid = (uint32_t)std::min<int64_t>(256, (a.ntiles + 7) / 8 * 8);
     const size_t ldsb = 3u * (size_t)(BM + BN) * 128u;        // the epilogue image lives in a ring slot
     hipStream_t st = (hipStream_t)stream;
-    int e;
-    if (dtype == GSW_F16) e = swap ? mm_launch_t<_Float16, true>(a, grid, ldsb, st) : mm_launch_t<_Float16, false>(a, grid, ldsb, st);
-    else e = swap ? mm_launch_t<__bf16, true>(a, grid, ldsb, st) : mm_launch_t<__bf16, false>(a, grid, ldsb, st);
+    const int epi = a.mode == MM_MODE_TRANS ? 3 : a.mode == MM_MODE_GEGLU ? 2 : (a.mode == MM_MODE_DENSE && !a.rowbias) ? 0 : 1;
+    const int e = dtype == GSW_F16 ? mm_launch_e<_Float16>(a, epi, grid, ldsb, st) : mm_launch_e<__bf16>(a, epi, grid, ldsb, st);
     if (e != 0) { g_last_hip_error = e; return GSW_ERR_HIP; }
     return GSW_OK;
 }
