@@ -2,10 +2,12 @@
 
 Reference: extract.py:49-69 runs a stock diffusers 0.26.0 `StableDiffusionPipeline` whose scheduler is
 `DDIMInverseScheduler` (prompt "", guidance_scale 1, fp16, output_type 'latent'); the older closed form survives as
-bytecode in __pycache__/inverse_stable_diffusion_gs.cpython-38.pyc (`backward_ddim`, `backward_diffusion`).  diffusers is
-not vendored in the reference nor installed here, so the schedule below restates the published DDIM update with the SD
-scheduler constants (scaled-linear betas 0.00085..0.012, 1000 train steps, 'leading' spacing, steps_offset 1,
-set_alpha_to_one False) -- PARITY UNPINNED at this boundary.
+bytecode in __pycache__/inverse_stable_diffusion_gs.cpython-38.pyc (`backward_ddim`, `backward_diffusion`).  The step
+arithmetic and the loop structure below (timestep order, prev_timestep, final_alpha_cumprod, the alpha swap of the
+inversion, classifier-free guidance) are PINNED against vectors obtained by executing that bytecode
+(tests/golden/make_golden_ddim.py, tests/test_ddim_bytecode_golden.py, tests/test_gpu_ddim.py); the timestep list and the
+alpha table themselves are the published SD scheduler config (scaled-linear betas 0.00085..0.012, 1000 train steps,
+'leading' spacing, steps_offset 1, set_alpha_to_one False) -- diffusers itself is not available here.
 
 MI355X design: the per-step scalars (a_t, b_t) are computed once on the host in fp64; each step is ONE UNet evaluation
 (MFMA through hipBLASLt / MIOpen / flash attention) plus ONE fused HIP kernel for the whole scheduler step

@@ -10,11 +10,15 @@ Pinning status
     PINNED against golden vectors produced by importing the reference (tests/golden/make_golden.py,
     run under /opt/conda/bin/python3.9 with the real `cryptography`/OpenSSL, scipy, numpy) and against
     the RFC 8439 known-answer vectors.
-  * DDIM inversion step/loop (`ddim_*` below): PARITY UNPINNED.  The arithmetic lives in
-    diffusers==0.26.0 (requirements.txt:1), which is neither vendored in /root/reference nor installed
-    here, and the older closed form only survives as py3.8 bytecode
-    (__pycache__/inverse_stable_diffusion_gs.cpython-38.pyc).  The restatement follows the closed form
-    recovered from that bytecode and the published DDIM (eta=0) update.
+  * DDIM step / loops (`backward_ddim`, `ddim_coefficients`, `ddim_schedule` below): PINNED against vectors
+    produced by EXECUTING the reference's own shipped bytecode
+    (__pycache__/inverse_stable_diffusion_gs.cpython-38.pyc: backward_ddim, forward_ddim,
+    InversableStableDiffusionPipeline.backward_diffusion) -- tests/golden/make_golden_ddim.py ->
+    tests/golden/ddim_bytecode.json, checked by tests/test_ddim_bytecode_golden.py.  What the bytecode reads
+    from diffusers objects (the timestep list of DDIMScheduler.set_timesteps, the alphas_cumprod table) is an
+    INPUT of those vectors, restated from the published SD scheduler config: diffusers==0.26.0
+    (requirements.txt:1) itself is neither vendored in /root/reference nor installed here.
+  * DPM-Solver++ inversion (`dpms_invert_reference`): parity unpinned (it exists only inside diffusers).
 
 Every function cites the reference file:line it follows (paths relative to /root/reference).
 """
@@ -282,7 +286,7 @@ def bits_to_bytes(bits: str) -> bytes:
 
 
 # ----------------------------------------------------------------------------------------------
-# X2 / G1: DDIM (eta = 0) step -- PARITY UNPINNED (see module docstring)
+# X2 / G1: DDIM (eta = 0) step -- pinned against the reference's bytecode (see module docstring)
 # ----------------------------------------------------------------------------------------------
 def sd_alphas_cumprod(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012) -> np.ndarray:
     """Stable-Diffusion 'scaled_linear' schedule (scheduler_config.json of stabilityai/stable-diffusion-2-1-base)."""

@@ -178,8 +178,9 @@ def main():
                           "torch": types.SimpleNamespace(cat=lambda xs: np.concatenate([np.asarray(a) for a in xs], axis=0))}
                 loop = types.FunctionType(co_loop39, g_loop, "backward_diffusion")
                 x0 = np.random.RandomState(100 + S).standard_normal((2, 24))
-                res = loop(me, text_embeddings="ctx", latents=x0.copy(), num_inference_steps=S, guidance_scale=guidance,
-                           reverse_process=reverse)
+                # (the defaults of the original `def` live on the function object, not in the code object: every argument is passed)
+                res = loop(me, use_old_emb_i=25, text_embeddings="ctx", old_text_embeddings=None, new_text_embeddings=None, latents=x0.copy(),
+                           num_inference_steps=S, guidance_scale=guidance, callback=None, callback_steps=1, reverse_process=reverse)
                 out["loops"].append({"steps": S, "reverse_process": reverse, "guidance_scale": guidance,
                                      "timesteps_input": list(ts), "model_t": seen_t,
                                      "alpha_t": [c[0] for c in rec.calls], "alpha_tm1": [c[1] for c in rec.calls],

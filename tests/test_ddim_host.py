@@ -1,5 +1,5 @@
 """CPU: host-side DDIM schedule of the product (ddim.py) against the oracle's independent restatement (both follow the
-closed form recovered from inverse_stable_diffusion_gs.pyc / the published DDIM update; PARITY UNPINNED vs diffusers)."""
+closed form of inverse_stable_diffusion_gs.pyc; both are pinned against the bytecode itself in test_ddim_bytecode_golden.py)."""
 import numpy as np
 import pytest
 

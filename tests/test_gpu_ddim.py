@@ -111,3 +111,41 @@ def test_dpms_inversion_vs_numpy_oracle(P, keys):
     zi = P.ddim.dpms_invert(analytic_eps, x0, ctx, sched)
     ref = O.dpms_invert_reference(lambda x, t: analytic_eps_np(x, t), x0.cpu().double().numpy(), 20)
     np.testing.assert_allclose(zi.cpu().numpy(), ref, rtol=0, atol=1e-3 * max(1.0, np.abs(ref).max()))
+
+
+# ---- the device loops against vectors produced by executing the reference's shipped bytecode (tests/golden/make_golden_ddim.py)
+import json as _json
+import os as _os
+
+_BYTECODE = _json.load(open(_os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "golden", "ddim_bytecode.json")))
+
+
+def _bc_eps(x, t, ctx):
+    xf = x.double()
+    tf = t.double()
+    e = 0.3 * torch.tanh(xf) + 0.05 * torch.sin(3.0 * xf + 0.01 * tf)
+    if ctx is not None and ctx.shape[0] == x.shape[0] and bool(ctx.flatten()[-1] != 0):      # CFG batch: second half is the conditional branch
+        h = x.shape[0] // 2
+        e[h:] = e[h:] + 0.1 * torch.cos(2.0 * xf[h:] - 0.003 * tf)
+    return e.to(x.dtype)
+
+
+@pytest.mark.parametrize("i", range(12))
+def test_device_loops_vs_reference_bytecode(P, i):
+    """gsw_ddim_step / gsw_ddim_step_cfg inside ddim_sample / ddim_invert reproduce `backward_diffusion` of
+    inverse_stable_diffusion_gs.pyc (fp32 state on the device vs the bytecode's float64: 1e-5 after up to 50 steps)."""
+    g = _BYTECODE["loops"][i]
+    S, rev, gs = g["steps"], g["reverse_process"], g["guidance_scale"]
+    sched = P.ddim.DDIMSchedule(S)
+    x_in = torch.tensor(g["x_in"], dtype=torch.float32).cuda().contiguous()
+    pad = (-x_in.numel()) % 8                                   # the step kernel works on 16-byte vectors
+    xp = torch.cat([x_in.flatten(), torch.zeros(pad, device="cuda")]).view(2, -1).contiguous() if pad else x_in
+    B = xp.shape[0]
+    if rev:
+        out = P.ddim.ddim_invert(_bc_eps, xp, torch.zeros(B, 1, device="cuda"), sched)
+    elif gs > 1.0:
+        out = P.ddim.ddim_sample(_bc_eps, xp, torch.ones(B, 1, device="cuda"), sched, ctx_uncond=torch.zeros(B, 1, device="cuda"), guidance_scale=gs)
+    else:
+        out = P.ddim.ddim_sample(_bc_eps, xp, torch.zeros(B, 1, device="cuda"), sched, guidance_scale=1.0)
+    got = out.flatten()[: x_in.numel()].view_as(x_in).double().cpu().numpy()
+    np.testing.assert_allclose(got, np.array(g["x_out"]), rtol=0, atol=1e-5)

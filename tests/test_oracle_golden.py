@@ -190,7 +190,7 @@ def test_bit_accuracy(golden):
         assert ob == c["original_bin"] and acc == c["accuracy"]
 
 
-# ------------------------------------------------------------------ DDIM (parity unpinned: self-consistency only)
+# ------------------------------------------------------------------ DDIM self-consistency (the bytecode pin lives in test_ddim_bytecode_golden.py)
 def test_ddim_closed_form_equals_coefficients():
     ac = O.sd_alphas_cumprod()
     rng = np.random.RandomState(0)
