@@ -10,7 +10,7 @@ alpha table themselves are the published SD scheduler config (scaled-linear beta
 'leading' spacing, steps_offset 1, set_alpha_to_one False) -- diffusers itself is not available here.
 
 MI355X design: the per-step scalars (a_t, b_t) are computed once on the host in fp64; each step is ONE UNet evaluation
-(MFMA through hipBLASLt / MIOpen / flash attention) plus ONE fused HIP kernel for the whole scheduler step
+(the hand-written MFMA kernels of libgswm) plus ONE fused HIP kernel for the whole scheduler step
 (x' = a x + b eps, with classifier-free guidance folded in when sampling: libgswm `gsw_ddim_step[_cfg]`), and the last
 inversion step is fused with the Gaussian-CDF quantiser and the majority vote (`gsw_ddim_step_extract`) so the inverted
 latent never makes an extra trip through HBM -- and never visits the host (the reference's `.cpu()`, extract.py:70).
@@ -49,9 +49,11 @@ class DDIMSchedule:
     steps_offset: int = 1
     prediction_type: str = "epsilon"
     set_alpha_to_one: bool = False
+    beta_start: float = 0.00085
+    beta_end: float = 0.012
 
     def __post_init__(self):
-        self.alphas_cumprod = sd_alphas_cumprod(self.num_train_timesteps)
+        self.alphas_cumprod = sd_alphas_cumprod(self.num_train_timesteps, self.beta_start, self.beta_end)
         self.final_alpha = 1.0 if self.set_alpha_to_one else float(self.alphas_cumprod[0])
         self.ratio = self.num_train_timesteps // self.num_inference_steps
         ts = (np.arange(self.num_inference_steps) * self.ratio).round().astype(np.int64) + self.steps_offset
@@ -131,7 +133,7 @@ def ddim_invert_extract(eps_model: EpsModel, x0: torch.Tensor, ctx: torch.Tensor
 # `--scheduler DPMs` of the reference (extract.py:49-50): diffusers' DPMSolverMultistepInverseScheduler with its defaults on the
 # SD scheduler config -- DPM-Solver++ (data prediction), solver_order 2, midpoint, 'linspace' timestep spacing,
 # lower_order_final (only effective below 15 steps), no Karras sigmas.  Restated from the published algorithm
-# (Lu et al., "DPM-Solver++", multistep 2M) in diffusers' sigma parametrisation; PARITY UNPINNED like the DDIM loop.
+# (Lu et al., "DPM-Solver++", multistep 2M) in diffusers' sigma parametrisation; parity unpinned: this scheduler exists only inside diffusers (the DDIM loop, by contrast, is pinned against the reference bytecode).
 # Every update is linear in (x, eps, previous x0 prediction), so a step is 2-3 launches of the fused scheduler-step kernel.
 # =====================================================================================================================
 @dataclass

@@ -79,9 +79,9 @@ def calculate_bit_accuracy(original_message_hex, extracted_message_bin):
 # =====================================================================================================================
 # X1 + X2 + H1: the rest of extract.py -- image -> latents -> DDIM inversion, the per-image / per-directory harness and
 # the CLI.  Same function names, `args` fields, stdout / result.txt text as the reference (extract.py:23-70,112-211).
-# Differences that are the point of the port: the models are loaded ONCE (the reference calls from_pretrained per image,
-# extract.py:56-60), images of a directory go through the UNet loop as a batch, and the inverted latents stay on the
-# device for the vote (the reference returns `.cpu()`, extract.py:70).
+# Differences that are the point of the build: the models are loaded ONCE (the reference calls from_pretrained per image,
+# extract.py:56-60), the images of ALL directories of a run go through the UNet loop in full device batches, and the inverted
+# latents stay on the device for the vote (the reference returns `.cpu()`, extract.py:70).
 # =====================================================================================================================
 import glob
 import os
@@ -90,55 +90,107 @@ from datetime import datetime
 
 _MODEL_CACHE = {}
 
+# Results are only meaningful with real checkpoint weights.  When `model_id` is not a local diffusers directory (the reference's default hub
+# id cannot be downloaded here) the harness REFUSES to run unless synthetic weights are allowed explicitly: this switch, the environment
+# variable GSW_ALLOW_SYNTHETIC_WEIGHTS=1 or the CLI flag --allow_synthetic_weights (bench and tests set it; every result file then carries
+# a SYNTHETIC WEIGHTS marker and no roll-up line is written).
+ALLOW_SYNTHETIC_WEIGHTS = False
+
+
+def _synthetic_allowed(args=None) -> bool:
+    return bool(ALLOW_SYNTHETIC_WEIGHTS or os.environ.get("GSW_ALLOW_SYNTHETIC_WEIGHTS", "0") == "1" or (args is not None and getattr(args, "allow_synthetic_weights", False)))
+
+
+def _read_json(path):
+    import json
+    with open(path) as f:
+        return json.load(f)
+
+
+def _unet_from_config(cfg: dict):
+    """unet/config.json (diffusers UNet2DConditionModel) -> the own module.  `attention_head_dim` is the number of heads in the SD 1.x /
+    2.x configs (an int or one entry per block); head width = channels / heads."""
+    from . import unet as U
+    boc = tuple(cfg.get("block_out_channels", (320, 640, 1280, 1280)))
+    ahd = cfg.get("attention_head_dim", 8)
+    heads = tuple(ahd) if isinstance(ahd, (list, tuple)) else (int(ahd),) * len(boc)
+    down = cfg.get("down_block_types", ["CrossAttnDownBlock2D"] * (len(boc) - 1) + ["DownBlock2D"])
+    for k, want in (("layers_per_block", 2), ("norm_num_groups", 32), ("act_fn", "silu"), ("center_input_sample", False), ("flip_sin_to_cos", True), ("freq_shift", 0)):
+        if cfg.get(k, want) != want:
+            raise ValueError(f"unet/config.json: {k}={cfg[k]!r} is not supported (expected {want!r})")
+    return U.UNet2DCondition(in_channels=int(cfg.get("in_channels", 4)), out_channels=int(cfg.get("out_channels", 4)), block_out_channels=boc,
+                             layers_per_block=2, cross_attention_dim=int(cfg.get("cross_attention_dim", 1024)), num_heads=heads, head_dim=None,
+                             attn_blocks=tuple(t.startswith("CrossAttn") for t in down))
+
+
+def _vae_from_config(cfg: dict):
+    from . import vae as V
+    if cfg.get("layers_per_block", 2) != 2 or cfg.get("norm_num_groups", 32) != 32:
+        raise ValueError("vae/config.json: only layers_per_block 2 / 32 norm groups (the SD autoencoder) are supported")
+    return V.AutoencoderKL(block_out_channels=tuple(cfg.get("block_out_channels", (128, 256, 512, 512))), latent_channels=int(cfg.get("latent_channels", 4)))
+
 
 class Models:
-    """UNet + VAE (+ the context of the empty prompt) of one `model_id`.
+    """UNet + VAE + scheduler constants + the context of the empty prompt of one `model_id` (a local directory in diffusers layout: unet/,
+    vae/, scheduler/, optionally text_encoder/ + tokenizer/).  The modules are built from the directory's config.json files, so SD 1.x
+    and 2.x checkpoints both load."""
 
-    `model_id` is a local directory in diffusers layout (unet/, vae/, optionally text_encoder/ + tokenizer/): the weights
-    are loaded from it.  Anything else (e.g. the reference's default hub id 'stabilityai/stable-diffusion-2-1-base') cannot
-    be downloaded here, so seeded synthetic weights of the same architecture are used and a warning is printed -- the data
-    path and its cost are real, the recovered bits are only meaningful with real weights."""
-
-    def __init__(self, model_id, device="cuda", dtype=torch.float16):
+    def __init__(self, model_id, device="cuda", dtype=torch.float16, allow_synthetic=False):
         from . import unet as U, vae as V
-        self.device, self.dtype = torch.device(device), dtype
-        self.synthetic = not os.path.isdir(str(model_id))
-        self.unet = U.UNet2DCondition()
-        self.vae = V.AutoencoderKL()
+        self.device, self.dtype, self.model_id = torch.device(device), dtype, str(model_id)
+        self.synthetic = not os.path.isdir(self.model_id)
+        self.scheduler = {}
         if self.synthetic:
-            print(f"[gswm] '{model_id}' is not a local diffusers directory: using synthetic weights (results are not meaningful)", file=sys.stderr)
-            U.synthetic_init_(self.unet, 0)
-            V.synthetic_init_(self.vae, 1)
+            if not allow_synthetic:
+                raise FileNotFoundError(
+                    f"'{model_id}' is not a local directory in diffusers layout and there is no network to fetch it from. Pass a checkpoint directory as "
+                    "--model_id; for pipeline tests / benchmarks with seeded SYNTHETIC weights (bit accuracies are then meaningless) opt in with "
+                    "--allow_synthetic_weights, GSW_ALLOW_SYNTHETIC_WEIGHTS=1 or extract.ALLOW_SYNTHETIC_WEIGHTS = True.")
+            print(f"[gswm] '{model_id}' is not a local diffusers directory: SYNTHETIC weights (results are not meaningful)", file=sys.stderr)
+            self.unet = U.synthetic_init_(U.UNet2DCondition(), 0)
+            self.vae = V.synthetic_init_(V.AutoencoderKL(), 1)
         else:
-            U.load_diffusers_state_dict(self.unet, model_id)
-            V.load_diffusers_state_dict(self.vae, model_id)
+            ucfg = os.path.join(self.model_id, "unet", "config.json")
+            vcfg = os.path.join(self.model_id, "vae", "config.json")
+            self.unet = _unet_from_config(_read_json(ucfg)) if os.path.exists(ucfg) else U.UNet2DCondition()
+            self.vae = _vae_from_config(_read_json(vcfg)) if os.path.exists(vcfg) else V.AutoencoderKL()
+            U.load_diffusers_state_dict(self.unet, self.model_id)
+            V.load_diffusers_state_dict(self.vae, self.model_id)
+            scfg = os.path.join(self.model_id, "scheduler", "scheduler_config.json")
+            if os.path.exists(scfg):
+                self.scheduler = _read_json(scfg)
         self.unet.to(self.device, dtype).eval()
         self.vae.to(self.device, dtype).eval()
-        self.prediction_type = "epsilon"
-        cfg = os.path.join(str(model_id), "scheduler", "scheduler_config.json")
-        if os.path.exists(cfg):
-            import json
-            self.prediction_type = json.load(open(cfg)).get("prediction_type", "epsilon")
-        self.ctx_empty = self._empty_prompt_context(model_id)
+        self.prediction_type = self.scheduler.get("prediction_type", "epsilon")
+        self.ctx_dim = self.unet.mid_block.attentions[0].transformer_blocks[0].attn2.to_k.in_features
+        self.ctx_empty = self._empty_prompt_context()
 
-    def _empty_prompt_context(self, model_id):
-        """Context of prompt "" (extract.py:66): CLIP text encoder when the directory ships one, else a fixed synthetic tensor."""
-        te = os.path.join(str(model_id), "text_encoder")
-        if os.path.isdir(te):
-            from transformers import CLIPTextModel, CLIPTokenizer
-            tok = CLIPTokenizer.from_pretrained(os.path.join(str(model_id), "tokenizer"))
-            enc = CLIPTextModel.from_pretrained(te).to(self.device, self.dtype).eval()
-            ids = tok("", padding="max_length", max_length=tok.model_max_length, truncation=True, return_tensors="pt").input_ids.to(self.device)
-            with torch.no_grad():
-                return enc(ids)[0].to(self.dtype)
+    def schedule_kwargs(self) -> dict:
+        """DDIM constants of scheduler/scheduler_config.json (defaults = the SD config)."""
+        c = self.scheduler
+        if c and c.get("beta_schedule", "scaled_linear") != "scaled_linear":
+            raise ValueError(f"scheduler_config.json: beta_schedule {c['beta_schedule']!r} is not supported")
+        return dict(num_train_timesteps=int(c.get("num_train_timesteps", 1000)), steps_offset=int(c.get("steps_offset", 1)),
+                    set_alpha_to_one=bool(c.get("set_alpha_to_one", False)), beta_start=float(c.get("beta_start", 0.00085)),
+                    beta_end=float(c.get("beta_end", 0.012)))
+
+    def _empty_prompt_context(self):
+        """Context of prompt "" (extract.py:66): the CLIP text encoder of the directory (text.py), else -- synthetic weights only -- a fixed
+        seeded tensor of the right shape."""
+        te = os.path.join(self.model_id, "text_encoder")
+        if not self.synthetic and os.path.isdir(te):
+            from . import text
+            return text.encode_prompt_from_dir(self.model_id, [""], self.device, self.dtype)
+        if not self.synthetic:
+            raise FileNotFoundError(f"{te} is missing: the inversion needs the context of the empty prompt (extract.py:66)")
         g = torch.Generator().manual_seed(77)
-        return torch.randn(1, 77, 1024, generator=g).to(self.device, self.dtype)
+        return torch.randn(1, 77, self.ctx_dim, generator=g).to(self.device, self.dtype)
 
 
-def load_models(model_id, device="cuda", dtype=torch.float16) -> Models:
+def load_models(model_id, device="cuda", dtype=torch.float16, allow_synthetic=None) -> Models:
     k = (str(model_id), str(device), dtype)
     if k not in _MODEL_CACHE:
-        _MODEL_CACHE[k] = Models(model_id, device, dtype)
+        _MODEL_CACHE[k] = Models(model_id, device, dtype, allow_synthetic=_synthetic_allowed() if allow_synthetic is None else allow_synthetic)
     return _MODEL_CACHE[k]
 
 
@@ -154,13 +206,18 @@ def load_image(imgname, target_size=None) -> torch.Tensor:
     return torch.from_numpy(a.copy()).permute(2, 0, 1).float().div_(255.0)[None]
 
 
-def load_images_device(image_paths, target_size=None, *, device="cuda", out="f16") -> torch.Tensor:
-    """Batch form of load_image + the `.to(float16)` / `2.*x - 1.` that follow it (extract.py:31-37,48,40), resized and normalised on
-    the device (imaging.resize_lanczos, bit-identical to the PIL / torchvision chain).  File decoding stays on the host; images of
-    one call must share a size (they do in the reference's use: all outputs of one generation run)."""
+def decode_image_file(path) -> np.ndarray:
+    """Host side of load_image: file -> uint8 [H, W, 3] (PIL decode + RGB conversion, extract.py:32)."""
     from PIL import Image
+    with Image.open(path) as im:
+        return np.asarray(im.convert("RGB"), dtype=np.uint8).copy()
+
+
+def images_to_device(arrs, target_size=None, *, device="cuda", out="f16") -> torch.Tensor:
+    """uint8 images -> the tensor `load_image(...).to(float16)` / `2.*x - 1.` produce (extract.py:31-37,48,40), resized and normalised on
+    the device (imaging.resize_lanczos, bit-identical to the PIL / torchvision chain).  Images of one call must share a size after resizing
+    (they do in the reference's use: --width / --height)."""
     from . import imaging
-    arrs = [np.asarray(Image.open(p).convert("RGB"), dtype=np.uint8) for p in image_paths]
     if isinstance(target_size, int):
         target_size = (target_size, target_size)
     groups = {}
@@ -177,6 +234,11 @@ def load_images_device(image_paths, target_size=None, *, device="cuda", out="f16
     return torch.stack(outs)
 
 
+def load_images_device(image_paths, target_size=None, *, device="cuda", out="f16") -> torch.Tensor:
+    """Batch form of load_image + normalisation: file decoding on the host, everything else on the device."""
+    return images_to_device([decode_image_file(p) for p in image_paths], target_size, device=device, out=out)
+
+
 def img_to_latents(x: torch.Tensor, vae):
     """extract.py:39-43."""
     from . import vae as V
@@ -185,8 +247,9 @@ def img_to_latents(x: torch.Tensor, vae):
 
 def _scheduler_steps(args, models):
     from .ddim import DDIMSchedule
+    kw = models.schedule_kwargs() if hasattr(models, "schedule_kwargs") else {}
     if args.scheduler == "DDIM":
-        return DDIMSchedule(num_inference_steps=int(args.num_inference_steps), prediction_type=models.prediction_type)
+        return DDIMSchedule(num_inference_steps=int(args.num_inference_steps), prediction_type=models.prediction_type, **kw)
     if args.scheduler == "DPMs":
         from .ddim import DPMSolverInverseSchedule
         return DPMSolverInverseSchedule(num_inference_steps=int(args.num_inference_steps), prediction_type=models.prediction_type)
@@ -194,21 +257,26 @@ def _scheduler_steps(args, models):
 
 
 @torch.no_grad()
-def exactract_latents_batch(image_paths, args, *, device="cuda") -> torch.Tensor:
-    """Batch form of exactract_latents: [B,4,h,w] fp16 latents on the DEVICE."""
+def invert_decoded_images(arrs, args, *, device="cuda") -> torch.Tensor:
+    """uint8 RGB images -> [B,4,h,w] inverted latents on the DEVICE (resize, normalise, VAE encode, DDIM / DPM-Solver++ inversion)."""
     from .ddim import ddim_invert, dpms_invert, DPMSolverInverseSchedule
-    models = load_models(args.model_id, device)
-    sched = _scheduler_steps(args, models)
     from . import vae as V
+    models = load_models(args.model_id, device, allow_synthetic=_synthetic_allowed(args))
+    sched = _scheduler_steps(args, models)
     if models.dtype == torch.float16:
-        xn = load_images_device(image_paths, [args.width, args.height], device=models.device, out="f16")      # = 2 * fp16(ToTensor) - 1
+        xn = images_to_device(arrs, [args.width, args.height], device=models.device, out="f16")      # = 2 * fp16(ToTensor) - 1
     else:
-        xn = 2.0 * load_images_device(image_paths, [args.width, args.height], device=models.device, out="f32").to(models.dtype) - 1.0
+        xn = 2.0 * images_to_device(arrs, [args.width, args.height], device=models.device, out="f32").to(models.dtype) - 1.0
     latents = V.normalised_img_to_latents(xn, models.vae)
     ctx = models.ctx_empty.expand(latents.shape[0], -1, -1)
     if isinstance(sched, DPMSolverInverseSchedule):
         return dpms_invert(models.unet, latents, ctx, sched)
     return ddim_invert(models.unet, latents, ctx, sched)
+
+
+def exactract_latents_batch(image_paths, args, *, device="cuda") -> torch.Tensor:
+    """Batch form of exactract_latents: [B,4,h,w] fp16 latents on the DEVICE."""
+    return invert_decoded_images([decode_image_file(p) for p in image_paths], args, device=device)
 
 
 def exactract_latents(args, *, device="cuda") -> torch.Tensor:
@@ -218,6 +286,9 @@ def exactract_latents(args, *, device="cuda") -> torch.Tensor:
 
 def get_result_for_one_image(args):
     """extract.py:112-117 (same stdout text)."""
+    if not os.path.isdir(str(args.model_id)):
+        load_models(args.model_id, allow_synthetic=_synthetic_allowed(args))
+        print(f"{SYNTHETIC_MARKER}: '{args.model_id}' is not a local checkpoint, the bit accuracy below is not meaningful", file=sys.stderr)
     reversed_latents = exactract_latents_batch([args.single_image_path], args)
     extracted_message_bin = recover_exactracted_message(reversed_latents, args)
     original_message_bin, bit_accuracy = calculate_bit_accuracy(args.original_message_hex, extracted_message_bin)
@@ -226,67 +297,128 @@ def get_result_for_one_image(args):
 
 
 def write_batch_info(result_file, args):
-    """extract.py:165-175."""
-    result_file.write("=" * 40 + "Batch Info" + "=" * 40 + "\n")
-    current_time = datetime.now().strftime("%Y-%m-%d %H:%M:%S")
-    result_file.write(f"Time,{str(current_time)}\n")
-    result_file.write(f"key_hex,{args.key_hex}\n")
-    result_file.write(f"nonce_hex,{args.nonce_hex}\n")
-    result_file.write(f"original_message_hex,{args.original_message_hex}\n")
-    result_file.write(f"num_inference_steps,{args.num_inference_steps}\n")
-    result_file.write(f"scheduler,{args.scheduler}\n")
-    result_file.write("=" * 40 + "Batch Start" + "=" * 40 + "\n")
+    """The header block of a result.txt (wire format of extract.py:165-175)."""
+    bar = "=" * 40
+    stamp = datetime.now().strftime("%Y-%m-%d %H:%M:%S")
+    fields = [("Time", stamp)] + [(k, getattr(args, k)) for k in ("key_hex", "nonce_hex", "original_message_hex", "num_inference_steps", "scheduler")]
+    result_file.write(f"{bar}Batch Info{bar}\n" + "".join(f"{k},{v}\n" for k, v in fields) + f"{bar}Batch Start{bar}\n")
+
+
+SYNTHETIC_MARKER = "SYNTHETIC WEIGHTS"
+
+
+class _DirJob:
+    """One directory of the run: its image files in the reference's order (*.png then *.jpg, extract.py:135) and, after the device pass,
+    one outcome per file -- the recovered bit string or the exception that file raised."""
+
+    def __init__(self, path):
+        self.path = path
+        self.files = glob.glob(os.path.join(path, "*.png")) + glob.glob(os.path.join(path, "*.jpg"))
+        self.outcome = {}
+
+
+def _plan(args):
+    """The run as a flat script: ("banner", dir) / ("job", _DirJob) entries in the order the reference visits directories
+    (extract.py:120-132: every sub-directory of every os.walk level, or just the one directory)."""
+    script = []
+    if int(args.is_traverse_subdirectories) == 1:
+        for here, subdirs, _ in os.walk(args.images_directory_path):
+            script.append(("banner", here))
+            script += [("job", _DirJob(os.path.join(here, d))) for d in subdirs]
+    else:
+        script.append(("job", _DirJob(args.images_directory_path)))
+    return script
+
+
+def _recover_many(items, args, batch_size):
+    """items: [(job, file)] across ALL directories.  Decode every file on the host (a file that does not decode fails alone), then push
+    the decodable ones through resize -> VAE -> inversion -> vote in full device batches; if a batch raises, its images are redone one
+    by one so that each reports its own error, like the reference's per-image try / except (extract.py:148-155)."""
+    ready = []
+    for job, f in items:
+        try:
+            ready.append((job, f, decode_image_file(f)))
+        except Exception as e:
+            job.outcome[f] = e
+
+    def run(chunk):
+        latents = invert_decoded_images([a for _, _, a in chunk], args)
+        return recover_exactracted_message_batch(latents, args)
+
+    for i in range(0, len(ready), batch_size):
+        chunk = ready[i:i + batch_size]
+        try:
+            results = run(chunk)
+        except Exception:
+            results = []
+            for one in chunk:
+                try:
+                    results += run([one])
+                except Exception as e:
+                    results.append(e)
+        for (job, f, _), r in zip(chunk, results):
+            job.outcome[f] = r
+
+
+def _report(job, args, synthetic):
+    """Write one directory's result.txt block (+ the roll-up line in its parent) and echo the per-image text, byte for byte the
+    reference's (extract.py:112-117,139-163).  With synthetic weights a marker line follows the header and no roll-up is written."""
+    if not job.files:
+        return
+    accs = []
+    with open(os.path.join(job.path, "result.txt"), "a") as out:
+        write_batch_info(out, args)
+        if synthetic:
+            out.write(f"{SYNTHETIC_MARKER},'{args.model_id}' is not a local checkpoint: the bit accuracies below are not meaningful\n")
+        for f in job.files:
+            r = job.outcome.get(f, RuntimeError("not processed"))
+            if isinstance(r, Exception):
+                print(f"Error processing {f}: {r}\n")
+                out.write(f"Error processing {f}: {r}\n")
+                continue
+            original_message_bin, bit_accuracy = calculate_bit_accuracy(args.original_message_hex, r)
+            name = os.path.basename(f)
+            print(f"{name}\nOriginal Message: {original_message_bin} \nExtracted Message: {r}\nBit Accuracy: {bit_accuracy}\n")
+            out.write(f"{name}, Bit Accuracy, {bit_accuracy}\n")
+            accs.append(float(bit_accuracy))
+        if accs:
+            mean = sum(accs) / len(accs)
+            out.write(f"Average Bit Accuracy, {mean}\n\n" + "=" * 40 + "Batch End" + "=" * 40 + "\n")
+    if accs and not synthetic:
+        with open(os.path.join(os.path.dirname(job.path), "result.txt"), "a") as up:
+            up.write(f"{os.path.basename(job.path)}, Average Bit Accuracy, {mean}\n")
+
+
+def process_directory(args, *, batch_size=16):
+    """The directory harness (extract.py:120-163) in batch form: plan the whole run, recover every image of every directory in full device
+    batches, then write the result files in the reference's order and format."""
+    script = _plan(args)
+    jobs = [j for kind, j in script if kind == "job"]
+    synthetic = not os.path.isdir(str(args.model_id))
+    if any(j.files for j in jobs):
+        load_models(args.model_id, allow_synthetic=_synthetic_allowed(args))          # fail before touching any result file
+    _recover_many([(j, f) for j in jobs for f in j.files], args, batch_size)
+    traverse = int(args.is_traverse_subdirectories) == 1
+    if traverse:
+        with open(os.path.join(args.images_directory_path, "result.txt"), "a") as root:
+            write_batch_info(root, args)
+    for kind, x in script:
+        if kind == "banner":
+            print("=" * 20 + x + "=" * 20)
+        else:
+            _report(x, args, synthetic)
+    if traverse:
+        with open(os.path.join(args.images_directory_path, "result.txt"), "a") as root:
+            root.write("=" * 40 + "Batch End" + "=" * 40 + "\n\n")
 
 
 def process_single_directory(dir_path, args, *, batch_size=16):
-    """extract.py:134-163: same result.txt lines; images go through the inversion loop `batch_size` at a time."""
-    image_files = glob.glob(os.path.join(dir_path, "*.png")) + glob.glob(os.path.join(dir_path, "*.jpg"))
-    if not image_files:
-        return
-    total_bit_accuracy = 0
-    processed_images = 0
-    result_file_path = os.path.join(dir_path, "result.txt")
-    with open(result_file_path, "a") as result_file:
-        write_batch_info(result_file, args)
-        for i in range(0, len(image_files), batch_size):
-            chunk = image_files[i:i + batch_size]
-            try:
-                latents = exactract_latents_batch(chunk, args)
-                results = recover_exactracted_message_batch(latents, args)
-            except Exception as e:  # a failure of the whole chunk (unreadable image, ...) is reported per image like the reference
-                results = [e] * len(chunk)
-            for image_path, res in zip(chunk, results):
-                if isinstance(res, Exception):
-                    print(f"Error processing {image_path}: {res}\n")
-                    result_file.write(f"Error processing {image_path}: {res}\n")
-                    continue
-                original_message_bin, bit_accuracy = calculate_bit_accuracy(args.original_message_hex, res)
-                print(f"{os.path.basename(image_path)}\nOriginal Message: {original_message_bin} \nExtracted Message: {res}\nBit Accuracy: {bit_accuracy}\n")
-                result_file.write(f"{os.path.basename(image_path)}, Bit Accuracy, {bit_accuracy}\n")
-                total_bit_accuracy += float(bit_accuracy)
-                processed_images += 1
-        if processed_images > 0:
-            average_bit_accuracy = total_bit_accuracy / processed_images
-            result_file.write(f"Average Bit Accuracy, {average_bit_accuracy}\n\n")
-            result_file.write("=" * 40 + "Batch End" + "=" * 40 + "\n")
-            parent_dir = os.path.dirname(dir_path)
-            with open(os.path.join(parent_dir, "result.txt"), "a") as parent_result_file:
-                parent_result_file.write(f"{os.path.basename(dir_path)}, Average Bit Accuracy, {average_bit_accuracy}\n")
-
-
-def process_directory(args):
-    """extract.py:120-132."""
-    if int(args.is_traverse_subdirectories) == 1:
-        with open(os.path.join(args.images_directory_path, "result.txt"), "a") as root_result_file:
-            write_batch_info(root_result_file, args)
-        for root, dirs, files in os.walk(args.images_directory_path):
-            print("=" * 20 + root + "=" * 20)
-            for d in dirs:
-                process_single_directory(os.path.join(root, d), args)
-        with open(os.path.join(args.images_directory_path, "result.txt"), "a") as root_result_file:
-            root_result_file.write("=" * 40 + "Batch End" + "=" * 40 + "\n\n")
-    else:
-        process_single_directory(args.images_directory_path, args)
+    """One directory (extract.py:134-163)."""
+    job = _DirJob(dir_path)
+    if job.files:
+        load_models(args.model_id, allow_synthetic=_synthetic_allowed(args))
+        _recover_many([(job, f) for f in job.files], args, batch_size)
+        _report(job, args, not os.path.isdir(str(args.model_id)))
 
 
 def build_parser():
@@ -306,6 +438,8 @@ def build_parser():
     parser.add_argument("--width", type=int, default=1024, help="Width of the input image")
     parser.add_argument("--height", type=int, default=1024, help="Height of the input image")
     parser.add_argument("--message_length", type=int, default=1024, help="Length of the message in bits")
+    # not a reference flag: opt in to seeded synthetic weights when --model_id is not a local checkpoint directory (results meaningless)
+    parser.add_argument("--allow_synthetic_weights", action="store_true", help="run without a checkpoint (pipeline tests / benchmarks only)")
     return parser
 
 

@@ -582,7 +582,8 @@ def load_diffusers_state_dict(model: nn.Module, weight_dir: str) -> nn.Module:
     import os
     from safetensors.torch import load_file
     path = weight_dir
-    for cand in ("unet/diffusion_pytorch_model.safetensors", "diffusion_pytorch_model.safetensors"):
+    for cand in ("unet/diffusion_pytorch_model.safetensors", "unet/diffusion_pytorch_model.fp16.safetensors", "diffusion_pytorch_model.safetensors",
+                 "diffusion_pytorch_model.fp16.safetensors"):
         if os.path.exists(os.path.join(weight_dir, cand)):
             path = os.path.join(weight_dir, cand)
             break

@@ -306,7 +306,8 @@ def synthetic_init_(model: nn.Module, seed: int = 0) -> nn.Module:
 def load_diffusers_state_dict(model: nn.Module, weight_dir: str) -> nn.Module:
     from safetensors.torch import load_file
     path = weight_dir
-    for cand in ("vae/diffusion_pytorch_model.safetensors", "diffusion_pytorch_model.safetensors"):
+    for cand in ("vae/diffusion_pytorch_model.safetensors", "vae/diffusion_pytorch_model.fp16.safetensors", "diffusion_pytorch_model.safetensors",
+                 "diffusion_pytorch_model.fp16.safetensors"):
         if os.path.exists(os.path.join(weight_dir, cand)):
             path = os.path.join(weight_dir, cand)
             break

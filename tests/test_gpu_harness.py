@@ -25,7 +25,7 @@ def _args(**kw):
     a = types.SimpleNamespace(model_id="stabilityai/stable-diffusion-2-1-base", key_hex=README_KEY, nonce_hex=README_NONCE,
                               key=bytes.fromhex(README_KEY), nonce=bytes.fromhex(README_NONCE), original_message_hex=(b"lthero" + b"\0" * 26).hex(),
                               num_inference_steps=3, scheduler="DDIM", is_traverse_subdirectories=0, l=1, width=128, height=128,
-                              message_length=256, images_directory_path="", single_image_path="")
+                              message_length=256, images_directory_path="", single_image_path="", allow_synthetic_weights=True)
     a.__dict__.update(kw)
     return a
 
@@ -68,7 +68,8 @@ def test_directory_harness_result_files(E, tmp_path):
     E.process_directory(args)
     txt = (sub / "result.txt").read_text().splitlines()
     assert txt[0] == "=" * 40 + "Batch Info" + "=" * 40 and txt[7] == "=" * 40 + "Batch Start" + "=" * 40
-    body = [l for l in txt[8:] if l]
+    assert txt[8].startswith("SYNTHETIC WEIGHTS,")                          # no checkpoint here: every result file says so
+    body = [l for l in txt[9:] if l]
     good = [l for l in body if ", Bit Accuracy, " in l and not l.startswith("Average")]
     errs = [l for l in body if l.startswith("Error processing ")]
     assert len(good) + len(errs) == 4 and len(errs) >= 1
@@ -78,8 +79,61 @@ def test_directory_harness_result_files(E, tmp_path):
         assert len(avg) == 1 and abs(float(avg[0].split(", ")[1]) - sum(vals) / len(vals)) < 1e-12
         assert body[-1] == "=" * 40 + "Batch End" + "=" * 40
         roll = (root / "result.txt").read_text().splitlines()
-        assert any(l.startswith("setA, Average Bit Accuracy, ") for l in roll)
+        assert not any("Average Bit Accuracy" in l for l in roll)            # ... and nothing is rolled up from synthetic weights
         assert roll[0] == "=" * 40 + "Batch Info" + "=" * 40 and roll[-2] == "=" * 40 + "Batch End" + "=" * 40
+
+
+def test_harness_refuses_to_run_without_a_checkpoint(E, tmp_path, monkeypatch):
+    monkeypatch.delenv("GSW_ALLOW_SYNTHETIC_WEIGHTS", raising=False)
+    monkeypatch.setattr(E, "ALLOW_SYNTHETIC_WEIGHTS", False)
+    _write_images(str(tmp_path), 1)
+    args = _args(images_directory_path=str(tmp_path), allow_synthetic_weights=False, model_id="no/such-checkpoint")
+    with pytest.raises(FileNotFoundError, match="allow_synthetic_weights"):
+        E.process_directory(args)
+    assert not (tmp_path / "result.txt").exists()                               # failed before any result file was touched
+
+
+def test_harness_on_a_local_checkpoint_batches_across_directories(E, tmp_path, capsys):
+    """A (tiny) checkpoint directory in diffusers layout: modules built from its config files, context from its text encoder, images of
+    THREE directories recovered in shared device batches, result files per directory + roll-up lines in the reference's format; every
+    image's result agrees with the single-image entry point's on the same file."""
+    from test_harness_host import write_tiny_checkpoint
+    ck = str(tmp_path / "ckpt")
+    write_tiny_checkpoint(ck, dtype=torch.float16)
+    root = tmp_path / "root"
+    dirs = [root / "a", root / "b", root / "a" / "deep"]
+    for d in dirs:
+        d.mkdir(parents=True)
+    files = {str(d): _write_images(str(d), n) for d, n in zip(dirs, (3, 2, 1))}
+    (root / "b" / "broken.jpg").write_bytes(b"nope")
+    args = _args(model_id=ck, images_directory_path=str(root), is_traverse_subdirectories=1, allow_synthetic_weights=False, width=64, height=64,
+                 message_length=64, original_message_hex=(b"lthero" + b"\0" * 2).hex())
+    seen = []
+    real = E.invert_decoded_images
+    E.invert_decoded_images = lambda arrs, a, **kw: (seen.append(len(arrs)), real(arrs, a, **kw))[1]
+    try:
+        E.process_directory(args, batch_size=4)
+    finally:
+        E.invert_decoded_images = real
+    assert seen == [4, 2]                                                       # 6 decodable images of 3 directories -> two device batches
+    out = capsys.readouterr().out
+    assert out.startswith("=" * 20 + str(root) + "=" * 20 + "\n")
+    roll = (root / "result.txt").read_text().splitlines()
+    assert [l.split(",")[0] for l in roll if "Average Bit Accuracy" in l] == [os.path.basename(d) for d in next(os.walk(str(root)))[1]]
+    assert (root / "a" / "result.txt").read_text().count("deep, Average Bit Accuracy, ") == 1
+    for d in dirs:
+        txt = (d / "result.txt").read_text()
+        assert "SYNTHETIC" not in txt
+        for f in files[str(d)]:
+            one = _args(model_id=ck, single_image_path=f, allow_synthetic_weights=False, width=64, height=64, message_length=64,
+                        original_message_hex=args.original_message_hex)
+            _, bits, acc = E.get_result_for_one_image(one)
+            line = next(l for l in txt.splitlines() if l.startswith(f"{os.path.basename(f)}, Bit Accuracy, "))
+            # a batch of 4 and a batch of 1 may take different library GEMM kernels at this checkpoint's odd widths (64 / 128 channels are
+            # off the own engine's N % 160 grid), so marginal votes can flip: the two entry points agree to within a few bits
+            assert abs(float(line.split(", ")[2]) - acc) <= 6 / 64
+            assert f"{os.path.basename(f)}\nOriginal Message: " in out
+    assert f"Error processing {root / 'b' / 'broken.jpg'}: " in (root / "b" / "result.txt").read_text()
 
 
 def test_image_level_roundtrip_runs(E, keys):
@@ -88,7 +142,7 @@ def test_image_level_roundtrip_runs(E, keys):
     import gswm_amd
     from gswm_amd import codec, pipeline as P
     key, nonce = keys
-    m = E.load_models("stabilityai/stable-diffusion-2-1-base")
+    m = E.load_models("stabilityai/stable-diffusion-2-1-base", allow_synthetic=True)
     k = codec.pad_message("lthero", 32)
     pipe = P.GaussianShadingPipeline(m.unet, key, nonce, k, height=128, width=128, num_inference_steps=2, ctx_uncond=m.ctx_empty)
     B = 2

@@ -1,5 +1,6 @@
 """CPU: host side of the extract.py twin -- CLI flags/defaults, result.txt text, image loading (extract.py:31-37,165-211)."""
 import io
+import os
 import types
 
 import numpy as np
@@ -80,3 +81,166 @@ def test_unknown_scheduler_raises_like_reference():
     args = types.SimpleNamespace(scheduler="Euler", num_inference_steps=5)
     with pytest.raises(ValueError, match="Please choose 'DPMs' or 'DDIM'"):
         E._scheduler_steps(args, types.SimpleNamespace(prediction_type="epsilon"))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# model loading: fail closed without a checkpoint, build the modules from the checkpoint's own config files
+# ---------------------------------------------------------------------------------------------------------------------
+def write_tiny_checkpoint(root, *, dtype=torch.float32, fp16_names=False):
+    """A complete diffusers-layout directory with a two-level UNet, a small VAE, a scheduler config, a CLIP tokenizer and a one-layer
+    text encoder -- every file `Models` reads, at a size the CPU handles in a second."""
+    import json, os
+    from safetensors.torch import save_file
+    from test_text_host import _write_tokenizer
+    from gswm_amd import text as T
+    ucfg = {"in_channels": 4, "out_channels": 4, "block_out_channels": [64, 128], "layers_per_block": 2, "cross_attention_dim": 96,
+            "attention_head_dim": [1, 2], "down_block_types": ["CrossAttnDownBlock2D", "DownBlock2D"], "norm_num_groups": 32, "act_fn": "silu"}
+    vcfg = {"block_out_channels": [32, 64], "latent_channels": 4, "layers_per_block": 2, "norm_num_groups": 32}
+    scfg = {"num_train_timesteps": 1000, "beta_start": 0.00085, "beta_end": 0.012, "beta_schedule": "scaled_linear", "steps_offset": 1,
+            "set_alpha_to_one": False, "prediction_type": "v_prediction"}
+    unet = U.synthetic_init_(E._unet_from_config(ucfg), 3).to(dtype)
+    vae = V.synthetic_init_(E._vae_from_config(vcfg), 4).to(dtype)
+    name = "diffusion_pytorch_model.fp16.safetensors" if fp16_names else "diffusion_pytorch_model.safetensors"
+    for sub, mod, cfg in (("unet", unet, ucfg), ("vae", vae, vcfg)):
+        os.makedirs(os.path.join(root, sub))
+        save_file({k: v.contiguous() for k, v in mod.state_dict().items()}, os.path.join(root, sub, name))
+        with open(os.path.join(root, sub, "config.json"), "w") as f:
+            json.dump(cfg, f)
+    os.makedirs(os.path.join(root, "scheduler"))
+    with open(os.path.join(root, "scheduler", "scheduler_config.json"), "w") as f:
+        json.dump(scfg, f)
+    vocab = _write_tokenizer(os.path.join(root, "tokenizer"), "!")
+    tcfg = {"vocab_size": len(vocab), "hidden_size": 96, "intermediate_size": 192, "num_hidden_layers": 1, "num_attention_heads": 2,
+            "max_position_embeddings": 77, "hidden_act": "gelu", "layer_norm_eps": 1e-5}
+    torch.manual_seed(5)
+    enc = T.ClipTextEncoder(tcfg).to(dtype)
+    os.makedirs(os.path.join(root, "text_encoder"))
+    save_file({k: v.contiguous() for k, v in enc.state_dict().items()}, os.path.join(root, "text_encoder", "model.safetensors"))
+    with open(os.path.join(root, "text_encoder", "config.json"), "w") as f:
+        json.dump(tcfg, f)
+    return unet, vae, enc
+
+
+def test_models_fail_closed_without_checkpoint(monkeypatch):
+    monkeypatch.delenv("GSW_ALLOW_SYNTHETIC_WEIGHTS", raising=False)
+    monkeypatch.setattr(E, "ALLOW_SYNTHETIC_WEIGHTS", False)
+    with pytest.raises(FileNotFoundError, match="allow_synthetic_weights"):
+        E.Models("stabilityai/stable-diffusion-2-1-base", device="cpu", dtype=torch.float32)
+    a = E.build_parser().parse_args(["--key_hex", "00", "--nonce_hex", "", "--original_message_hex", "6c"])
+    assert a.allow_synthetic_weights is False and not E._synthetic_allowed(a)
+    a = E.build_parser().parse_args(["--key_hex", "00", "--nonce_hex", "", "--original_message_hex", "6c", "--allow_synthetic_weights"])
+    assert E._synthetic_allowed(a)
+    monkeypatch.setenv("GSW_ALLOW_SYNTHETIC_WEIGHTS", "1")
+    assert E._synthetic_allowed()
+
+
+@pytest.mark.parametrize("fp16_names", [False, True])
+def test_models_load_tiny_checkpoint_from_its_config_files(tmp_path, fp16_names):
+    root = str(tmp_path / "ckpt")
+    unet, vae, enc = write_tiny_checkpoint(root, fp16_names=fp16_names)
+    m = E.Models(root, device="cpu", dtype=torch.float32)
+    assert not m.synthetic and m.prediction_type == "v_prediction" and m.ctx_dim == 96
+    assert [b.resnets[0].conv1.out_channels for b in m.unet.down_blocks] == [64, 128]
+    assert m.unet.down_blocks[0].attentions[0].transformer_blocks[0].attn1.heads == 1 and m.unet.down_blocks[1].attentions is None
+    assert m.unet.mid_block.attentions[0].transformer_blocks[0].attn1.heads == 2
+    for mine, ref in ((m.unet, unet), (m.vae, vae)):
+        sd = ref.state_dict()
+        assert all(torch.equal(v, sd[k]) for k, v in mine.state_dict().items())
+    assert m.schedule_kwargs() == dict(num_train_timesteps=1000, steps_offset=1, set_alpha_to_one=False, beta_start=0.00085, beta_end=0.012)
+    sched = E._scheduler_steps(types.SimpleNamespace(scheduler="DDIM", num_inference_steps=10), m)
+    assert sched.prediction_type == "v_prediction" and len(sched.inversion()) == 10
+    # the context of the empty prompt comes from the directory's tokenizer + text encoder
+    from gswm_amd import text as T
+    ids = T.ClipTokenizer.from_dir(root + "/tokenizer")([""])
+    assert m.ctx_empty.shape == (1, 77, 96) and torch.allclose(m.ctx_empty, enc(ids), atol=1e-6)
+    # one CPU forward of the loaded UNet (plain-torch module path): the config-built module is wired consistently
+    y = m.unet(torch.randn(1, 4, 16, 16), torch.tensor([5]), m.ctx_empty)
+    assert y.shape == (1, 4, 16, 16) and torch.isfinite(y).all()
+
+
+def test_unsupported_configs_are_refused():
+    with pytest.raises(ValueError, match="layers_per_block"):
+        E._unet_from_config({"layers_per_block": 3})
+    with pytest.raises(ValueError, match="beta_schedule"):
+        m = types.SimpleNamespace(scheduler={"beta_schedule": "linear"})
+        E.Models.schedule_kwargs(m)
+
+
+def test_plan_follows_the_reference_visiting_order(tmp_path):
+    """extract.py:120-132: for every os.walk level a banner, then each of its sub-directories; images of a directory are *.png then *.jpg."""
+    root = tmp_path / "r"
+    for d in ("a", "b", "a/x"):
+        (root / d).mkdir(parents=True)
+    for f in ("a/1.jpg", "a/0.png", "a/x/2.png", "b/note.txt"):
+        (root / f).write_bytes(b"")
+    args = types.SimpleNamespace(images_directory_path=str(root), is_traverse_subdirectories=1)
+    script = E._plan(args)
+    import os
+    want = []
+    for here, subdirs, _ in os.walk(str(root)):
+        want.append(("banner", here))
+        want += [("job", os.path.join(here, d)) for d in subdirs]
+    assert [(k, x if k == "banner" else x.path) for k, x in script] == want
+    ja = next(x for k, x in script if k == "job" and x.path.endswith("/a"))
+    assert [os.path.basename(f) for f in ja.files] == ["0.png", "1.jpg"]
+    single = E._plan(types.SimpleNamespace(images_directory_path=str(root / "a"), is_traverse_subdirectories=0))
+    assert len(single) == 1 and single[0][0] == "job" and single[0][1].path == str(root / "a")
+
+
+def test_report_text_with_injected_outcomes(tmp_path, capsys):
+    """The writer alone (no device): result.txt of a directory and the roll-up line in its parent, byte for byte (extract.py:139-163)."""
+    d = tmp_path / "p" / "set"
+    d.mkdir(parents=True)
+    for f in ("a.png", "b.png", "c.jpg"):
+        (d / f).write_bytes(b"")
+    args = types.SimpleNamespace(key_hex="k", nonce_hex="n", original_message_hex="6c74", num_inference_steps=30, scheduler="DDIM", model_id=str(tmp_path))
+    job = E._DirJob(str(d))
+    bits_ok = "0110110001110100"
+    bits_bad = "0110110001110111"
+    job.outcome = {str(d / "a.png"): bits_ok, str(d / "b.png"): ValueError("boom"), str(d / "c.jpg"): bits_bad}
+    E._report(job, args, synthetic=False)
+    out = capsys.readouterr().out
+    _, acc_bad = E.calculate_bit_accuracy("6c74", bits_bad)
+    assert out == (f"a.png\nOriginal Message: {bits_ok} \nExtracted Message: {bits_ok}\nBit Accuracy: 1.0\n\n"
+                   f"Error processing {d / 'b.png'}: boom\n\n"
+                   f"c.jpg\nOriginal Message: {bits_ok} \nExtracted Message: {bits_bad}\nBit Accuracy: {acc_bad}\n\n")
+    lines = (d / "result.txt").read_text().split("\n")
+    bar = "=" * 40
+    assert lines[8:] == ["a.png, Bit Accuracy, 1.0", f"Error processing {d / 'b.png'}: boom", f"c.jpg, Bit Accuracy, {acc_bad}",
+                         f"Average Bit Accuracy, {(1.0 + acc_bad) / 2}", "", f"{bar}Batch End{bar}", ""]
+    assert (tmp_path / "p" / "result.txt").read_text() == f"set, Average Bit Accuracy, {(1.0 + acc_bad) / 2}\n"
+    # synthetic weights: marker line after the header, no roll-up
+    (tmp_path / "p" / "result.txt").unlink()
+    (d / "result.txt").unlink()
+    E._report(job, args, synthetic=True)
+    lines = (d / "result.txt").read_text().split("\n")
+    assert lines[8].startswith("SYNTHETIC WEIGHTS,") and lines[9] == "a.png, Bit Accuracy, 1.0"
+    assert not (tmp_path / "p" / "result.txt").exists()
+
+
+def test_recover_many_isolates_failures_per_image(tmp_path, monkeypatch):
+    """A file that does not decode fails alone; a device batch that raises is redone image by image so each reports its own error."""
+    from PIL import Image
+    d = tmp_path / "s"
+    d.mkdir()
+    for i in range(5):
+        Image.fromarray(np.full((8, 8, 3), i, dtype=np.uint8)).save(d / f"{i}.png")
+    (d / "zz.png").write_bytes(b"junk")
+    job = E._DirJob(str(d))
+    calls = []
+
+    def fake_invert(arrs, args, device="cuda"):
+        calls.append(len(arrs))
+        if any(int(a[0, 0, 0]) == 3 for a in arrs):
+            raise RuntimeError("poisoned image")
+        return torch.tensor([int(a[0, 0, 0]) for a in arrs])
+
+    monkeypatch.setattr(E, "invert_decoded_images", fake_invert)
+    monkeypatch.setattr(E, "recover_exactracted_message_batch", lambda lat, args: [f"bits{int(v)}" for v in lat])
+    E._recover_many([(job, f) for f in job.files], None, batch_size=4)
+    got = {os.path.basename(k): v for k, v in job.outcome.items()}
+    assert isinstance(got["zz.png"], Exception) and isinstance(got["3.png"], RuntimeError) and str(got["3.png"]) == "poisoned image"
+    assert [got[f"{i}.png"] for i in (0, 1, 2, 4)] == ["bits0", "bits1", "bits2", "bits4"]
+    good = [os.path.basename(f) for f in job.files if not f.endswith("zz.png")]          # glob order is the file system's
+    want = [4, 1, 1, 1, 1, 1] if "3.png" in good[:4] else [4, 1, 1]    # a batch that raises is redone singly; the other batch runs once
+    assert calls == want
