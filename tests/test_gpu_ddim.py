@@ -133,7 +133,8 @@ def _bc_eps(x, t, ctx):
 @pytest.mark.parametrize("i", range(12))
 def test_device_loops_vs_reference_bytecode(P, i):
     """gsw_ddim_step / gsw_ddim_step_cfg inside ddim_sample / ddim_invert reproduce `backward_diffusion` of
-    inverse_stable_diffusion_gs.pyc (fp32 state on the device vs the bytecode's float64: 1e-5 after up to 50 steps)."""
+    inverse_stable_diffusion_gs.pyc.  The device state is fp32, the bytecode ran in float64: after up to 50 steps (values reach |x| ~ 30 with
+    guidance 7.5) the tolerance is 1e-5 absolute + 2e-6 relative, i.e. a few dozen fp32 ulps."""
     g = _BYTECODE["loops"][i]
     S, rev, gs = g["steps"], g["reverse_process"], g["guidance_scale"]
     sched = P.ddim.DDIMSchedule(S)
@@ -148,4 +149,4 @@ def test_device_loops_vs_reference_bytecode(P, i):
     else:
         out = P.ddim.ddim_sample(_bc_eps, xp, torch.zeros(B, 1, device="cuda"), sched, guidance_scale=1.0)
     got = out.flatten()[: x_in.numel()].view_as(x_in).double().cpu().numpy()
-    np.testing.assert_allclose(got, np.array(g["x_out"]), rtol=0, atol=1e-5)
+    np.testing.assert_allclose(got, np.array(g["x_out"]), rtol=2e-6, atol=1e-5)
