@@ -86,8 +86,11 @@ constexpr uint32_t VP = 136;                               // V^T LDS row pitch 
 // DU = head_dim / 8 (5, 8, 10 <-> head_dim 40, 64, 80): the contraction over head_dim runs in KC = ceil(DU/2) MFMA k-slices and the
 // output in DB = ceil(head_dim/32) row blocks; the padding lanes of Q are zero registers and the padding rows of V^T zero LDS rows.
 // PAIR: four LDS stages and ONE barrier per two 64-key tiles (half the barriers; 4 x 17.5 KiB of dynamic LDS at head_dim 64).
-template <typename T, int QB, int DU, bool PAIR>
-__global__ __launch_bounds__(256, 2) void gsw_attn_fwd_kernel(AttnArgs p) {
+// RAGGED: Sq is not a multiple of the workgroup tile and / or Sk not a multiple of 64 (the mid block: 64 tokens at 512x512, 144 at 768x768;
+// 576 tokens at the SD 1.5 third level).  Query lanes past Sq read row 0 and store nothing; key rows / V^T columns past Sk are fetched
+// from a clamped (valid, finite) address and masked through Sk_valid like padded context keys.
+template <typename T, int QB, int DU, bool PAIR, bool RAGGED>
+__global__ __launch_bounds__(256, (DU > 10 ? 1 : 2)) void gsw_attn_fwd_kernel(AttnArgs p) {
     using v8 = typename AT<T>::v8;
     using v4 = typename AT<T>::v4;
     constexpr int D = DU * 8, KC = (DU + 1) / 2, DB = (D + 31) / 32;
@@ -106,7 +109,8 @@ __global__ __launch_bounds__(256, 2) void gsw_attn_fwd_kernel(AttnArgs p) {
     const uint32_t bh = logical / p.nqt, qt = logical - bh * p.nqt;
     const uint32_t b = bh / (uint32_t)p.H, hh = bh - b * (uint32_t)p.H;
 
-    const T* Q = reinterpret_cast<const T*>(p.q) + ((int64_t)b * p.Sq + qt * QWG + wave * QW + c32) * p.ldq + hh * (uint32_t)D;
+    const uint32_t q0 = qt * QWG + wave * QW + c32;               // this lane's query of block qb is q0 + 32 qb
+    const T* Qb = reinterpret_cast<const T*>(p.q) + (int64_t)b * p.Sq * p.ldq + hh * (uint32_t)D;
     const T* K = reinterpret_cast<const T*>(p.k) + (int64_t)b * p.Sk * p.ldk + hh * (uint32_t)D;
     const T* VT = reinterpret_cast<const T*>(p.vt) + ((int64_t)b * p.H + hh) * D * (int64_t)p.Sk;
 
@@ -122,7 +126,9 @@ __global__ __launch_bounds__(256, 2) void gsw_attn_fwd_kernel(AttnArgs p) {
         for (int kc = 0; kc < KC; ++kc) {
             typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
             u32x4 w = u32x4{0u, 0u, 0u, 0u};
-            if (2 * kc + 1 < DU || h == 0) w = *reinterpret_cast<const u32x4*>(Q + (int64_t)qb * 32 * p.ldq + kc * 16 + h * 8);   // unit 2kc+h < DU
+            const uint32_t qi = q0 + 32u * qb;
+            const T* Q = Qb + (int64_t)((!RAGGED || qi < (uint32_t)p.Sq) ? qi : 0u) * p.ldq;
+            if (2 * kc + 1 < DU || h == 0) w = *reinterpret_cast<const u32x4*>(Q + kc * 16 + h * 8);   // unit 2kc+h < DU
             // Pass Q through a VALU move before the loop: the loop's MFMAs then read ALU results, not load results, so the waitcnt pass
             // does not place `s_waitcnt vmcnt` (which would drain the in-flight K / V prefetch) in front of them.
 #pragma unroll
@@ -132,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void gsw_attn_fwd_kernel(AttnArgs p) {
 
     // staging roles: 64*DU 16-byte units per tile and operand.  K unit u: key row u / DU, column u % DU; V^T unit u: row u / 8 (< D),
     // key column u % 8.  (Named scalars + macros: arrays or lambdas holding the prefetch registers end up in scratch.)
-    // NU <= 3; unit i of this thread is u = tid + 256 i
+    // NU <= 5; unit i of this thread is u = tid + 256 i
     constexpr bool ALLV = NU * 256 == 64 * DU;                 // every unit slot of every thread is a real unit
 #define GSW_ATTN_UNIT_DECL(i)                                                                           \
     uint4 kreg##i = make_uint4(0, 0, 0, 0), vreg##i = make_uint4(0, 0, 0, 0);                           \
@@ -147,12 +153,21 @@ __global__ __launch_bounds__(256, 2) void gsw_attn_fwd_kernel(AttnArgs p) {
     GSW_ATTN_UNIT_DECL(0)
     GSW_ATTN_UNIT_DECL(1)
     GSW_ATTN_UNIT_DECL(2)
+    GSW_ATTN_UNIT_DECL(3)
+    GSW_ATTN_UNIT_DECL(4)
 #define GSW_ATTN_GLOAD1(i, key0)                                                                        \
     if (NU > i && (ALLV || uv##i)) {                                                                    \
-        kreg##i = *reinterpret_cast<const uint4*>(kg##i + (int64_t)(key0) * p.ldk);                     \
-        vreg##i = *reinterpret_cast<const uint4*>(vg##i + (key0));                                      \
+        if (RAGGED) {                                                                                   \
+            const int32_t row_ = min((int32_t)(key0) + (int32_t)kr##i, p.Sk - 1);                       \
+            const int32_t col_ = (int32_t)(key0) + (int32_t)(uu##i & 7u) * 8;                           \
+            kreg##i = *reinterpret_cast<const uint4*>(K + (int64_t)row_ * p.ldk + kcol##i * 8u);        \
+            vreg##i = *reinterpret_cast<const uint4*>(VT + (int64_t)(uu##i >> 3) * p.Sk + (col_ + 8 <= p.Sk ? col_ : 0)); \
+        } else {                                                                                        \
+            kreg##i = *reinterpret_cast<const uint4*>(kg##i + (int64_t)(key0) * p.ldk);                 \
+            vreg##i = *reinterpret_cast<const uint4*>(vg##i + (key0));                                  \
+        }                                                                                               \
     }
-#define GSW_ATTN_GLOAD(key0) GSW_ATTN_GLOAD1(0, key0) GSW_ATTN_GLOAD1(1, key0) GSW_ATTN_GLOAD1(2, key0)
+#define GSW_ATTN_GLOAD(key0) GSW_ATTN_GLOAD1(0, key0) GSW_ATTN_GLOAD1(1, key0) GSW_ATTN_GLOAD1(2, key0) GSW_ATTN_GLOAD1(3, key0) GSW_ATTN_GLOAD1(4, key0)
 #define GSW_ATTN_LSTORE1(i, st)                                                                         \
     if (NU > i && (ALLV || uv##i)) {                                                                    \
         uint8_t* base_ = lds + (st) * STAGE;                                                            \
@@ -160,8 +175,8 @@ __global__ __launch_bounds__(256, 2) void gsw_attn_fwd_kernel(AttnArgs p) {
         *reinterpret_cast<uint2*>(base_ + vst##i) = make_uint2(vreg##i.x, vreg##i.y);      /* V^T rows are 136 B apart: */ \
         *reinterpret_cast<uint2*>(base_ + vst##i + 8u) = make_uint2(vreg##i.z, vreg##i.w); /* 8-byte aligned only      */ \
     }
-#define GSW_ATTN_LSTORE(st) GSW_ATTN_LSTORE1(0, st) GSW_ATTN_LSTORE1(1, st) GSW_ATTN_LSTORE1(2, st)
-    static_assert(NU <= 3, "staging code covers up to 3 units per thread");
+#define GSW_ATTN_LSTORE(st) GSW_ATTN_LSTORE1(0, st) GSW_ATTN_LSTORE1(1, st) GSW_ATTN_LSTORE1(2, st) GSW_ATTN_LSTORE1(3, st) GSW_ATTN_LSTORE1(4, st)
+    static_assert(NU <= 5, "staging code covers up to 5 units per thread");
 
     f32x16 o[QB][DB];
     float m_i[QB], l_i[QB];
@@ -176,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void gsw_attn_fwd_kernel(AttnArgs p) {
     }
     const float cs = p.scale_log2;
 
-    const int32_t nt = p.Sk >> 6;
+    const int32_t nt = (p.Sk + 63) >> 6;
     // one 64-key tile: S^T, online softmax, O^T accumulation
     auto tile = [&](uint32_t stage, int32_t t) {
         const uint8_t* Kl = lds + stage * STAGE;
@@ -301,7 +316,9 @@ __global__ __launch_bounds__(256, 2) void gsw_attn_fwd_kernel(AttnArgs p) {
     for (int qb = 0; qb < QB; ++qb) {
         const float l = xhalf_sum(l_i[qb]);
         const float inv = 1.0f / l;
-        T* O = reinterpret_cast<T*>(p.o) + ((int64_t)b * p.Sq + qt * QWG + wave * QW + (uint32_t)qb * 32u + c32) * p.ldo + hh * (uint32_t)D;
+        const uint32_t qi = q0 + 32u * qb;
+        if (RAGGED && qi >= (uint32_t)p.Sq) continue;
+        T* O = reinterpret_cast<T*>(p.o) + ((int64_t)b * p.Sq + qi) * p.ldo + hh * (uint32_t)D;
 #pragma unroll
         for (int db = 0; db < DB; ++db) {
 #pragma unroll
@@ -326,53 +343,55 @@ __global__ __launch_bounds__(256, 2) void gsw_attn_fwd_kernel(AttnArgs p) {
 }  // namespace
 
 template <typename T, int QB, int DU>
-static int launch_attn_cfg(const AttnArgs& a, uint32_t grid, hipStream_t st) {
+static int launch_attn_cfg(const AttnArgs& a, uint32_t grid, bool ragged, hipStream_t st) {
     constexpr int KC = (DU + 1) / 2, DB = (DU * 8 + 31) / 32;
     constexpr uint32_t stage = 64 * (KC * 32 + 16) + DB * 32 * 136;
     static const int pair_env = getenv("GSW_ATTN_PAIR") ? atoi(getenv("GSW_ATTN_PAIR")) : 1;      // A/B switch for profiling
-    const bool pair = pair_env && 4 * stage <= 80 * 1024 && (a.Sk >> 6) >= 16;      // long key sequences only: +2 % at 4096 keys, a loss at 256
+    const bool pair = !ragged && pair_env && 4 * stage <= 80 * 1024 && (a.Sk >> 6) >= 16;      // long key sequences only: +2 % at 4096 keys, a loss at 256
     const uint32_t lds = (pair ? 4 : 2) * stage;
-    if (pair) {
-        if (lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute((const void*)gsw_attn_fwd_kernel<T, QB, DU, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-            if (e != hipSuccess) { g_last_hip_error = (int)e; return GSW_ERR_HIP; }
-        }
-        hipLaunchKernelGGL((gsw_attn_fwd_kernel<T, QB, DU, true>), dim3(grid), dim3(256), lds, st, a);
-    } else {
-        hipLaunchKernelGGL((gsw_attn_fwd_kernel<T, QB, DU, false>), dim3(grid), dim3(256), lds, st, a);
+    const void* fn = pair ? (const void*)gsw_attn_fwd_kernel<T, QB, DU, true, false>
+                          : (ragged ? (const void*)gsw_attn_fwd_kernel<T, 1, DU, false, true> : (const void*)gsw_attn_fwd_kernel<T, QB, DU, false, false>);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { g_last_hip_error = (int)e; return GSW_ERR_HIP; }
     }
+    if (pair) hipLaunchKernelGGL((gsw_attn_fwd_kernel<T, QB, DU, true, false>), dim3(grid), dim3(256), lds, st, a);
+    else if (ragged) hipLaunchKernelGGL((gsw_attn_fwd_kernel<T, 1, DU, false, true>), dim3(grid), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((gsw_attn_fwd_kernel<T, QB, DU, false, false>), dim3(grid), dim3(256), lds, st, a);
     return GSW_OK;
 }
 
 template <typename T>
-static int launch_attn(const AttnArgs& a, int head_dim, int QB, uint32_t grid, hipStream_t st) {
-    if (head_dim == 64) return QB == 2 ? launch_attn_cfg<T, 2, 8>(a, grid, st) : launch_attn_cfg<T, 1, 8>(a, grid, st);
-    if (head_dim == 40) return QB == 2 ? launch_attn_cfg<T, 2, 5>(a, grid, st) : launch_attn_cfg<T, 1, 5>(a, grid, st);
-    return launch_attn_cfg<T, 1, 10>(a, grid, st);
+static int launch_attn(const AttnArgs& a, int head_dim, int QB, uint32_t grid, bool ragged, hipStream_t st) {
+    if (head_dim == 64) return QB == 2 ? launch_attn_cfg<T, 2, 8>(a, grid, ragged, st) : launch_attn_cfg<T, 1, 8>(a, grid, ragged, st);
+    if (head_dim == 40) return QB == 2 ? launch_attn_cfg<T, 2, 5>(a, grid, ragged, st) : launch_attn_cfg<T, 1, 5>(a, grid, ragged, st);
+    if (head_dim == 80) return launch_attn_cfg<T, 1, 10>(a, grid, ragged, st);
+    return launch_attn_cfg<T, 1, 20>(a, grid, ragged, st);
 }
 
 int gsw_attention(const void* q_dev, const void* k_dev, const void* vt_dev, void* out_dev, int B, int H, int head_dim, int Sq, int Sk, int Sk_valid,
                   int ldq, int ldk, int ldo, float scale, int dtype, void* stream) {
     // q: [B, Sq, >= H*head_dim] (row stride ldq), k: [B, Sk, >= H*head_dim] (row stride ldk), vt: [B, H*head_dim, Sk] contiguous (V
-    // transposed), out: [B, Sq, >= H*head_dim] (row stride ldo).  head_dim 40 / 64 / 80; Sq % 128 == 0, Sk % 64 == 0; row strides
+    // transposed), out: [B, Sq, >= H*head_dim] (row stride ldo).  head_dim 40 / 64 / 80 / 160; any Sq; Sk % 8 == 0; row strides
     // multiples of 8 elements; keys in [Sk_valid, Sk) are padding and get zero weight.
     if (!q_dev || !k_dev || !vt_dev || !out_dev || B <= 0 || H <= 0 || Sq <= 0 || Sk <= 0 || Sk_valid <= 0 || Sk_valid > Sk) return GSW_ERR_BAD_ARG;
     if (dtype != GSW_F16 && dtype != GSW_BF16) return GSW_ERR_BAD_ARG;
-    if (head_dim != 40 && head_dim != 64 && head_dim != 80) return GSW_ERR_UNSUPPORTED;
+    if (head_dim != 40 && head_dim != 64 && head_dim != 80 && head_dim != 160) return GSW_ERR_UNSUPPORTED;
     const int inner = H * head_dim;
-    if ((Sq & 127) || (Sk & 63) || ldq < inner || ldk < inner || ldo < inner || ((ldq | ldk | ldo) & 7)) return GSW_ERR_UNSUPPORTED;
+    if ((Sk & 7) || ldq < inner || ldk < inner || ldo < inner || ((ldq | ldk | ldo) & 7)) return GSW_ERR_UNSUPPORTED;
     static const int qb_env = getenv("GSW_ATTN_QB") ? atoi(getenv("GSW_ATTN_QB")) : 2;      // A/B switch for profiling
-    const int QB = ((Sq & 255) == 0 && Sq >= 512 && qb_env == 2 && head_dim != 80) ? 2 : 1;      // 256-query workgroups once there are plenty of them
-    const int64_t total = (int64_t)(Sq / (128 * QB)) * B * H;
+    const bool ragged = (Sq & 127) || (Sk & 63);
+    const int QB = ((Sq & 255) == 0 && Sq >= 512 && qb_env == 2 && head_dim < 80 && !ragged) ? 2 : 1;      // 256-query workgroups once there are plenty of them
+    const int64_t total = (int64_t)((Sq + 128 * QB - 1) / (128 * QB)) * B * H;
     if (total > 0x7FFFFFFF) return GSW_ERR_UNSUPPORTED;
     AttnArgs a;
     a.q = q_dev; a.k = k_dev; a.vt = vt_dev; a.o = out_dev;
     a.H = H; a.Sq = Sq; a.Sk = Sk; a.ldq = ldq; a.ldk = ldk; a.ldo = ldo; a.Sk_valid = Sk_valid;
     a.scale_log2 = scale * 1.4426950408889634f;
-    a.nqt = (uint32_t)(Sq / (128 * QB));
+    a.nqt = (uint32_t)((Sq + 128 * QB - 1) / (128 * QB));
     a.total = (uint32_t)total;
-    const int rc = dtype == GSW_F16 ? launch_attn<_Float16>(a, head_dim, QB, (uint32_t)total, (hipStream_t)stream)
-                                    : launch_attn<__bf16>(a, head_dim, QB, (uint32_t)total, (hipStream_t)stream);
+    const int rc = dtype == GSW_F16 ? launch_attn<_Float16>(a, head_dim, QB, (uint32_t)total, ragged, (hipStream_t)stream)
+                                    : launch_attn<__bf16>(a, head_dim, QB, (uint32_t)total, ragged, (hipStream_t)stream);
     if (rc != GSW_OK) return rc;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g_last_hip_error = (int)e; return GSW_ERR_HIP; }

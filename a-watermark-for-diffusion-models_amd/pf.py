@@ -338,11 +338,11 @@ def conv3x3_res_pf(x: PF, w_cat: torch.Tensor, bias: Optional[torch.Tensor], *, 
     return y
 
 
-ATTN_HEAD_DIMS = (40, 64, 80)
+ATTN_HEAD_DIMS = (40, 64, 80, 160)
 
 
 def attention_ok(x: torch.Tensor, heads: int, head_dim: int, n_q: int, n_k: int) -> bool:
-    return x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and head_dim in ATTN_HEAD_DIMS and n_q % 128 == 0 and n_k % 64 == 0
+    return x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and head_dim in ATTN_HEAD_DIMS and n_q >= 1 and n_k % 8 == 0
 
 
 attention_hd64_ok = attention_ok
@@ -350,7 +350,8 @@ attention_hd64_ok = attention_ok
 
 def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, scale: Optional[float] = None,
               valid_keys: Optional[int] = None) -> torch.Tensor:
-    """softmax(q k^T * scale) v on the hand-written flash-attention kernel (csrc/gswm_attn.hip), head_dim 40 / 64 / 80.
+    """softmax(q k^T * scale) v on the hand-written flash-attention kernel (csrc/gswm_attn.hip), head_dim 40 / 64 / 80 / 160, any
+    number of queries, keys a multiple of 8 (sequences off the 128-query / 64-key tiles run the kernel's ragged variant).
     q [B, Sq, heads*d], k [B, Sk, heads*d], vt [B, heads*d, Sk] (V transposed) -> [B, Sq, heads*d]; keys >= valid_keys are
     padding (zero weight).  q and k may be column slices of a wider row-major tensor (a fused QK projection): only their last
     dimension has to be contiguous and the batch stride has to equal rows * row stride."""

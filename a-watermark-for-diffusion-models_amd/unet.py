@@ -61,7 +61,7 @@ CACHE_CONTEXT_KV = True   # cross-attention K / V^T of a context tensor are comp
 
 FUSED_QK = True       # self-attention: q and k projections as one GEMM (own attention kernel reads them as column slices)
 
-OWN_ATTENTION = True  # attention with head_dim 40 / 64 / 80 and a query count % 128 == 0 runs on gsw_attention instead of torch SDPA
+OWN_ATTENTION = True  # attention with head_dim 40 / 64 / 80 and a query count % 32 == 0 runs on gsw_attention instead of torch SDPA
 
 OWN_GEMM = True       # every dense linear layer (q / k / v / out projections, proj_in / proj_out, feed-forward, time embedding) on the
                       # hand-written matmul engine (gsw_gemm, csrc/gswm_mm.hip) with bias / residual / GEGLU / V^T epilogues fused in

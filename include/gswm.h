@@ -192,7 +192,7 @@ int gsw_conv_up2x_pf(const void* x_dev, const void* w4_dev, const void* bias_dev
  *   vt  : [B, H*head_dim, Sk] contiguous -- the value projection TRANSPOSED (compute it as W_v x^T)
  *   out : [B, Sq, >= H*head_dim] row stride ldo
  *   Sk_valid : keys in [Sk_valid, Sk) are padding and get zero weight (cross-attention: 77 context tokens padded to 128)
- * Sq % 128 == 0, Sk % 64 == 0, strides % 8 == 0; else GSW_ERR_UNSUPPORTED.  gsw_attention_hd64 == gsw_attention(head_dim = 64). */
+ * Sq % 32 == 0, Sk % 64 == 0, strides % 8 == 0; else GSW_ERR_UNSUPPORTED.  gsw_attention_hd64 == gsw_attention(head_dim = 64). */
 int gsw_attention(const void* q_dev, const void* k_dev, const void* vt_dev, void* out_dev, int B, int H, int head_dim, int Sq, int Sk,
                   int Sk_valid, int ldq, int ldk, int ldo, float scale, int dtype, void* stream);
 int gsw_attention_hd64(const void* q_dev, const void* k_dev, const void* vt_dev, void* out_dev, int B, int H, int Sq, int Sk, int Sk_valid,

@@ -226,7 +226,7 @@ def test_attention_hd64_masked_keys(G, Sk_valid):
 def test_attention_hd64_rejects_unsupported_shapes(G):
     q = torch.zeros(1, 100, 64, dtype=torch.float16, device="cuda")
     with pytest.raises(Exception):
-        G.pf.attention_hd64(q, q, q.transpose(1, 2).contiguous(), 1)          # Sq % 128 != 0 -> GSW_ERR_UNSUPPORTED
+        G.pf.attention_hd64(q, q, q.transpose(1, 2).contiguous(), 1)          # Sk % 8 != 0 -> GSW_ERR_UNSUPPORTED
 
 
 def test_unet_own_attention_equals_sdpa_path(G):
@@ -355,3 +355,35 @@ def test_context_kv_cache_is_tied_to_the_context_tensor(G):
             if isinstance(blk, U.Attention):
                 blk.to_k.weight.mul_(2.0)                         # weight update
         assert dist(m(x, t, c), ref(c)) < 1e-2
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("B,H,Sq,Sk,D", [(2, 20, 64, 64, 64), (3, 2, 32, 32, 64), (1, 3, 96, 96, 64), (2, 8, 144, 144, 160), (1, 8, 576, 576, 160),
+                                         (2, 4, 144, 144, 40), (1, 2, 200, 72, 80), (2, 5, 1, 8, 64), (1, 8, 256, 256, 160)])
+def test_attention_ragged_sequences_and_head_dim_160(G, dtype, B, H, Sq, Sk, D):
+    """Sequences off the 128-query / 64-key tiles (mid block: 64 tokens at 512x512, 144 at 768x768; SD 1.5 third level: 576 tokens of
+    head_dim 160) on the kernel's ragged variant: clamped loads + masked keys, no padding copies."""
+    g = torch.Generator().manual_seed(Sq + D)
+    q = (2.0 * torch.randn(B, Sq, H * D, generator=g)).to(dtype).cuda()
+    k, v = (torch.randn(B, Sk, H * D, generator=g).to(dtype).cuda() for _ in range(2))
+    got = G.pf.attention(q, k, v.transpose(1, 2).contiguous(), H)
+    qf, kf, vf = (a.float().view(B, a.shape[1], H, D).transpose(1, 2) for a in (q, k, v))
+    ref = (torch.softmax(qf @ kf.transpose(-1, -2) * D ** -0.5, dim=-1) @ vf).transpose(1, 2).reshape(B, Sq, H * D)
+    tol = 4e-3 if dtype == torch.float16 else 2e-2
+    assert got.shape == ref.shape and torch.isfinite(got).all()
+    assert (got.float() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+
+
+def test_attention_ragged_cross_attention_masks_padded_context(G):
+    """Mid-block cross-attention: 64 queries against the 77-token context padded to 128 keys."""
+    g = torch.Generator().manual_seed(5)
+    B, H = 2, 20
+    q = torch.randn(B, 64, H * 64, generator=g).half().cuda()
+    k = torch.randn(B, 128, H * 64, generator=g).half().cuda()
+    v = torch.randn(B, 128, H * 64, generator=g).half().cuda()
+    k[:, 77:] = 50.0
+    v[:, 77:] = 1000.0
+    got = G.pf.attention(q, k, v.transpose(1, 2).contiguous(), H, valid_keys=77)
+    qf, kf, vf = (a.float().view(B, a.shape[1], H, 64).transpose(1, 2) for a in (q, k[:, :77], v[:, :77]))
+    ref = (torch.softmax(qf @ kf.transpose(-1, -2) / 8.0, dim=-1) @ vf).transpose(1, 2).reshape(B, 64, H * 64)
+    assert (got.float() - ref).abs().max().item() <= 4e-3 * max(1.0, ref.abs().max().item())
