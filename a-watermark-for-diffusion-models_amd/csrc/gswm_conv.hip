@@ -21,6 +21,7 @@
 #include <stdlib.h>
 
 #include "../../include/gswm.h"
+#include "gswm_mm.h"
 
 typedef _Float16 gsw_h8 __attribute__((ext_vector_type(8)));
 typedef __bf16 gsw_b8 __attribute__((ext_vector_type(8)));
@@ -999,7 +1000,11 @@ extern __attribute__((visibility("hidden"))) thread_local int g_last_hip_error; 
 // Launch the halo kernel for a prepared ConvArgs: double-buffered weights when the LDS image (halo'd activation tile + 2 weight tiles)
 // fits two workgroups per CU (<= 80 KiB), single-buffered weights for wider rows (e.g. the 96-wide lattice of BASELINE config 5),
 // GSW_ERR_UNSUPPORTED beyond that.  GSW_CONV_WDB=0 forces the single-buffered variant (profiling A/B).
+static int launch_engine(const ConvArgs& a, int64_t M, int N, int dtype, void* stream);
+static bool use_engine(const ConvArgs& a, int N);
+
 static int launch_halo(const ConvArgs& a, int64_t M, int N, int dtype, void* stream) {
+    if (use_engine(a, N)) return launch_engine(a, M, N, dtype, stream);
     static const int wdb_env = getenv("GSW_CONV_WDB") ? atoi(getenv("GSW_CONV_WDB")) : 1;
     const int32_t HP = ((a.Wp + 1) + 7) & ~7;
     const size_t xbytes = (size_t)std::max(CW_BM + 2 * HP, 2 * CW_BM) * 128u, wbytes = (size_t)CW_BN * 128u;
@@ -1019,6 +1024,58 @@ static int launch_halo(const ConvArgs& a, int64_t M, int N, int dtype, void* str
 #undef GSW_HALO_LAUNCH
     GSW_CONV_HIP(hipGetLastError());
     return GSW_OK;
+}
+
+// The same convolution on the matmul engine (csrc/gswm_mm.hip): every tap is a row offset into the padded-flat activation, so the 3x3 (or
+// the 2x2 sub-pixel) convolution is a GEMM whose K dimension walks (channel block, tap row, tap) -- no halo tile, the activation slab of
+// each tap comes through L2.  GSW_CONV_ENGINE=1/0 is the A/B switch.
+// Zero the border rows of a padded-flat tensor [B, Hp, Wp, N] (row stride N): top and bottom rows, first and last column.
+__global__ __launch_bounds__(256) void gsw_pf_zero_border_kernel(uint16_t* __restrict__ y, int B, int Hp, int Wp, int n8) {
+    const int nb = 2 * Wp + 2 * (Hp - 2);
+    const int64_t total = (int64_t)B * nb * n8;
+    for (int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x; u < total; u += (int64_t)gridDim.x * 256) {
+        const int c8 = (int)(u % n8);
+        const int64_t t = u / n8;
+        const int j = (int)(t % nb), b = (int)(t / nb);
+        int row;
+        if (j < Wp) row = j;
+        else if (j < 2 * Wp) row = (Hp - 1) * Wp + (j - Wp);
+        else { const int k = j - 2 * Wp; row = (1 + (k >> 1)) * Wp + ((k & 1) ? Wp - 1 : 0); }
+        reinterpret_cast<uint4*>(y + ((int64_t)b * Hp * Wp + row) * (int64_t)n8 * 8)[c8] = make_uint4(0, 0, 0, 0);
+    }
+}
+
+static void zero_border(void* y, int B, int Hp, int Wp, int N, hipStream_t st) {
+    const int64_t total = (int64_t)B * (2 * Wp + 2 * (Hp - 2)) * (N / 8);
+    const uint32_t grid = (uint32_t)std::min<int64_t>((total + 255) / 256, 2048);
+    hipLaunchKernelGGL(gsw_pf_zero_border_kernel, dim3(grid), dim3(256), 0, st, (uint16_t*)y, B, Hp, Wp, N / 8);
+}
+
+static int launch_engine(const ConvArgs& a, int64_t M, int N, int dtype, void* stream) {
+    MMArgs m;
+    const int tw = a.ntaps == 9 ? 3 : a.ntaps == 4 ? 2 : 1;
+    m.seg[0] = MMSeg{a.x, a.ldx, a.C / 64, a.ntaps, tw, a.in_Wp, a.tap_off[0], 0};
+    m.seg[1] = MMSeg{a.x1 ? a.x1 : a.x, a.C1 ? a.C1 : a.ldx, a.C1 / 64, 1, 1, 0, 0, a.ntaps * a.C};
+    m.seg[2] = MMSeg{a.x2 ? a.x2 : a.x, a.C2 ? a.C2 : a.ldx, a.C2 / 64, 1, 1, 0, 0, a.ntaps * a.C + a.C1};
+    m.nseg = 1 + (a.C1 > 0) + (a.C2 > 0);
+    m.P = a.ntaps * (a.C / 64) + a.C1 / 64 + a.C2 / 64;
+    m.w = a.w; m.ldw = a.ntaps * a.C + a.C1 + a.C2;
+    // the M dimension enumerates interior pixels only (the padded border is 6 % of the rows at 64x64 and 56 % at 8x8); the border rows of
+    // the output are zeroed by a separate small kernel (the up2x caller does that once for its four parity launches)
+    const int B = (int)(M / ((int64_t)a.Hp * a.Wp));
+    m.M = B * (a.Hp - 2) * (a.Wp - 2); m.N = N;
+    m.flags = MM_FLAG_COMPACT;
+    m.bias = a.bias; m.rowbias = a.rowbias; m.resid = a.resid; m.y = a.y;
+    m.ldy = N; m.ldr = N;
+    m.mode = a.up ? MM_MODE_UP2X : MM_MODE_PF;
+    m.Hp = a.Hp; m.Wp = a.Wp; m.S = 1; m.Wimg = 1; m.up = a.up;
+    if (!a.up) zero_border(a.y, B, a.Hp, a.Wp, N, (hipStream_t)stream);
+    return gsw_mm_launch(m, dtype, stream);
+}
+
+static bool use_engine(const ConvArgs& a, int N) {
+    static const int env = getenv("GSW_CONV_ENGINE") ? atoi(getenv("GSW_CONV_ENGINE")) : 1;
+    return env && !a.dense && a.stride == 1 && (a.ntaps == 9 || a.ntaps == 4) && N % 160 == 0 && a.C % 64 == 0 && a.C1 % 64 == 0 && a.C2 % 64 == 0;
 }
 
 static bool halo_fits(int Wp) {
@@ -1059,6 +1116,7 @@ static int launch_conv_gemm(ConvArgs& a, int64_t M, int N, int dtype, void* stre
     static const bool narrow_only = getenv("GSW_CONV_NARROW") != nullptr;      // A/B switches for profiling
     static const int wm_env = getenv("GSW_CONV_WM") ? atoi(getenv("GSW_CONV_WM")) : 2;
     hipStream_t st = (hipStream_t)stream;
+    if (use_engine(a, N)) return launch_engine(a, M, N, dtype, stream);
     if (N % CW_BN == 0 && !narrow_only) {
         static const bool no_halo = getenv("GSW_CONV_NOHALO") != nullptr;
         if (!a.dense && a.ntaps == 9 && a.stride == 1 && !no_halo && halo_fits(a.Wp)) {
@@ -1168,8 +1226,7 @@ int gsw_conv_up2x_pf(const void* x_dev, const void* w4_dev, const void* bias_dev
     // output pixel (2i+dy, 2j+dx) only ever sees the 2x2 low-resolution neighbourhood (i+dy-1 .. i+dy, j+dx-1 .. j+dx), with the 3x3
     // weights summed over the taps that land on the same source pixel.  Four launches of the halo kernel (ntaps = 4, K = 4C), 2.25x
     // fewer FLOPs than convolving the upsampled tensor, and the upsampled tensor never exists.
-    //   x: PF [B, H, W, C];  w4: [4 (dy*2+dx)][N][4 (a*2+b)][C] pre-summed weights;  y: PF [B, 2H, 2W, N] -- only interior rows are
-    //   written: the caller provides zeroed border rows.
+    //   x: PF [B, H, W, C];  w4: [4 (dy*2+dx)][N][4 (a*2+b)][C] pre-summed weights;  y: PF [B, 2H, 2W, N] (border rows zeroed here).
     if (!x_dev || !w4_dev || !y_dev || B <= 0 || H <= 0 || W <= 0 || C <= 0 || N <= 0) return GSW_ERR_BAD_ARG;
     if (C % CV_BK || N % CW_BN) return GSW_ERR_UNSUPPORTED;
     if (dtype != GSW_F16 && dtype != GSW_BF16) return GSW_ERR_BAD_ARG;
@@ -1182,7 +1239,9 @@ int gsw_conv_up2x_pf(const void* x_dev, const void* w4_dev, const void* bias_dev
     a.M = (int32_t)M; a.ntaps = 4;
     a.dense = 0; a.geglu = 0; a.ldy = N;
     a.x1 = nullptr; a.x2 = nullptr; a.C1 = 0; a.C2 = 0;
-    if (!halo_fits(a.Wp)) return GSW_ERR_UNSUPPORTED;
+    a.stride = 1; a.dense = 0; a.up = 1;
+    if (!use_engine(a, N) && !halo_fits(a.Wp)) return GSW_ERR_UNSUPPORTED;
+    zero_border(y_dev, B, 2 * H + 2, 2 * W + 2, N, (hipStream_t)stream);
     const size_t esz = 2;
     for (int par = 0; par < 4; ++par) {
         const int dy = par >> 1, dx = par & 1;

@@ -15,7 +15,7 @@ struct MMSeg {
 };
 
 enum { MM_MODE_DENSE = 0, MM_MODE_PF = 1, MM_MODE_TOK2PF = 2, MM_MODE_UP2X = 3, MM_MODE_GEGLU = 4, MM_MODE_TRANS = 5 };
-enum { MM_FLAG_NONE = 0 };
+enum { MM_FLAG_NONE = 0, MM_FLAG_COMPACT = 1 };   // COMPACT (MM_MODE_PF / UP2X): M enumerates interior pixels, borders are not written
 
 struct MMArgs {
     MMSeg seg[3];
@@ -23,7 +23,7 @@ struct MMArgs {
     int32_t P;            // stages (K / 64 summed over segments and taps) per tile
     const void* w;        // [N][ldw]
     int32_t ldw;
-    int32_t M, N;
+    int32_t M, N;         // M: rows of the output row space (all padded-flat rows, or the interior pixels with MM_FLAG_COMPACT)
     int32_t tiles_n, ntiles;      // filled by gsw_mm_launch
     const void* bias;     // [N] or null
     const void* rowbias;  // [images][N] or null (MM_MODE_PF)
@@ -34,7 +34,7 @@ struct MMArgs {
     int32_t Hp, Wp;       // padded geometry of the output row space (PF / UP2X) or of the target PF tensor (TOK2PF)
     int32_t S, Wimg;      // tokens per image (TRANS, TOK2PF), image width (TOK2PF)
     int32_t up;           // UP2X: 1 + dy * 2 + dx
-    int32_t flags;        // filled by gsw_mm_launch
+    int32_t flags;        // MM_FLAG_*
 };
 
 int gsw_mm_launch(MMArgs& a, int dtype, void* stream);

@@ -162,6 +162,19 @@ __global__ __launch_bounds__(512, 2) void gsw_mm_kernel(const MMArgs p) {
     int32_t pr_arow[NPA], pr_wrow[NPW + 1];
     const T* pa[NPA];
     const T* pw[NPW + 1];
+    // MM_FLAG_COMPACT (convolutions): the M dimension enumerates INTERIOR pixels (b, y, x) only; the padded-flat row is computed per tile.
+    // The border rows of the output are not this kernel's business then (gsw_pf_zero_border writes them).
+    const bool compact = (p.flags & MM_FLAG_COMPACT) != 0;
+    const int32_t HpWp = p.Hp * p.Wp;
+    auto pf_row = [&](int32_t m, int32_t& b, int32_t& yy, int32_t& xx) -> int32_t {      // interior index -> (image, padded y, padded x), row
+        const int32_t Wi = p.Wp - 2, HW = (p.Hp - 2) * Wi;
+        b = m / HW;
+        const int32_t r = m - b * HW;
+        yy = r / Wi;
+        xx = r - yy * Wi + 1;
+        yy += 1;
+        return b * HpWp + yy * p.Wp + xx;
+    };
     auto setup_tile = [&](uint32_t it) {
         int32_t tm, tn;
         decode_tile(it * G + slotx, tm, tn);
@@ -169,7 +182,9 @@ __global__ __launch_bounds__(512, 2) void gsw_mm_kernel(const MMArgs p) {
 #pragma unroll
         for (int i = 0; i < NPA; ++i) {
             const int32_t m = m0 + 8 * (int32_t)(wave + 8u * i) + (int32_t)prow;
-            pr_arow[i] = m < p.M ? m : p.M - 1;
+            const int32_t mc = m < p.M ? m : p.M - 1;
+            int32_t b_, y_, x_;
+            pr_arow[i] = compact ? pf_row(mc, b_, y_, x_) : mc;
         }
 #pragma unroll
         for (int i = 0; i <= NPW; ++i) {
@@ -268,7 +283,6 @@ __global__ __launch_bounds__(512, 2) void gsw_mm_kernel(const MMArgs p) {
     const uint16_t* rowbias = reinterpret_cast<const uint16_t*>(p.rowbias);
     const uint16_t* resid = reinterpret_cast<const uint16_t*>(p.resid);
     uint16_t* Y = reinterpret_cast<uint16_t*>(p.y);
-    const int32_t HpWp = p.Hp * p.Wp;
     mm_f4 acc[5][4];
 #pragma unroll
     for (int a = 0; a < 5; ++a)
@@ -381,10 +395,16 @@ __global__ __launch_bounds__(512, 2) void gsw_mm_kernel(const MMArgs p) {
                 live[pr] = m < p.M; border[pr] = false; img_b[pr] = 0; orow[pr] = m;
                 const int32_t mc = live[pr] ? m : 0;
                 if (p.mode == MM_MODE_PF || p.mode == MM_MODE_UP2X) {
-                    const int32_t b = mc / HpWp, r = mc - b * HpWp;
-                    const int32_t yy = r / p.Wp, xx = r - yy * p.Wp;
+                    int32_t b, yy, xx;
+                    if (compact) {
+                        orow[pr] = pf_row(mc, b, yy, xx);
+                    } else {
+                        b = mc / HpWp;
+                        const int32_t r = mc - b * HpWp;
+                        yy = r / p.Wp; xx = r - yy * p.Wp;
+                        border[pr] = (yy == 0) | (yy == p.Hp - 1) | (xx == 0) | (xx == p.Wp - 1);
+                    }
                     img_b[pr] = b;
-                    border[pr] = (yy == 0) | (yy == p.Hp - 1) | (xx == 0) | (xx == p.Wp - 1);
                     if (p.mode == MM_MODE_UP2X) {             // low-resolution pixel (yy-1, xx-1) -> pixel (2(yy-1)+dy, 2(xx-1)+dx) of a [B, 2H+2, 2W+2] PF tensor
                         const int32_t dy = (p.up - 1) >> 1, dx = (p.up - 1) & 1;
                         orow[pr] = ((int64_t)b * (2 * p.Hp - 2) + (2 * (yy - 1) + dy + 1)) * (2 * p.Wp - 2) + (2 * (xx - 1) + dx + 1);
@@ -612,7 +632,6 @@ int gsw_mm_launch(MMArgs& a, int dtype, void* stream) {
     if (tiles_m * tiles_n > 0x7FFFFFFF) return GSW_ERR_UNSUPPORTED;
     a.tiles_n = (int32_t)tiles_n;
     a.ntiles = (int32_t)(tiles_m * tiles_n);
-    a.flags = 0;
     const uint32_t grid = (uint32_t)std::min<int64_t>(256, (a.ntiles + 7) / 8 * 8);
     const size_t ldsb = 3u * (size_t)(BM + BN) * 128u;        // the epilogue image lives in a ring slot
     hipStream_t st = (hipStream_t)stream;
@@ -637,7 +656,7 @@ int gsw_gemm(const void* x_dev, const void* w_dev, const void* bias_dev, const v
     a.M = (int32_t)M; a.N = N;
     a.bias = bias_dev; a.rowbias = nullptr; a.resid = resid_dev; a.y = y_dev;
     a.ldy = mode == GSW_GEMM_GEGLU ? N / 2 : N; a.ldr = N;
-    a.Hp = 1; a.Wp = 1; a.S = S > 0 ? S : 1; a.Wimg = Wimg > 0 ? Wimg : 1; a.up = 0;
+    a.Hp = 1; a.Wp = 1; a.S = S > 0 ? S : 1; a.Wimg = Wimg > 0 ? Wimg : 1; a.up = 0; a.flags = MM_FLAG_NONE;
     a.mode = MM_MODE_DENSE;
     if (mode == GSW_GEMM_GEGLU) a.mode = MM_MODE_GEGLU;
     else if (mode == GSW_GEMM_TRANS) a.mode = MM_MODE_TRANS;

@@ -7,6 +7,8 @@ from __future__ import annotations
 
 from typing import Optional
 
+import os
+
 import torch
 
 from . import _native as N
@@ -122,10 +124,17 @@ def _halo_lds_bytes(W: int) -> int:
     return max(128 + 2 * hp, 256) * 128 + 160 * 128        # single-buffered weights: what the widest supported rows need
 
 
+# 3x3 stride-1 convolutions with N % 160 == 0 run on the matmul engine (csrc/gswm_mm.hip) unless GSW_CONV_ENGINE=0 (the round-1 halo kernel,
+# kept for A/B profiling); the same switch is read by csrc/gswm_conv.hip
+CONV_ENGINE = os.environ.get("GSW_CONV_ENGINE", "1") != "0"
+
+
 def _conv_kernel_name(W: int, n_out: int, ksize: int, stride: int) -> str:
     """Which kernel launch_conv_gemm (csrc/gswm_conv.hip) selects -- for the timer's buckets only."""
     if n_out % 160:
         return "gsw_conv_gemm_kernel"
+    if ksize == 3 and stride == 1 and CONV_ENGINE:
+        return "gsw_mm_kernel(conv3x3)"
     if ksize == 3 and stride == 1 and _halo_lds_bytes(W) <= 80 * 1024:
         return "gsw_conv3x3_halo_kernel"
     return "gsw_conv_gemm_wide_kernel"
@@ -308,7 +317,7 @@ def groupnorm_pf2(x: PF, x2: Optional[PF], gamma: torch.Tensor, beta: torch.Tens
 
 def conv3x3_res_fusable(x: PF, n_out: int) -> bool:
     """The fused conv2 + shortcut kernel needs N % 160 == 0, C % 64 == 0 and a halo tile that fits LDS."""
-    return n_out % 160 == 0 and x.C % 64 == 0 and _halo_lds_bytes(x.W) <= 80 * 1024
+    return n_out % 160 == 0 and x.C % 64 == 0 and (CONV_ENGINE or _halo_lds_bytes(x.W) <= 80 * 1024)
 
 
 def conv3x3_res_pf(x: PF, w_cat: torch.Tensor, bias: Optional[torch.Tensor], *, rowbias: Optional[torch.Tensor] = None,
@@ -334,7 +343,8 @@ def conv3x3_res_pf(x: PF, w_cat: torch.Tensor, bias: Optional[torch.Tensor], *, 
                                            _dt(x.buf.dtype), _stream_ptr()))
         if tm is not None:
             k = 9 * x.C + (x1.C if x1 is not None else 0) + (x2.C if x2 is not None else 0)
-            tm.stop(e0, ("gsw_conv3x3_halo_kernel", x.B, x.H, x.W, k, Nn, 1) if tm.by_shape else "gsw_conv3x3_halo_kernel", 2.0 * x.B * x.H * x.W * Nn * k)
+            name = _conv_kernel_name(x.W, Nn, 3, 1)
+            tm.stop(e0, (name, x.B, x.H, x.W, k, Nn, 1) if tm.by_shape else name, 2.0 * x.B * x.H * x.W * Nn * k)
     return y
 
 
@@ -399,7 +409,7 @@ def pack_upsample_weight(w: torch.Tensor) -> torch.Tensor:
 
 
 def conv_up2x_fusable(x: PF, n_out: int) -> bool:
-    return n_out % 160 == 0 and x.C % 64 == 0 and _halo_lds_bytes(x.W) <= 80 * 1024
+    return n_out % 160 == 0 and x.C % 64 == 0 and (CONV_ENGINE or _halo_lds_bytes(x.W) <= 80 * 1024)
 
 
 def conv_up2x_pf(x: PF, w4: torch.Tensor, bias: Optional[torch.Tensor]) -> PF:
@@ -407,15 +417,14 @@ def conv_up2x_pf(x: PF, w4: torch.Tensor, bias: Optional[torch.Tensor]) -> PF:
     Nn = w4.shape[1]
     _same(w4, x.buf, "w4", 4 * Nn * 4 * x.C)
     _same(bias, x.buf, "bias", Nn)
-    y = PF.empty(x.B, 2 * x.H, 2 * x.W, Nn, x.buf.dtype, x.buf.device)
-    g = y.grid
-    g[:, 0].zero_(); g[:, -1].zero_(); g[:, :, 0].zero_(); g[:, :, -1].zero_()        # the kernel writes interior rows only
+    y = PF.empty(x.B, 2 * x.H, 2 * x.W, Nn, x.buf.dtype, x.buf.device)          # gsw_conv_up2x_pf zeroes the border rows itself
     tm = CONV_TIMER
     with torch.cuda.device(x.buf.device):
         e0 = tm.start() if tm is not None else None
         N.check(N.lib().gsw_conv_up2x_pf(x.rows.data_ptr(), w4.data_ptr(), bias.data_ptr() if bias is not None else None, y.rows.data_ptr(),
                                          x.B, x.H, x.W, x.C, Nn, _dt(x.buf.dtype), _stream_ptr()))
         if tm is not None:      # EXECUTED FLOPs (16 C MACs per output: four 2x2 convolutions); the 3x3-on-upsampled form it replaces is 2.25x that
-            tm.stop(e0, ("gsw_conv3x3_halo_kernel(up2x)", x.B, 2 * x.H, 2 * x.W, 4 * x.C, Nn, 1) if tm.by_shape else "gsw_conv3x3_halo_kernel(up2x)",
+            name = "gsw_mm_kernel(up2x)" if CONV_ENGINE else "gsw_conv3x3_halo_kernel(up2x)"
+            tm.stop(e0, (name, x.B, 2 * x.H, 2 * x.W, 4 * x.C, Nn, 1) if tm.by_shape else name,
                     2.0 * x.B * 4 * x.H * x.W * Nn * 4 * x.C, launches=4)
     return y
