@@ -398,6 +398,82 @@ int gsw_attention(const void* q_dev, const void* k_dev, const void* vt_dev, void
     return GSW_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Row softmax in place: x[r, 0:cols] <- softmax(scale * x[r, 0:cols]).  The single-head, 512-wide attention of the VAE mid block
+// (diffusers AutoencoderKL, reached from extract.py:41 `vae.encode` and the pipelines' decode_image) does not fit the flash kernel's
+// register budget, so it runs as two products on the matmul engine (S = Q K^T per image, O = P V) with this kernel in between.
+// One workgroup per row, three passes over the row (max, sum of exponentials, write); the row (<= 18 KiB at 768x768) stays in L2.
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void gsw_softmax_rows_kernel(T* __restrict__ x, int64_t ld, int32_t cols, float scale_log2) {
+    __shared__ float red[4];
+    T* row = x + (int64_t)blockIdx.x * ld;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const int32_t nv = cols >> 3;
+    auto load8 = [&](int32_t v, float (&f)[8]) {
+        const uint4 u = reinterpret_cast<const uint4*>(row)[v];
+        const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            T lo, hi;
+            const uint16_t a = (uint16_t)w[k], b = (uint16_t)(w[k] >> 16);
+            __builtin_memcpy(&lo, &a, 2); __builtin_memcpy(&hi, &b, 2);
+            f[2 * k] = (float)lo; f[2 * k + 1] = (float)hi;
+        }
+    };
+    auto wg_reduce = [&](float v, bool is_max) -> float {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const float t = __shfl_xor(v, o); v = is_max ? fmaxf(v, t) : v + t; }
+        __syncthreads();
+        if (lane == 0) red[wave] = v;
+        __syncthreads();
+        const float a = red[0], b = red[1], c = red[2], d = red[3];
+        return is_max ? fmaxf(fmaxf(a, b), fmaxf(c, d)) : (a + b) + (c + d);
+    };
+    float mx = -INFINITY;
+    for (int32_t v = tid; v < nv; v += 256) {
+        float f[8];
+        load8(v, f);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) mx = fmaxf(mx, f[k]);
+    }
+    mx = wg_reduce(mx, true) * scale_log2;
+    float sum = 0.f;
+    for (int32_t v = tid; v < nv; v += 256) {
+        float f[8];
+        load8(v, f);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sum += __builtin_amdgcn_exp2f(fmaf(f[k], scale_log2, -mx));
+    }
+    const float inv = 1.0f / wg_reduce(sum, false);
+    for (int32_t v = tid; v < nv; v += 256) {
+        float f[8];
+        load8(v, f);
+        uint32_t w[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const T lo = (T)(__builtin_amdgcn_exp2f(fmaf(f[2 * k], scale_log2, -mx)) * inv), hi = (T)(__builtin_amdgcn_exp2f(fmaf(f[2 * k + 1], scale_log2, -mx)) * inv);
+            uint16_t a, b;
+            __builtin_memcpy(&a, &lo, 2); __builtin_memcpy(&b, &hi, 2);
+            w[k] = (uint32_t)a | ((uint32_t)b << 16);
+        }
+        reinterpret_cast<uint4*>(row)[v] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+int gsw_softmax_rows(void* x_dev, int64_t rows, int cols, int64_t ld, float scale, int dtype, void* stream) {
+    if (!x_dev || rows < 0 || cols <= 0 || ld < cols) return GSW_ERR_BAD_ARG;
+    if (dtype != GSW_F16 && dtype != GSW_BF16) return GSW_ERR_BAD_ARG;
+    if ((cols & 7) || (ld & 7) || rows > 0x7FFFFFFF) return GSW_ERR_UNSUPPORTED;
+    if (rows == 0) return GSW_OK;
+    const float sl2 = scale * 1.4426950408889634f;
+    if (dtype == GSW_F16) hipLaunchKernelGGL(gsw_softmax_rows_kernel<_Float16>, dim3((uint32_t)rows), dim3(256), 0, (hipStream_t)stream, (_Float16*)x_dev, ld, cols, sl2);
+    else hipLaunchKernelGGL(gsw_softmax_rows_kernel<__bf16>, dim3((uint32_t)rows), dim3(256), 0, (hipStream_t)stream, (__bf16*)x_dev, ld, cols, sl2);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { g_last_hip_error = (int)e; return GSW_ERR_HIP; }
+    return GSW_OK;
+}
+
 int gsw_attention_hd64(const void* q_dev, const void* k_dev, const void* vt_dev, void* out_dev, int B, int H, int Sq, int Sk, int Sk_valid, int ldq,
                        int ldk, int ldo, float scale, int dtype, void* stream) {
     return gsw_attention(q_dev, k_dev, vt_dev, out_dev, B, H, 64, Sq, Sk, Sk_valid, ldq, ldk, ldo, scale, dtype, stream);

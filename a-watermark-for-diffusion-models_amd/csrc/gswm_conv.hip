@@ -1075,7 +1075,10 @@ static int launch_engine(const ConvArgs& a, int64_t M, int N, int dtype, void* s
 
 static bool use_engine(const ConvArgs& a, int N) {
     static const int env = getenv("GSW_CONV_ENGINE") ? atoi(getenv("GSW_CONV_ENGINE")) : 1;
-    return env && !a.dense && a.stride == 1 && (a.ntaps == 9 || a.ntaps == 4) && N % 160 == 0 && a.C % 64 == 0 && a.C1 % 64 == 0 && a.C2 % 64 == 0;
+    // N: any multiple of 8 from 128 up (a partial last 160-column tile costs a full one: 128 / 256 / 512 channels of the VAE run at 80 %);
+    // narrower outputs (the 4-channel edge padded to 64) stay on the 64-column kernel
+    return env && !a.dense && a.stride == 1 && (a.ntaps == 9 || a.ntaps == 4 || a.ntaps == 1) && N % 8 == 0 && N >= 128 && a.C % 64 == 0 && a.C1 % 64 == 0 &&
+           a.C2 % 64 == 0;
 }
 
 static bool halo_fits(int Wp) {

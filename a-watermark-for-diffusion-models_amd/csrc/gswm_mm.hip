@@ -327,7 +327,8 @@ __global__ __launch_bounds__(512, 2) void gsw_mm_kernel(const MMArgs p) {
 #pragma unroll
         for (int in = 0; in < 5; ++in) {
             bq_raw[in] = make_uint2(0, 0);
-            if (!SWAP && bias) bq_raw[in] = *reinterpret_cast<const uint2*>(bias + n0 + (int32_t)(grp * HC + (uint32_t)in * 16u + q * 4u));
+            const int32_t nb = n0 + (int32_t)(grp * HC + (uint32_t)in * 16u + q * 4u);       // N % 8 == 0: a 4-column group is inside N or outside
+            if (!SWAP && bias && nb < p.N) bq_raw[in] = *reinterpret_cast<const uint2*>(bias + nb);
         }
         auto bias4 = [&](int in, float (&bq)[4]) {
             bq[0] = MM<T>::up((uint16_t)bq_raw[in].x); bq[1] = MM<T>::up((uint16_t)(bq_raw[in].x >> 16));
@@ -360,7 +361,10 @@ __global__ __launch_bounds__(512, 2) void gsw_mm_kernel(const MMArgs p) {
 #pragma unroll
                 for (int in = 0; in < 5; ++in)
 #pragma unroll
-                    for (int pr = 0; pr < 2; ++pr) rs[in][pr] = *reinterpret_cast<const uint4*>(rrow[pr] + in * 16);
+                    for (int pr = 0; pr < 2; ++pr) {
+                        rs[in][pr] = make_uint4(0, 0, 0, 0);
+                        if (colb + in * 16 < p.N) rs[in][pr] = *reinterpret_cast<const uint4*>(rrow[pr] + in * 16);
+                    }
             }
 #pragma unroll
             for (int in = 0; in < 5; ++in) {
@@ -381,7 +385,7 @@ __global__ __launch_bounds__(512, 2) void gsw_mm_kernel(const MMArgs p) {
                             w4[k] = MM<T>::cvt2(MM<T>::up((uint16_t)w4[k]) + MM<T>::up((uint16_t)rsw[k]),
                                                 MM<T>::up((uint16_t)(w4[k] >> 16)) + MM<T>::up((uint16_t)(rsw[k] >> 16)));
                     }
-                    if (live[pr]) *reinterpret_cast<uint4*>(yrow[pr] + in * 16) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+                    if (live[pr] && colb + in * 16 < p.N) *reinterpret_cast<uint4*>(yrow[pr] + in * 16) = make_uint4(w4[0], w4[1], w4[2], w4[3]);      // the last N tile may be partial
                 }
             }
         } else if (EPI == 1) {
@@ -429,7 +433,7 @@ __global__ __launch_bounds__(512, 2) void gsw_mm_kernel(const MMArgs p) {
                     pack4(acc[in][2 * pr + 1], bq, b0, b1);
                     swap16(a0, b0);
                     swap16(a1, b1);
-                    if (!live[pr]) continue;
+                    if (!live[pr] || col >= p.N) continue;
                     uint32_t w4[4] = {a0, a1, b0, b1};
                     if (border[pr]) { w4[0] = w4[1] = w4[2] = w4[3] = 0u; }
                     else if (rowbias || resid) {
@@ -504,7 +508,8 @@ __global__ __launch_bounds__(512, 2) void gsw_mm_kernel(const MMArgs p) {
 #pragma unroll
             for (int in = 0; in < 5; ++in) {
                 const int32_t nrow = n0 + (int32_t)(grp * HC + (uint32_t)in * 16u + li);
-                const float bv = bias ? MM<T>::up(bias[nrow]) : 0.f;
+                const bool nok = nrow < p.N;
+                const float bv = bias && nok ? MM<T>::up(bias[nrow]) : 0.f;
                 const float bq[4] = {bv, bv, bv, bv};
 #pragma unroll
                 for (int pr = 0; pr < 2; ++pr) {
@@ -514,7 +519,7 @@ __global__ __launch_bounds__(512, 2) void gsw_mm_kernel(const MMArgs p) {
                     swap16(a0, b0);
                     swap16(a1, b1);
                     const int32_t m = m0 + (int32_t)(wm * 64u + (uint32_t)(2 * pr + (int)(q & 1u)) * 16u + (q >> 1) * 8u);      // first of 8 consecutive tokens
-                    if (m >= p.M) continue;
+                    if (m >= p.M || !nok) continue;
                     const int32_t b = m / p.S, sidx = m - b * p.S;
                     *reinterpret_cast<uint4*>(Y + ((int64_t)b * p.N + nrow) * p.S + sidx) = make_uint4(a0, a1, b0, b1);
                 }
@@ -625,10 +630,10 @@ extern __attribute__((visibility("hidden"))) thread_local int g_last_hip_error; 
 // Launch the engine for a prepared MMArgs (segments, weights, epilogue); fills the tiling fields.
 int gsw_mm_launch(MMArgs& a, int dtype, void* stream) {
     if (dtype != GSW_F16 && dtype != GSW_BF16) return GSW_ERR_BAD_ARG;
-    if (a.N % 160 || a.M <= 0 || a.P <= 0) return GSW_ERR_UNSUPPORTED;
-    const bool swap = a.mode == MM_MODE_TRANS;
+    // N: any multiple of 8 (the last 160-column tile may be partial: weight rows are clamped, stores masked); GEGLU pairs columns inside a tile
+    if (a.N % 8 || (a.mode == MM_MODE_GEGLU && a.N % 160) || a.M <= 0 || a.P <= 0) return GSW_ERR_UNSUPPORTED;
     constexpr int BM = 256, BN = 160;
-    const int64_t tiles_m = ((int64_t)a.M + BM - 1) / BM, tiles_n = a.N / BN;
+    const int64_t tiles_m = ((int64_t)a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
     if (tiles_m * tiles_n > 0x7FFFFFFF) return GSW_ERR_UNSUPPORTED;
     a.tiles_n = (int32_t)tiles_n;
     a.ntiles = (int32_t)(tiles_m * tiles_n);
@@ -641,25 +646,34 @@ int gsw_mm_launch(MMArgs& a, int dtype, void* stream) {
     return GSW_OK;
 }
 
-int gsw_gemm(const void* x_dev, const void* w_dev, const void* bias_dev, const void* resid_dev, void* y_dev, int64_t M, int K, int N,
-             int mode, int S, int Wimg, int dtype, void* stream) {
+int gsw_gemm_strided(const void* x_dev, int64_t ldx, const void* w_dev, int64_t ldw, const void* bias_dev, const void* resid_dev, int64_t ldr,
+                     void* y_dev, int64_t ldy, int64_t M, int K, int N, int mode, int S, int Wimg, int dtype, void* stream) {
     if (!x_dev || !w_dev || !y_dev || M <= 0 || K <= 0 || N <= 0) return GSW_ERR_BAD_ARG;
     if (mode != GSW_GEMM_PLAIN && mode != GSW_GEMM_GEGLU && mode != GSW_GEMM_TRANS && mode != GSW_GEMM_TOK2PF) return GSW_ERR_BAD_ARG;
-    if (K % 64 || N % 160 || M > 0x7FFFFF00 || M * (int64_t)K >= ((int64_t)1 << 40) || (int64_t)N * K >= ((int64_t)1 << 31)) return GSW_ERR_UNSUPPORTED;
+    if (K % 64 || N % 8 || (mode == GSW_GEMM_GEGLU && N % 160) || M > 0x7FFFFF00 || ldx < K || ldw < K || (ldx & 7) || (ldw & 7) || (ldy & 7) || (ldr & 7)
+        || M * ldx >= ((int64_t)1 << 40) || (int64_t)N * ldw >= ((int64_t)1 << 31) || ldx >= ((int64_t)1 << 31) || ldy >= ((int64_t)1 << 31) || ldr >= ((int64_t)1 << 31))
+        return GSW_ERR_UNSUPPORTED;
     if (mode == GSW_GEMM_GEGLU && resid_dev) return GSW_ERR_UNSUPPORTED;
     if (mode == GSW_GEMM_TRANS && (resid_dev || S <= 0 || (S & 7) || M % S)) return GSW_ERR_UNSUPPORTED;
     if (mode == GSW_GEMM_TOK2PF && (S <= 0 || Wimg <= 0 || S % Wimg || M % S)) return GSW_ERR_BAD_ARG;
+    const int64_t ncols = mode == GSW_GEMM_GEGLU ? N / 2 : N;
+    if (mode != GSW_GEMM_TRANS && (ldy < ncols || (resid_dev && ldr < ncols))) return GSW_ERR_BAD_ARG;
     MMArgs a;
-    for (int i = 0; i < 3; ++i) a.seg[i] = MMSeg{x_dev, K, K / 64, 1, 1, 0, 0, 0};
+    for (int i = 0; i < 3; ++i) a.seg[i] = MMSeg{x_dev, (int32_t)ldx, K / 64, 1, 1, 0, 0, 0};
     a.nseg = 1; a.P = K / 64;
-    a.w = w_dev; a.ldw = K;
+    a.w = w_dev; a.ldw = (int32_t)ldw;
     a.M = (int32_t)M; a.N = N;
     a.bias = bias_dev; a.rowbias = nullptr; a.resid = resid_dev; a.y = y_dev;
-    a.ldy = mode == GSW_GEMM_GEGLU ? N / 2 : N; a.ldr = N;
+    a.ldy = (int32_t)ldy; a.ldr = (int32_t)ldr;
     a.Hp = 1; a.Wp = 1; a.S = S > 0 ? S : 1; a.Wimg = Wimg > 0 ? Wimg : 1; a.up = 0; a.flags = MM_FLAG_NONE;
     a.mode = MM_MODE_DENSE;
     if (mode == GSW_GEMM_GEGLU) a.mode = MM_MODE_GEGLU;
     else if (mode == GSW_GEMM_TRANS) a.mode = MM_MODE_TRANS;
     else if (mode == GSW_GEMM_TOK2PF) { a.mode = MM_MODE_TOK2PF; a.Wp = Wimg + 2; a.Hp = S / Wimg + 2; }
     return gsw_mm_launch(a, dtype, stream);
+}
+
+int gsw_gemm(const void* x_dev, const void* w_dev, const void* bias_dev, const void* resid_dev, void* y_dev, int64_t M, int K, int N,
+             int mode, int S, int Wimg, int dtype, void* stream) {
+    return gsw_gemm_strided(x_dev, K, w_dev, K, bias_dev, resid_dev, N, y_dev, mode == GSW_GEMM_GEGLU ? N / 2 : N, M, K, N, mode, S, Wimg, dtype, stream);
 }

@@ -131,10 +131,10 @@ CONV_ENGINE = os.environ.get("GSW_CONV_ENGINE", "1") != "0"
 
 def _conv_kernel_name(W: int, n_out: int, ksize: int, stride: int) -> str:
     """Which kernel launch_conv_gemm (csrc/gswm_conv.hip) selects -- for the timer's buckets only."""
+    if stride == 1 and CONV_ENGINE and n_out % 8 == 0 and n_out >= 128:
+        return "gsw_mm_kernel(conv3x3)" if ksize == 3 else "gsw_mm_kernel(conv1x1)"
     if n_out % 160:
         return "gsw_conv_gemm_kernel"
-    if ksize == 3 and stride == 1 and CONV_ENGINE:
-        return "gsw_mm_kernel(conv3x3)"
     if ksize == 3 and stride == 1 and _halo_lds_bytes(W) <= 80 * 1024:
         return "gsw_conv3x3_halo_kernel"
     return "gsw_conv_gemm_wide_kernel"
@@ -177,6 +177,65 @@ def conv_pf(x: PF, w_packed: torch.Tensor, bias: Optional[torch.Tensor], *, ksiz
             name = _conv_kernel_name(Wo, Nn, ksize, stride)
             tm.stop(e0, (name, x.B, Ho, Wo, ksize * ksize * C, Nn, stride) if tm.by_shape else name, 2.0 * x.B * Ho * Wo * Nn * ksize * ksize * C)
     return y
+
+
+def _rows2d(t: torch.Tensor, like: torch.Tensor, name: str):
+    """A 2-D operand that may be a column slice of a wider matrix: unit stride along the row, row stride a multiple of 8, 16-byte aligned."""
+    if t.dim() != 2 or not t.is_cuda or t.device != like.device or t.dtype != like.dtype:
+        raise ValueError(f"{name} must be a 2-D {like.dtype} tensor on {like.device}")
+    if t.stride(1) != 1 or t.stride(0) % 8 or t.stride(0) < t.shape[1] or t.data_ptr() % 16:
+        raise ValueError(f"{name}: rows must be contiguous, 16-byte aligned and a multiple of 8 elements apart")
+    return t.stride(0)
+
+
+def gemm_strided(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[M, N] = x[M, K] @ w[N, K]^T (+ bias) on the matmul engine, every operand addressed through its own row stride (column slices of
+    wider matrices are fine).  K % 64 == 0, N % 8 == 0."""
+    if x.dtype not in (torch.float16, torch.bfloat16):
+        raise ValueError(f"gemm_strided: fp16 / bf16 only (got {x.dtype})")
+    ldx, ldw, ldy = _rows2d(x, x, "x"), _rows2d(w, x, "w"), _rows2d(out, x, "out")
+    M, K = x.shape
+    Nn = w.shape[0]
+    if w.shape[1] != K or tuple(out.shape) != (M, Nn):
+        raise ValueError("gemm_strided: shapes do not chain")
+    _same(bias, x, "bias", Nn)
+    tm = CONV_TIMER
+    with torch.cuda.device(x.device):
+        e0 = tm.start() if tm is not None else None
+        N.check(N.lib().gsw_gemm_strided(x.data_ptr(), ldx, w.data_ptr(), ldw, bias.data_ptr() if bias is not None else None, None, ldy,
+                                         out.data_ptr(), ldy, M, K, Nn, 0, 0, 0, _dt(x.dtype), _stream_ptr()))
+        if tm is not None:
+            tm.stop(e0, ("gsw_mm_kernel", M, K, Nn, "plain") if tm.by_shape else "gsw_mm_kernel", 2.0 * M * K * Nn)
+    return out
+
+
+def softmax_rows_(x: torch.Tensor, scale: float) -> torch.Tensor:
+    """In place: every row of the 2-D tensor x becomes softmax(scale * row) (gsw_softmax_rows)."""
+    ld = _rows2d(x, x, "x")
+    with torch.cuda.device(x.device):
+        N.check(N.lib().gsw_softmax_rows(x.data_ptr(), x.shape[0], x.shape[1], ld, float(scale), _dt(x.dtype), _stream_ptr()))
+    return x
+
+
+def attention_single_head(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor) -> torch.Tensor:
+    """softmax(q k^T / sqrt(d)) v for ONE head of any width d % 64 == 0 (the VAE mid block: d = 512), as two matmul-engine products per image
+    with the row softmax kernel in between.  q, k: [B, S, d] (column slices of a fused projection are fine), vt: [B, d, S] (V transposed,
+    what gemm(mode="trans") produces) -> [B, S, d].  S % 8 == 0; when S is not a multiple of 64 (the second product's K dimension) the key
+    axis is zero-padded: zero probabilities times zero values."""
+    B, S, d = q.shape
+    if k.shape != (B, S, d) or vt.shape != (B, d, S) or d % 64 or S % 8:
+        raise ValueError("attention_single_head: q, k [B, S, d], vt [B, d, S], d % 64 == 0, S % 8 == 0")
+    Sp = (S + 63) // 64 * 64
+    out = torch.empty((B, S, d), dtype=q.dtype, device=q.device)
+    scores = torch.empty((S, Sp), dtype=q.dtype, device=q.device)         # one image at a time: S x S fp16 (32 MiB at 512x512) is reused
+    if Sp != S:
+        scores[:, S:].zero_()
+        vt = torch.cat([vt, vt.new_zeros(B, d, Sp - S)], dim=2)
+    for b in range(B):
+        gemm_strided(q[b], k[b], scores[:, :S])
+        softmax_rows_(scores[:, :S], d ** -0.5)
+        gemm_strided(scores, vt[b], out[b])
+    return out
 
 
 _GN_WS = {}

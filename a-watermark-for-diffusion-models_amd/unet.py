@@ -70,6 +70,9 @@ FALLBACKS = {}        # (reason -> count) of GPU half-precision calls that left 
 
 
 def _note_fallback(why: str):
+    if why not in FALLBACKS:       # loud, once per reason: a GPU run that leaves the hand-written kernels should never be silent
+        import warnings
+        warnings.warn("gswm unet: " + why, RuntimeWarning, stacklevel=3)
     FALLBACKS[why] = FALLBACKS.get(why, 0) + 1
 
 
@@ -492,6 +495,8 @@ class UNet2DCondition(nn.Module):
         temb = F.silu(temb)                      # every resnet applies SiLU to the same embedding: do it once
         if self._pf_ok(x):
             return self._forward_pf(x, temb, ctx)
+        if USE_PF and FUSED_KERNELS and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16):
+            _note_fallback(f"UNet forward on {tuple(x.shape)}: off the padded-flat path (conv channels % 64, lattice % {1 << (len(self.down_blocks) - 1)}): plain torch modules")
         h = self.conv_in(x)
         skips = [h]
         for blk in self.down_blocks:

@@ -23,6 +23,17 @@ SCALING_FACTOR = 0.18215  # extract.py:42
 # hand-written MFMA implicit GEMM with bias and residual fused in its epilogue, GroupNorm+SiLU the PF kernels; plain torch ops
 # remain for CPU / fp32 tensors.
 USE_PF = True
+FALLBACKS = {}        # (reason -> count) of GPU half-precision calls that ran the plain-torch module path instead of the hand-written kernels
+
+
+def _fell_off(what: str, x: torch.Tensor) -> None:
+    """A half-precision device tensor is about to run the plain-torch path (MIOpen / hipBLASLt / aotriton): say so, once per reason."""
+    if USE_PF and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16):
+        why = f"{what}: input {tuple(x.shape)} is off the padded-flat path (H, W multiples of 8; channel counts multiples of 64)"
+        if why not in FALLBACKS:
+            import warnings
+            warnings.warn("gswm vae: " + why + " -- running the plain torch modules", RuntimeWarning, stacklevel=3)
+        FALLBACKS[why] = FALLBACKS.get(why, 0) + 1
 
 
 def _pw(conv: nn.Conv2d, cin_pad: int = 0, cout_pad: int = 0):
@@ -109,10 +120,20 @@ class VaeAttention(nn.Module):
         return x + self.to_out[0](o).transpose(1, 2).reshape(b, c, h, w)
 
     def forward_pf(self, x):
+        from .pf import attention_single_head, cached, gemm
         y = _gn_pf(x, self.group_norm, act=False, tokens=True)          # GroupNorm writes dense tokens [B, H*W, C]
-        q, k, v = self.to_q(y)[:, None], self.to_k(y)[:, None], self.to_v(y)[:, None]
-        o = F.scaled_dot_product_attention(q, k, v)[:, 0]
-        x.interior.add_(self.to_out[0](o).view(x.B, x.H, x.W, x.C))
+        C, S = x.C, x.H * x.W
+        if C % 64 or S % 8:
+            raise RuntimeError(f"VaeAttention: {C} channels x {S} tokens is off the hand-written path (channels % 64, tokens % 8)")
+        # q | k from one GEMM over the tokens, V^T from a transposing GEMM, softmax(q k^T) v per image on the matmul engine, and the output
+        # projection + residual written straight into the PF tensor's interior rows
+        wqk, bqk = cached(self, "_gsw_wqk", (self.to_q.weight, self.to_k.weight, self.to_q.bias, self.to_k.bias),
+                          lambda: (torch.cat([self.to_q.weight.detach(), self.to_k.weight.detach()]).contiguous(),
+                                   torch.cat([self.to_q.bias.detach(), self.to_k.bias.detach()]).contiguous()))
+        qk = gemm(y, wqk, bqk)
+        vt = gemm(y, self.to_v.weight.detach(), self.to_v.bias.detach(), mode="trans", tokens=S)
+        o = attention_single_head(qk[..., :C], qk[..., C:], vt)
+        gemm(o, self.to_out[0].weight.detach(), self.to_out[0].bias.detach(), resid=x.rows, mode="tok2pf", tokens=S, width=x.W, out=x.rows)
         return x
 
 
@@ -206,6 +227,7 @@ class Encoder(nn.Module):
     def forward(self, x):
         if _pf_ok(x) and self._pf_shapes_ok():
             return self.forward_pf(x)
+        _fell_off("Encoder", x)
         x = self.conv_in(x)
         for b in self.down_blocks:
             x = b(x)
@@ -237,6 +259,7 @@ class Decoder(nn.Module):
     def forward(self, z):
         if _pf_ok(z) and self._pf_shapes_ok():
             return self.forward_pf(z)
+        _fell_off("Decoder", z)
         x = self.mid_block(self.conv_in(z))
         for b in self.up_blocks:
             x = b(x)

@@ -156,14 +156,15 @@ int gsw_conv3x3_res_pf(const void* x_dev, const void* w_dev, const void* bias_de
 int gsw_add_layernorm(const void* x_dev, const void* delta_dev, const void* gamma_dev, const void* beta_dev, void* xnew_dev, void* y_dev,
                       int64_t rows, int C, float eps, int dtype, void* stream);
 
-/* Round-1 name of the dense linear layer: gsw_gemm(mode = geglu ? GSW_GEMM_GEGLU : GSW_GEMM_PLAIN).  K % 64 == 0, N % 160 == 0. */
+/* Round-1 name of the dense linear layer: gsw_gemm(mode = geglu ? GSW_GEMM_GEGLU : GSW_GEMM_PLAIN). */
 int gsw_linear(const void* x_dev, const void* w_dev, const void* bias_dev, const void* resid_dev, void* y_dev, int64_t M, int K, int N,
                int geglu, int dtype, void* stream);
 
 /* X2 / G1 -- every dense linear layer of the eps model (diffusers BasicTransformerBlock / Transformer2DModel / TimestepEmbedding /
  * ResnetBlock2D.time_emb_proj, which the reference reaches through `pipe(...)` at extract.py:66-69) on the hand-written matmul engine
- * (csrc/gswm_mm.hip: persistent 256 x 160 / 128 x 320 tiles, 4-stage LDS-DMA ring, two wave groups in ping-pong on each SIMD):
- *   x: [M, K] row-major, w: [N, K] (nn.Linear layout), bias: [N] or NULL; K % 32 == 0, N % 160 == 0; GSW_F16 / GSW_BF16.
+ * (csrc/gswm_mm.hip: persistent 256 x 160 tiles, 8 waves in lockstep, three-stage LDS-DMA ring of 64-wide K slices):
+ *   x: [M, K] row-major, w: [N, K] (nn.Linear layout), bias: [N] or NULL; K % 64 == 0, N % 8 == 0 (N % 160 == 0 for GEGLU; a partial last
+ *   160-column tile costs a full one); GSW_F16 / GSW_BF16.
  *   mode GSW_GEMM_PLAIN : y[M, N] = x w^T + bias (+ resid[M, N])
  *        GSW_GEMM_GEGLU : rows of w / bias interleaved per 160-wide tile as [80 value | 80 gate] (pf.pack_geglu_weight);
  *                         y[M, N/2] = value * gelu(gate) -- diffusers' GEGLU without the [M, N] intermediate
@@ -177,22 +178,31 @@ int gsw_linear(const void* x_dev, const void* w_dev, const void* bias_dev, const
 #define GSW_GEMM_TOK2PF 3
 int gsw_gemm(const void* x_dev, const void* w_dev, const void* bias_dev, const void* resid_dev, void* y_dev, int64_t M, int K, int N,
              int mode, int S, int Wimg, int dtype, void* stream);
+/* The same with explicit row strides (elements, multiples of 8): x rows ldx >= K, w rows ldw >= K, resid rows ldr, y rows ldy -- operands may be
+ * column slices of wider matrices (the per-image Q K^T and P V products of the VAE's single-head attention). */
+int gsw_gemm_strided(const void* x_dev, int64_t ldx, const void* w_dev, int64_t ldw, const void* bias_dev, const void* resid_dev, int64_t ldr,
+                     void* y_dev, int64_t ldy, int64_t M, int K, int N, int mode, int S, int Wimg, int dtype, void* stream);
+
+/* X1 / G1 tail -- diffusers AutoencoderKL mid-block attention (one head as wide as the block, 512): softmax over the rows of the score matrix
+ * between the two engine products.  In place: x[r, 0:cols] <- softmax(scale * x[r, 0:cols]); rows `ld` elements apart; cols % 8 == 0. */
+int gsw_softmax_rows(void* x_dev, int64_t rows, int cols, int64_t ld, float scale, int dtype, void* stream);
 
 /* diffusers Upsample2D (nearest 2x + 3x3 convolution) from the low-resolution PF input, by sub-pixel decomposition: w4 =
  * [4 output parities (dy*2+dx)][N][4 taps (a*2+b)][C], the 3x3 weights pre-summed over the taps that read the same source pixel
- * (pf.pack_upsample_weight).  y: PF [B, 2H, 2W, N] whose border rows the caller has zeroed; only interior rows are written. */
+ * (pf.pack_upsample_weight).  y: PF [B, 2H, 2W, N] (interior rows from the four parity launches, border rows zeroed here). */
 int gsw_conv_up2x_pf(const void* x_dev, const void* w4_dev, const void* bias_dev, void* y_dev, int B, int H, int W, int C, int N, int dtype,
                      void* stream);
 
 /* Attention of the eps-model (diffusers BasicTransformerBlock.attn1 / attn2 inside the UNet the reference runs at extract.py:66-69):
  * out = softmax(q k^T * scale) v per (batch, head), fp16 / bf16, fp32 accumulation -- a flash-attention forward.
- *   head_dim : 64 (SD 2.x), 40 or 80 (SD 1.x levels with 8 heads); other widths return GSW_ERR_UNSUPPORTED
+ *   head_dim : 64 (SD 2.x), 40 / 80 / 160 (SD 1.x levels with 8 heads); other widths return GSW_ERR_UNSUPPORTED
  *   q   : [B, Sq, >= H*head_dim] row stride ldq elements, head h in columns [h*head_dim, (h+1)*head_dim)
  *   k   : [B, Sk, >= H*head_dim] row stride ldk
  *   vt  : [B, H*head_dim, Sk] contiguous -- the value projection TRANSPOSED (compute it as W_v x^T)
  *   out : [B, Sq, >= H*head_dim] row stride ldo
  *   Sk_valid : keys in [Sk_valid, Sk) are padding and get zero weight (cross-attention: 77 context tokens padded to 128)
- * Sq % 32 == 0, Sk % 64 == 0, strides % 8 == 0; else GSW_ERR_UNSUPPORTED.  gsw_attention_hd64 == gsw_attention(head_dim = 64). */
+ * Any Sq; Sk % 8 == 0; strides % 8 == 0; else GSW_ERR_UNSUPPORTED (sequences off the 128-query / 64-key tiles run a variant with clamped
+ * loads and masked keys).  gsw_attention_hd64 == gsw_attention(head_dim = 64). */
 int gsw_attention(const void* q_dev, const void* k_dev, const void* vt_dev, void* out_dev, int B, int H, int head_dim, int Sq, int Sk,
                   int Sk_valid, int ldq, int ldk, int ldo, float scale, int dtype, void* stream);
 int gsw_attention_hd64(const void* q_dev, const void* k_dev, const void* vt_dev, void* out_dev, int B, int H, int Sq, int Sk, int Sk_valid,

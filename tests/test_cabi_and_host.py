@@ -169,8 +169,7 @@ def test_argument_validation_of_eps_model_and_image_entry_points():
     # attention: null operand, head width, tile divisibility, strides
     assert lib.gsw_attention(None, p, p, p, 1, 5, 64, 256, 256, 256, 320, 320, 320, 0.125, 1, None) == BAD
     assert lib.gsw_attention(p, p, p, p, 1, 5, 48, 256, 256, 256, 240, 240, 240, 0.125, 1, None) == UNS          # head_dim 48
-    assert lib.gsw_attention(p, p, p, p, 1, 5, 64, 200, 256, 256, 320, 320, 320, 0.125, 1, None) == UNS          # Sq % 128
-    assert lib.gsw_attention(p, p, p, p, 1, 5, 64, 256, 100, 77, 320, 320, 320, 0.125, 1, None) == UNS           # Sk % 64
+    assert lib.gsw_attention(p, p, p, p, 1, 5, 64, 256, 100, 77, 320, 320, 320, 0.125, 1, None) == UNS           # Sk % 8
     assert lib.gsw_attention(p, p, p, p, 1, 5, 64, 256, 128, 129, 320, 320, 320, 0.125, 1, None) == BAD          # valid keys > keys
     assert lib.gsw_attention(p, p, p, p, 1, 5, 64, 256, 128, 77, 316, 320, 320, 0.125, 1, None) == UNS           # row stride < H * d
     assert lib.gsw_attention(p, p, p, p, 1, 5, 64, 256, 128, 77, 320, 320, 320, 0.125, 0, None) == BAD           # fp32
@@ -180,7 +179,16 @@ def test_argument_validation_of_eps_model_and_image_entry_points():
     assert lib.gsw_conv3x3_res_pf(p, p, None, None, None, p, 1, 8, 8, 64, 64, p, 64, None, 0, 1, None) == UNS    # N % 160
     assert lib.gsw_conv_up2x_pf(p, p, None, p, 1, 8, 8, 64, 64, 1, None) == UNS                                  # N % 160
     assert lib.gsw_conv_up2x_pf(None, p, None, p, 1, 8, 8, 64, 160, 1, None) == BAD
-    assert lib.gsw_conv_up2x_pf(p, p, None, p, 1, 8, 400, 64, 160, 1, None) == UNS                               # halo tile beyond LDS
+    # the matmul engine and the row softmax
+    assert lib.gsw_gemm_strided(p, 60, p, 64, None, None, 160, p, 160, 4, 64, 160, 0, 0, 0, 1, None) == UNS      # ldx < K
+    assert lib.gsw_gemm_strided(p, 64, p, 64, None, None, 160, p, 160, 4, 64, 164, 0, 0, 0, 1, None) == UNS      # N % 8
+    assert lib.gsw_gemm_strided(p, 64, p, 64, None, None, 160, p, 80, 4, 64, 168, 1, 0, 0, 1, None) == UNS       # GEGLU needs N % 160
+    assert lib.gsw_gemm_strided(p, 64, p, 64, None, None, 160, p, 100, 4, 64, 160, 0, 0, 0, 1, None) == UNS      # ldy % 8
+    assert lib.gsw_gemm_strided(p, 64, p, 64, None, None, 160, p, 96, 4, 64, 160, 0, 0, 0, 1, None) == BAD       # ldy < N
+    assert lib.gsw_gemm(None, p, None, None, p, 4, 64, 160, 0, 0, 0, 1, None) == BAD
+    assert lib.gsw_softmax_rows(p, 4, 100, 104, 1.0, 1, None) == UNS                                             # cols % 8
+    assert lib.gsw_softmax_rows(p, 4, 128, 64, 1.0, 1, None) == BAD                                              # ld < cols
+    assert lib.gsw_softmax_rows(p, 0, 128, 128, 1.0, 1, None) == N.GSW_OK
     assert lib.gsw_add_layernorm(p, None, p, p, None, p, 4, 1544, 1e-5, 1, None) == UNS                          # C > 1536
     assert lib.gsw_add_layernorm(p, p, p, p, None, p, 4, 320, 1e-5, 1, None) == BAD                              # delta without x_new
     # image stages

@@ -111,3 +111,64 @@ def test_gemm_rejects_bad_operands(P):
         P.gemm(torch.randn(64, 100).half().cuda(), torch.randn(320, 100).half().cuda(), None)    # K % 64
     with pytest.raises(Exception):
         P.gemm(x, torch.randn(100, 320).half().cuda(), None)                                     # N % 160
+
+
+# ---- N that is not a multiple of the 160-column tile (VAE: 128 / 256 / 512 channels), strided operands, row softmax, single-head attention
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,K,N", [(300, 128, 8), (1000, 512, 512), (4096, 512, 1024), (777, 256, 136), (64, 64, 168)])
+def test_gemm_partial_last_column_tile(P, dtype, M, K, N):
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, K, generator=g).to(dtype).cuda()
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(dtype).cuda()
+    b = torch.randn(N, generator=g).to(dtype).cuda()
+    r = torch.randn(M, N, generator=g).to(dtype).cuda()
+    guard = torch.full((M, N + 24), 7.0, dtype=dtype, device="cuda")
+    y = P.gemm(x, w, b, resid=r)
+    ref = x.float() @ w.float().t() + b.float() + r.float()
+    tol = 4e-3 if dtype == torch.float16 else 3e-2
+    assert (y.float() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+    # a strided destination: nothing is written past column N
+    P.gemm_strided(x, w, guard[:, :N], b)
+    assert (guard[:, N:] == 7.0).all()
+    assert (guard[:, :N].float() - (ref - r.float())).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+    yt = P.gemm(x.view(1, M, K) if M % 8 == 0 else x[: M // 8 * 8].reshape(1, -1, K).contiguous(), w, b, mode="trans", tokens=M // 8 * 8)
+    reft = (x[: M // 8 * 8].float() @ w.float().t() + b.float()).t()
+    assert yt.shape == (1, N, M // 8 * 8) and (yt[0].float() - reft).abs().max().item() <= tol * max(1.0, reft.abs().max().item())
+
+
+def test_gemm_strided_column_slices(P):
+    g = torch.Generator().manual_seed(3)
+    wide = torch.randn(512, 1024, generator=g).half().cuda()            # [q | k] of a fused projection
+    q, k = wide[:, :512], wide[:, 512:]
+    out = torch.empty(512, 512, dtype=torch.float16, device="cuda")
+    P.gemm_strided(q, k, out)
+    ref = q.float() @ k.float().t()
+    assert (out.float() - ref).abs().max().item() <= 4e-3 * ref.abs().max().item()
+    with pytest.raises(Exception):
+        P.gemm_strided(wide[:, 1:513], k, out)                        # misaligned slice
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("rows,cols", [(7, 8), (300, 4096), (64, 9216), (5, 1000)])
+def test_softmax_rows(P, dtype, rows, cols):
+    g = torch.Generator().manual_seed(cols)
+    x = (4.0 * torch.randn(rows, cols + 8, generator=g)).to(dtype).cuda()
+    keep = x.clone()
+    v = x[:, :cols]
+    P.softmax_rows_(v, 0.37)
+    ref = torch.softmax(0.37 * keep[:, :cols].float(), dim=-1)
+    tol = 2e-3 if dtype == torch.float16 else 1.6e-2
+    assert (v.float() - ref).abs().max().item() <= tol * ref.max().item() + 1e-6
+    assert torch.equal(x[:, cols:], keep[:, cols:])                      # the row stride is respected: nothing past `cols` is touched
+    assert (v.float().sum(-1) - 1).abs().max().item() < 2e-2
+
+
+@pytest.mark.parametrize("B,S,d", [(2, 256, 512), (1, 1024, 128), (3, 64, 64), (2, 48, 128)])
+def test_attention_single_head_vs_fp32(P, B, S, d):
+    g = torch.Generator().manual_seed(S)
+    qk = torch.randn(B, S, 2 * d, generator=g).half().cuda()
+    v = torch.randn(B, S, d, generator=g).half().cuda()
+    o = P.attention_single_head(qk[..., :d], qk[..., d:], v.transpose(1, 2).contiguous())
+    qf, kf, vf = qk[..., :d].float(), qk[..., d:].float(), v.float()
+    ref = torch.softmax(qf @ kf.transpose(1, 2) * d ** -0.5, dim=-1) @ vf
+    assert (o.float() - ref).abs().max().item() <= 6e-3 * max(1.0, ref.abs().max().item())
