@@ -592,7 +592,13 @@ __global__ __launch_bounds__(512, 2) void gsw_mm_kernel(const MMArgs p) {
         pin_order();
         MM_STAMP(4);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef MM_ODD_BARRIER
         MM_BARRIER();
+#else
+        // no barrier here: the next even phase only writes the slot freed by the barrier above and only reads the stage that barrier
+        // published, so the waves of a SIMD are free to drift by up to one phase -- one's DMA / fragment reads under the other's MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         MM_STAMP(5);
         rd_slot = nx_slot;
     };
