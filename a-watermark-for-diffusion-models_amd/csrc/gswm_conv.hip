@@ -1068,7 +1068,7 @@ static int launch_engine(const ConvArgs& a, int64_t M, int N, int dtype, void* s
     m.bias = a.bias; m.rowbias = a.rowbias; m.resid = a.resid; m.y = a.y;
     m.ldy = N; m.ldr = N;
     m.mode = a.up ? MM_MODE_UP2X : MM_MODE_PF;
-    m.Hp = a.Hp; m.Wp = a.Wp; m.S = 1; m.Wimg = 1; m.up = a.up;
+    m.Hp = a.Hp; m.Wp = a.Wp; m.in_Hp = a.in_Hp; m.in_Wp = a.in_Wp; m.stride = a.stride; m.S = 1; m.Wimg = 1; m.up = a.up;
     if (!a.up) zero_border(a.y, B, a.Hp, a.Wp, N, (hipStream_t)stream);
     return gsw_mm_launch(m, dtype, stream);
 }
@@ -1077,8 +1077,8 @@ static bool use_engine(const ConvArgs& a, int N) {
     static const int env = getenv("GSW_CONV_ENGINE") ? atoi(getenv("GSW_CONV_ENGINE")) : 1;
     // N: any multiple of 8 from 128 up (a partial last 160-column tile costs a full one: 128 / 256 / 512 channels of the VAE run at 80 %);
     // narrower outputs (the 4-channel edge padded to 64) stay on the 64-column kernel
-    return env && !a.dense && a.stride == 1 && (a.ntaps == 9 || a.ntaps == 4 || a.ntaps == 1) && N % 8 == 0 && N >= 128 && a.C % 64 == 0 && a.C1 % 64 == 0 &&
-           a.C2 % 64 == 0;
+    if (a.stride == 2 && (a.ntaps != 9 || a.C1 || a.C2 || a.up)) return false;
+    return env && !a.dense && (a.ntaps == 9 || a.ntaps == 4 || a.ntaps == 1) && N % 8 == 0 && N >= 128 && a.C % 64 == 0 && a.C1 % 64 == 0 && a.C2 % 64 == 0;
 }
 
 static bool halo_fits(int Wp) {

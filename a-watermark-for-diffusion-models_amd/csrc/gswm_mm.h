@@ -32,6 +32,8 @@ struct MMArgs {
     int32_t ldy, ldr;
     int32_t mode;
     int32_t Hp, Wp;       // padded geometry of the output row space (PF / UP2X) or of the target PF tensor (TOK2PF)
+    int32_t in_Hp, in_Wp; // MM_FLAG_COMPACT: padded geometry of the INPUT tensor (== Hp, Wp unless stride 2)
+    int32_t stride;       // MM_FLAG_COMPACT: 1 or 2 -- output pixel (y, x) reads input rows around (stride y, stride x)
     int32_t S, Wimg;      // tokens per image (TRANS, TOK2PF), image width (TOK2PF)
     int32_t up;           // UP2X: 1 + dy * 2 + dx
     int32_t flags;        // MM_FLAG_*

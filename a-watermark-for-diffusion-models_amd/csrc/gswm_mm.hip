@@ -199,6 +199,8 @@ __global__ __launch_bounds__(512, 2) void gsw_mm_kernel(const MMArgs p) {
             const int32_t mc = m < p.M ? m : p.M - 1;
             int32_t b_, y_, x_;
             pr_arow[i] = compact ? pf_row(mc, b_, y_, x_) : mc;
+            // stride 2: the window of output pixel (y, x) starts at padded input coordinates (2 (y-1), 2 (x-1)); taps add kh * in_Wp + kw
+            if (compact && p.stride == 2) pr_arow[i] = b_ * (p.in_Hp * p.in_Wp) + 2 * (y_ - 1) * p.in_Wp + 2 * (x_ - 1);
         }
 #pragma unroll
         for (int i = 0; i <= NPW; ++i) {
@@ -685,7 +687,7 @@ int gsw_gemm_strided(const void* x_dev, int64_t ldx, const void* w_dev, int64_t 
     a.M = (int32_t)M; a.N = N;
     a.bias = bias_dev; a.rowbias = nullptr; a.resid = resid_dev; a.y = y_dev;
     a.ldy = (int32_t)ldy; a.ldr = (int32_t)ldr;
-    a.Hp = 1; a.Wp = 1; a.S = S > 0 ? S : 1; a.Wimg = Wimg > 0 ? Wimg : 1; a.up = 0; a.flags = MM_FLAG_NONE;
+    a.Hp = 1; a.Wp = 1; a.in_Hp = 1; a.in_Wp = 1; a.stride = 1; a.S = S > 0 ? S : 1; a.Wimg = Wimg > 0 ? Wimg : 1; a.up = 0; a.flags = MM_FLAG_NONE;
     a.mode = MM_MODE_DENSE;
     if (mode == GSW_GEMM_GEGLU) a.mode = MM_MODE_GEGLU;
     else if (mode == GSW_GEMM_TRANS) a.mode = MM_MODE_TRANS;

@@ -131,8 +131,8 @@ CONV_ENGINE = os.environ.get("GSW_CONV_ENGINE", "1") != "0"
 
 def _conv_kernel_name(W: int, n_out: int, ksize: int, stride: int) -> str:
     """Which kernel launch_conv_gemm (csrc/gswm_conv.hip) selects -- for the timer's buckets only."""
-    if stride == 1 and CONV_ENGINE and n_out % 8 == 0 and n_out >= 128:
-        return "gsw_mm_kernel(conv3x3)" if ksize == 3 else "gsw_mm_kernel(conv1x1)"
+    if CONV_ENGINE and n_out % 8 == 0 and n_out >= 128 and (stride == 1 or ksize == 3):
+        return ("gsw_mm_kernel(conv3x3)" if stride == 1 else "gsw_mm_kernel(conv3x3 s2)") if ksize == 3 else "gsw_mm_kernel(conv1x1)"
     if n_out % 160:
         return "gsw_conv_gemm_kernel"
     if ksize == 3 and stride == 1 and _halo_lds_bytes(W) <= 80 * 1024:
