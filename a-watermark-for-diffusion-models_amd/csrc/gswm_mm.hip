@@ -117,15 +117,19 @@ __device__ __forceinline__ float mm_erf(float x) {
     return copysignf(fmaf(-pl * t, e, 1.0f), x);
 }
 
-template <typename T, int EPI>
-__global__ __launch_bounds__(512, 2) void gsw_mm_kernel(const MMArgs p) {
+// SPLIT: 12 waves -- waves 0-7 only read fragments and multiply, waves 8-11 (one per SIMD) own ALL the LDS-DMA: a global_load_lds holds
+// its wave for 60-185 cycles at issue, which an in-order wave that also carries MFMAs cannot hide; a producer wave can stall all it likes.
+// Three waves per SIMD cap a wave at 168 registers.
+template <typename T, int EPI, bool SPLIT>
+__global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kernel(const MMArgs p) {
     constexpr bool SWAP = EPI == 3;
     constexpr int WM = 4;                            // waves along M; 2 groups of 4 waves along N
     constexpr int BM = 256, BN = 160;
-    constexpr int NPA = BM / 8 / 8;                  // A pieces (8 rows x 128 B = 1 KiB) per wave per stage: 4
-    constexpr int NPW = BN / 8 / 8;                  // full rounds of W pieces per wave: 2
-    constexpr int NEXTRA = BN / 8 - 8 * NPW;         // waves that issue one more W piece: 4
-    constexpr int NDMA = NPA + NPW;                  // pieces per stage of a wave without the extra one: 6
+    constexpr int NPROD = SPLIT ? 4 : 8;             // waves that issue DMA
+    constexpr int NPA = BM / 8 / NPROD;              // A pieces (8 rows x 128 B = 1 KiB) per producing wave per stage: 4 (8 with SPLIT)
+    constexpr int NPW = BN / 8 / NPROD;              // full rounds of W pieces per producing wave: 2 (5 with SPLIT)
+    constexpr int NEXTRA = BN / 8 - NPROD * NPW;     // waves that issue one more W piece: 4 (0 with SPLIT)
+    constexpr int NDMA = NPA + NPW;                  // pieces per stage of a wave without the extra one: 6 (13 with SPLIT)
     constexpr uint32_t STAGE = (uint32_t)(BM + BN) * 128u;     // one stage = 64 k-values of every tile row: 52 KiB
     constexpr uint32_t RING = 3u * STAGE;
     constexpr int HC = BN / 2;                       // columns owned by a group
@@ -135,9 +139,10 @@ __global__ __launch_bounds__(512, 2) void gsw_mm_kernel(const MMArgs p) {
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
-    const uint32_t grp = wave >> 2, wm = wave & 3u;
+    const uint32_t grp = (wave >> 2) & 1u, wm = wave & 3u;
     constexpr uint32_t wnl = 0u;
-    const bool extra = wave < (uint32_t)NEXTRA;
+    const uint32_t pid = SPLIT ? (wave & 3u) : wave;          // index among the producing waves (SPLIT: waves 8..11)
+    const bool extra = pid < (uint32_t)NEXTRA;
 
     // LDS rows are 128 B (64 k-values); 16-byte chunks are XOR-swizzled with (row >> 1) & 7.
     // fragment read of k-half h: row = lane & 15 of a 16-row block, logical chunk = 4h + (lane >> 4); (row >> 1) & 7 = (lane >> 1) & 7
@@ -147,7 +152,7 @@ __global__ __launch_bounds__(512, 2) void gsw_mm_kernel(const MMArgs p) {
     // DMA source: lane -> row lane >> 3 of an 8-row piece, physical chunk lane & 7 holds logical chunk (lane & 7) ^ ((row >> 1) & 7);
     // a wave's pieces are wave, wave + 8, ...: (row >> 1) & 7 = (4 (wave & 1) + (lane >> 4)) & 7
     const uint32_t prow = lane >> 3;
-    const uint32_t chunk8 = ((lane & 7u) ^ ((4u * (wave & 1u) + (lane >> 4)) & 7u)) * 8u;
+    const uint32_t chunk8 = ((lane & 7u) ^ ((4u * (pid & 1u) + (lane >> 4)) & 7u)) * 8u;
 
     // tile schedule: hardware block b runs on XCD b % 8; consecutive logical tiles (N tiles fastest) go to ONE XCD, so the
     // workgroups sharing an activation tile find it in that XCD's L2
@@ -195,7 +200,7 @@ __global__ __launch_bounds__(512, 2) void gsw_mm_kernel(const MMArgs p) {
         const int32_t m0 = tm * BM, n0 = tn * BN;
 #pragma unroll
         for (int i = 0; i < NPA; ++i) {
-            const int32_t m = m0 + 8 * (int32_t)(wave + 8u * i) + (int32_t)prow;
+            const int32_t m = m0 + 8 * (int32_t)(pid + (uint32_t)NPROD * i) + (int32_t)prow;
             const int32_t mc = m < p.M ? m : p.M - 1;
             int32_t b_, y_, x_;
             pr_arow[i] = compact ? pf_row(mc, b_, y_, x_) : mc;
@@ -204,7 +209,7 @@ __global__ __launch_bounds__(512, 2) void gsw_mm_kernel(const MMArgs p) {
         }
 #pragma unroll
         for (int i = 0; i <= NPW; ++i) {
-            const int32_t n = n0 + 8 * (int32_t)(wave + 8u * i) + (int32_t)prow;
+            const int32_t n = n0 + 8 * (int32_t)(pid + (uint32_t)NPROD * i) + (int32_t)prow;
             pr_wrow[i] = n < p.N ? n : p.N - 1;              // (only the unused extra piece of waves >= NEXTRA can exceed the tile)
         }
     };
@@ -263,18 +268,18 @@ __global__ __launch_bounds__(512, 2) void gsw_mm_kernel(const MMArgs p) {
     auto dma_extra = [&]() {                                 // the W piece only waves < NEXTRA carry (wave-uniform branch, kept out of the main block)
         if (extra) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pw[NPW],
-                                             (__attribute__((address_space(3))) void*)(lds + pr_slot + (uint32_t)BM * 128u + (wave + 8u * NPW) * 1024u), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(lds + pr_slot + (uint32_t)BM * 128u + (pid + (uint32_t)NPROD * NPW) * 1024u), 16, 0, 0);
             pw[NPW] += w_step;
         }
     };
     auto dma_piece_a = [&](int i) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pa[i],
-                                         (__attribute__((address_space(3))) void*)(lds + pr_slot + (wave + 8u * i) * 1024u), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)(lds + pr_slot + (pid + (uint32_t)NPROD * i) * 1024u), 16, 0, 0);
         pa[i] += a_step;
     };
     auto dma_piece_w = [&](int i) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pw[i],
-                                         (__attribute__((address_space(3))) void*)(lds + pr_slot + (uint32_t)BM * 128u + (wave + 8u * i) * 1024u), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)(lds + pr_slot + (uint32_t)BM * 128u + (pid + (uint32_t)NPROD * i) * 1024u), 16, 0, 0);
         pw[i] += w_step;
     };
     auto dma_h1 = [&]() { dma_piece_a(0); dma_piece_a(1); dma_piece_w(0); };
@@ -282,14 +287,44 @@ __global__ __launch_bounds__(512, 2) void gsw_mm_kernel(const MMArgs p) {
         dma_piece_a(2); dma_piece_a(3); dma_piece_w(1);
         pr_slot = pr_slot + STAGE == RING ? 0u : pr_slot + STAGE;
     };
-    static_assert(NPA == 4 && NPW == 2, "the half-stage split assumes 4 + 2 (+1) pieces per wave");
-    // prologue: stages 0 and 1 and the first half of stage 2; wait for stage 0 (counted: the newer pieces stay in flight; exact for waves
-    // without the extra piece, conservative for the others; any other VMEM operation in flight only makes a wait longer)
-    setup_tile(0);
-    begin_run();
-    for (int i = 0; i < 2; ++i) { dma_h1(); dma_extra(); dma_h2(); if (--pr_run == 0) end_run(); }
-    dma_h1();
-    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NDMA + 3) : "memory");
+    if constexpr (SPLIT) {
+        if (wave >= 8u) {
+            // ------------------------------------------------------------ producer wave: every stage, all 13 of its pieces back to back.
+            // Barrier k (k = 0 .. stages) is the consumers' "stage k is in LDS and the slot of stage k-1 is free": stage s+2 is issued after
+            // barrier s-1... i.e. right after the barrier that retired the slot's previous tenant, and stage s+1 has landed before barrier s.
+            auto dma_stage = [&]() {
+#pragma unroll
+                for (int i = 0; i < NPA; ++i) dma_piece_a(i);
+#pragma unroll
+                for (int i = 0; i < NPW; ++i) dma_piece_w(i);
+                pr_slot = pr_slot + STAGE == RING ? 0u : pr_slot + STAGE;
+                if (--pr_run == 0) end_run();
+            };
+            setup_tile(0);
+            begin_run();
+            dma_stage();
+            dma_stage();
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NDMA) : "memory");          // stage 0 has landed
+            MM_BARRIER();
+            const uint32_t total = nt_mine * (uint32_t)p.P;
+            for (uint32_t sidx = 0; sidx < total; ++sidx) {
+                dma_stage();                                                     // stage sidx + 2 (a cached dummy location once the work is issued)
+                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NDMA) : "memory");      // stage sidx + 1 has landed
+                MM_BARRIER();
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // nothing may land in LDS after the workgroup is gone
+            return;
+        }
+    } else {
+        static_assert(SPLIT || (NPA == 4 && NPW == 2), "the half-stage split assumes 4 + 2 (+1) pieces per wave");
+        // prologue: stages 0 and 1 and the first half of stage 2; wait for stage 0 (counted: the newer pieces stay in flight; exact for waves
+        // without the extra piece, conservative for the others; any other VMEM operation in flight only makes a wait longer)
+        setup_tile(0);
+        begin_run();
+        for (int i = 0; i < 2; ++i) { dma_h1(); dma_extra(); dma_h2(); if (--pr_run == 0) end_run(); }
+        dma_h1();
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NDMA + 3) : "memory");
+    }
     MM_BARRIER();
 
     // ---------------------------------------------------------------- consumer: a STEP = one stage = two phases of 32 k-values; every wave:
@@ -557,46 +592,57 @@ __global__ __launch_bounds__(512, 2) void gsw_mm_kernel(const MMArgs p) {
     };
     // issue order of a phase's main block: three DMA pieces, each behind three MFMAs, then the nine fragment reads one per MFMA
     auto pin_order = [&]() {
+        // (fragment reads in FRONT of the DMA pieces / at one per MFMA from the start of the phase was measured 3-9 % slower in both variants)
+        if constexpr (SPLIT) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);    // one LDS-DMA piece
-        }
+            for (int i = 0; i < 9; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // one fragment read per two MFMAs
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        } else {
 #pragma unroll
-        for (int i = 0; i < 9; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // one fragment read
+            for (int i = 0; i < 3; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);    // one LDS-DMA piece
+            }
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // one fragment read
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 20 - 9 - 9, 0);
         }
-        __builtin_amdgcn_sched_group_barrier(0x008, 20 - 9 - 9, 0);
     };
     // X holds the fragments of (stage s, k-half 0) on entry; Y is filled with (s, k-half 1), then X with (s+1, k-half 0)
     auto step = [&](frag (&xX)[4], frag (&wX)[5], frag (&xY)[4], frag (&wY)[5]) {
         const uint32_t nx_slot = rd_slot + STAGE == RING ? 0u : rd_slot + STAGE;
         // ---- even phase: second half of stage s+2 (its slot held stage s-1, whose last reads completed before the previous barrier)
         MM_STAMP(0);
-        dma_extra();
-        dma_h2();
+        if constexpr (!SPLIT) { dma_extra(); dma_h2(); }
         read_frags(xY, wY, rd_slot, 1u);
         mfma20(xX, wX);
         pin_order();
-        if (--pr_run == 0) end_run();
+        if constexpr (!SPLIT) { if (--pr_run == 0) end_run(); }
         MM_STAMP(1);
         // stage s+1 is read in the odd phase: everything but the newest stage (s+2, both halves) must have landed
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NDMA) : "memory");
+        if constexpr (!SPLIT) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NDMA) : "memory");
         MM_STAMP(2);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         MM_BARRIER();
         MM_STAMP(3);
         // ---- odd phase: first half of stage s+3, into the slot of stage s (its last reads completed before the barrier above)
-        dma_h1();
+        if constexpr (!SPLIT) dma_h1();
         read_frags(xX, wX, nx_slot, 0u);
         mfma20(xY, wY);
         pin_order();
         MM_STAMP(4);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #ifdef MM_ODD_BARRIER
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         MM_BARRIER();
 #else
+        // no lgkmcnt(0) either: the compiler's own counted waits let the next phase's first MFMAs start as soon as THEIR fragments are in,
+        // and the slot these reads come from is only released by the next barrier, which drains them
         // no barrier here: the next even phase only writes the slot freed by the barrier above and only reads the stage that barrier
         // published, so the waves of a SIMD are free to drift by up to one phase -- one's DMA / fragment reads under the other's MFMAs
         __builtin_amdgcn_sched_barrier(0);
@@ -626,13 +672,18 @@ __global__ __launch_bounds__(512, 2) void gsw_mm_kernel(const MMArgs p) {
 // host ---------------------------------------------------------------------------------------------
 template <typename T, int EPI>
 int mm_launch_t(const MMArgs& a, uint32_t grid, size_t ldsb, hipStream_t st) {
-    static bool attr_done = false;          // benign race: setting the attribute twice is harmless
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)gsw_mm_kernel<T, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    // GSW_MM_SPLIT: bit e set = epilogue kind e runs the 12-wave variant whose waves 8-11 own the LDS-DMA (A/B switch)
+    static const int split_mask = getenv("GSW_MM_SPLIT") ? atoi(getenv("GSW_MM_SPLIT")) : 10;      // default: convolutions (1) and the transposed projection (3)
+    const int split_env = (split_mask >> EPI) & 1;
+    static bool attr_done[2] = {false, false};          // benign race: setting the attribute twice is harmless
+    const void* fn = split_env ? (const void*)gsw_mm_kernel<T, EPI, true> : (const void*)gsw_mm_kernel<T, EPI, false>;
+    if (!attr_done[split_env ? 1 : 0]) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
-        attr_done = true;
+        attr_done[split_env ? 1 : 0] = true;
     }
-    hipLaunchKernelGGL((gsw_mm_kernel<T, EPI>), dim3(grid), dim3(512), ldsb, st, a);
+    if (split_env) hipLaunchKernelGGL((gsw_mm_kernel<T, EPI, true>), dim3(grid), dim3(768), ldsb, st, a);
+    else hipLaunchKernelGGL((gsw_mm_kernel<T, EPI, false>), dim3(grid), dim3(512), ldsb, st, a);
     return (int)hipGetLastError();
 }
 template <typename T>
