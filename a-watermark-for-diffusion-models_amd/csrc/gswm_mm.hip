@@ -119,7 +119,9 @@ __device__ __forceinline__ float mm_erf(float x) {
 
 // SPLIT: 12 waves -- waves 0-7 only read fragments and multiply, waves 8-11 (one per SIMD) own ALL the LDS-DMA: a global_load_lds holds
 // its wave for 60-185 cycles at issue, which an in-order wave that also carries MFMAs cannot hide; a producer wave can stall all it likes.
-// Three waves per SIMD cap a wave at 168 registers.
+// Three waves per SIMD cap a wave at 168 registers.  (Producers that stage through registers -- 13 global_load_dwordx4 kept in flight, then
+// ds_write_b128 with the swizzle on the LDS address -- were tried instead of LDS-DMA: 1022-1077 vs 1290-1358 TFLOP/s on the 3x3 shapes; the
+// ds_write traffic slows the multiplying waves' fragment reads and the load latency no longer hides.)
 template <typename T, int EPI, bool SPLIT>
 __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kernel(const MMArgs p) {
     constexpr bool SWAP = EPI == 3;
@@ -293,25 +295,47 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
             // Barrier k (k = 0 .. stages) is the consumers' "stage k is in LDS and the slot of stage k-1 is free": stage s+2 is issued after
             // barrier s-1... i.e. right after the barrier that retired the slot's previous tenant, and stage s+1 has landed before barrier s.
             auto dma_stage = [&]() {
+#ifndef MM_ABL_NOA                                             // (ablation builds of tools/ubench/mm_trace.hip: results wrong by design)
 #pragma unroll
                 for (int i = 0; i < NPA; ++i) dma_piece_a(i);
+#endif
+#ifndef MM_ABL_NOW
 #pragma unroll
                 for (int i = 0; i < NPW; ++i) dma_piece_w(i);
+#endif
                 pr_slot = pr_slot + STAGE == RING ? 0u : pr_slot + STAGE;
                 if (--pr_run == 0) end_run();
             };
+#if defined(MM_ABL_NOW) && defined(MM_ABL_NOA)
+            constexpr int NWAIT = 0;
+#elif defined(MM_ABL_NOW)
+            constexpr int NWAIT = NPA;
+#else
+            constexpr int NWAIT = NDMA;
+#endif
             setup_tile(0);
             begin_run();
             dma_stage();
             dma_stage();
-            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NDMA) : "memory");          // stage 0 has landed
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NWAIT) : "memory");         // stage 0 has landed
             MM_BARRIER();
             const uint32_t total = nt_mine * (uint32_t)p.P;
+#ifdef MM_TRACE
+            unsigned long long tr_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tr_last = __builtin_amdgcn_s_memtime();
+#endif
             for (uint32_t sidx = 0; sidx < total; ++sidx) {
                 dma_stage();                                                     // stage sidx + 2 (a cached dummy location once the work is issued)
-                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NDMA) : "memory");      // stage sidx + 1 has landed
+                MM_STAMP(0);
+                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NWAIT) : "memory");     // stage sidx + 1 has landed
+                MM_STAMP(1);
                 MM_BARRIER();
+                MM_STAMP(2);
             }
+#ifdef MM_TRACE
+            if (blockIdx.x == 0 && lane == 0) {
+                for (int k = 0; k < 16; ++k) g_mm_trace_buf[wave * 16 + k] = tr_acc[k];
+            }
+#endif
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // nothing may land in LDS after the workgroup is gone
             return;
         }
@@ -620,8 +644,12 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
         // ---- even phase: second half of stage s+2 (its slot held stage s-1, whose last reads completed before the previous barrier)
         MM_STAMP(0);
         if constexpr (!SPLIT) { dma_extra(); dma_h2(); }
+#ifndef MM_ABL_NOREADS
         read_frags(xY, wY, rd_slot, 1u);
+#endif
+#ifndef MM_ABL_NOMFMA
         mfma20(xX, wX);
+#endif
         pin_order();
         if constexpr (!SPLIT) { if (--pr_run == 0) end_run(); }
         MM_STAMP(1);
@@ -633,8 +661,12 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
         MM_STAMP(3);
         // ---- odd phase: first half of stage s+3, into the slot of stage s (its last reads completed before the barrier above)
         if constexpr (!SPLIT) dma_h1();
+#ifndef MM_ABL_NOREADS
         read_frags(xX, wX, nx_slot, 0u);
+#endif
+#ifndef MM_ABL_NOMFMA
         mfma20(xY, wY);
+#endif
         pin_order();
         MM_STAMP(4);
 #ifdef MM_ODD_BARRIER

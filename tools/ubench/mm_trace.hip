@@ -2,7 +2,7 @@
 // per step: even-phase issue block | vmcnt wait | barrier | odd-phase issue block | barrier  (shader cycles).
 // hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ubench/mm_trace.hip -o tools/ubench/bin/mm_trace
 #define MM_TRACE 1
-thread_local int g_last_hip_error = 0;
+__attribute__((visibility("hidden"))) thread_local int g_last_hip_error = 0;
 #include "../../a-watermark-for-diffusion-models_amd/csrc/gswm_mm.hip"
 #include <stdio.h>
 #include <vector>
@@ -18,7 +18,7 @@ int main(int argc, char** argv) {
     hipMemcpyToSymbol(HIP_SYMBOL(g_mm_trace_buf), &tb, sizeof(tb));
     for (int r = 0; r < 3; ++r) { int rc = gsw_gemm(x, w, nullptr, nullptr, y, M, K, N, 0, 0, 0, GSW_F16, nullptr); if (rc) { printf("rc %d\n", rc); return 1; } }
     hipDeviceSynchronize();
-    std::vector<unsigned long long> h(8 * 16);
+    std::vector<unsigned long long> h(12 * 16);
     hipMemcpy(h.data(), tb, h.size() * 8, hipMemcpyDeviceToHost);
     const int P = K / 64;
     const long tiles = ((M + 255) / 256) * (N / 160);
@@ -33,6 +33,10 @@ int main(int argc, char** argv) {
         const double nt = my_tiles * 3.0;
         printf("        epilogue parts per tile: entry %5.0f | put0 %5.0f | barrier %5.0f | store0 %5.0f | bar+put1+bar %5.0f | store1 %5.0f | exit %5.0f\n", t[8] / nt, t[9] / nt, t[10] / nt,
                t[11] / nt, t[12] / nt, t[13] / nt, (t[6] - 0.0) / nt);
+    }
+    for (int wv : {8, 11}) {                                  // SPLIT only: the producer waves' step = issue | wait for the previous stage to land | barrier
+        const unsigned long long* t = &h[wv * 16];
+        if (t[0]) printf("producer wave %d: issue %6.0f | vmcnt wait %6.0f | barrier wait %6.0f per stage\n", wv, t[0] / steps, t[1] / steps, t[2] / steps);
     }
     return 0;
 }
