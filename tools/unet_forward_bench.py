@@ -22,8 +22,11 @@ if len(sys.argv) > 2 and sys.argv[2] == "convs":      # per-shape table of the c
     torch.cuda.synchronize()
     pf.CONV_TIMER = None
     tot = sum(v["ms"] for v in tm.summary().values())
-    print(f"conv total {tot/3:.1f} ms per forward")
+    print(f"matmul-engine / convolution launches: {tot/3:.1f} ms per forward")
     for k, v in sorted(tm.summary().items(), key=lambda kv: -kv[1]["ms"]):
-        name, b, h, w, kk, n, st = k
-        pad = (h + 2) * (w + 2) / (h * w)
-        print(f"{name:28s} {h:3d}x{w:<3d} K={kk:6d} N={n:5d} s{st} calls/fwd={v['calls']//3:3d} avg={v['avg_us']:8.1f} us  {v['tflops']:7.1f} TFLOP/s (x{pad:.2f} padded = {v['tflops']*pad:7.1f})  {v['ms']/tot*100:5.1f} %")
+        if len(k) == 7:          # convolution: (kernel, B, H, W, K, N, stride)
+            name, b, h, w, kk, n, st = k
+            print(f"{name:28s} {h:3d}x{w:<3d} K={kk:6d} N={n:5d} s{st} calls/fwd={v['calls']//3:3d} avg={v['avg_us']:8.1f} us  {v['tflops']:7.1f} TFLOP/s  {v['ms']/tot*100:5.1f} %")
+        else:                    # linear: (kernel, M, K, N, mode)
+            name, m_, kk, n, mode = k
+            print(f"{name + ' ' + mode:28s} M={m_:7d} K={kk:6d} N={n:5d}    calls/fwd={v['calls']//3:3d} avg={v['avg_us']:8.1f} us  {v['tflops']:7.1f} TFLOP/s  {v['ms']/tot*100:5.1f} %")
