@@ -431,20 +431,26 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
                 yrow[pr] = Y + mm * p.ldy + colb;
                 rrow[pr] = resid ? resid + mm * p.ldr + colb : nullptr;
             }
+            // residual chunks are fetched RSD column blocks ahead of their use: all five up front on the 8-wave variant, two on the 12-wave one
+            // (168 registers: 80 accumulators + the next tile's 36 fragment registers are live here)
+            constexpr int RSD = SPLIT ? 2 : 5;
             uint4 rs[5][2];
-            if (resid) {                                      // all residual chunks in flight before the first is used
+            auto load_rs = [&](int in) {
 #pragma unroll
-                for (int in = 0; in < 5; ++in)
+                for (int pr = 0; pr < 2; ++pr) {
+                    rs[in][pr] = make_uint4(0, 0, 0, 0);
+                    if (colb + in * 16 < p.N) rs[in][pr] = *reinterpret_cast<const uint4*>(rrow[pr] + in * 16);
+                }
+            };
+            if (resid) {
 #pragma unroll
-                    for (int pr = 0; pr < 2; ++pr) {
-                        rs[in][pr] = make_uint4(0, 0, 0, 0);
-                        if (colb + in * 16 < p.N) rs[in][pr] = *reinterpret_cast<const uint4*>(rrow[pr] + in * 16);
-                    }
+                for (int in = 0; in < RSD; ++in) load_rs(in);
             }
 #pragma unroll
             for (int in = 0; in < 5; ++in) {
                 float bq[4];
                 bias4(in, bq);
+                if (resid && in + RSD < 5) load_rs(in + RSD);
 #pragma unroll
                 for (int pr = 0; pr < 2; ++pr) {
                     uint32_t a0, a1, b0, b1;

@@ -221,7 +221,7 @@ def run_e2e(args, rank, world, local_rank):
                                "other_kernels": {k: {kk: v[kk] for kk in ("calls", "avg_us", "tflops")} | {"step_time_fraction": v["ms"] * 1e-3 / dt_instr}
                                                  for k, v in cs.items() if k != name}}
         out["roofline_unet"] = {"bound": "mfma", "kernel": "UNet2DCondition forward, aggregate (every convolution, linear layer and attention on "
-                                "the hand-written MFMA kernels; per-kernel shares in profiles/r02_e2e_b64_kernel_stats.csv)",
+                                "the hand-written MFMA kernels; per-kernel shares in profiles/r02h_e2e_b64_kernel_stats.csv)",
                                 "achieved": sm["tflops"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": sm["tflops"] / MFMA_PEAK_TFLOPS,
                                 "traffic": None, "algorithmic_flops_per_launch": sm["flops_per_call_avg"], "avg_launch_us": sm["avg_ms"] * 1e3,
                                 "calls": sm["calls"], "unet_time_fraction": sm["total_ms"] * 1e-3 / dt_instr, "flops_per_image_forward": flops_row,
