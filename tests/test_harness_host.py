@@ -244,3 +244,18 @@ def test_recover_many_isolates_failures_per_image(tmp_path, monkeypatch):
     good = [os.path.basename(f) for f in job.files if not f.endswith("zz.png")]          # glob order is the file system's
     want = [4, 1, 1, 1, 1, 1] if "3.png" in good[:4] else [4, 1, 1]    # a batch that raises is redone singly; the other batch runs once
     assert calls == want
+
+
+def test_comfy_node_interface_matches_the_reference_workflow_names():
+    """nodes.py:209-252: node keys, display names, input names / types / defaults, outputs, categories -- what a saved workflow JSON refers to."""
+    from gswm_amd import comfy as C
+    assert set(C.NODE_CLASS_MAPPINGS) == {"Lthero_GSLatent", "Lthero_GS_KSamplerAdvanced"}
+    assert C.NODE_DISPLAY_NAME_MAPPINGS == {"Lthero_GSLatent": "GS Latent Noise", "Lthero_GS_KSamplerAdvanced": "GS KSamplerAdvanced"}
+    n = C.GSLatent
+    req = n.INPUT_TYPES()["required"]
+    assert list(req) == ["use_seed", "seed", "width", "height", "key", "nonce", "message", "message_length", "batch_size"]
+    assert req["message_length"] == ("INT", {"default": -1, "min": 32, "max": 1024, "step": 32}) and req["batch_size"][1]["max"] == 64
+    assert req["key"][1]["default"] == "5822ff9cce6772f714192f43863f6bad1bf54b78326973897e6b66c3186b77a7" and req["message"][1]["default"] == "lthero"
+    assert n.RETURN_TYPES == ("LATENT", "IMAGE") and n.FUNCTION == "create_gs_latents" and n.CATEGORY == "GSWatermark-lthero/latent/noise"
+    k = C.GSKSamplerAdvanced
+    assert k.RETURN_TYPES == ("LATENT",) and k.FUNCTION == "sample" and k.CATEGORY == "GSWatermark-lthero/sampling"
