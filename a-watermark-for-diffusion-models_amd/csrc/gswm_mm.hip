@@ -121,7 +121,9 @@ __device__ __forceinline__ float mm_erf(float x) {
 // its wave for 60-185 cycles at issue, which an in-order wave that also carries MFMAs cannot hide; a producer wave can stall all it likes.
 // Three waves per SIMD cap a wave at 168 registers.  (Producers that stage through registers -- 13 global_load_dwordx4 kept in flight, then
 // ds_write_b128 with the swizzle on the LDS address -- were tried instead of LDS-DMA: 1022-1077 vs 1290-1358 TFLOP/s on the 3x3 shapes; the
-// ds_write traffic slows the multiplying waves' fragment reads and the load latency no longer hides.)
+// ds_write traffic slows the multiplying waves' fragment reads and the load latency no longer hides.  Splitting the duty -- weight pieces issued by
+// the multiplying waves, activation pieces by the producers, so that all twelve waves issue -- was measured too: 1227-1268; any global_load_lds in a
+// multiplying wave's stream costs more than the relief it gives the producers.)
 template <typename T, int EPI, bool SPLIT>
 __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kernel(const MMArgs p) {
     constexpr bool SWAP = EPI == 3;
@@ -135,14 +137,12 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
     constexpr uint32_t STAGE = (uint32_t)(BM + BN) * 128u;     // one stage = 64 k-values of every tile row: 52 KiB
     constexpr uint32_t RING = 3u * STAGE;
     constexpr int HC = BN / 2;                       // columns owned by a group
-    constexpr uint32_t PITCH = SWAP ? (uint32_t)BM * 2u + 8u : (uint32_t)HC * 2u + 8u;
     typedef typename MM<T>::frag frag;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const uint32_t grp = (wave >> 2) & 1u, wm = wave & 3u;
-    constexpr uint32_t wnl = 0u;
     const uint32_t pid = SPLIT ? (wave & 3u) : wave;          // index among the producing waves (SPLIT: waves 8..11)
     const bool extra = pid < (uint32_t)NEXTRA;
 

@@ -18,7 +18,8 @@ def G():
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("B,C,N,H,W,k,stride", [(2, 64, 64, 8, 8, 3, 1), (3, 128, 64, 10, 6, 3, 1), (2, 64, 128, 8, 12, 1, 1), (2, 64, 64, 8, 16, 3, 2),
                                                  (1, 320, 320, 32, 32, 3, 1), (5, 192, 64, 7, 9, 3, 1), (2, 128, 192, 16, 16, 3, 2),
-                                                 (1, 64, 320, 6, 96, 3, 1), (1, 64, 320, 4, 170, 3, 1), (1, 64, 320, 4, 200, 3, 1)])
+                                                 (1, 64, 320, 6, 96, 3, 1), (1, 64, 320, 4, 170, 3, 1), (1, 64, 320, 4, 200, 3, 1),
+                                                 (3, 64, 512, 12, 20, 3, 1), (2, 128, 320, 10, 6, 3, 2), (1, 256, 256, 24, 8, 1, 1), (5, 64, 136, 6, 6, 3, 1)])
 def test_conv_pf_vs_torch_fp32(G, dtype, B, C, N, H, W, k, stride):
     g = torch.Generator().manual_seed(C + N + H)
     x = torch.randn(B, C, H, W, generator=g).to(dtype).cuda()
