@@ -50,6 +50,17 @@ class GaussianShadingPipeline:
         ctx = self.ctx_uncond.expand(x0.shape[0], -1, -1) if self.ctx_uncond.shape[0] == 1 else self.ctx_uncond
         return ddim_invert(self.eps_model, x0, ctx, self.schedule)
 
+    def txt2img(self, ctx_text: torch.Tensor, vae, *, latents: Optional[torch.Tensor] = None, seed: int = 0, image_index0: int = 0,
+                guidance_scale: float = 7.5):
+        """The call of the reference's generation pipeline (`ModifiedStableDiffusionPipeline.__call__` of modified_stable_diffusion_gs.pyc:
+        `prepare_latents(latents=Z_s_T)`, keep a copy as `init_latents`, CFG sampling loop, `decode_latents`) with its return order:
+        (images [B,3,H,W] in [0,1], has_nsfw_concept = None (no safety checker here), init_latents).  latents=None embeds a fresh Z_s_T batch
+        the size of ctx_text."""
+        z_T = self.embed(ctx_text.shape[0], seed=seed, image_index0=image_index0) if latents is None else latents.to(self.device, self.dtype)
+        init_latents = z_T.clone()
+        x0 = self.generate(z_T, ctx_text, guidance_scale)
+        return decode_images(x0, vae), None, init_latents
+
     def roundtrip(self, batch: int, ctx_text: torch.Tensor, *, seed: int = 0, image_index0: int = 0, guidance_scale: float = 7.5):
         z_T = self.embed(batch, seed=seed, image_index0=image_index0)
         x0 = self.generate(z_T, ctx_text, guidance_scale)

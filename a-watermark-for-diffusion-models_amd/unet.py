@@ -495,8 +495,8 @@ class UNet2DCondition(nn.Module):
         temb = F.silu(temb)                      # every resnet applies SiLU to the same embedding: do it once
         if self._pf_ok(x):
             return self._forward_pf(x, temb, ctx)
-        if USE_PF and FUSED_KERNELS and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16):
-            _note_fallback(f"UNet forward on {tuple(x.shape)}: off the padded-flat path (conv channels % 64, lattice % {1 << (len(self.down_blocks) - 1)}): plain torch modules")
+        if USE_PF and FUSED_KERNELS and x.is_cuda:
+            _note_fallback(f"UNet forward on {tuple(x.shape)} {x.dtype}: off the padded-flat path (fp16 / bf16, conv channels % 64, lattice % {1 << (len(self.down_blocks) - 1)}): plain torch modules")
         h = self.conv_in(x)
         skips = [h]
         for blk in self.down_blocks:

@@ -28,8 +28,8 @@ FALLBACKS = {}        # (reason -> count) of GPU half-precision calls that ran t
 
 def _fell_off(what: str, x: torch.Tensor) -> None:
     """A half-precision device tensor is about to run the plain-torch path (MIOpen / hipBLASLt / aotriton): say so, once per reason."""
-    if USE_PF and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16):
-        why = f"{what}: input {tuple(x.shape)} is off the padded-flat path (H, W multiples of 8; channel counts multiples of 64)"
+    if USE_PF and x.is_cuda:
+        why = f"{what}: input {tuple(x.shape)} {x.dtype} is off the padded-flat path (fp16 / bf16; H, W multiples of 8; channel counts multiples of 64)"
         if why not in FALLBACKS:
             import warnings
             warnings.warn("gswm vae: " + why + " -- running the plain torch modules", RuntimeWarning, stacklevel=3)

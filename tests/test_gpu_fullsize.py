@@ -63,6 +63,9 @@ def test_config2_txt2img_batch8_50_steps_embed_only(G, sd21, vae, keys):
     x0 = pipe.generate(zT, ct, 7.5)
     assert x0.shape == (8, 4, 64, 64) and torch.isfinite(x0).all()
     img = G.pipeline.decode_images(x0, vae)
+    img2, nsfw, init = pipe.txt2img(ct, vae, latents=zT)                                       # the reference pipeline's call: (images, nsfw, init_latents)
+    assert nsfw is None and torch.equal(init, zT) and img2.shape == img.shape
+    assert (img2.float() - img.float()).abs().max().item() <= 2e-2                             # same path twice
     assert img.shape == (8, 3, 512, 512) and torch.isfinite(img).all() and 0 <= img.min() and img.max() <= 1
     u8 = G.imaging.tensor_to_image(img)
     assert u8.dtype == torch.uint8 and u8.shape == (8, 512, 512, 3)
