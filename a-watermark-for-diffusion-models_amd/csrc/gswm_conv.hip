@@ -1093,7 +1093,7 @@ int gsw_conv_pf(const void* x_dev, const void* w_dev, const void* bias_dev, cons
     // H, W: OUTPUT spatial size; input spatial size is (H*stride, W*stride)
     if (!x_dev || !w_dev || !y_dev || B <= 0 || H <= 0 || W <= 0 || C <= 0 || N <= 0) return GSW_ERR_BAD_ARG;
     if ((ksize != 1 && ksize != 3) || (stride != 1 && stride != 2) || (ksize == 1 && stride != 1)) return GSW_ERR_BAD_ARG;
-    if (C % CV_BK || N % CV_BN || ldx < C || (ldx & 7)) return GSW_ERR_UNSUPPORTED;
+    if (C % CV_BK || N % 8 || ldx < C || (ldx & 7)) return GSW_ERR_UNSUPPORTED;
     if (dtype != GSW_F16 && dtype != GSW_BF16) return GSW_ERR_BAD_ARG;
     ConvArgs a;
     a.x = x_dev; a.w = w_dev; a.bias = bias_dev; a.rowbias = rowbias_dev; a.resid = resid_dev; a.y = y_dev;
@@ -1112,6 +1112,7 @@ int gsw_conv_pf(const void* x_dev, const void* w_dev, const void* bias_dev, cons
     }
     a.dense = 0; a.geglu = 0; a.ldy = N;
     a.x1 = nullptr; a.x2 = nullptr; a.C1 = 0; a.C2 = 0; a.up = 0;
+    if (N % CV_BN && !use_engine(a, N)) return GSW_ERR_UNSUPPORTED;      // the round-1 kernels tile N by 64; the engine takes any N % 8 from 128 up
     return launch_conv_gemm(a, M, N, dtype, stream);
 }
 

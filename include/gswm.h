@@ -132,7 +132,9 @@ int gsw_geglu(const void* in_dev, void* out_dev, int64_t rows, int inner, int dt
  *              rows before row 0 and after the last row (x_dev points at row 0).
  *   y[m, n] = sum_taps sum_c x[row(m) + off_tap, c] * w[n, tap*C + c] + bias[n] + rowbias[b(m), n] + resid[m, n]; border rows = 0
  *   w_dev: [N][ksize*ksize*C] (tap-major, channel-minor), ksize 1 or 3, stride 1 or 2 (3x3 only); H, W = OUTPUT size;
- *   ldx: row stride of x in elements; C % 64 == 0, N % 64 == 0; dtype GSW_F16 / GSW_BF16; bias / rowbias / resid optional. */
+ *   ldx: row stride of x in elements; C % 64 == 0; N % 8 == 0 from 128 channels up (the matmul engine, csrc/gswm_mm.hip; a partial last 160-column
+ *   tile costs a full one), N % 64 == 0 below that (the 64-column kernel of round 1: the 4-channel edges padded to one tile);
+ *   dtype GSW_F16 / GSW_BF16; bias / rowbias / resid optional. */
 int gsw_conv_pf(const void* x_dev, const void* w_dev, const void* bias_dev, const void* rowbias_dev, const void* resid_dev, void* y_dev,
                 int B, int H, int W, int C, int N, int ksize, int stride, int ldx, int dtype, void* stream);
 
