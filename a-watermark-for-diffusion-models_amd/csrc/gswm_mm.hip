@@ -80,26 +80,8 @@ __device__ unsigned long long* g_mm_trace_buf;
 // LDS image traffic of the epilogue as inline asm: hipcc puts s_waitcnt vmcnt(0) in front of every LDS access it can see while an LDS-DMA
 // may be in flight (it cannot prove the image and the DMA destinations disjoint), which serialises the epilogue behind the prefetch of
 // the next tile and behind every one of its own stores (measured: 1800 cycles per put, 3600 per 5-chunk store, tools/ubench/mm_trace).
-__device__ __forceinline__ void mm_lds_write_b64(uint32_t addr, uint32_t lo, uint32_t hi) {
-    const uint2 v = make_uint2(lo, hi);
-    asm volatile("ds_write_b64 %0, %1" :: "v"(addr), "v"(v) : "memory");
-}
 // five 16-byte chunks (ten ds_read_b64) and their wait in ONE statement: the outputs are valid when it ends
-__device__ __forceinline__ void mm_lds_read5(const uint32_t (&a)[5], uint4 (&v)[5]) {
-    uint2 l0, h0, l1, h1, l2, h2, l3, h3, l4, h4;
-    asm volatile("ds_read_b64 %0, %10\n\tds_read_b64 %1, %10 offset:8\n\tds_read_b64 %2, %11\n\tds_read_b64 %3, %11 offset:8\n\t"
-                 "ds_read_b64 %4, %12\n\tds_read_b64 %5, %12 offset:8\n\tds_read_b64 %6, %13\n\tds_read_b64 %7, %13 offset:8\n\t"
-                 "ds_read_b64 %8, %14\n\tds_read_b64 %9, %14 offset:8\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(l0), "=&v"(h0), "=&v"(l1), "=&v"(h1), "=&v"(l2), "=&v"(h2), "=&v"(l3), "=&v"(h3), "=&v"(l4), "=&v"(h4)
-                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]) : "memory");
-    v[0] = make_uint4(l0.x, l0.y, h0.x, h0.y); v[1] = make_uint4(l1.x, l1.y, h1.x, h1.y); v[2] = make_uint4(l2.x, l2.y, h2.x, h2.y);
-    v[3] = make_uint4(l3.x, l3.y, h3.x, h3.y); v[4] = make_uint4(l4.x, l4.y, h4.x, h4.y);
-}
 // four 8-byte cells and their wait in one statement (GEGLU: the value waves pick up the gate cells they multiply into)
-__device__ __forceinline__ void mm_lds_read4x8(const uint32_t (&a)[4], uint2 (&v)[4]) {
-    asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %5\n\tds_read_b64 %2, %6\n\tds_read_b64 %3, %7\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]) : "memory");
-}
 
 // EPI: epilogue class the kernel is compiled for -- 0 dense rows (bias, optional residual), 1 generic (PF border / row bias / token scatter /
 // sub-pixel scatter), 2 GEGLU, 3 transposed output (MFMA operands swapped)
@@ -124,11 +106,15 @@ __device__ __forceinline__ float mm_erf(float x) {
 // ds_write traffic slows the multiplying waves' fragment reads and the load latency no longer hides.  Splitting the duty -- weight pieces issued by
 // the multiplying waves, activation pieces by the producers, so that all twelve waves issue -- was measured too: 1227-1268; any global_load_lds in a
 // multiplying wave's stream costs more than the relief it gives the producers.)
-template <typename T, int EPI, bool SPLIT>
+// MT: 16-row MFMA tiles per wave along M: 4 -> the 256 x 160 tile; 2 -> a 128 x 160 tile for launches whose 256-row tiling would leave CUs without
+// a tile (the 8 x 8 level at batch 64, everything deep at batch 8).
+template <typename T, int EPI, bool SPLIT, int MT>
 __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kernel(const MMArgs p) {
     constexpr bool SWAP = EPI == 3;
     constexpr int WM = 4;                            // waves along M; 2 groups of 4 waves along N
-    constexpr int BM = 256, BN = 160;
+    constexpr int BM = 64 * MT, BN = 160;
+    constexpr int NPR = MT / 2;                      // pairs of row tiles per wave (the epilogue's unit)
+    static_assert(MT == 4 || MT == 2, "wave tile of 64 or 32 rows");
     constexpr int NPROD = SPLIT ? 4 : 8;             // waves that issue DMA
     constexpr int NPA = BM / 8 / NPROD;              // A pieces (8 rows x 128 B = 1 KiB) per producing wave per stage: 4 (8 with SPLIT)
     constexpr int NPW = BN / 8 / NPROD;              // full rounds of W pieces per producing wave: 2 (5 with SPLIT)
@@ -149,7 +135,7 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
     // LDS rows are 128 B (64 k-values); 16-byte chunks are XOR-swizzled with (row >> 1) & 7.
     // fragment read of k-half h: row = lane & 15 of a 16-row block, logical chunk = 4h + (lane >> 4); (row >> 1) & 7 = (lane >> 1) & 7
     const uint32_t lane_rd0 = (lane & 15u) * 128u + ((((lane >> 4)) ^ ((lane >> 1) & 7u)) << 4);
-    const uint32_t a_rd0 = wm * 64u * 128u + lane_rd0, a_rd1 = a_rd0 ^ 64u;            // k-half 1 = chunk + 4 = byte offset ^ 64
+    const uint32_t a_rd0 = wm * (16u * MT) * 128u + lane_rd0, a_rd1 = a_rd0 ^ 64u;            // k-half 1 = chunk + 4 = byte offset ^ 64
     const uint32_t w_rd0 = (uint32_t)BM * 128u + (grp * (uint32_t)HC) * 128u + lane_rd0, w_rd1 = w_rd0 ^ 64u;
     // DMA source: lane -> row lane >> 3 of an 8-row piece, physical chunk lane & 7 holds logical chunk (lane & 7) ^ ((row >> 1) & 7);
     // a wave's pieces are wave, wave + 8, ...: (row >> 1) & 7 = (4 (wave & 1) + (lane >> 4)) & 7
@@ -284,9 +270,15 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
                                          (__attribute__((address_space(3))) void*)(lds + pr_slot + (uint32_t)BM * 128u + (pid + (uint32_t)NPROD * i) * 1024u), 16, 0, 0);
         pw[i] += w_step;
     };
-    auto dma_h1 = [&]() { dma_piece_a(0); dma_piece_a(1); dma_piece_w(0); };
+    auto dma_h1 = [&]() {
+#pragma unroll
+        for (int i = 0; i < NPA / 2; ++i) dma_piece_a(i);
+        dma_piece_w(0);
+    };
     auto dma_h2 = [&]() {                                    // completes the stage: the ring slot advances
-        dma_piece_a(2); dma_piece_a(3); dma_piece_w(1);
+#pragma unroll
+        for (int i = NPA / 2; i < NPA; ++i) dma_piece_a(i);
+        dma_piece_w(1);
         pr_slot = pr_slot + STAGE == RING ? 0u : pr_slot + STAGE;
     };
     if constexpr (SPLIT) {
@@ -340,14 +332,14 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
             return;
         }
     } else {
-        static_assert(SPLIT || (NPA == 4 && NPW == 2), "the half-stage split assumes 4 + 2 (+1) pieces per wave");
+        static_assert(SPLIT || ((NPA == 4 || NPA == 2) && NPW == 2), "the half-stage split assumes 4 (2) + 2 (+1) pieces per wave");
         // prologue: stages 0 and 1 and the first half of stage 2; wait for stage 0 (counted: the newer pieces stay in flight; exact for waves
         // without the extra piece, conservative for the others; any other VMEM operation in flight only makes a wait longer)
         setup_tile(0);
         begin_run();
         for (int i = 0; i < 2; ++i) { dma_h1(); dma_extra(); dma_h2(); if (--pr_run == 0) end_run(); }
         dma_h1();
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NDMA + 3) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NDMA + NPA / 2 + 1) : "memory");
     }
     MM_BARRIER();
 
@@ -358,21 +350,21 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
     const uint16_t* rowbias = reinterpret_cast<const uint16_t*>(p.rowbias);
     const uint16_t* resid = reinterpret_cast<const uint16_t*>(p.resid);
     uint16_t* Y = reinterpret_cast<uint16_t*>(p.y);
-    mm_f4 acc[5][4];
+    mm_f4 acc[5][MT];
 #pragma unroll
     for (int a = 0; a < 5; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = mm_f4{0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < MT; ++b) acc[a][b] = mm_f4{0.f, 0.f, 0.f, 0.f};
     uint32_t c_it = 0, rd_slot = 0;                           // rd_slot: ring offset of the stage being multiplied
 #ifdef MM_TRACE
     unsigned long long tr_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tr_last = __builtin_amdgcn_s_memtime();
 #endif
 
-    auto read_frags = [&](frag (&xf)[4], frag (&wf)[5], uint32_t slot, uint32_t khalf) {
+    auto read_frags = [&](frag (&xf)[MT], frag (&wf)[5], uint32_t slot, uint32_t khalf) {
         const uint8_t* ap = lds + ((khalf ? a_rd1 : a_rd0) + slot);
         const uint8_t* wp = lds + ((khalf ? w_rd1 : w_rd0) + slot);
 #pragma unroll
-        for (int im = 0; im < 4; ++im) xf[im] = *reinterpret_cast<const frag*>(ap + im * 2048);
+        for (int im = 0; im < MT; ++im) xf[im] = *reinterpret_cast<const frag*>(ap + im * 2048);
 #pragma unroll
         for (int in = 0; in < 5; ++in) wf[in] = *reinterpret_cast<const frag*>(wp + in * 2048);
     };
@@ -424,8 +416,8 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
             bool live[2];
             const int32_t colb = n0 + (int32_t)(grp * HC + (q >> 1) * 8u);
 #pragma unroll
-            for (int pr = 0; pr < 2; ++pr) {
-                const int32_t m = m0 + (int32_t)(wm * 64u + (uint32_t)(2 * pr + (int)(q & 1u)) * 16u + li);
+            for (int pr = 0; pr < NPR; ++pr) {
+                const int32_t m = m0 + (int32_t)(wm * (16u * MT) + (uint32_t)(2 * pr + (int)(q & 1u)) * 16u + li);
                 live[pr] = m < p.M;
                 const int64_t mm = live[pr] ? m : 0;
                 yrow[pr] = Y + mm * p.ldy + colb;
@@ -437,7 +429,7 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
             uint4 rs[5][2];
             auto load_rs = [&](int in) {
 #pragma unroll
-                for (int pr = 0; pr < 2; ++pr) {
+                for (int pr = 0; pr < NPR; ++pr) {
                     rs[in][pr] = make_uint4(0, 0, 0, 0);
                     if (colb + in * 16 < p.N) rs[in][pr] = *reinterpret_cast<const uint4*>(rrow[pr] + in * 16);
                 }
@@ -452,7 +444,7 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
                 bias4(in, bq);
                 if (resid && in + RSD < 5) load_rs(in + RSD);
 #pragma unroll
-                for (int pr = 0; pr < 2; ++pr) {
+                for (int pr = 0; pr < NPR; ++pr) {
                     uint32_t a0, a1, b0, b1;
                     pack4(acc[in][2 * pr], bq, a0, a1);
                     pack4(acc[in][2 * pr + 1], bq, b0, b1);
@@ -475,8 +467,8 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
             int32_t img_b[2];
             bool live[2], border[2];
 #pragma unroll
-            for (int pr = 0; pr < 2; ++pr) {
-                const int32_t m = m0 + (int32_t)(wm * 64u + (uint32_t)(2 * pr + (int)(q & 1u)) * 16u + li);
+            for (int pr = 0; pr < NPR; ++pr) {
+                const int32_t m = m0 + (int32_t)(wm * (16u * MT) + (uint32_t)(2 * pr + (int)(q & 1u)) * 16u + li);
                 live[pr] = m < p.M; border[pr] = false; img_b[pr] = 0; orow[pr] = m;
                 const int32_t mc = live[pr] ? m : 0;
                 if (p.mode == MM_MODE_PF || p.mode == MM_MODE_UP2X) {
@@ -508,7 +500,7 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
                 bias4(in, bq);
                 const int64_t col = (int64_t)n0 + grp * (uint32_t)HC + (uint32_t)in * 16u + (q >> 1) * 8u;
 #pragma unroll
-                for (int pr = 0; pr < 2; ++pr) {
+                for (int pr = 0; pr < NPR; ++pr) {
                     uint32_t a0, a1, b0, b1;
                     pack4(acc[in][2 * pr], bq, a0, a1);
                     pack4(acc[in][2 * pr + 1], bq, b0, b1);
@@ -540,9 +532,9 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
             for (int in = 0; in < 5; ++in) {
                 float bq[4];
                 bias4(in, bq);
-                uint32_t Wv[4];                               // per row tile im: (out j = lane >> 5 ? 1 : 0) | (out j + 2) << 16
+                uint32_t Wv[MT];                              // per row tile im: (out j = lane >> 5 ? 1 : 0) | (out j + 2) << 16
 #pragma unroll
-                for (int im = 0; im < 4; ++im) {
+                for (int im = 0; im < MT; ++im) {
                     // the projection as torch materialises it (rounded to the storage dtype), kept as fp32 bit patterns for the swaps
                     uint32_t f[4];
 #pragma unroll
@@ -559,7 +551,7 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
                     Wv[im] = (uint32_t)h[0] | ((uint32_t)h[1] << 16);
                 }
 #pragma unroll
-                for (int pr = 0; pr < 2; ++pr) {
+                for (int pr = 0; pr < NPR; ++pr) {
                     uint32_t a = Wv[2 * pr], b = Wv[2 * pr + 1];
                     swap32(a, b);                             // lanes < 32: outputs (0,2 | 1,3) of row tile 2p; lanes >= 32: of row tile 2p + 1
                     D[in][pr][0] = (a & 0xFFFFu) | (b << 16);             // outputs 4 qv + 0, 1
@@ -568,19 +560,19 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
             }
             const int64_t obase = (int64_t)tile_n * (BN / 2) + grp * 40u;
 #pragma unroll
-            for (int pr = 0; pr < 2; ++pr) {
+            for (int pr = 0; pr < NPR; ++pr) {
                 // n-tile pairs (0,1) and (2,3): one more swap round -> 8 consecutive outputs (16 bytes) per lane
 #pragma unroll
                 for (int ip = 0; ip < 2; ++ip) {
                     uint32_t a0 = D[2 * ip][pr][0], a1 = D[2 * ip][pr][1], b0 = D[2 * ip + 1][pr][0], b1 = D[2 * ip + 1][pr][1];
                     swap16(a0, b0);
                     swap16(a1, b1);
-                    const int32_t m = m0 + (int32_t)(wm * 64u + (uint32_t)(2 * pr + (int)(q >> 1)) * 16u + li);
+                    const int32_t m = m0 + (int32_t)(wm * (16u * MT) + (uint32_t)(2 * pr + (int)(q >> 1)) * 16u + li);
                     if (m < p.M)
                         *reinterpret_cast<uint4*>(Y + (int64_t)m * p.ldy + obase + (uint32_t)(2 * ip + (int)(q & 1u)) * 8u) = make_uint4(a0, a1, b0, b1);
                 }
                 // n-tile 4 has no partner: 8-byte stores (4 outputs per lane)
-                const int32_t m = m0 + (int32_t)(wm * 64u + (uint32_t)(2 * pr + (int)(lane >> 5)) * 16u + li);
+                const int32_t m = m0 + (int32_t)(wm * (16u * MT) + (uint32_t)(2 * pr + (int)(lane >> 5)) * 16u + li);
                 if (m < p.M)
                     *reinterpret_cast<uint2*>(Y + (int64_t)m * p.ldy + obase + 32u + qv * 4u) = make_uint2(D[4][pr][0], D[4][pr][1]);
             }
@@ -593,13 +585,13 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
                 const float bv = bias && nok ? MM<T>::up(bias[nrow]) : 0.f;
                 const float bq[4] = {bv, bv, bv, bv};
 #pragma unroll
-                for (int pr = 0; pr < 2; ++pr) {
+                for (int pr = 0; pr < NPR; ++pr) {
                     uint32_t a0, a1, b0, b1;
                     pack4(acc[in][2 * pr], bq, a0, a1);
                     pack4(acc[in][2 * pr + 1], bq, b0, b1);
                     swap16(a0, b0);
                     swap16(a1, b1);
-                    const int32_t m = m0 + (int32_t)(wm * 64u + (uint32_t)(2 * pr + (int)(q & 1u)) * 16u + (q >> 1) * 8u);      // first of 8 consecutive tokens
+                    const int32_t m = m0 + (int32_t)(wm * (16u * MT) + (uint32_t)(2 * pr + (int)(q & 1u)) * 16u + (q >> 1) * 8u);      // first of 8 consecutive tokens
                     if (m >= p.M || !nok) continue;
                     const int32_t b = m / p.S, sidx = m - b * p.S;
                     *reinterpret_cast<uint4*>(Y + ((int64_t)b * p.N + nrow) * p.S + sidx) = make_uint4(a0, a1, b0, b1);
@@ -609,43 +601,47 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
 #pragma unroll
         for (int a = 0; a < 5; ++a)
 #pragma unroll
-            for (int b = 0; b < 4; ++b) acc[a][b] = mm_f4{0.f, 0.f, 0.f, 0.f};
+            for (int b = 0; b < MT; ++b) acc[a][b] = mm_f4{0.f, 0.f, 0.f, 0.f};
         ++c_it;
     };
 
-    auto mfma20 = [&](frag (&xc)[4], frag (&wc)[5]) {
+    auto mfma20 = [&](frag (&xc)[MT], frag (&wc)[5]) {
 #pragma unroll
         for (int in = 0; in < 5; ++in)
 #pragma unroll
-            for (int im = 0; im < 4; ++im)
+            for (int im = 0; im < MT; ++im)
                 acc[in][im] = SWAP ? MM<T>::mma(xc[im], wc[in], acc[in][im]) : MM<T>::mma(wc[in], xc[im], acc[in][im]);
     };
     // issue order of a phase's main block: three DMA pieces, each behind three MFMAs, then the nine fragment reads one per MFMA
     auto pin_order = [&]() {
         // (fragment reads in FRONT of the DMA pieces / at one per MFMA from the start of the phase was measured 3-9 % slower in both variants)
+        constexpr int NM = 5 * MT, NR = MT + 5;              // MFMAs and fragment reads of a phase: 20 / 9, or 10 / 7
         if constexpr (SPLIT) {
+            constexpr int per = MT == 4 ? 2 : 1;             // MFMAs in front of each fragment read
 #pragma unroll
-            for (int i = 0; i < 9; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // one fragment read per two MFMAs
+            for (int i = 0; i < NR; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, per, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NM - per * NR, 0);
         } else {
+            constexpr int NV = NPA / 2 + 1;                  // DMA pieces of a phase (without the extra one): 3, or 2
+            constexpr int per = MT == 4 ? 3 : 1;             // MFMAs in front of each DMA piece
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            for (int i = 0; i < NV; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, per, 0);
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);    // one LDS-DMA piece
             }
 #pragma unroll
-            for (int i = 0; i < 9; ++i) {
+            for (int i = 0; i < NR; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // one fragment read
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, 20 - 9 - 9, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NM - per * NV - NR, 0);
         }
     };
     // X holds the fragments of (stage s, k-half 0) on entry; Y is filled with (s, k-half 1), then X with (s+1, k-half 0)
-    auto step = [&](frag (&xX)[4], frag (&wX)[5], frag (&xY)[4], frag (&wY)[5]) {
+    auto step = [&](frag (&xX)[MT], frag (&wX)[5], frag (&xY)[MT], frag (&wY)[5]) {
         const uint32_t nx_slot = rd_slot + STAGE == RING ? 0u : rd_slot + STAGE;
         // ---- even phase: second half of stage s+2 (its slot held stage s-1, whose last reads completed before the previous barrier)
         MM_STAMP(0);
@@ -691,7 +687,7 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
 
     // The step loop is a loop of its own (not one flat loop with the epilogue inside): hipcc then places the wait for the epilogue's
     // loads / stores once in front of it instead of inside the steady state.
-    frag xa[4], wa[5], xb[4], wb[5];
+    frag xa[MT], wa[5], xb[MT], wb[5];
     read_frags(xa, wa, 0u, 0u);                               // (stage 0, k-half 0)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     for (uint32_t it = 0; it < nt_mine; ++it) {
@@ -708,29 +704,33 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
 }
 
 // host ---------------------------------------------------------------------------------------------
-template <typename T, int EPI>
-int mm_launch_t(const MMArgs& a, uint32_t grid, size_t ldsb, hipStream_t st) {
-    // GSW_MM_SPLIT: bit e set = epilogue kind e runs the 12-wave variant whose waves 8-11 own the LDS-DMA (A/B switch)
-    static const int split_mask = getenv("GSW_MM_SPLIT") ? atoi(getenv("GSW_MM_SPLIT")) : 10;      // default: convolutions (1) and the transposed projection (3)
-    const int split_env = (split_mask >> EPI) & 1;
-    static bool attr_done[2] = {false, false};          // benign race: setting the attribute twice is harmless
-    const void* fn = split_env ? (const void*)gsw_mm_kernel<T, EPI, true> : (const void*)gsw_mm_kernel<T, EPI, false>;
-    if (!attr_done[split_env ? 1 : 0]) {
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+template <typename T, int EPI, bool SPLIT, int MT>
+int mm_launch_k(const MMArgs& a, uint32_t grid, hipStream_t st) {
+    static bool attr_done = false;          // benign race: setting the attribute twice is harmless
+    constexpr size_t ldsb = 3u * (size_t)(64 * MT + 160) * 128u;       // the three-stage ring
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)gsw_mm_kernel<T, EPI, SPLIT, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
-        attr_done[split_env ? 1 : 0] = true;
+        attr_done = true;
     }
-    if (split_env) hipLaunchKernelGGL((gsw_mm_kernel<T, EPI, true>), dim3(grid), dim3(768), ldsb, st, a);
-    else hipLaunchKernelGGL((gsw_mm_kernel<T, EPI, false>), dim3(grid), dim3(512), ldsb, st, a);
+    hipLaunchKernelGGL((gsw_mm_kernel<T, EPI, SPLIT, MT>), dim3(grid), dim3(SPLIT ? 768 : 512), ldsb, st, a);
     return (int)hipGetLastError();
 }
+template <typename T, int EPI>
+int mm_launch_t(const MMArgs& a, uint32_t grid, int mt, hipStream_t st) {
+    // GSW_MM_SPLIT: bit e set = epilogue kind e runs the 12-wave variant whose waves 8-11 own the LDS-DMA (A/B switch)
+    static const int split_mask = getenv("GSW_MM_SPLIT") ? atoi(getenv("GSW_MM_SPLIT")) : 10;      // default: convolutions (1) and the transposed projection (3)
+    const bool split = (split_mask >> EPI) & 1;
+    if (mt == 4) return split ? mm_launch_k<T, EPI, true, 4>(a, grid, st) : mm_launch_k<T, EPI, false, 4>(a, grid, st);
+    return split ? mm_launch_k<T, EPI, true, 2>(a, grid, st) : mm_launch_k<T, EPI, false, 2>(a, grid, st);
+}
 template <typename T>
-int mm_launch_e(const MMArgs& a, int epi, uint32_t grid, size_t ldsb, hipStream_t st) {
+int mm_launch_e(const MMArgs& a, int epi, uint32_t grid, int mt, hipStream_t st) {
     switch (epi) {
-        case 0: return mm_launch_t<T, 0>(a, grid, ldsb, st);
-        case 1: return mm_launch_t<T, 1>(a, grid, ldsb, st);
-        case 2: return mm_launch_t<T, 2>(a, grid, ldsb, st);
-        default: return mm_launch_t<T, 3>(a, grid, ldsb, st);
+        case 0: return mm_launch_t<T, 0>(a, grid, mt, st);
+        case 1: return mm_launch_t<T, 1>(a, grid, mt, st);
+        case 2: return mm_launch_t<T, 2>(a, grid, mt, st);
+        default: return mm_launch_t<T, 3>(a, grid, mt, st);
     }
 }
 
@@ -743,16 +743,22 @@ int gsw_mm_launch(MMArgs& a, int dtype, void* stream) {
     if (dtype != GSW_F16 && dtype != GSW_BF16) return GSW_ERR_BAD_ARG;
     // N: any multiple of 8 (the last 160-column tile may be partial: weight rows are clamped, stores masked); GEGLU pairs columns inside a tile
     if (a.N % 8 || (a.mode == MM_MODE_GEGLU && a.N % 160) || a.M <= 0 || a.P <= 0) return GSW_ERR_UNSUPPORTED;
-    constexpr int BM = 256, BN = 160;
-    const int64_t tiles_m = ((int64_t)a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
+    constexpr int BN = 160;
+    const int64_t tiles_n = (a.N + BN - 1) / BN;
+    // 256-row tiles unless they would leave CUs without one: then 128-row tiles (GSW_MM_BM=128 / 256 forces one for A/B runs)
+    static const int bm_env = getenv("GSW_MM_BM") ? atoi(getenv("GSW_MM_BM")) : 0;
+    // (pricing a 128-row tile at 0.55 of a 256-row one and minimising rounds of 256 workgroups -- e.g. 384 tiles -> 768 half tiles -- measured slower:
+    // the half tile re-fetches the weight tile twice as often)
+    int BM = (((int64_t)a.M + 255) / 256) * tiles_n < 256 && a.M > 128 ? 128 : 256;
+    if (bm_env == 128 || bm_env == 256) BM = bm_env;
+    const int64_t tiles_m = ((int64_t)a.M + BM - 1) / BM;
     if (tiles_m * tiles_n > 0x7FFFFFFF) return GSW_ERR_UNSUPPORTED;
     a.tiles_n = (int32_t)tiles_n;
     a.ntiles = (int32_t)(tiles_m * tiles_n);
     const uint32_t grid = (uint32_t)std::min<int64_t>(256, (a.ntiles + 7) / 8 * 8);
-    const size_t ldsb = 3u * (size_t)(BM + BN) * 128u;        // the epilogue image lives in a ring slot
     hipStream_t st = (hipStream_t)stream;
     const int epi = a.mode == MM_MODE_TRANS ? 3 : a.mode == MM_MODE_GEGLU ? 2 : (a.mode == MM_MODE_DENSE && !a.rowbias) ? 0 : 1;
-    const int e = dtype == GSW_F16 ? mm_launch_e<_Float16>(a, epi, grid, ldsb, st) : mm_launch_e<__bf16>(a, epi, grid, ldsb, st);
+    const int e = dtype == GSW_F16 ? mm_launch_e<_Float16>(a, epi, grid, BM / 64, st) : mm_launch_e<__bf16>(a, epi, grid, BM / 64, st);
     if (e != 0) { g_last_hip_error = e; return GSW_ERR_HIP; }
     return GSW_OK;
 }
