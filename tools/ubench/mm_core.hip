@@ -4,6 +4,8 @@
 //   MODE 1: same, but every fragment read hits ONE address per lane group (no bank traffic differences)
 //   MODE 2: same reads as MODE 0, MFMAs all on the same two operand registers (register-file pressure of operand fetch removed)
 //   MODE 3: MODE 0 without the reads (MFMAs + barrier only)
+//   NVALU (template): that many extra independent v_fma_f32 per phase, left to the scheduler to place between the MFMAs -- what an epilogue of the
+//   previous tile issued inside the next tile's main loop would cost
 // hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ubench/mm_core.hip -o tools/ubench/bin/mm_core
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -13,7 +15,7 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 #define BAR() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
 
 // RANDOM: LDS holds hashed fp16 values in (-1, 1) instead of a near-constant pattern (operand toggling costs power, power costs clock)
-template <int MODE, int THREADS, bool RANDOM = false>
+template <int MODE, int THREADS, bool RANDOM = false, int NVALU = 0>
 __global__ __launch_bounds__(THREADS, THREADS == 512 ? 2 : 1) void k(float* out, int iters) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     constexpr uint32_t STAGE = 416u * 128u, RING = 3u * STAGE;
@@ -69,6 +71,12 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 2 : 1) void k(float* out,
         for (int i = 0; i < 9; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
         __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
     };
+    float vx[8];
+    for (int i = 0; i < 8; ++i) vx[i] = 1.0f + 0.001f * (float)(lane + i);
+    auto valu = [&]() {
+#pragma unroll
+        for (int i = 0; i < NVALU; ++i) vx[i & 7] = __builtin_fmaf(vx[i & 7], 1.0001f, 0.0003f * (float)(i + 1));
+    };
     for (int i = 0; i < 4; ++i) xb[i] = h8{}; for (int i = 0; i < 5; ++i) wb[i] = h8{};
     read_frags(xa, wa, 0u, 0u);
     if (MODE == 3) { for (int i = 0; i < 4; ++i) { xa[i] = *reinterpret_cast<const h8*>(lds + a_rd0 + i * 2048); } for (int i = 0; i < 5; ++i) wa[i] = *reinterpret_cast<const h8*>(lds + w_rd0 + i * 2048);
@@ -79,27 +87,30 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 2 : 1) void k(float* out,
         const uint32_t nx = rd_slot + STAGE == RING ? 0u : rd_slot + STAGE;
         read_frags(xb, wb, rd_slot, 1u);
         mfma20(xa, wa);
+        valu();
         pin();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         BAR();
         read_frags(xa, wa, nx, 0u);
         mfma20(xb, wb);
+        valu();
         pin();
         __builtin_amdgcn_sched_barrier(0);
         rd_slot = nx;
     }
     float s = 0;
     for (int a = 0; a < 5; ++a) for (int b = 0; b < 4; ++b) s += acc[a][b][0] + acc[a][b][3];
+    for (int i = 0; i < 8; ++i) s += vx[i];
     out[blockIdx.x * THREADS + tid] = s;
 }
 
-template <int MODE, int THREADS, bool RANDOM = false>
+template <int MODE, int THREADS, bool RANDOM = false, int NVALU = 0>
 void run(const char* name, float* out, int iters = 2000) {
-    hipFuncSetAttribute((const void*)k<MODE, THREADS, RANDOM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)k<MODE, THREADS, RANDOM, NVALU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL((k<MODE, THREADS, RANDOM>), dim3(256), dim3(THREADS), 3 * 416 * 128, 0, out, 100);
+    hipLaunchKernelGGL((k<MODE, THREADS, RANDOM, NVALU>), dim3(256), dim3(THREADS), 3 * 416 * 128, 0, out, 100);
     hipEventRecord(e0);
-    hipLaunchKernelGGL((k<MODE, THREADS, RANDOM>), dim3(256), dim3(THREADS), 3 * 416 * 128, 0, out, iters);
+    hipLaunchKernelGGL((k<MODE, THREADS, RANDOM, NVALU>), dim3(256), dim3(THREADS), 3 * 416 * 128, 0, out, iters);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     const double ns = ms * 1e6 / iters;           // per stage (two phases): 40 MFMAs per wave, 80 per SIMD = 1280 pipe cycles
@@ -118,6 +129,9 @@ int main() {
     run<0, 512, true>("kernel addressing, RANDOM operands", out);
     run<3, 512, true>("MFMAs + barrier only, RANDOM operands", out);
     run<0, 768, true>("kernel addressing, 12 waves, RANDOM operands", out);
+    run<0, 512, true, 40>("kernel addressing, RANDOM operands, + 40 VALU per phase", out);
+    run<0, 512, true, 80>("kernel addressing, RANDOM operands, + 80 VALU per phase", out);
+    run<0, 512, true, 160>("kernel addressing, RANDOM operands, + 160 VALU per phase", out);
     run<0, 512, true>("kernel addressing, RANDOM operands, 100x longer run", out, 200000);
     run<0, 512, false>("kernel addressing, constant operands, 100x longer run", out, 200000);
     return 0;
