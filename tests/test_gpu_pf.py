@@ -21,6 +21,8 @@ def G():
                                                  (1, 64, 320, 6, 96, 3, 1), (1, 64, 320, 4, 170, 3, 1), (1, 64, 320, 4, 200, 3, 1),
                                                  (3, 64, 512, 12, 20, 3, 1), (2, 128, 320, 10, 6, 3, 2), (1, 256, 256, 24, 8, 1, 1), (5, 64, 136, 6, 6, 3, 1)])
 def test_conv_pf_vs_torch_fp32(G, dtype, B, C, N, H, W, k, stride):
+    if N % 64 and not G.pf.CONV_ENGINE:
+        pytest.skip("N % 64 != 0 needs the matmul engine (GSW_CONV_ENGINE=0 selects the round-1 kernels)")
     g = torch.Generator().manual_seed(C + N + H)
     x = torch.randn(B, C, H, W, generator=g).to(dtype).cuda()
     w = (torch.randn(N, C, k, k, generator=g) * (1.0 / (C * k * k)) ** 0.5).to(dtype).cuda()
