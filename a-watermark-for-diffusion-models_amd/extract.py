@@ -334,12 +334,23 @@ def _recover_many(items, args, batch_size):
     """items: [(job, file)] across ALL directories.  Decode every file on the host (a file that does not decode fails alone), then push
     the decodable ones through resize -> VAE -> inversion -> vote in full device batches; if a batch raises, its images are redone one
     by one so that each reports its own error, like the reference's per-image try / except (extract.py:148-155)."""
-    ready = []
-    for job, f in items:
+    def decode(item):
         try:
-            ready.append((job, f, decode_image_file(f)))
-        except Exception as e:
-            job.outcome[f] = e
+            return decode_image_file(item[1])
+        except Exception as e:                      # a file that does not decode fails alone
+            return e
+
+    ready = []
+    if items:
+        from concurrent.futures import ThreadPoolExecutor
+        # PIL releases the GIL while it reads and decodes: a few host threads keep the device batches fed on large directories
+        with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
+            decoded = list(pool.map(decode, items))
+        for (job, f), r in zip(items, decoded):
+            if isinstance(r, Exception):
+                job.outcome[f] = r
+            else:
+                ready.append((job, f, r))
 
     def run(chunk):
         latents = invert_decoded_images([a for _, _, a in chunk], args)
@@ -389,9 +400,10 @@ def _report(job, args, synthetic):
             up.write(f"{os.path.basename(job.path)}, Average Bit Accuracy, {mean}\n")
 
 
-def process_directory(args, *, batch_size=16):
+def process_directory(args, *, batch_size=None):
     """The directory harness (extract.py:120-163) in batch form: plan the whole run, recover every image of every directory in full device
     batches, then write the result files in the reference's order and format."""
+    batch_size = int(batch_size or getattr(args, "batch_size", 0) or 16)
     script = _plan(args)
     jobs = [j for kind, j in script if kind == "job"]
     synthetic = not os.path.isdir(str(args.model_id))
@@ -412,8 +424,9 @@ def process_directory(args, *, batch_size=16):
             root.write("=" * 40 + "Batch End" + "=" * 40 + "\n\n")
 
 
-def process_single_directory(dir_path, args, *, batch_size=16):
+def process_single_directory(dir_path, args, *, batch_size=None):
     """One directory (extract.py:134-163)."""
+    batch_size = int(batch_size or getattr(args, "batch_size", 0) or 16)
     job = _DirJob(dir_path)
     if job.files:
         load_models(args.model_id, allow_synthetic=_synthetic_allowed(args))
@@ -440,6 +453,7 @@ def build_parser():
     parser.add_argument("--message_length", type=int, default=1024, help="Length of the message in bits")
     # not a reference flag: opt in to seeded synthetic weights when --model_id is not a local checkpoint directory (results meaningless)
     parser.add_argument("--allow_synthetic_weights", action="store_true", help="run without a checkpoint (pipeline tests / benchmarks only)")
+    parser.add_argument("--batch_size", type=int, default=16, help="(not a reference flag) images per device batch of the directory harness")
     return parser
 
 
