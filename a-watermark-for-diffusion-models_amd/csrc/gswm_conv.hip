@@ -874,28 +874,47 @@ __global__ __launch_bounds__(512) void gsw_gn_pf_apply_kernel(const uint16_t* __
     const bool second = x2 && cvec * 8 >= Ca;
     const int32_t ld = x2 ? (second ? C - Ca : Ca) : C;
     const uint16_t* base = (second ? x2 + (cvec * 8 - Ca) : x + cvec * 8) + ((int64_t)b * HpWp) * ld;
-    for (int32_t i = i0 + prow; i < i1; i += P) {
-        const int32_t yy = i / Wp, xx = i - yy * Wp;
+    // One row = 16 bytes per thread.  The kernel was VALU-bound, not HBM-bound: an IEEE division per element for the sigmoid, an integer division
+    // per row for (y, x), one load in flight.  Now: sigmoid = v_rcp(1 + v_exp(-t log2 e)), (y, x) carried incrementally, four rows in flight.
+    auto emit = [&](const uint4& u, int32_t i, int32_t yy, int32_t xx) {
         const bool border = (yy == 0) | (yy == Hp - 1) | (xx == 0) | (xx == Wp - 1);
-        uint4 o = make_uint4(0, 0, 0, 0);
-        if (!border) {
-            float v[8];
-            ld8h(base + (int64_t)i * ld, v, bf);
-            uint16_t h[8];
+        float v[8];
+        up8h(u, v, bf);
+        uint16_t h[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                float t = fmaf(v[k], sc[k], sh[k]);
-                if (act) t = t / (1.0f + __expf(-t));
-                h[k] = cvt_h(t, bf);
-            }
-            o = make_uint4((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16),
-                           (uint32_t)h[4] | ((uint32_t)h[5] << 16), (uint32_t)h[6] | ((uint32_t)h[7] << 16));
+        for (int k = 0; k < 8; ++k) {
+            float t = fmaf(v[k], sc[k], sh[k]);
+            if (act) t = t * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * t));
+            h[k] = cvt_h(t, bf);
         }
+        uint4 o = make_uint4((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16),
+                             (uint32_t)h[4] | ((uint32_t)h[5] << 16), (uint32_t)h[6] | ((uint32_t)h[7] << 16));
+        if (border) o = make_uint4(0, 0, 0, 0);              // (border rows of a PF input are zeros in valid memory: loaded unconditionally)
         if (tokens) {
             if (!border) *reinterpret_cast<uint4*>(y + (((int64_t)b * H + (yy - 1)) * W + (xx - 1)) * C + cvec * 8) = o;
         } else {
             *reinterpret_cast<uint4*>(y + ((int64_t)b * HpWp + i) * C + cvec * 8) = o;
         }
+    };
+    int32_t i = i0 + prow;
+    int32_t yy = i / Wp, xx = i - yy * Wp;
+    auto advance = [&]() { xx += P; while (xx >= Wp) { xx -= Wp; ++yy; } };
+    for (; i + 3 * P < i1; i += 4 * P) {
+        uint4 u[4];
+        int32_t ys[4], xs[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            u[j] = *reinterpret_cast<const uint4*>(base + (int64_t)(i + j * P) * ld);
+            ys[j] = yy; xs[j] = xx;
+            advance();
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) emit(u[j], i + j * P, ys[j], xs[j]);
+    }
+    for (; i < i1; i += P) {
+        const uint4 u = *reinterpret_cast<const uint4*>(base + (int64_t)i * ld);
+        emit(u, i, yy, xx);
+        advance();
     }
 }
 
