@@ -22,6 +22,8 @@
 // Roofline: MFMA.  Measured (B=128, 5 heads, S=4096, fp16): 825-832 TFLOP/s = 33 % of the 2.5 PF nominal peak, MFMA pipe busy 40-42 % of
 // the cycles the chip actually runs (PMC: effective clock 1.87 GHz under this load); torch SDPA (aotriton) does 630-690 on the same shape.
 // At head_dim 64 every 16 MFMAs come with ~170 VALU instructions (32 v_exp_f32, max / sum / convert / rescale) per wave.
+// Tried and dropped: row sums of P on the matrix pipe (one more MFMA per 16-key slice with an all-ones A operand instead of 32 v_add_f32 per tile and
+// query block -- the pipe idles half the time): 813 vs 831 TFLOP/s at 4096 keys.
 // Tried and dropped: software pipelining over 32-key blocks (S^T of block u+1 issued before the softmax of block u, 3 LDS stages,
 // one barrier per tile): 790 vs 831 TFLOP/s -- the per-block max / exchange / rescale overhead doubles and hipcc does not interleave
 // the two streams any better than the wave scheduler already does across the 2-4 resident waves.
