@@ -1,18 +1,20 @@
-// gswm_conv.hip -- hand-written MFMA implicit-GEMM convolution for the eps model (rows X2 / G1), gfx950 only.
+// gswm_conv.hip -- convolution front end of the eps model (rows X2 / G1 of SURVEY.md section 8a), GroupNorm / LayerNorm kernels.  gfx950 only.
 //
 // Activation format "padded-flat NHWC" (PF): an image batch [B, H, W, C] is stored with a one-pixel zero border as a 2-D
 // matrix X[(b, y, x) -> b*Hp*Wp + y*Wp + x][C] (Hp = H+2, Wp = W+2), plus G = Wp+1 guard rows of zeros in front and behind.
 // In that domain a 3x3 tap is a CONSTANT row offset ((kh-1)*Wp + (kw-1)), so the convolution is one GEMM
 //     Y[m, n] = sum_t sum_c X[row(m) + off_t, c] * Wt[n, t*C + c]  (+ bias[n] + rowbias[b(m), n] + residual[m, n])
 // whose A-tile loader is a plain strided copy: no im2col buffer, no boundary tests in the K loop (border pixels read the
-// zero padding).  Border rows of Y are written as zeros so the result is again a valid PF tensor.  1x1 convolutions and
-// stride-2 downsampling are the same kernel with a different tap table / row map.
+// zero padding).  Border rows of Y are written as zeros so the result is again a valid PF tensor.  1x1 convolutions, the 2x2 sub-pixel
+// form of Upsample2D and stride-2 downsampling are the same GEMM with a different tap table / row map.
 //
-// Kernel: BM = 256 pixels x BN = 64 channels x BK = 64, 256 threads = 4 waves, each wave a 64 x 64 sub-tile as 2 x 2
-// v_mfma_f32_32x32x16 tiles (weights as the A operand, activations as the B operand, so a lane ends up with 4 consecutive
-// output channels of one pixel).  Operands are staged with global_load_lds (16 B per lane, 1 KiB per wave instruction) into
-// an LDS image whose 16-byte chunks are XOR-swizzled with (row >> 1) & 7 on the SOURCE address, which makes every
-// ds_read_b128 fragment read conflict-free.  ~3 workgroups per CU overlap each other's load and MFMA phases.
+// Every convolution with >= 128 output channels is translated here into the matmul engine's argument block (csrc/gswm_mm.hip: taps =
+// K runs of a segment, conv_shortcut over cat(x, skip) = two more segments).  What remains in this file as a kernel is the 64-column
+// tile for the 4-channel edges (conv_in / conv_out / VAE 3-channel and 8-channel ends padded to one 64-wide tile, 0.3 % of a run):
+// BM = 256 pixels x BN = 64 channels x BK = 64, 256 threads = 4 waves, each wave a 64 x 64 sub-tile as 2 x 2 v_mfma_f32_32x32x16 tiles
+// (weights as the A operand, activations as the B operand, so a lane ends up with 4 consecutive output channels of one pixel).
+// Operands are staged with global_load_lds (16 B per lane, 1 KiB per wave instruction) into an LDS image whose 16-byte chunks are
+// XOR-swizzled with (row >> 1) & 7 on the SOURCE address, which makes every ds_read_b128 fragment read conflict-free.
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <hip/hip_bf16.h>
@@ -49,11 +51,11 @@ struct ConvArgs {
     int32_t stride;       // 1 or 2
     int32_t ldx;          // row stride of x in elements (>= C; lets the input be a channel slice of a wider tensor)
     int32_t dense;        // 1: plain GEMM on a dense [M, C] matrix (no border rows, no row map)
-    int32_t geglu;        // 1: every 160-wide N tile holds [80 value | 80 gate] columns; the epilogue writes value * gelu(gate)
+    int32_t geglu;        // (unused since the dense linears moved to the matmul engine)
     int32_t ldy;          // row stride of y in elements (N, or N/2 with geglu)
-    int32_t up;           // halo kernel only: 0, or 1 + dy*2 + dx = this launch computes output parity (dy, dx) of a 2x nearest-neighbour
+    int32_t up;           // engine only: 0, or 1 + dy*2 + dx = this launch computes output parity (dy, dx) of a 2x nearest-neighbour
                           // upsample + 3x3 convolution from the LOW-resolution input (sub-pixel decomposition, ntaps == 4)
-    // halo kernel only: up to two extra 1x1 operand segments appended to the K loop (the resnet's conv_shortcut folded in,
+    // engine only: up to two extra 1x1 operand segments appended to the K loop (the resnet's conv_shortcut folded in,
     // its concatenated input given as two tensors): K = 9*C + C1 + C2, weights [N][9*C | C1 | C2]
     const void* x1; const void* x2;
     int32_t C1, C2;
@@ -235,521 +237,6 @@ __global__ __launch_bounds__(CV_THREADS) void gsw_conv_gemm_kernel(ConvArgs p) {
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Wide-N variant for the UNet's body (every N there is a multiple of 160): BM = 128 pixels x BN = 160 channels x BK = 64,
-// 4 waves as 2 (M) x 2 (N), each 64 x 80 as 4 x 5 v_mfma_f32_16x16x32 tiles.  Per K block the workgroup stages
-// (128 + 160) x 128 B = 36 KiB for 2.6 MFLOP -- 1.4x less L2 -> LDS traffic per flop than the 256 x 64 tile, which is what
-// bounds that kernel.  Same PF addressing, swizzle and fused epilogue.
-// ------------------------------------------------------------------------------------------------
-typedef float gsw_f4v __attribute__((ext_vector_type(4)));
-#define CW_BM 128
-#define CW_BN 160
-#define CW_OUT_STRIDE 168   // bytes per row of the 80-column epilogue image (160 + 8)
-
-template <typename T> struct Mfma16;
-template <> struct Mfma16<_Float16> {
-    static __device__ __forceinline__ gsw_f4v mma(gsw_h8 a, gsw_h8 b, gsw_f4v c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
-};
-template <> struct Mfma16<__bf16> {
-    static __device__ __forceinline__ gsw_f4v mma(gsw_b8 a, gsw_b8 b, gsw_f4v c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
-};
-
-// WM = waves along M (2 -> 128-row tile, 256 threads; 4 -> 256-row tile, 512 threads)
-// LIN = 1 compiles in the dense-matrix / GEGLU epilogue of gsw_linear; the convolution instantiation (LIN = 0) stays lean
-template <typename T, int WM, bool DB, bool LIN>
-__global__ __launch_bounds__(128 * WM, WM == 4 ? 4 : 1) void gsw_conv_gemm_wide_kernel(ConvArgs p) {
-    constexpr int BM = 64 * WM;
-    constexpr int NTHR = 128 * WM;
-    constexpr int NWAVE = 2 * WM;
-    constexpr int XI = BM / 8;                       // activation staging instructions per K block
-    constexpr int TI = XI + CW_BN / 8;               // + weight staging instructions
-    constexpr int PER_WAVE = (TI + NWAVE - 1) / NWAVE;
-    constexpr uint32_t STAGE_BYTES = (BM + CW_BN) * CV_BK * 2;
-    __shared__ __attribute__((aligned(16))) uint8_t lds[STAGE_BYTES * (DB ? 2 : 1)];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t wm = wave % WM, wn = wave / WM;
-    const uint32_t nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7u;
-    const uint32_t xcd = blockIdx.x & 7u, idx = blockIdx.x >> 3;
-    const uint32_t logical = (xcd < r8 ? xcd * (q8 + 1u) : r8 * (q8 + 1u) + (xcd - r8) * q8) + idx;
-    const uint32_t ntn = (uint32_t)p.N / CW_BN;
-    const uint32_t tile_n = logical % ntn, tile_m = logical / ntn;
-    const int32_t m0 = (int32_t)tile_m * BM, n0 = (int32_t)tile_n * CW_BN;
-    const int32_t HpWp = p.Hp * p.Wp;
-    const int32_t Ktot = p.ntaps * p.C;
-    const T* X = reinterpret_cast<const T*>(p.x);
-    const T* W = reinterpret_cast<const T*>(p.w);
-    const uint32_t pc = lane & 7u;
-
-    // 36 staging instructions (1 KiB each) per K block: j < 16 -> activation rows 8j.., else weight rows 8(j-16)..; 9 per wave
-    int32_t src_off[PER_WAVE];     // element offset (< 2^31, checked on the host) of this lane's 16-byte source chunk, w/o tap / K terms
-#pragma unroll
-    for (int i = 0; i < PER_WAVE; ++i) {
-        const uint32_t j = wave * PER_WAVE + i;
-        src_off[i] = 0;
-        if (j < (uint32_t)XI) {
-            const uint32_t r = j * 8u + (lane >> 3);
-            int32_t m = m0 + (int32_t)r;
-            if (m >= p.M) m = p.M - 1;
-            int32_t src = m;
-            if (p.stride == 2) {
-                const int32_t b = m / HpWp, q = m - b * HpWp;
-                int32_t yo = q / p.Wp - 1, xo = q - (q / p.Wp) * p.Wp - 1;
-                const int32_t Ho = p.Hp - 2, Wo = p.Wp - 2;
-                yo = yo < 0 ? 0 : (yo >= Ho ? Ho - 1 : yo);
-                xo = xo < 0 ? 0 : (xo >= Wo ? Wo - 1 : xo);
-                src = b * p.in_Hp * p.in_Wp + (2 * yo) * p.in_Wp + 2 * xo;
-            }
-            src_off[i] = src * p.ldx + (int32_t)((pc ^ ((r >> 1) & 7u)) * 8u);
-        } else if (j < (uint32_t)TI) {
-            const uint32_t r = (j - XI) * 8u + (lane >> 3);
-            src_off[i] = (n0 + (int32_t)r) * Ktot + (int32_t)((pc ^ ((r >> 1) & 7u)) * 8u);
-        }
-    }
-
-    gsw_f4v acc[5][4];
-#pragma unroll
-    for (int a = 0; a < 5; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = gsw_f4v{0.f, 0.f, 0.f, 0.f};
-
-    const int32_t kc_per_tap = p.C / CV_BK;
-    const int32_t nkb = p.ntaps * kc_per_tap;
-    auto stage = [&](int32_t kb, uint8_t* buf) {
-        // channel-block-major, tap-minor: the 9 taps of one 64-channel block read (almost) the same rows, shifted by a few
-        // pixels, so consecutive K blocks hit L2 instead of streaming every tap's shifted copy of the whole tensor from
-        // HBM (tap-major order: L2 hit rate 69 %, 13 GB fetched per launch for a 1.1 GB activation tensor)
-        const int32_t kc = kb / p.ntaps, t = kb - kc * p.ntaps;
-        const int64_t xoff = (int64_t)p.tap_off[t] * p.ldx + kc * CV_BK;
-        const int32_t woff = t * p.C + kc * CV_BK;
-#pragma unroll
-        for (int i = 0; i < PER_WAVE; ++i) {
-            const uint32_t j = wave * PER_WAVE + i;     // wave-uniform
-            if (j < (uint32_t)XI) {
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + ((int64_t)src_off[i] + xoff)),
-                                                 (__attribute__((address_space(3))) void*)(buf + j * 1024u), 16, 0, 0);
-            } else if (j < (uint32_t)TI) {
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W + ((int64_t)src_off[i] + woff)),
-                                                 (__attribute__((address_space(3))) void*)(buf + BM * CV_BK * 2 + (j - XI) * 1024u), 16, 0, 0);
-            }
-        }
-    };
-    auto compute = [&](const uint8_t* buf) {
-        const uint8_t* ldsX = buf;
-        const uint8_t* ldsW = buf + BM * CV_BK * 2;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const uint32_t lc = (uint32_t)ks * 4u + (lane >> 4);
-            typename Mfma<T>::frag xf[4];
-#pragma unroll
-            for (int im = 0; im < 4; ++im) {
-                const uint32_t r = wm * 64u + (uint32_t)im * 16u + (lane & 15u);
-                xf[im] = *reinterpret_cast<const typename Mfma<T>::frag*>(ldsX + r * 128u + ((lc ^ ((r >> 1) & 7u)) << 4));
-            }
-#pragma unroll
-            for (int in = 0; in < 5; ++in) {
-                const uint32_t r = wn * 80u + (uint32_t)in * 16u + (lane & 15u);
-                const typename Mfma<T>::frag wf = *reinterpret_cast<const typename Mfma<T>::frag*>(ldsW + r * 128u + ((lc ^ ((r >> 1) & 7u)) << 4));
-#pragma unroll
-                for (int im = 0; im < 4; ++im) acc[in][im] = Mfma16<T>::mma(wf, xf[im], acc[in][im]);
-            }
-        }
-    };
-    if (DB) {
-        // two LDS stages: K block kb+1 streams in (LDS-DMA) while kb is multiplied; one barrier per K block
-        stage(0, lds);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        for (int32_t kb = 0; kb < nkb; ++kb) {
-            uint8_t* cur = lds + (kb & 1) * STAGE_BYTES;
-            if (kb + 1 < nkb) stage(kb + 1, lds + ((kb + 1) & 1) * STAGE_BYTES);
-            compute(cur);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        }
-    } else {
-        for (int32_t kb = 0; kb < nkb; ++kb) {
-            stage(kb, lds);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            compute(lds);
-            __syncthreads();
-        }
-    }
-
-    // epilogue in two column halves (wn = 0, then wn = 1): D[n][m]: m = lane & 15 (+16 im), n = (lane >> 4) * 4 + reg (+16 in)
-    const uint16_t* bias = reinterpret_cast<const uint16_t*>(p.bias);
-    const uint16_t* rowbias = reinterpret_cast<const uint16_t*>(p.rowbias);
-    const uint16_t* resid = reinterpret_cast<const uint16_t*>(p.resid);
-    uint16_t* Y = reinterpret_cast<uint16_t*>(p.y);
-    auto put_half = [&](bool gelu_it) {          // this wave's 64 x 80 accumulators (+bias) -> LDS image [m][80]
-#pragma unroll
-        for (int in = 0; in < 5; ++in) {
-            const uint32_t n = (uint32_t)in * 16u + (lane >> 4) * 4u;
-            uint2 bw = make_uint2(0, 0);
-            if (bias) bw = *reinterpret_cast<const uint2*>(bias + n0 + wn * 80u + n);
-            const uint16_t bh[4] = {(uint16_t)bw.x, (uint16_t)(bw.x >> 16), (uint16_t)bw.y, (uint16_t)(bw.y >> 16)};
-#pragma unroll
-            for (int im = 0; im < 4; ++im) {
-                const uint32_t m = wm * 64u + (uint32_t)im * 16u + (lane & 15u);
-                uint16_t h[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float v = acc[in][im][j] + (bias ? Mfma<T>::up(bh[j]) : 0.f);
-                    if (gelu_it) {       // torch: F.gelu(gate) on the stored (rounded) gate, result rounded again
-                        v = Mfma<T>::up(Mfma<T>::cvt(v));
-                        v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
-                    }
-                    h[j] = Mfma<T>::cvt(v);
-                }
-                uint2 pk;
-                pk.x = (uint32_t)h[0] | ((uint32_t)h[1] << 16);
-                pk.y = (uint32_t)h[2] | ((uint32_t)h[3] << 16);
-                *reinterpret_cast<uint2*>(lds + m * CW_OUT_STRIDE + n * 2u) = pk;
-            }
-        }
-    };
-    auto store_image = [&](int64_t col0, int32_t ld) {   // LDS image [BM][80] -> Y[m][col0 ..+80] (+rowbias +resid, borders zero)
-#pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const uint32_t q = tid + (uint32_t)NTHR * i;
-            const uint32_t r = q / 10u, cc = q - r * 10u;
-            const int32_t m = m0 + (int32_t)r;
-            if (m < p.M) {
-                int32_t b = 0;
-                bool border = false;
-                if (!(LIN && p.dense)) {
-                    b = m / HpWp;
-                    const int32_t qq = m - b * HpWp;
-                    const int32_t yy = qq / p.Wp, xx = qq - yy * p.Wp;
-                    border = (yy == 0) | (yy == p.Hp - 1) | (xx == 0) | (xx == p.Wp - 1);
-                }
-                uint4 o = make_uint4(0, 0, 0, 0);
-                const int64_t col = col0 + cc * 8u;
-                if (!border) {
-                    const uint2 lo = *reinterpret_cast<const uint2*>(lds + r * CW_OUT_STRIDE + cc * 16u);
-                    const uint2 hi = *reinterpret_cast<const uint2*>(lds + r * CW_OUT_STRIDE + cc * 16u + 8u);
-                    uint32_t w4[4] = {lo.x, lo.y, hi.x, hi.y};
-                    if (rowbias || resid) {
-                        uint4 rb = make_uint4(0, 0, 0, 0), rs = make_uint4(0, 0, 0, 0);
-                        if (rowbias) rb = *reinterpret_cast<const uint4*>(rowbias + (int64_t)b * ld + col);
-                        if (resid) rs = *reinterpret_cast<const uint4*>(resid + (int64_t)m * ld + col);
-                        const uint32_t rbw[4] = {rb.x, rb.y, rb.z, rb.w}, rsw[4] = {rs.x, rs.y, rs.z, rs.w};
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const float a0 = Mfma<T>::up((uint16_t)w4[k]) + Mfma<T>::up((uint16_t)rbw[k]) + Mfma<T>::up((uint16_t)rsw[k]);
-                            const float a1 = Mfma<T>::up((uint16_t)(w4[k] >> 16)) + Mfma<T>::up((uint16_t)(rbw[k] >> 16)) + Mfma<T>::up((uint16_t)(rsw[k] >> 16));
-                            w4[k] = (uint32_t)Mfma<T>::cvt(a0) | ((uint32_t)Mfma<T>::cvt(a1) << 16);
-                        }
-                    }
-                    o = make_uint4(w4[0], w4[1], w4[2], w4[3]);
-                }
-                *reinterpret_cast<uint4*>(Y + (int64_t)m * ld + col) = o;
-            }
-        }
-    };
-    if (LIN && p.geglu) {
-        // wn = 1 waves hold the gate columns, wn = 0 waves the value columns of the SAME 80 outputs, with identical lane
-        // mapping: gate -> gelu -> LDS; barrier; value waves multiply in place; barrier; one 80-column store
-        if (wn == 1) put_half(true);
-        __syncthreads();
-        if (wn == 0) {
-#pragma unroll
-            for (int in = 0; in < 5; ++in) {
-                const uint32_t n = (uint32_t)in * 16u + (lane >> 4) * 4u;
-                uint2 bw = make_uint2(0, 0);
-                if (bias) bw = *reinterpret_cast<const uint2*>(bias + n0 + n);
-                const uint16_t bh[4] = {(uint16_t)bw.x, (uint16_t)(bw.x >> 16), (uint16_t)bw.y, (uint16_t)(bw.y >> 16)};
-#pragma unroll
-                for (int im = 0; im < 4; ++im) {
-                    const uint32_t m = wm * 64u + (uint32_t)im * 16u + (lane & 15u);
-                    uint2* cell = reinterpret_cast<uint2*>(lds + m * CW_OUT_STRIDE + n * 2u);
-                    const uint2 g = *cell;
-                    const uint16_t gh[4] = {(uint16_t)g.x, (uint16_t)(g.x >> 16), (uint16_t)g.y, (uint16_t)(g.y >> 16)};
-                    uint16_t h[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float v = Mfma<T>::up(Mfma<T>::cvt(acc[in][im][j] + (bias ? Mfma<T>::up(bh[j]) : 0.f)));
-                        h[j] = Mfma<T>::cvt(v * Mfma<T>::up(gh[j]));
-                    }
-                    *cell = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
-                }
-            }
-        }
-        __syncthreads();
-        store_image((int64_t)tile_n * 80, p.ldy);
-    } else {
-        for (uint32_t half = 0; half < 2; ++half) {
-            if (wn == half) put_half(false);
-            __syncthreads();
-            store_image((int64_t)n0 + half * 80u, p.ldy);
-            __syncthreads();
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Halo variant for stride-1 3x3 convolutions (the bulk of the UNet): the 128 output rows of a tile are CONSECUTIVE PF rows,
-// so the rows any tap needs are the contiguous range [m0 - (Wp+1), m0 + 128 + (Wp+1)).  That halo'd activation tile is
-// staged into LDS ONCE per 64-channel block and all 9 taps read their MFMA fragments from it at a row offset; only the
-// 20 KiB weight tile (L2-hot: every workgroup reads the same weights) is re-staged per tap.  L2 -> LDS traffic per
-// (tile, channel block) drops from 9 x 36 KiB to 34 + 9 x 20 KiB, and eight of nine load phases wait only on L2 hits.
-// Dynamic LDS: [(128 + 2*HP) rows x 128 B activations][160 rows x 128 B weights], HP = Wp+1 rounded up to 8.
-// ------------------------------------------------------------------------------------------------
-// WDB: two weight stages -- tap t+1's weights stream in while tap t is multiplied (one barrier per tap instead of two)
-template <typename T, bool WDB>
-__global__ __launch_bounds__(256, 2) void gsw_conv3x3_halo_kernel(ConvArgs p, int32_t HP) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const int32_t xrows = CW_BM + 2 * HP;
-    uint8_t* ldsX = lds;                                                    // halo tile, or two plain 128-row stages (1x1 segments)
-    uint8_t* ldsW = lds + (uint32_t)max(xrows, 2 * CW_BM) * 128u;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t wm = wave & 1u, wn = wave >> 1;
-    const uint32_t nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7u;
-    const uint32_t xcd = blockIdx.x & 7u, idx = blockIdx.x >> 3;
-    const uint32_t logical = (xcd < r8 ? xcd * (q8 + 1u) : r8 * (q8 + 1u) + (xcd - r8) * q8) + idx;
-    const uint32_t ntn = (uint32_t)p.N / CW_BN;
-    const uint32_t tile_n = logical % ntn, tile_m = logical / ntn;
-    const int32_t m0 = (int32_t)tile_m * CW_BM, n0 = (int32_t)tile_n * CW_BN;
-    const int32_t HpWp = p.Hp * p.Wp;
-    const int32_t NT = p.ntaps;                          // 9, or 4 for the sub-pixel upsampling form
-    const int32_t Ktot = NT * p.C + (p.x1 ? p.C1 : 0) + (p.x2 ? p.C2 : 0);
-    const T* X = reinterpret_cast<const T*>(p.x);
-    const T* W = reinterpret_cast<const T*>(p.w);
-    const uint32_t pc = lane & 7u;
-    const int32_t G = p.Wp + 1;                          // guard rows that exist before row 0 / after row M-1
-    const int32_t nxi = xrows >> 3;                      // activation staging instructions (8 rows each)
-    const int32_t nxi_wave = (nxi + 3) >> 2;
-
-    gsw_f4v acc[5][4];
-#pragma unroll
-    for (int a = 0; a < 5; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = gsw_f4v{0.f, 0.f, 0.f, 0.f};
-
-    // weight staging: 20 instructions, 5 per wave; per-lane element offset without the (tap, channel block) term
-    int32_t w_off[5];
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-        const uint32_t r = (wave * 5u + i) * 8u + (lane >> 3);
-        w_off[i] = (n0 + (int32_t)r) * Ktot + (int32_t)((pc ^ ((r >> 1) & 7u)) * 8u);
-    }
-    int32_t lrow[4];                                     // LDS row (tap offset excluded) of this lane's 4 activation fragments
-#pragma unroll
-    for (int im = 0; im < 4; ++im) lrow[im] = HP + (int32_t)(wm * 64u + (uint32_t)im * 16u + (lane & 15u));
-
-    const int32_t kc_blocks = p.C / CV_BK;
-    auto stage_x = [&](const T* Xs, int32_t ld, int32_t kc) {   // halo'd activation tile of one channel block (once for all 9 taps)
-        for (int32_t i = 0; i < nxi_wave; ++i) {
-            const int32_t j = (int32_t)wave * nxi_wave + i;
-            if (j < nxi) {
-                const int32_t r = j * 8 + (int32_t)(lane >> 3);                 // LDS row
-                int32_t src = m0 - HP + r;                                      // PF row; rows outside the guards are never used
-                src = src < -G ? -G : (src > p.M + G - 1 ? p.M + G - 1 : src);
-                const T* sp = Xs + ((int64_t)src * ld + kc * CV_BK + (int32_t)((pc ^ (((uint32_t)r >> 1) & 7u)) * 8u));
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sp,
-                                                 (__attribute__((address_space(3))) void*)(ldsX + (uint32_t)j * 1024u), 16, 0, 0);
-            }
-        }
-    };
-    auto stage_w = [&](int32_t woff, uint8_t* wbuf) {
-#pragma unroll
-        for (int i = 0; i < 5; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W + ((int64_t)w_off[i] + woff)),
-                                             (__attribute__((address_space(3))) void*)(wbuf + (wave * 5u + i) * 1024u), 16, 0, 0);
-    };
-    auto compute = [&](int32_t t, const uint8_t* wbuf) {
-        // all 18 fragment reads of the tap step are issued up front (both 32-channel halves), so the second half's LDS latency is
-        // covered by the first half's 20 MFMAs instead of a wait in front of every few MFMAs
-        const int32_t toff = p.tap_off[t];
-        typename Mfma<T>::frag xf[2][4], wf[2][5];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const uint32_t lc = (uint32_t)ks * 4u + (lane >> 4);
-#pragma unroll
-            for (int im = 0; im < 4; ++im) {
-                const uint32_t r = (uint32_t)(lrow[im] + toff);
-                xf[ks][im] = *reinterpret_cast<const typename Mfma<T>::frag*>(ldsX + r * 128u + ((lc ^ ((r >> 1) & 7u)) << 4));
-            }
-#pragma unroll
-            for (int in = 0; in < 5; ++in) {
-                const uint32_t r = wn * 80u + (uint32_t)in * 16u + (lane & 15u);
-                wf[ks][in] = *reinterpret_cast<const typename Mfma<T>::frag*>(wbuf + r * 128u + ((lc ^ ((r >> 1) & 7u)) << 4));
-            }
-        }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int in = 0; in < 5; ++in)
-#pragma unroll
-                for (int im = 0; im < 4; ++im) acc[in][im] = Mfma16<T>::mma(wf[ks][in], xf[ks][im], acc[in][im]);
-        // issue order: the first half's 9 reads, then one read of the second half per two MFMAs of the first, then the rest
-        __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);
-#pragma unroll
-        for (int i = 0; i < 9; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 22, 0);
-    };
-    for (int32_t kc = 0; kc < kc_blocks; ++kc) {
-        stage_x(X, p.ldx, kc);
-        if (WDB) {
-            stage_w(kc * CV_BK, ldsW);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            for (int32_t t = 0; t < NT; ++t) {
-                uint8_t* cur = ldsW + (uint32_t)(t & 1) * (CW_BN * 128u);
-                if (t < NT - 1) stage_w((t + 1) * p.C + kc * CV_BK, ldsW + (uint32_t)((t + 1) & 1) * (CW_BN * 128u));
-                compute(t, cur);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();      // next weights landed; everyone is done with `cur` (and, after tap 8, with the halo tile)
-            }
-        } else {
-            for (int32_t t = 0; t < NT; ++t) {
-                stage_w(t * p.C + kc * CV_BK, ldsW);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                compute(t, ldsW);
-                __syncthreads();
-            }
-        }
-    }
-    // extra 1x1 segments (conv_shortcut folded in, its concatenated input read as two tensors): K blocks at weight offset
-    // 9*C (+C1).  No halo needed: the activation area holds two plain 128-row stages, so both operands are double-buffered.
-    {
-        const int32_t n1 = (p.x1 && p.C1 > 0) ? p.C1 / CV_BK : 0;
-        const int32_t n2 = (p.x2 && p.C2 > 0) ? p.C2 / CV_BK : 0;
-        const int32_t nsteps = n1 + n2;
-        auto stage_seg = [&](int32_t step, uint32_t sel) {
-            const bool second = step >= n1;
-            const T* Xs = reinterpret_cast<const T*>(second ? p.x2 : p.x1);
-            const int32_t ld = second ? p.C2 : p.C1;
-            const int32_t kc = second ? step - n1 : step;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {                       // 16 instructions x 8 rows = the 128 tile rows
-                const uint32_t j = wave * 4u + i;
-                const uint32_t r = j * 8u + (lane >> 3);
-                int32_t src = m0 + (int32_t)r;
-                src = src > p.M + G - 1 ? p.M + G - 1 : src;
-                const T* sp = Xs + ((int64_t)src * ld + kc * CV_BK + (int32_t)((pc ^ ((r >> 1) & 7u)) * 8u));
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sp,
-                                                 (__attribute__((address_space(3))) void*)(ldsX + sel * (CW_BM * 128u) + j * 1024u), 16, 0, 0);
-            }
-            stage_w(NT * p.C + (second ? p.C1 : 0) + kc * CV_BK, ldsW + sel * (CW_BN * 128u));
-        };
-        auto compute_seg = [&](uint32_t sel) {
-            const uint8_t* xb = ldsX + sel * (CW_BM * 128u);
-            const uint8_t* wb = ldsW + sel * (CW_BN * 128u);
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const uint32_t lc = (uint32_t)ks * 4u + (lane >> 4);
-                typename Mfma<T>::frag xf[4];
-#pragma unroll
-                for (int im = 0; im < 4; ++im) {
-                    const uint32_t r = wm * 64u + (uint32_t)im * 16u + (lane & 15u);
-                    xf[im] = *reinterpret_cast<const typename Mfma<T>::frag*>(xb + r * 128u + ((lc ^ ((r >> 1) & 7u)) << 4));
-                }
-#pragma unroll
-                for (int in = 0; in < 5; ++in) {
-                    const uint32_t r = wn * 80u + (uint32_t)in * 16u + (lane & 15u);
-                    const typename Mfma<T>::frag wf = *reinterpret_cast<const typename Mfma<T>::frag*>(wb + r * 128u + ((lc ^ ((r >> 1) & 7u)) << 4));
-#pragma unroll
-                    for (int im = 0; im < 4; ++im) acc[in][im] = Mfma16<T>::mma(wf, xf[im], acc[in][im]);
-                }
-            }
-        };
-        if (nsteps > 0) {
-            if (WDB) {
-                stage_seg(0, 0u);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                for (int32_t i = 0; i < nsteps; ++i) {
-                    if (i + 1 < nsteps) stage_seg(i + 1, (uint32_t)((i + 1) & 1));
-                    compute_seg((uint32_t)(i & 1));
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __syncthreads();
-                }
-            } else {
-                for (int32_t i = 0; i < nsteps; ++i) {
-                    stage_seg(i, 0u);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __syncthreads();
-                    compute_seg(0u);
-                    __syncthreads();
-                }
-            }
-        }
-    }
-
-    // ---- epilogue (same as the wide kernel): two 80-column halves through an LDS image
-    const uint16_t* bias = reinterpret_cast<const uint16_t*>(p.bias);
-    const uint16_t* rowbias = reinterpret_cast<const uint16_t*>(p.rowbias);
-    const uint16_t* resid = reinterpret_cast<const uint16_t*>(p.resid);
-    uint16_t* Y = reinterpret_cast<uint16_t*>(p.y);
-    for (uint32_t half = 0; half < 2; ++half) {
-        if (wn == half) {
-#pragma unroll
-            for (int in = 0; in < 5; ++in) {
-                const uint32_t n = (uint32_t)in * 16u + (lane >> 4) * 4u;
-                uint2 bw = make_uint2(0, 0);
-                if (bias) bw = *reinterpret_cast<const uint2*>(bias + n0 + half * 80u + n);
-                const uint16_t bh[4] = {(uint16_t)bw.x, (uint16_t)(bw.x >> 16), (uint16_t)bw.y, (uint16_t)(bw.y >> 16)};
-#pragma unroll
-                for (int im = 0; im < 4; ++im) {
-                    const uint32_t m = wm * 64u + (uint32_t)im * 16u + (lane & 15u);
-                    uint16_t h[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) h[j] = Mfma<T>::cvt(acc[in][im][j] + (bias ? Mfma<T>::up(bh[j]) : 0.f));
-                    *reinterpret_cast<uint2*>(lds + m * CW_OUT_STRIDE + n * 2u) =
-                        make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
-                }
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const uint32_t q = tid + 256u * i;
-            const uint32_t r = q / 10u, cc = q - r * 10u;
-            const int32_t m = m0 + (int32_t)r;
-            if (m < p.M) {
-                const int32_t b = m / HpWp, qq = m - b * HpWp;
-                const int32_t yy = qq / p.Wp, xx = qq - yy * p.Wp;
-                const bool border = (yy == 0) | (yy == p.Hp - 1) | (xx == 0) | (xx == p.Wp - 1);
-                uint4 o = make_uint4(0, 0, 0, 0);
-                const int64_t col = n0 + (int32_t)(half * 80u + cc * 8u);
-                if (!border) {
-                    const uint2 lo = *reinterpret_cast<const uint2*>(lds + r * CW_OUT_STRIDE + cc * 16u);
-                    const uint2 hi = *reinterpret_cast<const uint2*>(lds + r * CW_OUT_STRIDE + cc * 16u + 8u);
-                    uint32_t w4[4] = {lo.x, lo.y, hi.x, hi.y};
-                    if (rowbias || resid) {
-                        uint4 rb = make_uint4(0, 0, 0, 0), rs = make_uint4(0, 0, 0, 0);
-                        if (rowbias) rb = *reinterpret_cast<const uint4*>(rowbias + (int64_t)b * p.N + col);
-                        if (resid) rs = *reinterpret_cast<const uint4*>(resid + (int64_t)m * p.N + col);
-                        const uint32_t rbw[4] = {rb.x, rb.y, rb.z, rb.w}, rsw[4] = {rs.x, rs.y, rs.z, rs.w};
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const float a0 = Mfma<T>::up((uint16_t)w4[k]) + Mfma<T>::up((uint16_t)rbw[k]) + Mfma<T>::up((uint16_t)rsw[k]);
-                            const float a1 = Mfma<T>::up((uint16_t)(w4[k] >> 16)) + Mfma<T>::up((uint16_t)(rbw[k] >> 16)) + Mfma<T>::up((uint16_t)(rsw[k] >> 16));
-                            w4[k] = (uint32_t)Mfma<T>::cvt(a0) | ((uint32_t)Mfma<T>::cvt(a1) << 16);
-                        }
-                    }
-                    o = make_uint4(w4[0], w4[1], w4[2], w4[3]);
-                }
-                if (p.up) {
-                    // sub-pixel upsampling: low-resolution pixel (yy-1, xx-1) -> high-resolution pixel (2(yy-1)+dy, 2(xx-1)+dx) of a
-                    // [B, 2H+2, 2W+2] PF tensor; the low-resolution border rows produce nothing
-                    if (!border) {
-                        const int32_t dy = (p.up - 1) >> 1, dx = (p.up - 1) & 1;
-                        const int64_t mo = ((int64_t)b * (2 * p.Hp - 2) + (2 * (yy - 1) + dy + 1)) * (2 * p.Wp - 2) + (2 * (xx - 1) + dx + 1);
-                        *reinterpret_cast<uint4*>(Y + mo * p.N + col) = o;
-                    }
-                } else
-                *reinterpret_cast<uint4*>(Y + (int64_t)m * p.N + col) = o;
-            }
-        }
-        __syncthreads();
-    }
-}
 
 // ------------------------------------------------------------------------------------------------
 // GroupNorm (+SiLU) on PF activations.  Channels of a group are NOT contiguous across pixels in NHWC, so the statistics
@@ -786,12 +273,12 @@ __device__ __forceinline__ uint16_t cvt_h(float f, bool bf) {
 __global__ __launch_bounds__(512) void gsw_gn_pf_stats_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ x2, int32_t Ca,
                                                              float* __restrict__ partial, int32_t C, int32_t G,
                                                              int32_t HpWp, int32_t slab_len, int32_t P, int bf) {
-    __shared__ float s_sum[GN_MAX_GROUPS], s_sq[GN_MAX_GROUPS];
+    // Deterministic reduction (no atomics: two runs on the same input give the same bits): every thread parks its 8 per-channel sums in LDS,
+    // one thread per channel folds the P pixel lanes in a fixed order, one thread per group folds the group's channels in a fixed order.
+    __shared__ float s_part[2][512 * 8];
     const int32_t b = blockIdx.y, s = blockIdx.x, nslab = gridDim.x;
     const int32_t cv = C >> 3, tid = threadIdx.x;
     const int32_t cvec = tid % cv, prow = tid / cv;
-    if (tid < GN_MAX_GROUPS) { s_sum[tid] = 0.f; s_sq[tid] = 0.f; }
-    __syncthreads();
     float sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const int32_t i0 = s * slab_len, i1 = min(HpWp, i0 + slab_len);
     const bool second = x2 && cvec * 8 >= Ca;
@@ -816,24 +303,28 @@ __global__ __launch_bounds__(512) void gsw_gn_pf_stats_kernel(const uint16_t* __
 #pragma unroll
         for (int k = 0; k < 8; ++k) { sum[k] += v[k]; sq[k] = fmaf(v[k], v[k], sq[k]); }
     }
-    const int32_t cpg = C / G;
-    {   // the thread's 8 consecutive channels span at most a few groups: merge runs in registers, one LDS atomic pair per run
-        int32_t g = (cvec * 8) / cpg, rem = cvec * 8 - g * cpg;
-        float rs = 0.f, rq = 0.f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            rs += sum[k]; rq += sq[k];
-            if (++rem == cpg || k == 7) {
-                atomicAdd(&s_sum[g], rs);
-                atomicAdd(&s_sq[g], rq);
-                rs = 0.f; rq = 0.f; rem = 0; ++g;
-            }
-        }
+    {
+        float4* ps = reinterpret_cast<float4*>(&s_part[0][(prow * cv + cvec) * 8]);
+        float4* pq = reinterpret_cast<float4*>(&s_part[1][(prow * cv + cvec) * 8]);
+        ps[0] = make_float4(sum[0], sum[1], sum[2], sum[3]); ps[1] = make_float4(sum[4], sum[5], sum[6], sum[7]);
+        pq[0] = make_float4(sq[0], sq[1], sq[2], sq[3]); pq[1] = make_float4(sq[4], sq[5], sq[6], sq[7]);
     }
     __syncthreads();
-    if (tid < G) {
-        float* o = partial + (((int64_t)b * nslab + s) * G + tid) * 2;
-        o[0] = s_sum[tid]; o[1] = s_sq[tid];
+    const int32_t nthr = cv * P;
+    for (int32_t c = tid; c < 2 * C; c += nthr) {           // channel c (sums), then channel c - C (squares): fold the pixel lanes into lane 0's slot
+        float* col = &s_part[c >= C ? 1 : 0][c >= C ? c - C : c];
+        float a = col[0];
+        for (int32_t pr = 1; pr < P; ++pr) a += col[pr * C];
+        col[0] = a;
+    }
+    __syncthreads();
+    const int32_t cpg = C / G;
+    if (tid < 2 * G) {
+        const int32_t g = tid >= G ? tid - G : tid;
+        const float* col = &s_part[tid >= G ? 1 : 0][g * cpg];
+        float a = col[0];
+        for (int32_t k = 1; k < cpg; ++k) a += col[k];
+        partial[(((int64_t)b * nslab + s) * G + g) * 2 + (tid >= G ? 1 : 0)] = a;
     }
 }
 
@@ -1016,38 +507,13 @@ __global__ __launch_bounds__(256) void gsw_add_layernorm_kernel(const uint16_t* 
 extern __attribute__((visibility("hidden"))) thread_local int g_last_hip_error;   // gswm_kernels.hip; read by gsw_last_hip_error()
 #define g_conv_hip_error g_last_hip_error
 #define GSW_CONV_HIP(call) do { hipError_t _e = (call); if (_e != hipSuccess) { g_conv_hip_error = (int)_e; return GSW_ERR_HIP; } } while (0)
-// Launch the halo kernel for a prepared ConvArgs: double-buffered weights when the LDS image (halo'd activation tile + 2 weight tiles)
-// fits two workgroups per CU (<= 80 KiB), single-buffered weights for wider rows (e.g. the 96-wide lattice of BASELINE config 5),
-// GSW_ERR_UNSUPPORTED beyond that.  GSW_CONV_WDB=0 forces the single-buffered variant (profiling A/B).
 static int launch_engine(const ConvArgs& a, int64_t M, int N, int dtype, void* stream);
 static bool use_engine(const ConvArgs& a, int N);
 
-static int launch_halo(const ConvArgs& a, int64_t M, int N, int dtype, void* stream) {
-    if (use_engine(a, N)) return launch_engine(a, M, N, dtype, stream);
-    static const int wdb_env = getenv("GSW_CONV_WDB") ? atoi(getenv("GSW_CONV_WDB")) : 1;
-    const int32_t HP = ((a.Wp + 1) + 7) & ~7;
-    const size_t xbytes = (size_t)std::max(CW_BM + 2 * HP, 2 * CW_BM) * 128u, wbytes = (size_t)CW_BN * 128u;
-    const bool wdb = wdb_env && xbytes + 2 * wbytes <= 80u * 1024u;
-    const size_t lds = xbytes + (wdb ? 2 : 1) * wbytes;
-    if (lds > 80u * 1024u) return GSW_ERR_UNSUPPORTED;
-    const uint32_t grid = (uint32_t)(((M + 127) / 128) * (N / CW_BN));
-    hipStream_t st = (hipStream_t)stream;
-#define GSW_HALO_LAUNCH(TT, DB)                                                                                                              \
-    do {                                                                                                                                     \
-        if (lds > 48u * 1024u)                                                                                                               \
-            GSW_CONV_HIP(hipFuncSetAttribute((const void*)gsw_conv3x3_halo_kernel<TT, DB>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)); \
-        hipLaunchKernelGGL((gsw_conv3x3_halo_kernel<TT, DB>), dim3(grid), dim3(256), lds, st, a, HP);                                        \
-    } while (0)
-    if (dtype == GSW_F16) { if (wdb) GSW_HALO_LAUNCH(_Float16, true); else GSW_HALO_LAUNCH(_Float16, false); }
-    else { if (wdb) GSW_HALO_LAUNCH(__bf16, true); else GSW_HALO_LAUNCH(__bf16, false); }
-#undef GSW_HALO_LAUNCH
-    GSW_CONV_HIP(hipGetLastError());
-    return GSW_OK;
-}
-
-// The same convolution on the matmul engine (csrc/gswm_mm.hip): every tap is a row offset into the padded-flat activation, so the 3x3 (or
+// Convolutions on the matmul engine (csrc/gswm_mm.hip): every tap is a row offset into the padded-flat activation, so the 3x3 (or
 // the 2x2 sub-pixel) convolution is a GEMM whose K dimension walks (channel block, tap row, tap) -- no halo tile, the activation slab of
-// each tap comes through L2.  GSW_CONV_ENGINE=1/0 is the A/B switch.
+// each tap comes through L2.  (The round-1 / round-2 halo and 128 x 160 kernels this replaced are gone: profiles/r02h_conv_engine_vs_halo.txt
+// holds the last A/B.)
 // Zero the border rows of a padded-flat tensor [B, Hp, Wp, N] (row stride N): top and bottom rows, first and last column.
 __global__ __launch_bounds__(256) void gsw_pf_zero_border_kernel(uint16_t* __restrict__ y, int B, int Hp, int Wp, int n8) {
     const int nb = 2 * Wp + 2 * (Hp - 2);
@@ -1093,16 +559,10 @@ static int launch_engine(const ConvArgs& a, int64_t M, int N, int dtype, void* s
 }
 
 static bool use_engine(const ConvArgs& a, int N) {
-    static const int env = getenv("GSW_CONV_ENGINE") ? atoi(getenv("GSW_CONV_ENGINE")) : 1;
     // N: any multiple of 8 from 128 up (a partial last 160-column tile costs a full one: 128 / 256 / 512 channels of the VAE run at 80 %);
     // narrower outputs (the 4-channel edge padded to 64) stay on the 64-column kernel
     if (a.stride == 2 && (a.ntaps != 9 || a.C1 || a.C2 || a.up)) return false;
-    return env && !a.dense && (a.ntaps == 9 || a.ntaps == 4 || a.ntaps == 1) && N % 8 == 0 && N >= 128 && a.C % 64 == 0 && a.C1 % 64 == 0 && a.C2 % 64 == 0;
-}
-
-static bool halo_fits(int Wp) {
-    const int32_t HP = ((Wp + 1) + 7) & ~7;
-    return (size_t)std::max(CW_BM + 2 * HP, 2 * CW_BM) * 128u + (size_t)CW_BN * 128u <= 80u * 1024u;
+    return (a.ntaps == 9 || a.ntaps == 4 || a.ntaps == 1) && N % 8 == 0 && N >= 128 && a.C % 64 == 0 && a.C1 % 64 == 0 && a.C2 % 64 == 0;
 }
 
 static int launch_conv_gemm(ConvArgs& a, int64_t M, int N, int dtype, void* stream);
@@ -1136,30 +596,12 @@ int gsw_conv_pf(const void* x_dev, const void* w_dev, const void* bias_dev, cons
 }
 
 static int launch_conv_gemm(ConvArgs& a, int64_t M, int N, int dtype, void* stream) {
-    static const bool narrow_only = getenv("GSW_CONV_NARROW") != nullptr;      // A/B switches for profiling
-    static const int wm_env = getenv("GSW_CONV_WM") ? atoi(getenv("GSW_CONV_WM")) : 2;
     hipStream_t st = (hipStream_t)stream;
     if (use_engine(a, N)) return launch_engine(a, M, N, dtype, stream);
-    if (N % CW_BN == 0 && !narrow_only) {
-        static const bool no_halo = getenv("GSW_CONV_NOHALO") != nullptr;
-        if (!a.dense && a.ntaps == 9 && a.stride == 1 && !no_halo && halo_fits(a.Wp)) {
-            return launch_halo(a, M, N, dtype, stream);
-        } else if (a.dense) {
-            return GSW_ERR_UNSUPPORTED;       // dense matrices run on the matmul engine (gsw_gemm)
-        } else if (wm_env == 4) {
-            const uint32_t grid = (uint32_t)(((M + 255) / 256) * (N / CW_BN));
-            if (dtype == GSW_F16) hipLaunchKernelGGL((gsw_conv_gemm_wide_kernel<_Float16, 4, false, false>), dim3(grid), dim3(512), 0, st, a);
-            else hipLaunchKernelGGL((gsw_conv_gemm_wide_kernel<__bf16, 4, false, false>), dim3(grid), dim3(512), 0, st, a);
-        } else {
-            const uint32_t grid = (uint32_t)(((M + 127) / 128) * (N / CW_BN));
-            if (dtype == GSW_F16) hipLaunchKernelGGL((gsw_conv_gemm_wide_kernel<_Float16, 2, false, false>), dim3(grid), dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((gsw_conv_gemm_wide_kernel<__bf16, 2, false, false>), dim3(grid), dim3(256), 0, st, a);
-        }
-    } else {
-        const uint32_t grid = (uint32_t)(((M + CV_BM - 1) / CV_BM) * (N / CV_BN));
-        if (dtype == GSW_F16) hipLaunchKernelGGL((gsw_conv_gemm_kernel<_Float16>), dim3(grid), dim3(CV_THREADS), 0, st, a);
-        else hipLaunchKernelGGL((gsw_conv_gemm_kernel<__bf16>), dim3(grid), dim3(CV_THREADS), 0, st, a);
-    }
+    if (N % CV_BN || a.C1 || a.C2 || a.up) return GSW_ERR_UNSUPPORTED;
+    const uint32_t grid = (uint32_t)(((M + CV_BM - 1) / CV_BM) * (N / CV_BN));
+    if (dtype == GSW_F16) hipLaunchKernelGGL((gsw_conv_gemm_kernel<_Float16>), dim3(grid), dim3(CV_THREADS), 0, st, a);
+    else hipLaunchKernelGGL((gsw_conv_gemm_kernel<__bf16>), dim3(grid), dim3(CV_THREADS), 0, st, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g_conv_hip_error = (int)e; return GSW_ERR_HIP; }
     return GSW_OK;
@@ -1228,7 +670,7 @@ int gsw_conv3x3_res_pf(const void* x_dev, const void* w_dev, const void* bias_de
     // w_dev = [N][9*C + C1 + C2].  The resnet's conv2 + conv_shortcut(cat(x1, x2)) + residual in a single kernel.
     if (!x_dev || !w_dev || !y_dev || B <= 0 || H <= 0 || W <= 0 || C <= 0 || N <= 0) return GSW_ERR_BAD_ARG;
     if ((x1_dev && C1 <= 0) || (x2_dev && (C2 <= 0 || !x1_dev))) return GSW_ERR_BAD_ARG;
-    if (C % CV_BK || N % CW_BN || (x1_dev && C1 % CV_BK) || (x2_dev && C2 % CV_BK)) return GSW_ERR_UNSUPPORTED;
+    if (C % CV_BK || N % 8 || N < 128 || (x1_dev && C1 % CV_BK) || (x2_dev && C2 % CV_BK)) return GSW_ERR_UNSUPPORTED;
     if (dtype != GSW_F16 && dtype != GSW_BF16) return GSW_ERR_BAD_ARG;
     ConvArgs a;
     a.x = x_dev; a.w = w_dev; a.bias = bias_dev; a.rowbias = rowbias_dev; a.resid = resid_dev; a.y = y_dev;
@@ -1241,17 +683,17 @@ int gsw_conv3x3_res_pf(const void* x_dev, const void* w_dev, const void* bias_de
         for (int kw = 0; kw < 3; ++kw) a.tap_off[kh * 3 + kw] = (kh - 1) * a.Wp + (kw - 1);
     a.dense = 0; a.geglu = 0; a.ldy = N;
     a.x1 = x1_dev; a.x2 = x2_dev; a.C1 = x1_dev ? C1 : 0; a.C2 = x2_dev ? C2 : 0; a.up = 0;
-    return launch_halo(a, M, N, dtype, stream);
+    return launch_engine(a, M, N, dtype, stream);
 }
 
 int gsw_conv_up2x_pf(const void* x_dev, const void* w4_dev, const void* bias_dev, void* y_dev, int B, int H, int W, int C, int N, int dtype, void* stream) {
     // nearest-neighbour 2x upsampling followed by a 3x3 convolution (diffusers Upsample2D), computed from the LOW-resolution input:
     // output pixel (2i+dy, 2j+dx) only ever sees the 2x2 low-resolution neighbourhood (i+dy-1 .. i+dy, j+dx-1 .. j+dx), with the 3x3
-    // weights summed over the taps that land on the same source pixel.  Four launches of the halo kernel (ntaps = 4, K = 4C), 2.25x
+    // weights summed over the taps that land on the same source pixel.  Four launches of the matmul engine (ntaps = 4, K = 4C), 2.25x
     // fewer FLOPs than convolving the upsampled tensor, and the upsampled tensor never exists.
     //   x: PF [B, H, W, C];  w4: [4 (dy*2+dx)][N][4 (a*2+b)][C] pre-summed weights;  y: PF [B, 2H, 2W, N] (border rows zeroed here).
     if (!x_dev || !w4_dev || !y_dev || B <= 0 || H <= 0 || W <= 0 || C <= 0 || N <= 0) return GSW_ERR_BAD_ARG;
-    if (C % CV_BK || N % CW_BN) return GSW_ERR_UNSUPPORTED;
+    if (C % CV_BK || N % 8 || N < 128) return GSW_ERR_UNSUPPORTED;
     if (dtype != GSW_F16 && dtype != GSW_BF16) return GSW_ERR_BAD_ARG;
     ConvArgs a;
     a.x = x_dev; a.bias = bias_dev; a.rowbias = nullptr; a.resid = nullptr; a.y = y_dev;
@@ -1263,7 +705,6 @@ int gsw_conv_up2x_pf(const void* x_dev, const void* w4_dev, const void* bias_dev
     a.dense = 0; a.geglu = 0; a.ldy = N;
     a.x1 = nullptr; a.x2 = nullptr; a.C1 = 0; a.C2 = 0;
     a.stride = 1; a.dense = 0; a.up = 1;
-    if (!use_engine(a, N) && !halo_fits(a.Wp)) return GSW_ERR_UNSUPPORTED;
     zero_border(y_dev, B, 2 * H + 2, 2 * W + 2, N, (hipStream_t)stream);
     const size_t esz = 2;
     for (int par = 0; par < 4; ++par) {
@@ -1273,7 +714,7 @@ int gsw_conv_up2x_pf(const void* x_dev, const void* w4_dev, const void* bias_dev
             for (int tb = 0; tb < 2; ++tb) a.tap_off[ta * 2 + tb] = (ta + dy - 1) * a.Wp + (tb + dx - 1);
         a.w = (const uint8_t*)w4_dev + (size_t)par * N * 4 * C * esz;
         a.up = 1 + par;
-        { const int rc = launch_halo(a, M, N, dtype, stream); if (rc != GSW_OK) return rc; }
+        { const int rc = launch_engine(a, M, N, dtype, stream); if (rc != GSW_OK) return rc; }
     }
     return GSW_OK;
 }

@@ -4,33 +4,41 @@
 //
 //   Y[m, n] = sum_k A[m, k] * W[n, k]  (+ bias[n] + rowbias[image(m), n] + resid[m, n]),   fp16 / bf16 in, fp32 accumulate
 //
-// Structure (one workgroup per CU, persistent over output tiles):
-//   * 512 threads = 8 waves = two GROUPS of four (one wave of each group per SIMD).  A tile is BM x BN = 256 x 160 (waves 4 x 2) or
-//     128 x 320 (2 x 4); a wave owns 64 x 80 outputs as 4 x 5 v_mfma_f32_16x16x32 tiles; group g owns columns [g*BN/2, (g+1)*BN/2).
-//   * K is consumed in PHASES of 32.  Operands of a phase are one STAGE of an LDS ring (4 stages x (BM + BN) rows x 64 B) filled by
-//     LDS-DMA (global_load_lds, 16 B per lane) three phases ahead; waits are COUNTED (s_waitcnt vmcnt(2n): the two newest stages stay in
-//     flight across the barrier), barriers are raw s_barrier.  The producer walks tiles independently of the consumer, so the next
-//     tile's first three stages stream in while the current tile's epilogue runs (HBM-bound shapes, K = 320, live off that).
-//   * The two groups run PING-PONG, offset by one slot: while group 0 multiplies phase p (20 MFMAs per wave, the SIMD's matrix pipe
-//     busy), group 1 -- the other wave on the same SIMD -- issues its DMA pieces and reads its 9 operand fragments for phase p, then
-//     they swap.  Every slot ends in one s_barrier, so a SIMD always has exactly one wave feeding MFMAs and one wave loading.
-//   * LDS rows are 64 B (32 k-values); 16-byte chunks are XOR-swizzled with (-(row >> 2)) & 3 on the DMA SOURCE address, which makes
-//     every ds_read_b128 fragment read conflict-free (the four 16-lane groups of a b128 read cover all sixteen 16-byte slots).
+// Structure (one persistent workgroup per CU, grid = 256, walking output tiles in an XCD-aware panel order):
+//   * Output tile BM x BN = 256 x 160 (MT = 4) or 128 x 160 (MT = 2, for launches whose 256-row tiling would leave CUs idle).  8 multiplying
+//     waves in LOCKSTEP as 4 (M) x 2 (N); a wave owns 64 (32) x 80 outputs as MT x 5 v_mfma_f32_16x16x32 accumulators.
+//   * K is consumed in STAGES of 64 k-values = two PHASES of 32.  A stage (BM + BN rows x 128 B = 52 KiB) goes global -> LDS by DMA
+//     (global_load_lds, 16 B per lane, 1 KiB per wave instruction) into a THREE-stage ring (156 of the 160 KiB).  Waits are counted
+//     (s_waitcnt vmcnt(N): the newest stage stays in flight across the barrier), barriers are raw s_barrier, ONE per stage.
+//   * Who issues the DMA: the 8-wave variant interleaves a stage's pieces, in two halves, sparsely between the MFMAs of two phases
+//     (sched_group_barrier pins the order); the 12-wave variant (SPLIT) adds four producer waves (one per SIMD) that issue all 52 pieces,
+//     so the multiplying waves carry no DMA and no tap bookkeeping (+7-9 % on the 3x3 convolutions).
+//   * LDS rows are 128 B (64 k-values); 16-byte chunks are XOR-swizzled with (row >> 1) & 7 on the DMA SOURCE address, which makes
+//     every ds_read_b128 fragment read conflict-free without padding.
 //   * A-operand rows come from up to three K SEGMENTS (pointer, row stride, channel count, tap table): a dense matrix is one segment
 //     with one tap; a 3x3 convolution on a padded-flat NHWC tensor is one segment with nine taps (a tap = a constant row offset, see
-//     gswm_conv.hip); the resnet's conv2 + 1x1 shortcut of cat(x, skip) is three segments.
-//   * Epilogue through an LDS image (16-byte coalesced stores): bias, per-image row bias, residual, GEGLU (value * gelu(gate) of a
-//     tile-interleaved projection), transposed output ([B, N, S] for the attention kernel's V^T operand; MFMA operands swapped so a lane
-//     holds 4 consecutive rows), PF border zeroing, tokens -> PF interior scatter (proj_out's residual add in place), sub-pixel scatter.
+//     gswm_conv.hip) whose M dimension enumerates INTERIOR pixels only; the resnet's conv2 + 1x1 shortcut of cat(x, skip) is three
+//     segments.  The producer only adds uniform steps to per-lane pointers per stage; tap / channel-block / segment / tile bookkeeping
+//     runs once per RUN of stages in a scalar slow path.
+//   * Epilogues straight from the accumulators (no LDS image, no barrier): bias, rounding, v_permlane16/32_swap rounds so that a lane
+//     holds 8 consecutive outputs -> 16-byte stores.  EPI 0 dense rows (+ residual), EPI 1 PF rows (+ per-image row bias + residual),
+//     tokens -> PF scatter, sub-pixel scatter; EPI 2 GEGLU (weight rows packed [8 value | 8 gate] per 16-row block, value * gelu(gate));
+//     EPI 3 transposed output ([B, N, S]: the attention kernel's V^T operand; MFMA operands swapped).
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <hip/hip_bf16.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <algorithm>
+#include <atomic>
 
 #include "../../include/gswm.h"
 #include "gswm_mm.h"
+
+// Process-wide tuning knobs of the engine (tests and A/B runs force a tiling; production leaves both on "auto").  Initialised from the environment
+// (GSW_MM_BM = 128 | 256, GSW_MM_SPLIT = bit mask over epilogue kinds) and settable through the C ABI (gsw_mm_config).
+static std::atomic<int> g_mm_tile_rows{getenv("GSW_MM_BM") ? atoi(getenv("GSW_MM_BM")) : 0};
+static std::atomic<int> g_mm_split_mask{getenv("GSW_MM_SPLIT") ? atoi(getenv("GSW_MM_SPLIT")) : 10 /* convolutions (EPI 1) and the transposed projection (EPI 3) */};
 
 namespace {
 
@@ -722,9 +730,8 @@ int mm_launch_k(const MMArgs& a, uint32_t grid, hipStream_t st) {
 }
 template <typename T, int EPI>
 int mm_launch_t(const MMArgs& a, uint32_t grid, int mt, hipStream_t st) {
-    // GSW_MM_SPLIT: bit e set = epilogue kind e runs the 12-wave variant whose waves 8-11 own the LDS-DMA (A/B switch)
-    static const int split_mask = getenv("GSW_MM_SPLIT") ? atoi(getenv("GSW_MM_SPLIT")) : 10;      // default: convolutions (1) and the transposed projection (3)
-    const bool split = (split_mask >> EPI) & 1;
+    // bit e of the split mask set = epilogue kind e runs the 12-wave variant whose waves 8-11 own the LDS-DMA (gsw_mm_config / GSW_MM_SPLIT: A/B switch)
+    const bool split = (g_mm_split_mask.load(std::memory_order_relaxed) >> EPI) & 1;
     if (mt == 4) return split ? mm_launch_k<T, EPI, true, 4>(a, grid, st) : mm_launch_k<T, EPI, false, 4>(a, grid, st);
     return split ? mm_launch_k<T, EPI, true, 2>(a, grid, st) : mm_launch_k<T, EPI, false, 2>(a, grid, st);
 }
@@ -742,6 +749,15 @@ int mm_launch_e(const MMArgs& a, int epi, uint32_t grid, int mt, hipStream_t st)
 
 extern __attribute__((visibility("hidden"))) thread_local int g_last_hip_error;   // gswm_kernels.hip
 
+
+int gsw_mm_config(int tile_rows, int split_mask) {
+    if (tile_rows != 0 && tile_rows != 128 && tile_rows != 256 && tile_rows != -1) return GSW_ERR_BAD_ARG;
+    if (split_mask < -1 || split_mask > 15) return GSW_ERR_BAD_ARG;
+    if (tile_rows != -1) g_mm_tile_rows.store(tile_rows, std::memory_order_relaxed);
+    if (split_mask != -1) g_mm_split_mask.store(split_mask, std::memory_order_relaxed);
+    return GSW_OK;
+}
+
 // Launch the engine for a prepared MMArgs (segments, weights, epilogue); fills the tiling fields.
 int gsw_mm_launch(MMArgs& a, int dtype, void* stream) {
     if (dtype != GSW_F16 && dtype != GSW_BF16) return GSW_ERR_BAD_ARG;
@@ -750,7 +766,7 @@ int gsw_mm_launch(MMArgs& a, int dtype, void* stream) {
     constexpr int BN = 160;
     const int64_t tiles_n = (a.N + BN - 1) / BN;
     // 256-row tiles unless they would leave CUs without one: then 128-row tiles (GSW_MM_BM=128 / 256 forces one for A/B runs)
-    static const int bm_env = getenv("GSW_MM_BM") ? atoi(getenv("GSW_MM_BM")) : 0;
+    const int bm_env = g_mm_tile_rows.load(std::memory_order_relaxed);
     // (pricing a 128-row tile at 0.55 of a 256-row one and minimising rounds of 256 workgroups -- e.g. 384 tiles -> 768 half tiles -- measured slower:
     // the half tile re-fetches the weight tile twice as often)
     int BM = (((int64_t)a.M + 255) / 256) * tiles_n < 256 && a.M > 128 ? 128 : 256;

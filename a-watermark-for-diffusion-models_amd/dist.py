@@ -31,6 +31,21 @@ def _comm_device() -> torch.device:
     return torch.device("cpu")
 
 
+def rank_world() -> Tuple[int, int]:
+    """(rank, world size) of the process group, (0, 1) without one."""
+    return (dist.get_rank(), dist.get_world_size()) if _on() else (0, 1)
+
+
+def gather_objects(obj) -> list:
+    """All-gather one small picklable object per rank -> [object of rank 0, ..., object of rank world-1] on every rank (control plane only:
+    the per-window outcome text of the directory harness).  Identity without a process group."""
+    if not _on():
+        return [obj]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, obj)
+    return out
+
+
 def shard_range(total: int, rank: Optional[int] = None, world: Optional[int] = None) -> Tuple[int, int]:
     """Contiguous slice [lo, hi) of `total` images owned by `rank`; remainders go to the lowest ranks."""
     if rank is None:

@@ -188,10 +188,16 @@ class Models:
 
 
 def load_models(model_id, device="cuda", dtype=torch.float16, allow_synthetic=None) -> Models:
+    allow = _synthetic_allowed() if allow_synthetic is None else bool(allow_synthetic)
     k = (str(model_id), str(device), dtype)
-    if k not in _MODEL_CACHE:
-        _MODEL_CACHE[k] = Models(model_id, device, dtype, allow_synthetic=_synthetic_allowed() if allow_synthetic is None else allow_synthetic)
-    return _MODEL_CACHE[k]
+    m = _MODEL_CACHE.get(k)
+    if m is not None and m.synthetic and not allow:
+        # a synthetic model cached by an earlier opt-in call must not be handed to a fail-closed one
+        raise FileNotFoundError(f"'{model_id}' is not a local checkpoint directory and synthetic weights are not allowed for this call "
+                                "(a synthetic model of that name is cached from an earlier, explicitly allowed call)")
+    if m is None:
+        m = _MODEL_CACHE[k] = Models(model_id, device, dtype, allow_synthetic=allow)
+    return m
 
 
 def load_image(imgname, target_size=None) -> torch.Tensor:
@@ -305,6 +311,7 @@ def write_batch_info(result_file, args):
 
 
 SYNTHETIC_MARKER = "SYNTHETIC WEIGHTS"
+UNPINNED_MARKER = "PARITY UNPINNED"
 
 
 class _DirJob:
@@ -330,50 +337,81 @@ def _plan(args):
     return script
 
 
-def _recover_many(items, args, batch_size):
-    """items: [(job, file)] across ALL directories.  Decode every file on the host (a file that does not decode fails alone), then push
-    the decodable ones through resize -> VAE -> inversion -> vote in full device batches; if a batch raises, its images are redone one
-    by one so that each reports its own error, like the reference's per-image try / except (extract.py:148-155)."""
-    def decode(item):
+class _RemoteError(Exception):
+    """An exception raised for one image on another rank: only its text travels (the result files hold `str(e)`)."""
+
+
+DECODE_WINDOW_BATCHES = 2      # host-decoded images held at a time = this many device batches per rank (bounds host memory on large trees)
+
+
+def _recover_items(items, args, batch_size, pool=None):
+    """items: [file] -> [outcome] (the recovered bit string or the exception that file raised), in order.  Decode the files on the host
+    (a file that does not decode fails alone), push the decodable ones through resize -> VAE -> inversion -> vote in full device batches;
+    if a batch raises, its images are redone one by one so that each reports its own error, like the reference's per-image try / except
+    (extract.py:148-155).  The decoded arrays die with this call."""
+    def decode(f):
         try:
-            return decode_image_file(item[1])
+            return decode_image_file(f)
         except Exception as e:                      # a file that does not decode fails alone
             return e
 
-    ready = []
-    if items:
-        from concurrent.futures import ThreadPoolExecutor
-        # PIL releases the GIL while it reads and decodes: a few host threads keep the device batches fed on large directories
-        with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
-            decoded = list(pool.map(decode, items))
-        for (job, f), r in zip(items, decoded):
-            if isinstance(r, Exception):
-                job.outcome[f] = r
-            else:
-                ready.append((job, f, r))
+    decoded = list(pool.map(decode, items)) if pool is not None else [decode(f) for f in items]
+    out = list(decoded)
+    ready = [i for i, r in enumerate(decoded) if not isinstance(r, Exception)]
 
-    def run(chunk):
-        latents = invert_decoded_images([a for _, _, a in chunk], args)
+    def run(idx):
+        latents = invert_decoded_images([decoded[i] for i in idx], args)
         return recover_exactracted_message_batch(latents, args)
 
-    for i in range(0, len(ready), batch_size):
-        chunk = ready[i:i + batch_size]
+    for k in range(0, len(ready), batch_size):
+        idx = ready[k:k + batch_size]
         try:
-            results = run(chunk)
+            results = run(idx)
         except Exception:
             results = []
-            for one in chunk:
+            for i in idx:
                 try:
-                    results += run([one])
+                    results += run([i])
                 except Exception as e:
                     results.append(e)
-        for (job, f, _), r in zip(chunk, results):
-            job.outcome[f] = r
+        for i, r in zip(idx, results):
+            out[i] = r
+    return out
+
+
+def _recover_many(items, args, batch_size, on_window=None):
+    """items: [(job, file)] across ALL directories, in plan order.  The run is cut into WINDOWS of world x DECODE_WINDOW_BATCHES x batch_size
+    images: inside a window rank r takes the contiguous slice dist.shard_range gives it (images are independent: no collective on the data
+    path), the outcomes of the window are all-gathered as text, and every rank records them -- so at most a window's worth of decoded
+    images is alive per process, and `on_window()` (rank 0: flush the result files of every directory that is now complete) runs as the
+    work proceeds.  One process: the same loop with world = 1."""
+    from . import dist as gdist
+    from concurrent.futures import ThreadPoolExecutor
+    rank, world = gdist.rank_world()
+    window = world * DECODE_WINDOW_BATCHES * batch_size
+    # PIL releases the GIL while it reads and decodes: a few host threads keep the device batches fed on large directories
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
+        for w0 in range(0, len(items), window):
+            win = items[w0:w0 + window]
+            lo, hi = gdist.shard_range(len(win), rank, world)
+            mine = _recover_items([f for _, f in win[lo:hi]], args, batch_size, pool)
+            if world > 1:
+                wire = [("err", f"{r}") if isinstance(r, Exception) else ("ok", r) for r in mine]
+                parts = gdist.gather_objects(wire)
+                flat = [x for part in parts for x in part]
+                outcomes = [_RemoteError(v) if k == "err" else v for k, v in flat]
+            else:
+                outcomes = mine
+            for (job, f), r in zip(win, outcomes):
+                job.outcome[f] = r
+            if on_window is not None:
+                on_window()
 
 
 def _report(job, args, synthetic):
     """Write one directory's result.txt block (+ the roll-up line in its parent) and echo the per-image text, byte for byte the
-    reference's (extract.py:112-117,139-163).  With synthetic weights a marker line follows the header and no roll-up is written."""
+    reference's (extract.py:112-117,139-163).  With synthetic weights (or the parity-unpinned DPM-Solver++ scheduler) a marker line
+    follows the header; no roll-up is written with synthetic weights."""
     if not job.files:
         return
     accs = []
@@ -381,6 +419,9 @@ def _report(job, args, synthetic):
         write_batch_info(out, args)
         if synthetic:
             out.write(f"{SYNTHETIC_MARKER},'{args.model_id}' is not a local checkpoint: the bit accuracies below are not meaningful\n")
+        if str(getattr(args, "scheduler", "DDIM")) == "DPMs":
+            out.write(f"{UNPINNED_MARKER},--scheduler DPMs restates DPM-Solver++ (2M) from the paper: diffusers' DPMSolverMultistepInverseScheduler "
+                      "(extract.py:49-50) could not be executed to pin it; --scheduler DDIM is pinned against the reference\n")
         for f in job.files:
             r = job.outcome.get(f, RuntimeError("not processed"))
             if isinstance(r, Exception):
@@ -400,38 +441,84 @@ def _report(job, args, synthetic):
             up.write(f"{os.path.basename(job.path)}, Average Bit Accuracy, {mean}\n")
 
 
+class _Reporter:
+    """Replays the plan in the reference's order as directories complete: a directory's block is written as soon as every image of it
+    AND of every directory before it has an outcome (so a crash mid-run leaves the finished directories' result.txt behind, like the
+    reference's append-as-you-go loop, extract.py:143-155, and stdout / roll-up lines keep the reference's order)."""
+
+    def __init__(self, script, args, synthetic):
+        self.script, self.args, self.synthetic, self.pos = script, args, synthetic, 0
+
+    def flush(self):
+        while self.pos < len(self.script):
+            kind, x = self.script[self.pos]
+            if kind == "banner":
+                print("=" * 20 + x + "=" * 20)
+            else:
+                if any(f not in x.outcome for f in x.files):
+                    return
+                _report(x, self.args, self.synthetic)
+            self.pos += 1
+
+
+import contextlib
+
+
+@contextlib.contextmanager
+def _strictness(args, synthetic):
+    """--strict_kernels: a half-precision GPU call that would leave the hand-written kernels (a checkpoint whose shapes miss the engine's
+    K % 64 / N % 8 grid, an odd lattice) raises instead of warning.  Default: on with a real checkpoint, off with synthetic weights.
+    Scoped to the harness call: the previous setting is restored on the way out."""
+    from . import unet as U, vae as V
+    want = getattr(args, "strict_kernels", None)
+    strict = (not synthetic) if want is None else bool(int(want))
+    before = (U.STRICT, V.STRICT)
+    U.STRICT = V.STRICT = strict
+    try:
+        yield strict
+    finally:
+        U.STRICT, V.STRICT = before
+
+
 def process_directory(args, *, batch_size=None):
-    """The directory harness (extract.py:120-163) in batch form: plan the whole run, recover every image of every directory in full device
-    batches, then write the result files in the reference's order and format."""
+    """The directory harness (extract.py:120-163) in batch form: plan the whole run, recover the images of every directory in full device
+    batches -- sharded over the ranks of the process group when there is one (`--gpus N`), streamed in bounded windows -- and write the
+    result files in the reference's order and format as the directories complete (rank 0 writes; the other ranks stay silent)."""
+    from . import dist as gdist
     batch_size = int(batch_size or getattr(args, "batch_size", 0) or 16)
+    rank, _ = gdist.rank_world()
     script = _plan(args)
     jobs = [j for kind, j in script if kind == "job"]
     synthetic = not os.path.isdir(str(args.model_id))
-    if any(j.files for j in jobs):
-        load_models(args.model_id, allow_synthetic=_synthetic_allowed(args))          # fail before touching any result file
-    _recover_many([(j, f) for j in jobs for f in j.files], args, batch_size)
-    traverse = int(args.is_traverse_subdirectories) == 1
-    if traverse:
-        with open(os.path.join(args.images_directory_path, "result.txt"), "a") as root:
-            write_batch_info(root, args)
-    for kind, x in script:
-        if kind == "banner":
-            print("=" * 20 + x + "=" * 20)
-        else:
-            _report(x, args, synthetic)
-    if traverse:
-        with open(os.path.join(args.images_directory_path, "result.txt"), "a") as root:
-            root.write("=" * 40 + "Batch End" + "=" * 40 + "\n\n")
+    with _strictness(args, synthetic):
+        if any(j.files for j in jobs):
+            load_models(args.model_id, allow_synthetic=_synthetic_allowed(args))          # fail before touching any result file
+        traverse = int(args.is_traverse_subdirectories) == 1
+        writer = rank == 0
+        if traverse and writer:
+            with open(os.path.join(args.images_directory_path, "result.txt"), "a") as root:
+                write_batch_info(root, args)
+        reporter = _Reporter(script, args, synthetic)
+        _recover_many([(j, f) for j in jobs for f in j.files], args, batch_size, on_window=reporter.flush if writer else None)
+        if writer:
+            reporter.flush()
+            if traverse:
+                with open(os.path.join(args.images_directory_path, "result.txt"), "a") as root:
+                    root.write("=" * 40 + "Batch End" + "=" * 40 + "\n\n")
 
 
 def process_single_directory(dir_path, args, *, batch_size=None):
     """One directory (extract.py:134-163)."""
+    from . import dist as gdist
     batch_size = int(batch_size or getattr(args, "batch_size", 0) or 16)
     job = _DirJob(dir_path)
     if job.files:
-        load_models(args.model_id, allow_synthetic=_synthetic_allowed(args))
-        _recover_many([(job, f) for f in job.files], args, batch_size)
-        _report(job, args, not os.path.isdir(str(args.model_id)))
+        synthetic = not os.path.isdir(str(args.model_id))
+        with _strictness(args, synthetic):
+            load_models(args.model_id, allow_synthetic=_synthetic_allowed(args))
+            _recover_many([(job, f) for f in job.files], args, batch_size)
+        if gdist.rank_world()[0] == 0:
+            _report(job, args, synthetic)
 
 
 def build_parser():
@@ -454,23 +541,62 @@ def build_parser():
     # not a reference flag: opt in to seeded synthetic weights when --model_id is not a local checkpoint directory (results meaningless)
     parser.add_argument("--allow_synthetic_weights", action="store_true", help="run without a checkpoint (pipeline tests / benchmarks only)")
     parser.add_argument("--batch_size", type=int, default=16, help="(not a reference flag) images per device batch of the directory harness")
+    parser.add_argument("--gpus", type=int, default=1, help="(not a reference flag) shard the images of a directory run over this many GPUs of the node: "
+                                                           "one process per GPU, started here unless a launcher (torch.distributed.run) already did")
+    parser.add_argument("--strict_kernels", type=int, choices=[0, 1], default=None,
+                        help="(not a reference flag) 1: raise when a GPU half-precision call would leave the hand-written kernels instead of warning "
+                             "(default: 1 with a real checkpoint, 0 with synthetic weights)")
     return parser
 
 
+def _init_ranks(args):
+    """Join the process group a launcher prepared (RANK / WORLD_SIZE in the environment): RCCL with one GPU per rank, or gloo on a host
+    without GPUs (CPU tests of the sharding logic)."""
+    import torch.distributed as dist
+    world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
+    if world != int(args.gpus):
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    backend = os.environ.get("GSW_DIST_BACKEND", "nccl" if torch.cuda.is_available() else "gloo")
+    if backend == "nccl":
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        dist.init_process_group(backend)
+
+
 def main(argv=None):
-    """extract.py:179-211."""
+    """extract.py:179-211 (+ `--gpus N`: one process per GPU, the images of a directory run sharded over them)."""
+    argv = list(sys.argv[1:] if argv is None else argv)
     args = build_parser().parse_args(argv)
+    from . import launch
+    if int(args.gpus) > 1 and not launch.under_launcher():
+        # start the ranks BEFORE anything touches the GPU; plain children (never a re-exec), stopped by PID if one of them fails
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        env = {"PYTHONPATH": os.pathsep.join([root] + [p for p in os.environ.get("PYTHONPATH", "").split(os.pathsep) if p])}
+        raise SystemExit(launch.spawn_ranks([sys.executable, "-m", "gswm_amd.extract"] + argv, int(args.gpus), env_extra=env))
     args.key = bytes.fromhex(args.key_hex)
     if args.nonce_hex != "":
         args.nonce = bytes.fromhex(args.nonce_hex)
     else:
         args.nonce = bytes.fromhex(args.key_hex[16:48])
-    if args.images_directory_path != "":
-        process_directory(args)
-    elif args.single_image_path != "":
-        get_result_for_one_image(args)
-    else:
-        print("Please set the argument 'images_directory_path' or 'single_image_path'")
+    ranks = int(args.gpus) > 1
+    if ranks:
+        _init_ranks(args)
+    try:
+        if args.images_directory_path != "":
+            process_directory(args)
+        elif args.single_image_path != "":
+            from . import dist as gdist
+            if gdist.rank_world()[0] == 0:            # one image: nothing to shard
+                with _strictness(args, not os.path.isdir(str(args.model_id))):
+                    get_result_for_one_image(args)
+        else:
+            print("Please set the argument 'images_directory_path' or 'single_image_path'")
+    finally:
+        if ranks:
+            import torch.distributed as dist
+            if dist.is_initialized():
+                dist.destroy_process_group()
 
 
 if __name__ == "__main__":

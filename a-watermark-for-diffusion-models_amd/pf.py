@@ -7,8 +7,6 @@ from __future__ import annotations
 
 from typing import Optional
 
-import os
-
 import torch
 
 from . import _native as N
@@ -119,25 +117,11 @@ class ConvTimer:
 CONV_TIMER: Optional[ConvTimer] = None
 
 
-def _halo_lds_bytes(W: int) -> int:
-    hp = ((W + 3) + 7) & ~7
-    return max(128 + 2 * hp, 256) * 128 + 160 * 128        # single-buffered weights: what the widest supported rows need
-
-
-# 3x3 stride-1 convolutions with N % 160 == 0 run on the matmul engine (csrc/gswm_mm.hip) unless GSW_CONV_ENGINE=0 (the round-1 halo kernel,
-# kept for A/B profiling); the same switch is read by csrc/gswm_conv.hip
-CONV_ENGINE = os.environ.get("GSW_CONV_ENGINE", "1") != "0"
-
-
 def _conv_kernel_name(W: int, n_out: int, ksize: int, stride: int) -> str:
     """Which kernel launch_conv_gemm (csrc/gswm_conv.hip) selects -- for the timer's buckets only."""
-    if CONV_ENGINE and n_out % 8 == 0 and n_out >= 128 and (stride == 1 or ksize == 3):
+    if n_out % 8 == 0 and n_out >= 128 and (stride == 1 or ksize == 3):
         return ("gsw_mm_kernel(conv3x3)" if stride == 1 else "gsw_mm_kernel(conv3x3 s2)") if ksize == 3 else "gsw_mm_kernel(conv1x1)"
-    if n_out % 160:
-        return "gsw_conv_gemm_kernel"
-    if ksize == 3 and stride == 1 and _halo_lds_bytes(W) <= 80 * 1024:
-        return "gsw_conv3x3_halo_kernel"
-    return "gsw_conv_gemm_wide_kernel"
+    return "gsw_conv_gemm_kernel"
 
 
 def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
@@ -375,8 +359,8 @@ def groupnorm_pf2(x: PF, x2: Optional[PF], gamma: torch.Tensor, beta: torch.Tens
 
 
 def conv3x3_res_fusable(x: PF, n_out: int) -> bool:
-    """The fused conv2 + shortcut kernel needs N % 160 == 0, C % 64 == 0 and a halo tile that fits LDS."""
-    return n_out % 160 == 0 and x.C % 64 == 0 and (CONV_ENGINE or _halo_lds_bytes(x.W) <= 80 * 1024)
+    """The fused conv2 + shortcut launch runs on the matmul engine: N % 8 == 0 from 128 channels up, C % 64 == 0."""
+    return n_out % 8 == 0 and n_out >= 128 and x.C % 64 == 0
 
 
 def conv3x3_res_pf(x: PF, w_cat: torch.Tensor, bias: Optional[torch.Tensor], *, rowbias: Optional[torch.Tensor] = None,
@@ -468,7 +452,7 @@ def pack_upsample_weight(w: torch.Tensor) -> torch.Tensor:
 
 
 def conv_up2x_fusable(x: PF, n_out: int) -> bool:
-    return n_out % 160 == 0 and x.C % 64 == 0 and (CONV_ENGINE or _halo_lds_bytes(x.W) <= 80 * 1024)
+    return n_out % 8 == 0 and n_out >= 128 and x.C % 64 == 0
 
 
 def conv_up2x_pf(x: PF, w4: torch.Tensor, bias: Optional[torch.Tensor]) -> PF:
@@ -483,7 +467,7 @@ def conv_up2x_pf(x: PF, w4: torch.Tensor, bias: Optional[torch.Tensor]) -> PF:
         N.check(N.lib().gsw_conv_up2x_pf(x.rows.data_ptr(), w4.data_ptr(), bias.data_ptr() if bias is not None else None, y.rows.data_ptr(),
                                          x.B, x.H, x.W, x.C, Nn, _dt(x.buf.dtype), _stream_ptr()))
         if tm is not None:      # EXECUTED FLOPs (16 C MACs per output: four 2x2 convolutions); the 3x3-on-upsampled form it replaces is 2.25x that
-            name = "gsw_mm_kernel(up2x)" if CONV_ENGINE else "gsw_conv3x3_halo_kernel(up2x)"
+            name = "gsw_mm_kernel(up2x)"
             tm.stop(e0, (name, x.B, 2 * x.H, 2 * x.W, 4 * x.C, Nn, 1) if tm.by_shape else name,
                     2.0 * x.B * 4 * x.H * x.W * Nn * 4 * x.C, launches=4)
     return y

@@ -44,9 +44,10 @@ def gn_act(x: torch.Tensor, norm: nn.GroupNorm, act: bool = True, pre_bias: Opti
     return F.silu(y) if act else y
 
 
-# Padded-flat NHWC path: every 3x3 / 1x1 / stride-2 convolution of the UNet runs as the hand-written MFMA implicit GEMM
-# (csrc/gswm_conv.hip) with bias, time-embedding and residual adds fused into its epilogue, GroupNorm+SiLU as the PF kernels;
-# only conv_in / conv_out (4 channels), the upsampler's nearest-neighbour copy and the transformer blocks stay on torch ops.
+# Padded-flat NHWC path: every 3x3 / 1x1 / stride-2 convolution of the UNet runs as a hand-written MFMA implicit GEMM (the matmul engine of
+# csrc/gswm_mm.hip through csrc/gswm_conv.hip; conv_in / conv_out's 4-channel side padded to one 64-wide tile) with bias, time-embedding and
+# residual adds fused into its epilogue, GroupNorm+SiLU as the PF kernels, Upsample2D as four sub-pixel launches; the transformer blocks run on
+# the same engine (OWN_GEMM) and the flash-attention kernel (OWN_ATTENTION).
 USE_PF = True
 
 
@@ -61,15 +62,20 @@ CACHE_CONTEXT_KV = True   # cross-attention K / V^T of a context tensor are comp
 
 FUSED_QK = True       # self-attention: q and k projections as one GEMM (own attention kernel reads them as column slices)
 
-OWN_ATTENTION = True  # attention with head_dim 40 / 64 / 80 and a query count % 32 == 0 runs on gsw_attention instead of torch SDPA
+OWN_ATTENTION = True  # attention with head_dim 40 / 64 / 80 / 160, any query count, keys % 8 == 0 runs on gsw_attention instead of torch SDPA
 
 OWN_GEMM = True       # every dense linear layer (q / k / v / out projections, proj_in / proj_out, feed-forward, time embedding) on the
                       # hand-written matmul engine (gsw_gemm, csrc/gswm_mm.hip) with bias / residual / GEGLU / V^T epilogues fused in
 
 FALLBACKS = {}        # (reason -> count) of GPU half-precision calls that left the hand-written path; bench and the full-size tests assert it stays empty
 
+STRICT = False        # True: leaving the hand-written path raises instead of warning (extract.py --strict_kernels; default with a real checkpoint)
+
 
 def _note_fallback(why: str):
+    if STRICT:
+        raise RuntimeError("gswm unet (strict kernels): " + why + " -- this call would run a library kernel (hipBLASLt / MIOpen / SDPA); "
+                           "pass --strict_kernels 0 to allow it")
     if why not in FALLBACKS:       # loud, once per reason: a GPU run that leaves the hand-written kernels should never be silent
         import warnings
         warnings.warn("gswm unet: " + why, RuntimeWarning, stacklevel=3)
@@ -77,10 +83,10 @@ def _note_fallback(why: str):
 
 
 def _own_gemm_ok(x: torch.Tensor, K: int, N: int) -> bool:
-    """The matmul engine takes fp16 / bf16 device tensors with K % 64 == 0 and N % 160 == 0 (every SD 1.x / 2.x linear)."""
+    """The matmul engine takes fp16 / bf16 device tensors with K % 64 == 0 and N % 8 == 0 (every SD 1.x / 2.x linear)."""
     if not (OWN_GEMM and USE_PF and FUSED_KERNELS and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16)):
         return False
-    if K % 64 or N % 160:
+    if K % 64 or N % 8:
         _note_fallback(f"linear K={K} N={N}: library GEMM")
         return False
     return True
@@ -495,7 +501,7 @@ class UNet2DCondition(nn.Module):
         temb = F.silu(temb)                      # every resnet applies SiLU to the same embedding: do it once
         if self._pf_ok(x):
             return self._forward_pf(x, temb, ctx)
-        if USE_PF and FUSED_KERNELS and x.is_cuda:
+        if USE_PF and FUSED_KERNELS and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16):
             _note_fallback(f"UNet forward on {tuple(x.shape)} {x.dtype}: off the padded-flat path (fp16 / bf16, conv channels % 64, lattice % {1 << (len(self.down_blocks) - 1)}): plain torch modules")
         h = self.conv_in(x)
         skips = [h]

@@ -26,10 +26,15 @@ USE_PF = True
 FALLBACKS = {}        # (reason -> count) of GPU half-precision calls that ran the plain-torch module path instead of the hand-written kernels
 
 
+STRICT = False        # True: leaving the hand-written path raises instead of warning (extract.py --strict_kernels)
+
+
 def _fell_off(what: str, x: torch.Tensor) -> None:
     """A half-precision device tensor is about to run the plain-torch path (MIOpen / hipBLASLt / aotriton): say so, once per reason."""
-    if USE_PF and x.is_cuda:
-        why = f"{what}: input {tuple(x.shape)} {x.dtype} is off the padded-flat path (fp16 / bf16; H, W multiples of 8; channel counts multiples of 64)"
+    if USE_PF and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16):
+        why = f"{what}: input {tuple(x.shape)} {x.dtype} is off the padded-flat path (fp16 / bf16; H, W multiples of 8; mid-block tokens % 8; channel counts multiples of 64)"
+        if STRICT:
+            raise RuntimeError("gswm vae (strict kernels): " + why + " -- pass --strict_kernels 0 to allow the library kernels")
         if why not in FALLBACKS:
             import warnings
             warnings.warn("gswm vae: " + why + " -- running the plain torch modules", RuntimeWarning, stacklevel=3)
@@ -53,6 +58,39 @@ def _pw(conv: nn.Conv2d, cin_pad: int = 0, cout_pad: int = 0):
     return cached(conv, "_gsw_packed", (conv.weight, conv.bias), build)
 
 
+def _pw_out_folded(conv_out: nn.Conv2d, post: nn.Conv2d):
+    """conv_out followed by a 1x1 convolution (`quant_conv(encoder(x))`, extract.py:41 -> diffusers AutoencoderKL.encode) as ONE 3x3
+    convolution: W' = W_post W_out per tap, b' = W_post b_out + b_post (composed in fp32, rounded once), zero-padded to 64 outputs."""
+    from .pf import cached, pack_conv_weight
+
+    def build():
+        wp = post.weight.detach().float()[:, :, 0, 0]
+        w = torch.einsum("oc,cikl->oikl", wp, conv_out.weight.detach().float())
+        b = wp @ conv_out.bias.detach().float() + post.bias.detach().float()
+        w = torch.cat([w, w.new_zeros(64 - w.shape[0], *w.shape[1:])], dim=0).to(conv_out.weight.dtype)
+        b = torch.cat([b, b.new_zeros(64 - b.shape[0])]).to(conv_out.weight.dtype)
+        return pack_conv_weight(w), b.contiguous()
+
+    return cached(conv_out, "_gsw_folded", (conv_out.weight, conv_out.bias, post.weight, post.bias), build)
+
+
+def _pw_in_folded(conv_in: nn.Conv2d, pre: nn.Conv2d):
+    """A 1x1 convolution followed by conv_in (`decoder(post_quant_conv(z))`, diffusers AutoencoderKL.decode) as ONE 3x3 convolution over
+    [z | 1]: W'[:, c] = W_in W_pre[:, c] per tap, and the 1x1 bias rides on a constant-one input channel (weights W_in b_pre per tap) --
+    exact at the image border too, where the zero padding applies to the 1x1 output, not to its input."""
+    from .pf import cached, pack_conv_weight
+
+    def build():
+        wi = conv_in.weight.detach().float()
+        wp, bp = pre.weight.detach().float()[:, :, 0, 0], pre.bias.detach().float()
+        w = torch.einsum("oikl,ic->ockl", wi, wp)
+        w1 = torch.einsum("oikl,i->okl", wi, bp)[:, None]
+        w = torch.cat([w, w1, w.new_zeros(w.shape[0], 64 - w.shape[1] - 1, *w.shape[2:])], dim=1).to(conv_in.weight.dtype)
+        return pack_conv_weight(w), conv_in.bias.detach().contiguous()
+
+    return cached(conv_in, "_gsw_folded", (conv_in.weight, conv_in.bias, pre.weight, pre.bias), build)
+
+
 def _gn_pf(x, norm: nn.GroupNorm, act=True, tokens=False):
     from .pf import groupnorm_pf
     return groupnorm_pf(x, norm.weight, norm.bias, norm.num_groups, norm.eps, act=act, tokens=tokens)
@@ -72,12 +110,14 @@ def _convs_fit_pf(module: nn.Module) -> bool:
     return ok
 
 
-def _to_pf64(x: torch.Tensor):
-    """NCHW tensor with <= 64 channels -> PF tensor with 64 channels (zero-filled)."""
+def _to_pf64(x: torch.Tensor, ones_channel: bool = False):
+    """NCHW tensor with < 64 channels -> PF tensor with 64 channels (zero-filled; ones_channel: channel C of every real pixel is 1)."""
     from .pf import PF
     B, C, H, W = x.shape
     p = PF.zeros(B, H, W, 64, x.dtype, x.device)
     p.interior[..., :C].copy_(x.permute(0, 2, 3, 1))
+    if ones_channel:
+        p.interior[..., C].fill_(1.0)
     return p
 
 
@@ -123,7 +163,7 @@ class VaeAttention(nn.Module):
         from .pf import attention_single_head, cached, gemm
         y = _gn_pf(x, self.group_norm, act=False, tokens=True)          # GroupNorm writes dense tokens [B, H*W, C]
         C, S = x.C, x.H * x.W
-        if C % 64 or S % 8:
+        if C % 64 or S % 8:          # (Encoder._pf_tokens_ok / _pf_ok keep such inputs on the plain-torch path with a loud warning)
             raise RuntimeError(f"VaeAttention: {C} channels x {S} tokens is off the hand-written path (channels % 64, tokens % 8)")
         # q | k from one GEMM over the tokens, V^T from a transposing GEMM, softmax(q k^T) v per image on the matmul engine, and the output
         # projection + residual written straight into the PF tensor's interior rows
@@ -224,25 +264,32 @@ class Encoder(nn.Module):
         self.conv_norm_out = nn.GroupNorm(32, chs[-1], eps=1e-6)
         self.conv_out = nn.Conv2d(chs[-1], 2 * latent, 3, padding=1)
 
-    def forward(self, x):
-        if _pf_ok(x) and self._pf_shapes_ok():
-            return self.forward_pf(x)
+    def forward(self, x, post: nn.Conv2d = None):
+        """post: the 1x1 `quant_conv` that follows the encoder -- folded into conv_out on the hand-written path"""
+        if _pf_ok(x) and self._pf_shapes_ok() and self._pf_tokens_ok(x):
+            return self.forward_pf(x, post)
         _fell_off("Encoder", x)
         x = self.conv_in(x)
         for b in self.down_blocks:
             x = b(x)
-        return self.conv_out(F.silu(self.conv_norm_out(self.mid_block(x))))
+        x = self.conv_out(F.silu(self.conv_norm_out(self.mid_block(x))))
+        return x if post is None else post(x)
 
     def _pf_shapes_ok(self):
         return _convs_fit_pf(self)
 
-    def forward_pf(self, x):
+    def _pf_tokens_ok(self, x):
+        """the mid block's single-head attention takes token counts in multiples of 8"""
+        f = 1 << (len(self.down_blocks) - 1)
+        return ((x.shape[-2] // f) * (x.shape[-1] // f)) % 8 == 0
+
+    def forward_pf(self, x, post: nn.Conv2d = None):
         from .pf import conv_pf
         h = conv_pf(_to_pf64(x), *_pw(self.conv_in, cin_pad=64))
         for b in self.down_blocks:
             h = b.forward_pf(h)
         h = _gn_pf(self.mid_block.forward_pf(h), self.conv_norm_out)
-        y = conv_pf(h, *_pw(self.conv_out, cout_pad=64))
+        y = conv_pf(h, *(_pw(self.conv_out, cout_pad=64) if post is None else _pw_out_folded(self.conv_out, post)))
         return y.interior[..., : self.conv_out.out_channels].permute(0, 3, 1, 2).contiguous()
 
 
@@ -256,11 +303,12 @@ class Decoder(nn.Module):
         self.conv_norm_out = nn.GroupNorm(32, rev[-1], eps=1e-6)
         self.conv_out = nn.Conv2d(rev[-1], 3, 3, padding=1)
 
-    def forward(self, z):
+    def forward(self, z, pre: nn.Conv2d = None):
+        """pre: the 1x1 `post_quant_conv` that precedes the decoder -- folded into conv_in on the hand-written path"""
         if _pf_ok(z) and self._pf_shapes_ok():
-            return self.forward_pf(z)
+            return self.forward_pf(z, pre)
         _fell_off("Decoder", z)
-        x = self.mid_block(self.conv_in(z))
+        x = self.mid_block(self.conv_in(z if pre is None else pre(z)))
         for b in self.up_blocks:
             x = b(x)
         return self.conv_out(F.silu(self.conv_norm_out(x)))
@@ -268,9 +316,10 @@ class Decoder(nn.Module):
     def _pf_shapes_ok(self):
         return _convs_fit_pf(self)
 
-    def forward_pf(self, z):
+    def forward_pf(self, z, pre: nn.Conv2d = None):
         from .pf import conv_pf
-        h = self.mid_block.forward_pf(conv_pf(_to_pf64(z), *_pw(self.conv_in, cin_pad=64)))
+        h0 = conv_pf(_to_pf64(z), *_pw(self.conv_in, cin_pad=64)) if pre is None else conv_pf(_to_pf64(z, ones_channel=True), *_pw_in_folded(self.conv_in, pre))
+        h = self.mid_block.forward_pf(h0)
         for b in self.up_blocks:
             h = b.forward_pf(h)
         y = conv_pf(_gn_pf(h, self.conv_norm_out), *_pw(self.conv_out, cout_pad=64))
@@ -288,10 +337,10 @@ class AutoencoderKL(nn.Module):
 
     def encode_mean(self, x: torch.Tensor) -> torch.Tensor:
         """`vae.encode(x).latent_dist.mean` (extract.py:41-42): first half of the moments."""
-        return self.quant_conv(self.encoder(x))[:, : self.latent_channels]
+        return self.encoder(x, post=self.quant_conv)[:, : self.latent_channels]
 
     def decode(self, z: torch.Tensor) -> torch.Tensor:
-        return self.decoder(self.post_quant_conv(z))
+        return self.decoder(z, pre=self.post_quant_conv)
 
 
 @torch.no_grad()

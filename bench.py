@@ -92,22 +92,15 @@ def cpu_baseline(n_images: int, message_length: int):
 
 def self_launch(args) -> int:
     """`python bench.py --gpus N` from a bare shell (no torch.distributed.run around it): start N rank processes -- one per GPU, RCCL over
-    127.0.0.1 -- and return the worst exit code.  The parent never touches HIP (it does not even import torch), and no process replaces
-    itself: the ranks are plain children, rank 0 prints the one JSON line."""
-    import socket
-    import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    procs = []
-    for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    rc = 0
-    for pr in procs:
-        rc = max(rc, abs(pr.wait()))
-    return rc
+    127.0.0.1 -- poll them, stop the siblings as soon as one fails, and return the worst exit code.  The parent never touches HIP (it does
+    not even import torch: the launcher is loaded by file path), and no process replaces itself: the ranks are plain children, rank 0
+    prints the one JSON line."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gswm_launch", os.path.join(ROOT, "a-watermark-for-diffusion-models_amd", "launch.py"))
+    launch = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(launch)
+    limit = float(os.environ.get("GSW_BENCH_TIMEOUT_S", "3600"))
+    return launch.spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus, timeout=limit)
 
 
 def init_dist(args):

@@ -28,7 +28,12 @@
 extern "C" {
 #endif
 
-#define GSW_VERSION 100 /* 0.1.0 */
+/* libgswm.so is built with -fvisibility=hidden: only what this header declares is exported */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
+
+#define GSW_VERSION 200 /* 0.2.0: GEGLU weights packed per 16-row block (see gsw_gemm) */
 
 #define GSW_MSG_INLINE_MAX 256 /* message bytes carried inside the kernel arguments (2048 bit) */
 
@@ -168,8 +173,11 @@ int gsw_linear(const void* x_dev, const void* w_dev, const void* bias_dev, const
  *   x: [M, K] row-major, w: [N, K] (nn.Linear layout), bias: [N] or NULL; K % 64 == 0, N % 8 == 0 (N % 160 == 0 for GEGLU; a partial last
  *   160-column tile costs a full one); GSW_F16 / GSW_BF16.
  *   mode GSW_GEMM_PLAIN : y[M, N] = x w^T + bias (+ resid[M, N])
- *        GSW_GEMM_GEGLU : rows of w / bias interleaved per 160-wide tile as [80 value | 80 gate] (pf.pack_geglu_weight);
- *                         y[M, N/2] = value * gelu(gate) -- diffusers' GEGLU without the [M, N] intermediate
+ *        GSW_GEMM_GEGLU : rows of w / bias interleaved per 16-ROW BLOCK as [8 value | 8 gate]: with I = N / 2 outputs, packed row
+ *                         16 j + r holds value row 8 j + r for r < 8 and gate row I + 8 j + (r - 8) for r >= 8 of diffusers' [2 I, K]
+ *                         projection (pf.pack_geglu_weight; bias packed the same way).  y[M, N/2] = value * gelu(gate) -- diffusers'
+ *                         GEGLU without the [M, N] intermediate.  (ABI 0.1.x documented a per-160-row-tile [80 | 80] packing that the
+ *                         engine never implemented since 0.2.0: GSW_VERSION >= 200 means the 16-row packing.)
  *        GSW_GEMM_TRANS : y[M/S][N][S] = per-image transpose of x w^T + bias (the attention kernel's V^T operand); S % 8 == 0
  *        GSW_GEMM_TOK2PF: rows are tokens (b, y, x) of S = H*W-token images of width Wimg; y_dev is row 0 of a padded-flat NHWC tensor
  *                         [B, H+2, W+2, N] and token rows land on its interior rows: y[pf(m)] = x w^T + bias (+ resid[pf(m)], which may
@@ -184,6 +192,13 @@ int gsw_gemm(const void* x_dev, const void* w_dev, const void* bias_dev, const v
  * column slices of wider matrices (the per-image Q K^T and P V products of the VAE's single-head attention). */
 int gsw_gemm_strided(const void* x_dev, int64_t ldx, const void* w_dev, int64_t ldw, const void* bias_dev, const void* resid_dev, int64_t ldr,
                      void* y_dev, int64_t ldy, int64_t M, int K, int N, int mode, int S, int Wimg, int dtype, void* stream);
+
+/* Process-wide tuning knobs of the matmul engine, for parity tests and A/B measurements only (production leaves both on "auto"; this is the
+ * one piece of global state behind the ABI, also settable through the environment as GSW_MM_BM / GSW_MM_SPLIT before the first launch):
+ *   tile_rows  : 0 = automatic (256-row output tiles unless they would leave CUs without one, then 128), 128 or 256 = forced; -1 = keep
+ *   split_mask : bit e set = epilogue kind e (0 dense rows, 1 PF / convolution, 2 GEGLU, 3 transposed) runs the 12-wave variant whose
+ *                waves 8-11 own the LDS-DMA; -1 = keep (default 10: convolutions and the transposed projection) */
+int gsw_mm_config(int tile_rows, int split_mask);
 
 /* X1 / G1 tail -- diffusers AutoencoderKL mid-block attention (one head as wide as the block, 512): softmax over the rows of the score matrix
  * between the two engine products.  In place: x[r, 0:cols] <- softmax(scale * x[r, 0:cols]); rows `ld` elements apart; cols % 8 == 0. */
@@ -275,6 +290,10 @@ typedef enum gsw_pointwise_op {
 } gsw_pointwise_op;
 int gsw_image_pointwise(const uint8_t* rgb_dev, int B, int H, int W, int op, float strength, uint64_t seed, uint64_t image_index0,
                         void* out_dev, int out_mode, uint64_t* workspace_dev, void* stream);
+
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 
 #ifdef __cplusplus
 }

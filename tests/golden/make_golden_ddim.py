@@ -25,6 +25,7 @@ set_alpha_to_one False), init_noise_sigma = 1, scale_model_input = identity, and
 Output: tests/golden/ddim_bytecode.json -- data only (inputs + the values the reference's bytecode returned).
 """
 import dis
+import hashlib
 import json
 import marshal
 import os
@@ -35,6 +36,15 @@ import numpy as np
 
 sys.dont_write_bytecode = True
 PYC = "/root/reference/__pycache__/inverse_stable_diffusion_gs.cpython-38.pyc"
+# The reference tree is untrusted input: the file is pinned by hash before it is unmarshalled, the code objects may only name what the
+# loop is known to use, and they run with a builtins dict of two functions.  (The opcode allow-list below is about 3.8 == 3.9 encoding,
+# not a sandbox.)  Only the JSON this script writes is consumed by the tests.
+PYC_SHA256 = "1fa7486a416112cc66e8043e39e27a3c786fe4007b46644e4cffa428730716e1"
+ALLOWED_NAMES = {"backward_ddim": set(), "forward_ddim": {"backward_ddim"},
+                 "backward_diffusion": {"scheduler", "set_timesteps", "timesteps", "to", "device", "init_noise_sigma", "enumerate", "progress_bar",
+                                        "reversed", "torch", "cat", "scale_model_input", "unet", "sample", "chunk", "config", "num_train_timesteps",
+                                        "num_inference_steps", "alphas_cumprod", "final_alpha_cumprod", "backward_ddim"}}
+SAFE_BUILTINS = {"enumerate": enumerate, "reversed": reversed}
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ddim_bytecode.json")
 
 assert sys.version_info[:2] == (3, 9), "run under /opt/conda/bin/python3.9 (3.8 bytecode, see the docstring)"
@@ -103,15 +113,21 @@ class Timesteps(list):
 
 
 def main():
-    module = marshal.loads(open(PYC, "rb").read()[16:])
+    raw = open(PYC, "rb").read()
+    assert hashlib.sha256(raw).hexdigest() == PYC_SHA256, "the reference's .pyc is not the file this generator was written against"
+    module = marshal.loads(raw[16:])
     co_bd, co_fd = find_code(module, "backward_ddim"), find_code(module, "forward_ddim")
     co_loop = find_code(module, "backward_diffusion")
+    for co in (co_bd, co_fd, co_loop):
+        extra = set(co.co_names) - ALLOWED_NAMES[co.co_name]
+        assert not extra, f"{co.co_name} names {sorted(extra)}: not on the allow-list"
+        assert not any(isinstance(k, types.CodeType) for k in co.co_consts), "nested code objects are not expected"
     for co in (co_bd, co_fd):
         _, n = port_38_to_39(co)
         assert n == 0
     co_loop39, n_reenc = port_38_to_39(co_loop)
 
-    g_step = {"__builtins__": __builtins__}
+    g_step = {"__builtins__": dict(SAFE_BUILTINS)}
     backward_ddim = types.FunctionType(co_bd, g_step, "backward_ddim")
     g_step["backward_ddim"] = backward_ddim
     forward_ddim = types.FunctionType(co_fd, g_step, "forward_ddim")
@@ -174,7 +190,7 @@ def main():
                     return types.SimpleNamespace(sample=s.view(Arr))
 
                 me = types.SimpleNamespace(scheduler=Sched(), unet=unet, device="cpu", progress_bar=lambda it: it)
-                g_loop = {"__builtins__": __builtins__, "backward_ddim": rec,
+                g_loop = {"__builtins__": dict(SAFE_BUILTINS), "backward_ddim": rec,
                           "torch": types.SimpleNamespace(cat=lambda xs: np.concatenate([np.asarray(a) for a in xs], axis=0))}
                 loop = types.FunctionType(co_loop39, g_loop, "backward_diffusion")
                 x0 = np.random.RandomState(100 + S).standard_normal((2, 24))

@@ -106,8 +106,9 @@ def test_harness_on_a_local_checkpoint_batches_across_directories(E, tmp_path, c
         d.mkdir(parents=True)
     files = {str(d): _write_images(str(d), n) for d, n in zip(dirs, (3, 2, 1))}
     (root / "b" / "broken.jpg").write_bytes(b"nope")
+    # (the tiny checkpoint's 32 / 64-channel VAE is off the hand-written path: strict mode, the default with a real checkpoint, would raise)
     args = _args(model_id=ck, images_directory_path=str(root), is_traverse_subdirectories=1, allow_synthetic_weights=False, width=64, height=64,
-                 message_length=64, original_message_hex=(b"lthero" + b"\0" * 2).hex())
+                 message_length=64, original_message_hex=(b"lthero" + b"\0" * 2).hex(), strict_kernels=0)
     seen = []
     real = E.invert_decoded_images
     E.invert_decoded_images = lambda arrs, a, **kw: (seen.append(len(arrs)), real(arrs, a, **kw))[1]
@@ -126,7 +127,7 @@ def test_harness_on_a_local_checkpoint_batches_across_directories(E, tmp_path, c
         assert "SYNTHETIC" not in txt
         for f in files[str(d)]:
             one = _args(model_id=ck, single_image_path=f, allow_synthetic_weights=False, width=64, height=64, message_length=64,
-                        original_message_hex=args.original_message_hex)
+                        original_message_hex=args.original_message_hex, strict_kernels=0)
             _, bits, acc = E.get_result_for_one_image(one)
             line = next(l for l in txt.splitlines() if l.startswith(f"{os.path.basename(f)}, Bit Accuracy, "))
             # a batch of 4 and a batch of 1 may take different library GEMM kernels at this checkpoint's odd widths (64 / 128 channels are
@@ -134,6 +135,16 @@ def test_harness_on_a_local_checkpoint_batches_across_directories(E, tmp_path, c
             assert abs(float(line.split(", ")[2]) - acc) <= 6 / 64
             assert f"{os.path.basename(f)}\nOriginal Message: " in out
     assert f"Error processing {root / 'b' / 'broken.jpg'}: " in (root / "b" / "result.txt").read_text()
+    # strict mode (the default with a real checkpoint): the same run reports every image as an error instead of silently using library kernels
+    strict_root = tmp_path / "strict"
+    strict_root.mkdir()
+    _write_images(str(strict_root), 2)
+    sargs = _args(model_id=ck, images_directory_path=str(strict_root), is_traverse_subdirectories=0, allow_synthetic_weights=False, width=64, height=64,
+                  message_length=64, original_message_hex=args.original_message_hex)
+    E.process_directory(sargs, batch_size=4)
+    assert (strict_root / "result.txt").read_text().count("strict kernels") == 2
+    from gswm_amd import unet as U_, vae as V_
+    assert not U_.STRICT and not V_.STRICT                                      # scoped to the harness call
 
 
 def test_image_level_roundtrip_runs(E, keys):

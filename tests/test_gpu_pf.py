@@ -21,8 +21,6 @@ def G():
                                                  (1, 64, 320, 6, 96, 3, 1), (1, 64, 320, 4, 170, 3, 1), (1, 64, 320, 4, 200, 3, 1),
                                                  (3, 64, 512, 12, 20, 3, 1), (2, 128, 320, 10, 6, 3, 2), (1, 256, 256, 24, 8, 1, 1), (5, 64, 136, 6, 6, 3, 1)])
 def test_conv_pf_vs_torch_fp32(G, dtype, B, C, N, H, W, k, stride):
-    if N % 64 and not G.pf.CONV_ENGINE:
-        pytest.skip("N % 64 != 0 needs the matmul engine (GSW_CONV_ENGINE=0 selects the round-1 kernels)")
     g = torch.Generator().manual_seed(C + N + H)
     x = torch.randn(B, C, H, W, generator=g).to(dtype).cuda()
     w = (torch.randn(N, C, k, k, generator=g) * (1.0 / (C * k * k)) ** 0.5).to(dtype).cuda()
@@ -139,16 +137,20 @@ def test_unet_pf_path_equals_torch_path(G, chs, heads):
         U.USE_PF = False
         y0 = m(x, t, c)
         U.USE_PF = True
-        yref = m.float()(x.float(), t, c.float())
+        U.FUSED_KERNELS = False                                  # the fp32 judge is plain torch end to end
+        try:
+            yref = m.float()(x.float(), t, c.float())
+        finally:
+            U.FUSED_KERNELS = True
+    scale = max(1.0, yref.abs().max().item())
     e1 = (y1.float() - yref).abs().max().item()
-    e0 = (y0.float() - yref).abs().max().item()
-    assert y1.shape == y0.shape and e1 <= max(2 * e0, 2e-2), (e1, e0)
+    e0 = (y0.float() - yref).abs().max().item()                  # torch's own fp16 path: reported, not part of the bound
+    assert y1.shape == y0.shape and e1 <= 1e-2 * scale, (e1, e0, scale)
 
 
 def test_sd15_shape_unet_on_96x96_lattice(G):
-    """BASELINE config 5's eps-model: SD 1.5 UNet (8 heads, head_dim 40/80/160, ctx 768) on the 4x96x96 lattice -- the PF path
-    (96-wide rows run the halo kernel with single-buffered weights: the halo tile + two weight tiles exceed the 80 KiB that
-    keep two workgroups per CU) against the torch path of the same module."""
+    """BASELINE config 5's eps-model: SD 1.5 UNet (8 heads, head_dim 40/80/160, ctx 768) on the 4x96x96 lattice -- the PF path against the torch
+    path of the same module."""
     U = G.unet
     m = U.synthetic_init_(U.UNet2DCondition.sd15(), 0).cuda().half().eval()
     g = torch.Generator().manual_seed(0)
@@ -190,7 +192,9 @@ def test_vae_pf_path_equals_torch_path(G, chs, hw, fp32_ref):
     assert e1.shape == (2, 4, hw[0] // 8, hw[1] // 8) and d1.shape == (2, 3, *hw)
     for a1, a0, ar in ((e1, e0, er), (d1, d0, dr)):
         err1, err0 = (a1.float() - ar).abs().max().item(), (a0.float() - ar).abs().max().item()
-        assert err1 <= max(2 * err0, 2e-2 * max(1.0, ar.abs().max().item())), (err1, err0)
+        # absolute bound at the output's scale (fp32 judge for the small configuration; the SD-width one is judged against fp32 in
+        # tests/test_gpu_mm_production.py::test_full_vae_vs_fp32_torch)
+        assert err1 <= 2e-2 * max(1.0, ar.abs().max().item()), (err1, err0)
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
@@ -320,8 +324,7 @@ def test_packed_weight_caches_follow_weight_updates(G):
 
 def test_context_kv_cache_is_tied_to_the_context_tensor(G):
     """Cross-attention K / V^T are cached per context tensor: a second context (even one that reuses the freed storage), an in-place
-    edit of the context and a weight update must all be noticed.  (Forwards are not bit-reproducible run to run -- float atomics in the
-    GroupNorm statistics, stream-K GEMMs -- so "same" means within 1 % of the output scale and "different" well outside it.)"""
+    edit of the context and a weight update must all be noticed.  ("same" = within 1 % of the output scale, "different" = well outside it.)"""
     U = G.unet
     m = U.synthetic_init_(U.UNet2DCondition(block_out_channels=(64, 128, 128, 128), cross_attention_dim=64, num_heads=(1, 2, 2, 2), head_dim=64), 0)
     m = m.cuda().half().eval()

@@ -76,8 +76,8 @@ def test_unet_fused_equals_unfused(G):
         y1 = m(x, t, c)
         U.FUSED_KERNELS = False
         y0 = m(x, t, c)
+        yref = m.float()(x.float(), t, c.float())            # plain torch fp32 end to end (FUSED_KERNELS still off)
         U.FUSED_KERNELS = True
-        yref = m.float()(x.float(), t, c.float())
     e1 = (y1.float() - yref).abs().max().item()
-    e0 = (y0.float() - yref).abs().max().item()
-    assert e1 <= max(2 * e0, 2e-2), (e1, e0)          # the fused path is as close to the fp32 model as torch's fp16 path
+    e0 = (y0.float() - yref).abs().max().item()             # torch's own fp16 path: reported only
+    assert e1 <= 1e-2 * max(1.0, yref.abs().max().item()), (e1, e0)      # absolute bound at the output's scale
