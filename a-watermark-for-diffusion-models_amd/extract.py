@@ -161,6 +161,8 @@ class Models:
                 self.scheduler = _read_json(scfg)
         self.unet.to(self.device, dtype).eval()
         self.vae.to(self.device, dtype).eval()
+        from .graph import graphed
+        self.eps = graphed(self.unet)           # the eps model of the loops: HIP-graph replay of the forward for small batches (graph.py), eager above
         self.prediction_type = self.scheduler.get("prediction_type", "epsilon")
         self.ctx_dim = self.unet.mid_block.attentions[0].transformer_blocks[0].attn2.to_k.in_features
         self.ctx_empty = self._empty_prompt_context()
@@ -276,8 +278,8 @@ def invert_decoded_images(arrs, args, *, device="cuda") -> torch.Tensor:
     latents = V.normalised_img_to_latents(xn, models.vae)
     ctx = models.ctx_empty.expand(latents.shape[0], -1, -1)
     if isinstance(sched, DPMSolverInverseSchedule):
-        return dpms_invert(models.unet, latents, ctx, sched)
-    return ddim_invert(models.unet, latents, ctx, sched)
+        return dpms_invert(models.eps, latents, ctx, sched)
+    return ddim_invert(models.eps, latents, ctx, sched)
 
 
 def exactract_latents_batch(image_paths, args, *, device="cuda") -> torch.Tensor:

@@ -1,0 +1,163 @@
+"""HIP-graph replay of the eps model for the small-batch regime of the DDIM loops (rows X2 / G1 of SURVEY.md section 8a).
+
+The reference's own use is one image per call (extract.py:112-117: `exactract_latents` -> 50 UNet evaluations for ONE latent) and BASELINE
+configs[1] is batch 8.  There a UNet forward is ~520 kernel launches of a few microseconds each: issued one by one from Python through ctypes the
+host cannot keep the GPU fed, so the loop runs at the speed of the launch path, not of the kernels.  The loops of ddim.py are free of host
+synchronisation and every operand of a forward except (x, t, context) is a weight, so ONE forward is captured into a HIP graph per
+(rows, lattice, dtype, context shape) and replayed for every step of every loop:
+
+    x_s.copy_(x); t_s.copy_(t); graph.replay(); eps = out_s            # 3 tiny launches + one graph launch per step
+
+What the graph bakes in, and how it stays valid:
+  * the static input buffers x_s / t_s / ctx_s and the output -- owned by the entry;
+  * the padded context copy and the cross-attention K / V^T of every layer (computed ONCE per context, outside the graph, cached on the
+    context tensor by unet.Attention) -- when the caller passes a different context, ctx_s is overwritten and those are recomputed IN PLACE
+    (unet._padded_ctx / Attention refresh into their existing buffers), so the addresses the graph reads never change;
+  * weights and their packed copies -- replacing or editing parameters (load_state_dict, .to()) invalidates every graph (checked through the
+    parameters' version counters and storage pointers whenever the context changes, i.e. once per loop; `reset()` forces it).
+Capture failing for any reason falls back to eager IN THIS PROCESS (never a re-exec) and is reported once.
+
+A graph replay runs exactly the launches of the eager forward with the same arguments: outputs are bit-identical (tests/test_gpu_graph.py).
+"""
+from __future__ import annotations
+
+import os
+import warnings
+from typing import Dict, Optional, Tuple
+
+import torch
+
+
+def _env_mode() -> str:
+    return os.environ.get("GSW_GRAPH", "auto").lower()
+
+
+# "auto": graphs for forwards of at most AUTO_MAX_ROWS rows (above that a forward is tens of milliseconds of GPU work and the launch path is
+# hidden behind it; the graph would only pin a second copy of the activation memory)
+AUTO_MAX_ROWS = 32
+
+
+class _Entry:
+    __slots__ = ("graph", "x_s", "t_s", "ctx_s", "out", "ctx_id", "replays")
+
+
+def _ctx_identity(ctx: torch.Tensor):
+    """What makes two `ctx` arguments "the same context": the tensor that owns the storage (held by reference, so its address cannot be
+    recycled for other contents), its version counter, and the view geometry -- `ctx_empty.expand(B, -1, -1)` is a new view object per loop
+    but the same context."""
+    base = ctx._base if ctx._base is not None else ctx
+    return (base, ctx._version, ctx.storage_offset(), tuple(ctx.shape), tuple(ctx.stride()))
+
+
+def _same_ctx(a, b) -> bool:
+    return a[0] is b[0] and a[1:] == b[1:]
+
+
+class GraphedEpsModel:
+    """Callable `eps_model(x, t, ctx)` for ddim.py that replays a captured forward of `model` when that pays, else calls it eagerly.
+
+    mode: "auto" (default; env GSW_GRAPH overrides) -> graphs up to AUTO_MAX_ROWS rows; "always"; "never".
+    The returned tensor is the graph's static output buffer: it is valid until the next call with the same shape (the loops consume it in the
+    scheduler-step kernel right away)."""
+
+    def __init__(self, model, mode: Optional[str] = None, max_rows: int = AUTO_MAX_ROWS):
+        self.model = model
+        m = (mode or _env_mode()).lower()
+        self.mode = {"1": "always", "0": "never", "on": "always", "off": "never"}.get(m, m)
+        if self.mode not in ("auto", "always", "never"):
+            raise ValueError(f"GSW_GRAPH / mode must be auto | always | never (got {m!r})")
+        self.max_rows = max_rows
+        self._entries: Dict[Tuple, _Entry] = {}
+        self._weights_key = None
+        self._failed: Dict[Tuple, str] = {}
+        self.stats = {"captures": 0, "replays": 0, "eager": 0, "context_refreshes": 0}
+
+    # anything else (parameters(), eval(), ...) is the wrapped module's
+    def __getattr__(self, name):
+        return getattr(self.__dict__["model"], name)
+
+    def _wants_graph(self, x: torch.Tensor) -> bool:
+        if self.mode == "never" or not x.is_cuda:
+            return False
+        if torch.cuda.is_current_stream_capturing():      # already inside somebody else's capture: just be part of it
+            return False
+        return self.mode == "always" or x.shape[0] <= self.max_rows
+
+    def _params_key(self):
+        # has any parameter been replaced or edited since the graphs were captured?
+        return tuple((p.data_ptr(), p._version) for p in self.model.parameters())
+
+    def reset(self):
+        self._entries.clear()
+        self._failed.clear()
+
+    def _capture(self, key, x, t, ctx) -> Optional[_Entry]:
+        e = _Entry()
+        e.x_s = torch.empty_like(x, memory_format=torch.contiguous_format).copy_(x)
+        e.t_s = torch.empty_like(t).copy_(t)
+        e.ctx_s = torch.empty(ctx.shape, dtype=ctx.dtype, device=ctx.device).copy_(ctx)
+        e.ctx_id, e.replays = _ctx_identity(ctx), 0
+        try:
+            # warm-up on a side stream: builds the packed weights, the padded context + cross-attention K / V^T (cached on ctx_s, OUTSIDE the
+            # graph's pool), kernel attributes and workspaces, so that the captured forward contains the per-step launches only
+            side = torch.cuda.Stream(device=x.device)
+            side.wait_stream(torch.cuda.current_stream(x.device))
+            with torch.cuda.stream(side), torch.no_grad():
+                self.model(e.x_s, e.t_s, e.ctx_s)
+                self.model(e.x_s, e.t_s, e.ctx_s)
+            torch.cuda.current_stream(x.device).wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.no_grad(), torch.cuda.graph(g):
+                e.out = self.model(e.x_s, e.t_s, e.ctx_s)
+            e.graph = g
+        except Exception as exc:      # noqa: BLE001 -- any capture failure means "run eagerly", in this process
+            self._failed[key] = f"{type(exc).__name__}: {exc}"
+            warnings.warn(f"gswm graph: capture of the eps model for {key} failed ({self._failed[key]}); running it eagerly", RuntimeWarning, stacklevel=3)
+            return None
+        self.stats["captures"] += 1
+        return e
+
+    @torch.no_grad()
+    def __call__(self, x: torch.Tensor, t: torch.Tensor, ctx: torch.Tensor) -> torch.Tensor:
+        if not self._wants_graph(x):
+            self.stats["eager"] += 1
+            return self.model(x, t, ctx)
+        if not torch.is_tensor(t):
+            t = torch.as_tensor(t, device=x.device)
+        key = (tuple(x.shape), x.dtype, str(x.device), tuple(t.shape), t.dtype, tuple(ctx.shape), ctx.dtype)
+        if key in self._failed:
+            self.stats["eager"] += 1
+            return self.model(x, t, ctx)
+        e = self._entries.get(key)
+        cid = _ctx_identity(ctx)
+        if e is None or not _same_ctx(cid, e.ctx_id):
+            # (checked when a graph is captured and whenever the context changes, i.e. once per loop, not per step: ~700 parameters)
+            wk = self._params_key()
+            if wk != self._weights_key:         # parameters replaced / edited: every captured address or packed copy may be stale
+                self._entries.clear()
+                self._weights_key = wk
+                e = None
+        if e is None:
+            e = self._capture(key, x, t, ctx)
+            if e is None:
+                self.stats["eager"] += 1
+                return self.model(x, t, ctx)
+            self._entries[key] = e
+        elif not _same_ctx(cid, e.ctx_id):
+            # a different context: overwrite the static copy and bring the padded copy + every layer's K / V^T up to date IN PLACE (eagerly, on
+            # this stream, ordered in front of the replay).  Holding a reference to the caller's tensor keeps the identity test sound.
+            e.ctx_s.copy_(ctx)
+            e.ctx_id = cid
+            self.model.prepare_context(e.ctx_s)
+            self.stats["context_refreshes"] += 1
+        e.x_s.copy_(x)
+        e.t_s.copy_(t)
+        e.graph.replay()
+        e.replays += 1
+        self.stats["replays"] += 1
+        return e.out
+
+
+def graphed(model, mode: Optional[str] = None):
+    """Wrap an eps model once (idempotent)."""
+    return model if isinstance(model, GraphedEpsModel) else GraphedEpsModel(model, mode)

@@ -20,6 +20,9 @@ class GaussianShadingPipeline:
     def __init__(self, eps_model, key: bytes, nonce: bytes, message: bytes, *, height: int = 512, width: int = 512,
                  num_inference_steps: int = 50, dtype: torch.dtype = torch.float16, device="cuda",
                  ctx_uncond: Optional[torch.Tensor] = None, prediction_type: str = "epsilon"):
+        if hasattr(eps_model, "prepare_context"):          # a unet.UNet2DCondition: small batches replay a captured HIP graph of the forward (graph.py)
+            from .graph import graphed
+            eps_model = graphed(eps_model)
         self.eps_model = eps_model
         self.key, self.nonce, self.message = key, nonce, message
         self.shape = (4, height // 8, width // 8)

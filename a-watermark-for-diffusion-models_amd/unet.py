@@ -100,25 +100,27 @@ def _wb(lin: nn.Linear, x: torch.Tensor):
     return lin.weight, lin.bias
 
 
-def _lin(x: torch.Tensor, lin: nn.Linear, resid: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Linear (+ residual in the epilogue) on the matmul engine, else torch."""
+def _lin(x: torch.Tensor, lin: nn.Linear, resid: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Linear (+ residual in the epilogue) on the matmul engine, else torch.  out: written in place (same shape, contiguous)."""
     if _own_gemm_ok(x, lin.in_features, lin.out_features):
         from .pf import gemm
         w, b = _wb(lin, x)
-        return gemm(x.contiguous(), w, b, resid=None if resid is None else resid.contiguous())
+        return gemm(x.contiguous(), w, b, resid=None if resid is None else resid.contiguous(), out=out)
     y = lin(x)
-    return y if resid is None else y + resid
+    y = y if resid is None else y + resid
+    return y if out is None else out.copy_(y)
 
 
-def _lin_t(x: torch.Tensor, lin: nn.Linear) -> torch.Tensor:
+def _lin_t(x: torch.Tensor, lin: nn.Linear, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """[B, S, K] -> (lin(x))^T = [B, N, S]: the value projection in the layout the attention kernel consumes."""
     b, n, _ = x.shape
     if _own_gemm_ok(x, lin.in_features, lin.out_features) and n % 8 == 0:
         from .pf import gemm
         w, bias = _wb(lin, x)
-        return gemm(x.contiguous(), w, bias, mode="trans", tokens=n)
+        return gemm(x.contiguous(), w, bias, mode="trans", tokens=n, out=out)
     vt = torch.bmm(lin.weight.unsqueeze(0).expand(b, -1, -1), x.transpose(1, 2))
-    return vt if lin.bias is None else vt + lin.bias[None, :, None]
+    vt = vt if lin.bias is None else vt + lin.bias[None, :, None]
+    return vt if out is None else out.copy_(vt)
 
 
 def _gn_pf(x, norm: nn.GroupNorm, act=True, tokens=False):
@@ -189,10 +191,16 @@ def _padded_ctx(ctx: torch.Tensor):
     if n % 64 == 0:
         return ctx, n
     cached = getattr(ctx, "_gsw_pad", None)              # (tensor version at padding time, padded copy)
-    if cached is not None and cached[0] == ctx._version and cached[1].device == ctx.device and cached[1].dtype == ctx.dtype:
+    if cached is not None and cached[1].device == ctx.device and cached[1].dtype == ctx.dtype:
+        if cached[0] == ctx._version:
+            return cached[1], n
+        # the context was edited in place: refresh the padded copy IN PLACE too, so that its address -- which a captured HIP graph of the
+        # forward (graph.py) has baked in -- stays valid; in-place edits of ctx bump _version, the copy_ below bumps the pad's own
+        cached[1][:, :n].copy_(ctx)
+        ctx._gsw_pad = (ctx._version, cached[1])
         return cached[1], n
     pad = F.pad(ctx, (0, 0, 0, (-n) % 64)).contiguous()
-    ctx._gsw_pad = (ctx._version, pad)                   # in-place edits of ctx bump _version and invalidate the copy
+    ctx._gsw_pad = (ctx._version, pad)
     return pad, n
 
 
@@ -208,6 +216,22 @@ class Attention(nn.Module):
         self.to_v = nn.Linear(ctx_dim, inner, bias=False)
         self.to_out = nn.ModuleList([nn.Linear(inner, dim)])
 
+    def context_kv(self, src: torch.Tensor):
+        """Cross-attention keys / values^T of a (padded) context tensor: they depend on the context only, so they are computed once per
+        (context tensor, layer) and reused by every step of a sampling / inversion loop.  The cache lives ON the context tensor (it dies with
+        it) and is keyed by the tensor's and the weights' version counters, so in-place edits recompute it -- INTO the existing buffers: a
+        captured HIP graph of the forward (graph.py) reads K / V^T at fixed addresses."""
+        store = getattr(src, "_gsw_kv", None)
+        if store is None:
+            store = {}
+            src._gsw_kv = store
+        ver = (src._version, self.to_k.weight._version, self.to_v.weight._version, self.to_k.weight.data_ptr(), self.to_v.weight.data_ptr())
+        ent = store.get(id(self))
+        if ent is None or ent[0] != ver:
+            ent = (ver, _lin(src, self.to_k, out=None if ent is None else ent[1]), _lin_t(src, self.to_v, out=None if ent is None else ent[2]))
+            store[id(self)] = ent
+        return ent[1], ent[2]
+
     def forward(self, x, ctx=None, resid=None):
         """resid: added to the output projection (in its GEMM epilogue on the own path): `x + attn(norm(x))` of the transformer block"""
         b, n, _ = x.shape
@@ -219,19 +243,8 @@ class Attention(nn.Module):
                 # (V^T = W_v src^T, one GEMM either way) because the kernel consumes V^T tiles.  Padded context rows are zero and
                 # masked by `valid`.
                 if ctx is not None and CACHE_CONTEXT_KV:
-                    # cross-attention keys / values depend on the context only: computed once per (context tensor, layer) and reused by
-                    # every step of a sampling / inversion loop.  The cache lives ON the context tensor (it dies with it) and is keyed
-                    # by the tensor's and the weights' version counters, so in-place edits recompute it.
-                    store = getattr(src, "_gsw_kv", None)
-                    if store is None:
-                        store = {}
-                        src._gsw_kv = store
-                    ver = (src._version, self.to_k.weight._version, self.to_v.weight._version, self.to_k.weight.data_ptr(), self.to_v.weight.data_ptr())
-                    ent = store.get(id(self))
-                    if ent is None or ent[0] != ver:
-                        ent = (ver, _lin(src, self.to_k), _lin_t(src, self.to_v))
-                        store[id(self)] = ent
-                    o = attention(_lin(x, self.to_q), ent[1], ent[2], self.heads, valid_keys=valid)
+                    k_ctx, vt_ctx = self.context_kv(src)
+                    o = attention(_lin(x, self.to_q), k_ctx, vt_ctx, self.heads, valid_keys=valid)
                     return _lin(o, self.to_out[0], resid)
                 vt = _lin_t(src, self.to_v)
                 if ctx is None and FUSED_QK:
@@ -561,6 +574,21 @@ def _unet_forward_pf(self, x: torch.Tensor, temb: torch.Tensor, ctx: torch.Tenso
     return y.interior[..., : self.conv_out.out_channels].permute(0, 3, 1, 2).contiguous()
 
 
+def _unet_prepare_context(self, ctx: torch.Tensor) -> None:
+    """Bring the per-context caches (padded copy, every cross-attention layer's K / V^T) up to date for `ctx` without running a forward --
+    in place when they exist (graph.py calls this after overwriting a captured graph's static context buffer)."""
+    if not (OWN_ATTENTION and FUSED_KERNELS and CACHE_CONTEXT_KV and ctx.is_cuda):
+        return
+    from .pf import attention_ok
+    src, _ = _padded_ctx(ctx)
+    for blk in self.modules():
+        if isinstance(blk, BasicTransformerBlock):
+            a = blk.attn2
+            if attention_ok(ctx, a.heads, a.to_q.out_features // a.heads, 1, src.shape[1]):
+                a.context_kv(src)
+
+
+UNet2DCondition.prepare_context = _unet_prepare_context
 UNet2DCondition._pf_ok = _unet_pf_ok
 UNet2DCondition._forward_pf = _unet_forward_pf
 

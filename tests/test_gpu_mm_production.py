@@ -41,7 +41,7 @@ def _rel(y, ref):
 # tiling >= 256 tiles and an uneven number of tiles per workgroup
 CONV_SHAPES = [(18, 320, 320, 64, 64, 3, 1), (9, 960, 320, 64, 64, 3, 1), (40, 640, 640, 32, 32, 3, 1), (24, 1920, 640, 32, 32, 3, 1),
                (72, 1280, 1280, 16, 16, 3, 1), (40, 2560, 1280, 16, 16, 3, 1), (136, 1280, 1280, 8, 8, 3, 1),
-               (72, 640, 640, 16, 16, 3, 2), (20, 320, 320, 32, 32, 3, 2), (24, 640, 1280, 32, 32, 1, 1)]
+               (65, 640, 640, 32, 32, 3, 2), (33, 320, 320, 64, 64, 3, 2), (25, 640, 1280, 32, 32, 1, 1)]
 
 
 @pytest.mark.parametrize("B,C,N,H,W,k,stride", CONV_SHAPES)
