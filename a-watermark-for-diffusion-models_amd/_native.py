@@ -74,6 +74,7 @@ _PROTOTYPES = {
                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "gsw_softmax_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_float, C.c_int, C.c_void_p]),
     "gsw_mm_config": (C.c_int, [C.c_int, C.c_int]),
+    "gsw_mm_set_workspace": (C.c_int, [C.c_void_p, C.c_int64, C.c_int]),
     "gsw_linear": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
                              C.c_void_p]),
 }

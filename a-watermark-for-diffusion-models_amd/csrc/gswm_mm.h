@@ -37,6 +37,8 @@ struct MMArgs {
     int32_t S, Wimg;      // tokens per image (TRANS, TOK2PF), image width (TOK2PF)
     int32_t up;           // UP2X: 1 + dy * 2 + dx
     int32_t flags;        // MM_FLAG_*
+    int32_t splits;       // filled by gsw_mm_launch: > 1 = split-K (the K stages of a tile are shared by `splits` workgroups, fp32 partials in ws)
+    float* ws;            // filled by gsw_mm_launch: split-K workspace, [splits][ntiles][8 waves][5 * MT accumulators][64 lanes] float4
 };
 
 int gsw_mm_launch(MMArgs& a, int dtype, void* stream);

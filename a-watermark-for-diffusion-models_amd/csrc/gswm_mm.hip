@@ -119,6 +119,10 @@ __device__ __forceinline__ float mm_erf(float x) {
 template <typename T, int EPI, bool SPLIT, int MT>
 __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kernel(const MMArgs p) {
     constexpr bool SWAP = EPI == 3;
+    // EPI 4 (split-K, always the 12-wave variant): the workgroup multiplies a RANGE of its tile's K stages and dumps the fp32 accumulators into a
+    // workspace slab; gsw_mm_reduce_kernel sums the slabs of a tile in a fixed order and runs the epilogue of the launch's mode
+    constexpr bool PART = EPI == 4;
+    static_assert(!PART || SPLIT, "split-K partial launches use the producer-wave variant");
     constexpr int WM = 4;                            // waves along M; 2 groups of 4 waves along N
     constexpr int BM = 64 * MT, BN = 160;
     constexpr int NPR = MT / 2;                      // pairs of row tiles per wave (the epilogue's unit)
@@ -155,8 +159,13 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
     const uint32_t G = gridDim.x;
     const uint32_t slotx = (blockIdx.x & 7u) * (G >> 3) + (blockIdx.x >> 3);
     const uint32_t ntiles = (uint32_t)p.ntiles;
-    const uint32_t nt_mine = ntiles > slotx ? (ntiles - slotx + G - 1u) / G : 0u;
+    const uint32_t nvirt = PART ? ntiles * (uint32_t)p.splits : ntiles;      // split-K: (tile, K range) pairs, at most one per workgroup
+    const uint32_t nt_mine = nvirt > slotx ? (nvirt - slotx + G - 1u) / G : 0u;
     if (nt_mine == 0u) return;
+    // split-K: virtual tile v = split * ntiles + tile; stages [k_lo, k_hi) of the tile's P
+    const uint32_t part_split = PART ? slotx / ntiles : 0u;
+    const int32_t k_lo = PART ? (int32_t)(((int64_t)part_split * p.P) / p.splits) : 0;
+    const int32_t P_mine = PART ? (int32_t)(((int64_t)(part_split + 1u) * p.P) / p.splits) - k_lo : p.P;
     const T* Wbase = reinterpret_cast<const T*>(p.w);
     // logical tile -> (tile_m, tile_n): N is walked in PANELS of 8 tiles (M fastest across panels' rows), so the 32 tiles an XCD works on
     // at a time are a 4 x 8 block: 4 activation tiles + 8 weight tiles in its L2 instead of 1 + 32 for a wide projection
@@ -192,7 +201,7 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
     };
     auto setup_tile = [&](uint32_t it) {
         int32_t tm, tn;
-        decode_tile(it * G + slotx, tm, tn);
+        decode_tile(PART ? slotx % ntiles : it * G + slotx, tm, tn);
         const int32_t m0 = tm * BM, n0 = tn * BN;
 #pragma unroll
         for (int i = 0; i < NPA; ++i) {
@@ -294,6 +303,7 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
             // ------------------------------------------------------------ producer wave: every stage, all 13 of its pieces back to back.
             // Barrier k (k = 0 .. stages) is the consumers' "stage k is in LDS and the slot of stage k-1 is free": stage s+2 is issued after
             // barrier s-1... i.e. right after the barrier that retired the slot's previous tenant, and stage s+1 has landed before barrier s.
+            int32_t pr_left = 0x7FFFFFFF;                                    // (PART) stages of this workgroup's K range still to issue
             auto dma_stage = [&]() {
 #ifndef MM_ABL_NOA                                             // (ablation builds of tools/ubench/mm_trace.hip: results wrong by design)
 #pragma unroll
@@ -304,6 +314,16 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
                 for (int i = 0; i < NPW; ++i) dma_piece_w(i);
 #endif
                 pr_slot = pr_slot + STAGE == RING ? 0u : pr_slot + STAGE;
+                if constexpr (PART) {
+                    if (--pr_left == 0) {                        // the K range of this workgroup is issued: filler reads from here on (see end_run)
+                        pr_run = 0x7FFFFFFF; a_step = 0; w_step = 0;
+#pragma unroll
+                        for (int i = 0; i < NPA; ++i) pa[i] = Wbase + chunk8;
+#pragma unroll
+                        for (int i = 0; i <= NPW; ++i) pw[i] = Wbase + chunk8;
+                        return;
+                    }
+                }
                 if (--pr_run == 0) end_run();
             };
 #if defined(MM_ABL_NOW) && defined(MM_ABL_NOA)
@@ -314,12 +334,30 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
             constexpr int NWAIT = NDMA;
 #endif
             setup_tile(0);
-            begin_run();
+            if constexpr (PART) {
+                // enter the tile's stage sequence at stage k_lo: segment, channel block, tap row, and the position inside the run
+                const MMSeg& s0 = p.seg[0]; const MMSeg& s1 = p.seg[1];
+                int32_t st = k_lo;
+                const int32_t len0 = s0.kblocks * s0.ntaps, len1 = s1.kblocks * s1.ntaps;
+                if (p.nseg > 1 && st >= len0) { st -= len0; pr_seg = 1; if (p.nseg > 2 && st >= len1) { st -= len1; pr_seg = 2; } }
+                const int32_t nt = pr_seg == 0 ? s0.ntaps : 1, tw = pr_seg == 0 ? s0.tw : 1;      // segments 1 and 2 are 1x1 (one tap)
+                int32_t skip = st;
+                if (nt != 1) { pr_kc = st / nt; const int32_t r = st - pr_kc * nt; pr_kh = r / tw; skip = r - pr_kh * tw; }
+                begin_run();
+#pragma unroll
+                for (int i = 0; i < NPA; ++i) pa[i] += (int64_t)skip * a_step;
+#pragma unroll
+                for (int i = 0; i <= NPW; ++i) pw[i] += (int64_t)skip * w_step;
+                pr_run -= skip;
+                pr_left = P_mine;
+            } else {
+                begin_run();
+            }
             dma_stage();
             dma_stage();
             asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NWAIT) : "memory");         // stage 0 has landed
             MM_BARRIER();
-            const uint32_t total = nt_mine * (uint32_t)p.P;
+            const uint32_t total = nt_mine * (uint32_t)P_mine;
 #ifdef MM_TRACE
             unsigned long long tr_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tr_last = __builtin_amdgcn_s_memtime();
 #endif
@@ -390,9 +428,22 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
     // gelu(gate), two more swap rounds collect 8 consecutive outputs per lane.
     auto epilogue = [&]() {
         int32_t tile_m, tile_n;
-        decode_tile(c_it * G + slotx, tile_m, tile_n);
+        decode_tile(PART ? slotx % ntiles : c_it * G + slotx, tile_m, tile_n);
         const int32_t m0 = tile_m * BM, n0 = tile_n * BN;
         const uint32_t q = lane >> 4, li = lane & 15u;
+        if constexpr (PART) {
+            // slab of virtual tile v: [wave][5 * MT accumulators][lane] float4 -- one coalesced 1 KiB store per accumulator; 16-row blocks past M are
+            // neither stored nor read back
+            float* slab = p.ws + ((size_t)slotx * 8u + wave) * (size_t)(5 * MT * 64 * 4);
+#pragma unroll
+            for (int in = 0; in < 5; ++in)
+#pragma unroll
+                for (int im = 0; im < MT; ++im)
+                    if (m0 + (int32_t)(wm * (16u * MT)) + im * 16 < p.M)
+                        *reinterpret_cast<mm_f4*>(slab + ((in * MT + im) * 64 + (int)lane) * 4) = acc[in][im];
+            ++c_it;
+            return;
+        }
         auto pack4 = [&](const mm_f4& a, const float (&b)[4], uint32_t& lo, uint32_t& hi) {
             lo = MM<T>::cvt2(a[0] + b[0], a[1] + b[1]);
             hi = MM<T>::cvt2(a[2] + b[2], a[3] + b[3]);
@@ -703,7 +754,7 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
     read_frags(xa, wa, 0u, 0u);                               // (stage 0, k-half 0)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     for (uint32_t it = 0; it < nt_mine; ++it) {
-        for (int32_t i = 0; i < p.P; ++i) step(xa, wa, xb, wb);
+        for (int32_t i = 0; i < P_mine; ++i) step(xa, wa, xb, wb);
         epilogue();
         MM_STAMP(6);
     }
@@ -713,6 +764,105 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
     }
 #endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the filler DMA of the last steps
+}
+
+
+// Second half of a split-K launch: every thread owns one float4 of a tile's accumulator image (the layout the EPI 4 kernel dumps: [wave][5 * MT
+// accumulators][lane]; lane (q = lane >> 4, i = lane & 15) holds columns 16 in + 4 q .. + 3 of row 16 im + i of the wave's 16 MT x 80 block), adds the
+// `splits` slabs in split order (fixed order: deterministic) and runs the epilogue of the launch's mode with the rounding points of the fused epilogues.
+template <typename T>
+__global__ __launch_bounds__(256) void gsw_mm_reduce_kernel(const MMArgs p, const int MT) {
+    const int32_t BM = 64 * MT, upt = 8 * 5 * MT * 64;         // float4 units per tile
+    const int64_t total = (int64_t)p.ntiles * upt;
+    const size_t split_stride = (size_t)total * 4;              // floats between the slabs of consecutive splits
+    const uint16_t* bias = reinterpret_cast<const uint16_t*>(p.bias);
+    const uint16_t* rowbias = reinterpret_cast<const uint16_t*>(p.rowbias);
+    const uint16_t* resid = reinterpret_cast<const uint16_t*>(p.resid);
+    uint16_t* Y = reinterpret_cast<uint16_t*>(p.y);
+    const bool compact = (p.flags & MM_FLAG_COMPACT) != 0;
+    const int32_t HpWp = p.Hp * p.Wp;
+    const uint32_t tiles_m = (uint32_t)p.ntiles / (uint32_t)p.tiles_n;
+    for (int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x; u < total; u += (int64_t)gridDim.x * 256) {
+        const uint32_t lane = (uint32_t)u & 63u;
+        uint32_t r = (uint32_t)(u >> 6);
+        const uint32_t accidx = r % (uint32_t)(5 * MT); r /= (uint32_t)(5 * MT);
+        const uint32_t wave = r & 7u, L = r >> 3;
+        const uint32_t in = accidx / (uint32_t)MT, im = accidx - in * (uint32_t)MT;
+        const uint32_t wm = wave & 3u, grp = wave >> 2, q = lane >> 4, li = lane & 15u;
+        // logical tile -> (tile_m, tile_n): the panel order of the engine
+        const uint32_t full = tiles_m * 8u, pn = L / full, rem = L - pn * full;
+        const uint32_t width = min(8u, (uint32_t)p.tiles_n - pn * 8u);
+        const int32_t tile_m = (int32_t)(rem / width), tile_n = (int32_t)(pn * 8u + rem - (rem / width) * width);
+        const int32_t m = tile_m * BM + (int32_t)(wm * (uint32_t)(16 * MT) + im * 16u + li);
+        const int32_t n = tile_n * 160 + (int32_t)(grp * 80u + in * 16u + q * 4u);
+        const bool geglu = p.mode == MM_MODE_GEGLU;
+        if (m >= p.M || n >= p.N || (geglu && q >= 2u)) continue;
+        mm_f4 a = mm_f4{0.f, 0.f, 0.f, 0.f}, g = mm_f4{0.f, 0.f, 0.f, 0.f};
+        const float* src = p.ws + (size_t)u * 4;
+        for (int s = 0; s < p.splits; ++s) {
+            a += *reinterpret_cast<const mm_f4*>(src + (size_t)s * split_stride);
+            if (geglu) g += *reinterpret_cast<const mm_f4*>(src + (size_t)s * split_stride + 32 * 4);       // the gate columns: lane + 32
+        }
+        float b4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (bias) { for (int j = 0; j < 4; ++j) b4[j] = MM<T>::up(bias[n + j]); }
+        uint16_t h[4];
+        for (int j = 0; j < 4; ++j) h[j] = MM<T>::cvt(a[j] + b4[j]);
+        if (geglu) {
+            for (int j = 0; j < 4; ++j) {
+                const float gb = bias ? MM<T>::up(bias[n + 8 + j]) : 0.f;
+                const float gg = MM<T>::up(MM<T>::cvt(g[j] + gb));
+                const float ge = MM<T>::up(MM<T>::cvt(0.5f * gg * (1.0f + mm_erf(gg * 0.70710678118654752f))));
+                h[j] = MM<T>::cvt(MM<T>::up(h[j]) * ge);
+            }
+            const int64_t ocol = (int64_t)tile_n * 80 + grp * 40u + in * 8u + q * 4u;
+            *reinterpret_cast<uint2*>(Y + (int64_t)m * p.ldy + ocol) = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+            continue;
+        }
+        if (p.mode == MM_MODE_TRANS) {
+            const int32_t b = m / p.S, sidx = m - b * p.S;
+            for (int j = 0; j < 4; ++j) Y[((int64_t)b * p.N + n + j) * p.S + sidx] = h[j];
+            continue;
+        }
+        int64_t orow = m;
+        int32_t img = 0;
+        bool border = false;
+        if (p.mode == MM_MODE_PF || p.mode == MM_MODE_UP2X) {
+            int32_t b, yy, xx;
+            if (compact) {
+                const int32_t Wi = p.Wp - 2, HW = (p.Hp - 2) * Wi;
+                b = m / HW;
+                const int32_t rr = m - b * HW;
+                yy = rr / Wi; xx = rr - yy * Wi + 1; yy += 1;
+                orow = (int64_t)b * HpWp + yy * p.Wp + xx;
+            } else {
+                b = m / HpWp;
+                const int32_t rr = m - b * HpWp;
+                yy = rr / p.Wp; xx = rr - yy * p.Wp;
+                border = (yy == 0) | (yy == p.Hp - 1) | (xx == 0) | (xx == p.Wp - 1);
+            }
+            img = b;
+            if (p.mode == MM_MODE_UP2X) {
+                if (border) continue;
+                const int32_t dy = (p.up - 1) >> 1, dx = (p.up - 1) & 1;
+                orow = ((int64_t)b * (2 * p.Hp - 2) + (2 * (yy - 1) + dy + 1)) * (2 * p.Wp - 2) + (2 * (xx - 1) + dx + 1);
+            }
+        } else if (p.mode == MM_MODE_TOK2PF) {
+            const int32_t b = m / p.S, ii = m - b * p.S;
+            const int32_t yy = ii / p.Wimg, xx = ii - yy * p.Wimg;
+            img = b;
+            orow = (int64_t)b * HpWp + (int64_t)(yy + 1) * p.Wp + (xx + 1);
+        }
+        if (border) { h[0] = h[1] = h[2] = h[3] = 0; }
+        else if (rowbias || resid) {
+            for (int j = 0; j < 4; ++j) {
+                float f = MM<T>::up(h[j]);
+                if (p.mode == MM_MODE_DENSE && !rowbias) f += MM<T>::up(resid[orow * p.ldr + n + j]);       // EPI 0: one add
+                else f = f + (rowbias ? MM<T>::up(rowbias[(int64_t)img * p.N + n + j]) : 0.f) + (resid ? MM<T>::up(resid[orow * p.ldr + n + j]) : 0.f);
+                h[j] = MM<T>::cvt(f);
+            }
+        }
+        *reinterpret_cast<uint2*>(Y + orow * p.ldy + n) = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+    }
 }
 
 // host ---------------------------------------------------------------------------------------------
@@ -736,6 +886,17 @@ int mm_launch_t(const MMArgs& a, uint32_t grid, int mt, hipStream_t st) {
     return split ? mm_launch_k<T, EPI, true, 2>(a, grid, st) : mm_launch_k<T, EPI, false, 2>(a, grid, st);
 }
 template <typename T>
+int mm_launch_splitk(const MMArgs& a, uint32_t grid, int mt, hipStream_t st) {
+    // always 128-row tiles: the launches that split have few rows, and the 256-row variant of this kernel does not fit the 168 registers of the
+    // 12-wave form (80 accumulators + both fragment sets + the slab addressing)
+    if (mt != 2) return (int)hipErrorInvalidValue;
+    const int e = mm_launch_k<T, 4, true, 2>(a, grid, st);
+    if (e != 0) return e;
+    const int64_t units = (int64_t)a.ntiles * 8 * 5 * mt * 64;
+    hipLaunchKernelGGL((gsw_mm_reduce_kernel<T>), dim3((uint32_t)std::min<int64_t>((units + 255) / 256, 2048)), dim3(256), 0, st, a, mt);
+    return (int)hipGetLastError();
+}
+template <typename T>
 int mm_launch_e(const MMArgs& a, int epi, uint32_t grid, int mt, hipStream_t st) {
     switch (epi) {
         case 0: return mm_launch_t<T, 0>(a, grid, mt, st);
@@ -749,6 +910,19 @@ int mm_launch_e(const MMArgs& a, int epi, uint32_t grid, int mt, hipStream_t st)
 
 extern __attribute__((visibility("hidden"))) thread_local int g_last_hip_error;   // gswm_kernels.hip
 
+
+// Split-K workspace of the calling thread (caller-owned device memory, see gsw_mm_set_workspace in include/gswm.h) and the split policy
+static thread_local void* t_mm_ws = nullptr;
+static thread_local int64_t t_mm_ws_bytes = 0;
+static thread_local int t_mm_max_splits = 0;          // 0 auto, 1 off, k > 1: split every launch whose K allows it up to k ways (tests)
+
+int gsw_mm_set_workspace(void* ws_dev, int64_t bytes, int max_splits) {
+    if (bytes < 0 || (bytes > 0 && !ws_dev) || max_splits < 0 || max_splits > 64 || ((uintptr_t)ws_dev & 15)) return GSW_ERR_BAD_ARG;
+    t_mm_ws = bytes > 0 ? ws_dev : nullptr;
+    t_mm_ws_bytes = bytes;
+    t_mm_max_splits = max_splits;
+    return GSW_OK;
+}
 
 int gsw_mm_config(int tile_rows, int split_mask) {
     if (tile_rows != 0 && tile_rows != 128 && tile_rows != 256 && tile_rows != -1) return GSW_ERR_BAD_ARG;
@@ -771,12 +945,33 @@ int gsw_mm_launch(MMArgs& a, int dtype, void* stream) {
     // the half tile re-fetches the weight tile twice as often)
     int BM = (((int64_t)a.M + 255) / 256) * tiles_n < 256 && a.M > 128 ? 128 : 256;
     if (bm_env == 128 || bm_env == 256) BM = bm_env;
+    hipStream_t st = (hipStream_t)stream;
+    a.splits = 1; a.ws = nullptr;
+    // Split-K for launches that cannot fill the chip with output tiles (the deep levels at small batch: 8 x 8 pixels of one image are ONE row tile
+    // against 180-360 K stages): `splits` workgroups share a tile's stages, fp32 partials go through the caller's workspace, a second small kernel
+    // adds them in a fixed order and runs the epilogue.  Needs a workspace (gsw_mm_set_workspace); without one the launch runs unsplit.
+    if (t_mm_ws && t_mm_max_splits != 1) {
+        const int bm_s = 128;
+        const int64_t nt = (((int64_t)a.M + bm_s - 1) / bm_s) * tiles_n;
+        int splits = 1;
+        if (t_mm_max_splits > 1) splits = std::min<int64_t>(std::min<int64_t>(t_mm_max_splits, a.P), 256 / std::max<int64_t>(nt, 1));
+        else if (nt <= 128 && a.P >= 8) splits = (int)std::min<int64_t>(std::min<int64_t>(256 / nt, a.P / 4), 16);
+        const int64_t need = (int64_t)splits * nt * 8 * 5 * (bm_s / 64) * 64 * 16;
+        if (splits >= 2 && need <= t_mm_ws_bytes) {
+            a.tiles_n = (int32_t)tiles_n;
+            a.ntiles = (int32_t)nt;
+            a.splits = splits; a.ws = (float*)t_mm_ws;
+            const uint32_t grid = (uint32_t)((nt * splits + 7) / 8 * 8);
+            const int e = dtype == GSW_F16 ? mm_launch_splitk<_Float16>(a, grid, bm_s / 64, st) : mm_launch_splitk<__bf16>(a, grid, bm_s / 64, st);
+            if (e != 0) { g_last_hip_error = e; return GSW_ERR_HIP; }
+            return GSW_OK;
+        }
+    }
     const int64_t tiles_m = ((int64_t)a.M + BM - 1) / BM;
     if (tiles_m * tiles_n > 0x7FFFFFFF) return GSW_ERR_UNSUPPORTED;
     a.tiles_n = (int32_t)tiles_n;
     a.ntiles = (int32_t)(tiles_m * tiles_n);
     const uint32_t grid = (uint32_t)std::min<int64_t>(256, (a.ntiles + 7) / 8 * 8);
-    hipStream_t st = (hipStream_t)stream;
     const int epi = a.mode == MM_MODE_TRANS ? 3 : a.mode == MM_MODE_GEGLU ? 2 : (a.mode == MM_MODE_DENSE && !a.rowbias) ? 0 : 1;
     const int e = dtype == GSW_F16 ? mm_launch_e<_Float16>(a, epi, grid, BM / 64, st) : mm_launch_e<__bf16>(a, epi, grid, BM / 64, st);
     if (e != 0) { g_last_hip_error = e; return GSW_ERR_HIP; }

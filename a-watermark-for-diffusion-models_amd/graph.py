@@ -38,7 +38,7 @@ AUTO_MAX_ROWS = 32
 
 
 class _Entry:
-    __slots__ = ("graph", "x_s", "t_s", "ctx_s", "out", "ctx_id", "replays")
+    __slots__ = ("graph", "x_s", "t_s", "ctx_s", "out", "ctx_id", "replays", "ws")
 
 
 def _ctx_identity(ctx: torch.Tensor):
@@ -97,6 +97,9 @@ class GraphedEpsModel:
         e.t_s = torch.empty_like(t).copy_(t)
         e.ctx_s = torch.empty(ctx.shape, dtype=ctx.dtype, device=ctx.device).copy_(ctx)
         e.ctx_id, e.replays = _ctx_identity(ctx), 0
+        from . import pf
+        # the split-K scratch of the matmul engine is baked into the graph too: one per graph, so replays never share scratch with eager launches
+        e.ws = torch.empty(pf.SPLITK_BYTES, dtype=torch.uint8, device=x.device)
         try:
             # warm-up on a side stream: builds the packed weights, the padded context + cross-attention K / V^T (cached on ctx_s, OUTSIDE the
             # graph's pool), kernel attributes and workspaces, so that the captured forward contains the per-step launches only
@@ -107,7 +110,7 @@ class GraphedEpsModel:
                 self.model(e.x_s, e.t_s, e.ctx_s)
             torch.cuda.current_stream(x.device).wait_stream(side)
             g = torch.cuda.CUDAGraph()
-            with torch.no_grad(), torch.cuda.graph(g):
+            with torch.no_grad(), pf.splitk_workspace(e.ws), torch.cuda.graph(g):
                 e.out = self.model(e.x_s, e.t_s, e.ctx_s)
             e.graph = g
         except Exception as exc:      # noqa: BLE001 -- any capture failure means "run eagerly", in this process

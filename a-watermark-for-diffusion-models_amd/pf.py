@@ -70,6 +70,49 @@ class PF:
         return self.interior.reshape(self.B, self.H * self.W, self.C)
 
 
+# ---- split-K workspace of the matmul engine (gsw_mm_set_workspace): one scratch buffer per (device, stream), handed to the library whenever the
+# calling thread's (device, stream) changes.  Launches on one stream share it (a launch and its reduce kernel are stream-ordered).
+SPLITK_BYTES = 20 << 20        # 256 slabs of 80 KiB: every launch that splits fits
+SPLITK_MAX = 0                 # 0 automatic, 1 never split, k > 1: force k-way splits wherever K allows (parity tests)
+_WS = {}
+_WS_TLS = __import__("threading").local()
+_WS_OVERRIDE: Optional[torch.Tensor] = None
+
+
+def _ensure_workspace(device) -> None:
+    dev = torch.device(device)
+    ov = _WS_OVERRIDE
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream if ov is None else ("override", ov.data_ptr()), SPLITK_MAX)
+    if getattr(_WS_TLS, "last", None) == key:
+        return
+    ws = ov
+    if ws is None:
+        ws = _WS.get(key[:2])
+        if ws is None:
+            ws = _WS[key[:2]] = torch.empty(SPLITK_BYTES, dtype=torch.uint8, device=dev)
+    N.check(N.lib().gsw_mm_set_workspace(ws.data_ptr(), ws.numel(), int(SPLITK_MAX)))
+    _WS_TLS.last = key
+
+
+class splitk_workspace:
+    """with splitk_workspace(buf): every engine launch of the block uses `buf` (a uint8 device tensor) as its split-K scratch -- graph.py pins one
+    per captured graph, so replays never share scratch with eager launches or other graphs."""
+
+    def __init__(self, buf: Optional[torch.Tensor]):
+        self.buf = buf
+
+    def __enter__(self):
+        global _WS_OVERRIDE
+        self.prev, _WS_OVERRIDE = _WS_OVERRIDE, self.buf
+        return self
+
+    def __exit__(self, *exc):
+        global _WS_OVERRIDE
+        _WS_OVERRIDE = self.prev
+        _WS_TLS.last = None
+        return False
+
+
 def cached(owner, name: str, params, build):
     """Derived-weight cache on a module attribute, keyed by the source parameters' storage, version counter, device and dtype, so
     that `.to()`, `load_state_dict` or any in-place edit of the weights rebuilds the packed copy."""
@@ -152,6 +195,7 @@ def conv_pf(x: PF, w_packed: torch.Tensor, bias: Optional[torch.Tensor], *, ksiz
         xp += (x.W + 2 + 1) * x.C * x.buf.element_size()
     tm = CONV_TIMER
     with torch.cuda.device(x.buf.device):
+        _ensure_workspace(x.buf.device)
         e0 = tm.start() if tm is not None else None
         N.check(N.lib().gsw_conv_pf(xp, w_packed.data_ptr(), bias.data_ptr() if bias is not None else None,
                                     rowbias.data_ptr() if rowbias is not None else None,
@@ -185,6 +229,7 @@ def gemm_strided(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, bias: Opti
     _same(bias, x, "bias", Nn)
     tm = CONV_TIMER
     with torch.cuda.device(x.device):
+        _ensure_workspace(x.device)
         e0 = tm.start() if tm is not None else None
         N.check(N.lib().gsw_gemm_strided(x.data_ptr(), ldx, w.data_ptr(), ldw, bias.data_ptr() if bias is not None else None, None, ldy,
                                          out.data_ptr(), ldy, M, K, Nn, 0, 0, 0, _dt(x.dtype), _stream_ptr()))
@@ -271,6 +316,7 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], *, re
     Nn = w.shape[0]
     out = torch.empty((*x.shape[:-1], Nn // 2 if geglu else Nn), dtype=x.dtype, device=x.device)
     with torch.cuda.device(x.device):
+        _ensure_workspace(x.device)
         N.check(N.lib().gsw_linear(x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None,
                                    resid.data_ptr() if resid is not None else None, out.data_ptr(), M, K, Nn, 1 if geglu else 0,
                                    _dt(x.dtype), _stream_ptr()))
@@ -332,6 +378,7 @@ def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
         _same(resid, x, "resid", rows * Nn)
     tm = CONV_TIMER
     with torch.cuda.device(x.device):
+        _ensure_workspace(x.device)
         e0 = tm.start() if tm is not None else None
         N.check(N.lib().gsw_gemm(x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None,
                                  resid.data_ptr() if resid is not None else None, y.data_ptr(), M, K, Nn, m, tokens, width,
@@ -376,6 +423,7 @@ def conv3x3_res_pf(x: PF, w_cat: torch.Tensor, bias: Optional[torch.Tensor], *, 
     y = PF.empty(x.B, x.H, x.W, Nn, x.buf.dtype, x.buf.device)
     tm = CONV_TIMER
     with torch.cuda.device(x.buf.device):
+        _ensure_workspace(x.buf.device)
         e0 = tm.start() if tm is not None else None
         N.check(N.lib().gsw_conv3x3_res_pf(x.rows.data_ptr(), w_cat.data_ptr(), bias.data_ptr() if bias is not None else None,
                                            rowbias.data_ptr() if rowbias is not None else None,
@@ -463,6 +511,7 @@ def conv_up2x_pf(x: PF, w4: torch.Tensor, bias: Optional[torch.Tensor]) -> PF:
     y = PF.empty(x.B, 2 * x.H, 2 * x.W, Nn, x.buf.dtype, x.buf.device)          # gsw_conv_up2x_pf zeroes the border rows itself
     tm = CONV_TIMER
     with torch.cuda.device(x.buf.device):
+        _ensure_workspace(x.buf.device)
         e0 = tm.start() if tm is not None else None
         N.check(N.lib().gsw_conv_up2x_pf(x.rows.data_ptr(), w4.data_ptr(), bias.data_ptr() if bias is not None else None, y.rows.data_ptr(),
                                          x.B, x.H, x.W, x.C, Nn, _dt(x.buf.dtype), _stream_ptr()))

@@ -200,6 +200,17 @@ int gsw_gemm_strided(const void* x_dev, int64_t ldx, const void* w_dev, int64_t 
  *                waves 8-11 own the LDS-DMA; -1 = keep (default 10: convolutions and the transposed projection) */
 int gsw_mm_config(int tile_rows, int split_mask);
 
+/* Split-K workspace of the CALLING THREAD (caller-owned device memory on the device of the streams it launches on; 16-byte aligned).
+ * Small-batch launches of the eps model -- one image's 8 x 8 level is a single 64-row tile against 180-360 K stages (the reference's own use:
+ * extract.py:112-117 inverts ONE latent per call) -- cannot fill 256 CUs with output tiles.  When a workspace is set, a launch whose 128-row
+ * tiling has <= 128 tiles and >= 8 K stages lets up to 16 workgroups share a tile's stages: each dumps its fp32 accumulators into a slab
+ * ([splits][tiles][8 waves][10 accumulators][64 lanes] float4), and a second kernel adds the slabs in split order (deterministic) and runs
+ * the epilogue of the launch's mode.  bytes = 0 removes it (launches run unsplit).  20 MiB covers every launch (256 slabs of 80 KiB).
+ * The workspace is scratch between a launch and its reduce kernel, both on the launch's stream: launches on ONE stream may share it, launches
+ * on different streams need different workspaces (set one per stream before launching there).
+ *   max_splits : 0 = automatic, 1 = never split, k > 1 = split every launch min(k, stages, 256 / tiles) ways (parity tests) */
+int gsw_mm_set_workspace(void* ws_dev, int64_t bytes, int max_splits);
+
 /* X1 / G1 tail -- diffusers AutoencoderKL mid-block attention (one head as wide as the block, 512): softmax over the rows of the score matrix
  * between the two engine products.  In place: x[r, 0:cols] <- softmax(scale * x[r, 0:cols]); rows `ld` elements apart; cols % 8 == 0. */
 int gsw_softmax_rows(void* x_dev, int64_t rows, int cols, int64_t ld, float scale, int dtype, void* stream);

@@ -56,7 +56,7 @@ def test_graph_replay_is_bit_identical_across_steps_and_contexts(G, rows):
         c1 = c2[:1].contiguous()
         for _ in range(2):
             assert torch.equal(gm(x, td, c1.expand(rows, -1, -1)), m(x, td, c1.expand(rows, -1, -1).contiguous()))
-        assert gm.stats["context_refreshes"] == 3
+        assert gm.stats["context_refreshes"] == (3 if rows > 1 else 2)      # one row: the "expanded" view IS c2 (same storage, geometry, version)
     assert G.unet.FALLBACKS == {}, G.unet.FALLBACKS
 
 
