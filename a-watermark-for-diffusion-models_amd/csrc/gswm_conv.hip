@@ -39,7 +39,7 @@ struct ConvArgs {
     const void* x;        // PF activations, pointer to row 0 (guards live at negative rows)
     const void* w;        // [N][T*C] K-contiguous weights
     const void* bias;     // [N] or null
-    const void* rowbias;  // [B][N] or null (time-embedding projection)
+    const void* rowbias;  // [B][ldrb] or null (time-embedding projection; rows ldrb >= N elements apart)
     const void* resid;    // [M][N] or null (PF, same geometry as the output)
     void* y;              // [M][N] PF output
     int32_t tap_off[9];   // row offset of each tap in the INPUT PF domain
@@ -49,6 +49,7 @@ struct ConvArgs {
     int32_t Hp, Wp;       // output padded geometry
     int32_t in_Hp, in_Wp; // input padded geometry
     int32_t stride;       // 1 or 2
+    int32_t ldrb;         // row stride of rowbias in elements
     int32_t ldx;          // row stride of x in elements (>= C; lets the input be a channel slice of a wider tensor)
     int32_t dense;        // 1: plain GEMM on a dense [M, C] matrix (no border rows, no row map)
     int32_t geglu;        // (unused since the dense linears moved to the matmul engine)
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(CV_THREADS) void gsw_conv_gemm_kernel(ConvArgs p) {
             uint32_t w4[4] = {lo.x, lo.y, hi.x, hi.y};
             if (rowbias || resid) {
                 uint4 rb = make_uint4(0, 0, 0, 0), rs = make_uint4(0, 0, 0, 0);
-                if (rowbias) rb = *reinterpret_cast<const uint4*>(rowbias + (int64_t)b * p.N + n0 + cc * 8);
+                if (rowbias) rb = *reinterpret_cast<const uint4*>(rowbias + (int64_t)b * p.ldrb + n0 + cc * 8);
                 if (resid) rs = *reinterpret_cast<const uint4*>(resid + (int64_t)m * p.N + n0 + cc * 8);
                 const uint32_t rbw[4] = {rb.x, rb.y, rb.z, rb.w}, rsw[4] = {rs.x, rs.y, rs.z, rs.w};
 #pragma unroll
@@ -551,7 +552,7 @@ static int launch_engine(const ConvArgs& a, int64_t M, int N, int dtype, void* s
     m.M = B * (a.Hp - 2) * (a.Wp - 2); m.N = N;
     m.flags = MM_FLAG_COMPACT;
     m.bias = a.bias; m.rowbias = a.rowbias; m.resid = a.resid; m.y = a.y;
-    m.ldy = N; m.ldr = N;
+    m.ldy = N; m.ldr = N; m.ldrb = a.ldrb;
     m.mode = a.up ? MM_MODE_UP2X : MM_MODE_PF;
     m.Hp = a.Hp; m.Wp = a.Wp; m.in_Hp = a.in_Hp; m.in_Wp = a.in_Wp; m.stride = a.stride; m.S = 1; m.Wimg = 1; m.up = a.up;
     if (!a.up) zero_border(a.y, B, a.Hp, a.Wp, N, (hipStream_t)stream);
@@ -567,15 +568,17 @@ static bool use_engine(const ConvArgs& a, int N) {
 
 static int launch_conv_gemm(ConvArgs& a, int64_t M, int N, int dtype, void* stream);
 
-int gsw_conv_pf(const void* x_dev, const void* w_dev, const void* bias_dev, const void* rowbias_dev, const void* resid_dev, void* y_dev,
+int gsw_conv_pf(const void* x_dev, const void* w_dev, const void* bias_dev, const void* rowbias_dev, int ld_rowbias, const void* resid_dev, void* y_dev,
                 int B, int H, int W, int C, int N, int ksize, int stride, int ldx, int dtype, void* stream) {
     // H, W: OUTPUT spatial size; input spatial size is (H*stride, W*stride)
     if (!x_dev || !w_dev || !y_dev || B <= 0 || H <= 0 || W <= 0 || C <= 0 || N <= 0) return GSW_ERR_BAD_ARG;
     if ((ksize != 1 && ksize != 3) || (stride != 1 && stride != 2) || (ksize == 1 && stride != 1)) return GSW_ERR_BAD_ARG;
     if (C % CV_BK || N % 8 || ldx < C || (ldx & 7)) return GSW_ERR_UNSUPPORTED;
     if (dtype != GSW_F16 && dtype != GSW_BF16) return GSW_ERR_BAD_ARG;
+    if (rowbias_dev && ld_rowbias != 0 && (ld_rowbias < N || (ld_rowbias & 7))) return GSW_ERR_BAD_ARG;
     ConvArgs a;
     a.x = x_dev; a.w = w_dev; a.bias = bias_dev; a.rowbias = rowbias_dev; a.resid = resid_dev; a.y = y_dev;
+    a.ldrb = rowbias_dev && ld_rowbias ? ld_rowbias : N;
     a.C = C; a.N = N; a.Hp = H + 2; a.Wp = W + 2; a.stride = stride; a.ldx = ldx;
     a.in_Hp = H * stride + 2; a.in_Wp = W * stride + 2;
     const int64_t M = (int64_t)B * a.Hp * a.Wp;
@@ -664,7 +667,7 @@ int gsw_linear(const void* x_dev, const void* w_dev, const void* bias_dev, const
     return gsw_gemm(x_dev, w_dev, bias_dev, resid_dev, y_dev, M, K, N, geglu ? GSW_GEMM_GEGLU : GSW_GEMM_PLAIN, 0, 0, dtype, stream);
 }
 
-int gsw_conv3x3_res_pf(const void* x_dev, const void* w_dev, const void* bias_dev, const void* rowbias_dev, const void* resid_dev, void* y_dev,
+int gsw_conv3x3_res_pf(const void* x_dev, const void* w_dev, const void* bias_dev, const void* rowbias_dev, int ld_rowbias, const void* resid_dev, void* y_dev,
                        int B, int H, int W, int C, int N, const void* x1_dev, int C1, const void* x2_dev, int C2, int dtype, void* stream) {
     // 3x3 stride-1 convolution of x plus 1x1 convolutions of x1 (C1 channels) and x2 (C2 channels) in ONE GEMM:
     // w_dev = [N][9*C + C1 + C2].  The resnet's conv2 + conv_shortcut(cat(x1, x2)) + residual in a single kernel.
@@ -672,8 +675,10 @@ int gsw_conv3x3_res_pf(const void* x_dev, const void* w_dev, const void* bias_de
     if ((x1_dev && C1 <= 0) || (x2_dev && (C2 <= 0 || !x1_dev))) return GSW_ERR_BAD_ARG;
     if (C % CV_BK || N % 8 || N < 128 || (x1_dev && C1 % CV_BK) || (x2_dev && C2 % CV_BK)) return GSW_ERR_UNSUPPORTED;
     if (dtype != GSW_F16 && dtype != GSW_BF16) return GSW_ERR_BAD_ARG;
+    if (rowbias_dev && ld_rowbias != 0 && (ld_rowbias < N || (ld_rowbias & 7))) return GSW_ERR_BAD_ARG;
     ConvArgs a;
     a.x = x_dev; a.w = w_dev; a.bias = bias_dev; a.rowbias = rowbias_dev; a.resid = resid_dev; a.y = y_dev;
+    a.ldrb = rowbias_dev && ld_rowbias ? ld_rowbias : N;
     a.C = C; a.N = N; a.Hp = H + 2; a.Wp = W + 2; a.stride = 1; a.ldx = C; a.in_Hp = a.Hp; a.in_Wp = a.Wp;
     const int64_t M = (int64_t)B * a.Hp * a.Wp;
     const int64_t cmax = std::max<int64_t>(C, std::max(C1, C2));
@@ -696,7 +701,7 @@ int gsw_conv_up2x_pf(const void* x_dev, const void* w4_dev, const void* bias_dev
     if (C % CV_BK || N % 8 || N < 128) return GSW_ERR_UNSUPPORTED;
     if (dtype != GSW_F16 && dtype != GSW_BF16) return GSW_ERR_BAD_ARG;
     ConvArgs a;
-    a.x = x_dev; a.bias = bias_dev; a.rowbias = nullptr; a.resid = nullptr; a.y = y_dev;
+    a.x = x_dev; a.bias = bias_dev; a.rowbias = nullptr; a.ldrb = N; a.resid = nullptr; a.y = y_dev;
     a.C = C; a.N = N; a.Hp = H + 2; a.Wp = W + 2; a.stride = 1; a.ldx = C; a.in_Hp = a.Hp; a.in_Wp = a.Wp;
     const int64_t M = (int64_t)B * a.Hp * a.Wp;
     const int64_t Mo = (int64_t)B * (2 * H + 2) * (2 * W + 2);

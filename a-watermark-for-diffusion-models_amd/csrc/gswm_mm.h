@@ -26,10 +26,11 @@ struct MMArgs {
     int32_t M, N;         // M: rows of the output row space (all padded-flat rows, or the interior pixels with MM_FLAG_COMPACT)
     int32_t tiles_n, ntiles;      // filled by gsw_mm_launch
     const void* bias;     // [N] or null
-    const void* rowbias;  // [images][N] or null (MM_MODE_PF)
+    const void* rowbias;  // [images][ldrb] or null (MM_MODE_PF): per-image row bias, rows ldrb elements apart (a column slice of a wider matrix)
     const void* resid;    // [rows][ldr] or null, addressed like the output
     void* y;
     int32_t ldy, ldr;
+    int32_t ldrb;         // row stride of rowbias (>= N, multiple of 8)
     int32_t mode;
     int32_t Hp, Wp;       // padded geometry of the output row space (PF / UP2X) or of the target PF tensor (TOK2PF)
     int32_t in_Hp, in_Wp; // MM_FLAG_COMPACT: padded geometry of the INPUT tensor (== Hp, Wp unless stride 2)

@@ -570,7 +570,7 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
                     if (border[pr]) { w4[0] = w4[1] = w4[2] = w4[3] = 0u; }
                     else if (rowbias || resid) {
                         uint4 rb = make_uint4(0, 0, 0, 0), rs = make_uint4(0, 0, 0, 0);
-                        if (rowbias) rb = *reinterpret_cast<const uint4*>(rowbias + (int64_t)img_b[pr] * p.N + col);
+                        if (rowbias) rb = *reinterpret_cast<const uint4*>(rowbias + (int64_t)img_b[pr] * p.ldrb + col);
                         if (resid) rs = *reinterpret_cast<const uint4*>(resid + orow[pr] * p.ldr + col);
                         const uint32_t rbw[4] = {rb.x, rb.y, rb.z, rb.w}, rsw[4] = {rs.x, rs.y, rs.z, rs.w};
 #pragma unroll
@@ -857,7 +857,7 @@ __global__ __launch_bounds__(256) void gsw_mm_reduce_kernel(const MMArgs p, cons
             for (int j = 0; j < 4; ++j) {
                 float f = MM<T>::up(h[j]);
                 if (p.mode == MM_MODE_DENSE && !rowbias) f += MM<T>::up(resid[orow * p.ldr + n + j]);       // EPI 0: one add
-                else f = f + (rowbias ? MM<T>::up(rowbias[(int64_t)img * p.N + n + j]) : 0.f) + (resid ? MM<T>::up(resid[orow * p.ldr + n + j]) : 0.f);
+                else f = f + (rowbias ? MM<T>::up(rowbias[(int64_t)img * p.ldrb + n + j]) : 0.f) + (resid ? MM<T>::up(resid[orow * p.ldr + n + j]) : 0.f);
                 h[j] = MM<T>::cvt(f);
             }
         }
@@ -955,7 +955,17 @@ int gsw_mm_launch(MMArgs& a, int dtype, void* stream) {
         const int64_t nt = (((int64_t)a.M + bm_s - 1) / bm_s) * tiles_n;
         int splits = 1;
         if (t_mm_max_splits > 1) splits = std::min<int64_t>(std::min<int64_t>(t_mm_max_splits, a.P), 256 / std::max<int64_t>(nt, 1));
-        else if (nt <= 128 && a.P >= 8) splits = (int)std::min<int64_t>(std::min<int64_t>(256 / nt, a.P / 4), 16);
+        else if (nt <= 128 && a.P >= 8) {
+            // cost model fitted to tools/splitk_sweep.py (profiles/r03d_splitk_sweep.txt), microseconds: a workgroup pays ~3 to get going and ~0.55 per
+            // stage; a split launch adds the reduce kernel (~4.5 for the second launch and its latency) and the slab traffic (80 KiB per slab at ~3 MB/us).
+            // Split only for a predicted gain of 20 % or more (the medium dense shapes lose: their reduce costs more than their short K loop).
+            const double t_un = 3.0 + 0.55 * (double)a.P;
+            double best = 0.8 * t_un;
+            for (int s_ = 2; s_ <= 16 && s_ * nt <= 256 && 2 * s_ <= a.P; ++s_) {
+                const double t = 3.0 + 0.55 * (double)((a.P + s_ - 1) / s_) + 4.5 + 0.027 * (double)(s_ * nt);
+                if (t < best) { best = t; splits = s_; }
+            }
+        }
         const int64_t need = (int64_t)splits * nt * 8 * 5 * (bm_s / 64) * 64 * 16;
         if (splits >= 2 && need <= t_mm_ws_bytes) {
             a.tiles_n = (int32_t)tiles_n;
@@ -996,7 +1006,7 @@ int gsw_gemm_strided(const void* x_dev, int64_t ldx, const void* w_dev, int64_t 
     a.w = w_dev; a.ldw = (int32_t)ldw;
     a.M = (int32_t)M; a.N = N;
     a.bias = bias_dev; a.rowbias = nullptr; a.resid = resid_dev; a.y = y_dev;
-    a.ldy = (int32_t)ldy; a.ldr = (int32_t)ldr;
+    a.ldy = (int32_t)ldy; a.ldr = (int32_t)ldr; a.ldrb = N;
     a.Hp = 1; a.Wp = 1; a.in_Hp = 1; a.in_Wp = 1; a.stride = 1; a.S = S > 0 ? S : 1; a.Wimg = Wimg > 0 ? Wimg : 1; a.up = 0; a.flags = MM_FLAG_NONE;
     a.mode = MM_MODE_DENSE;
     if (mode == GSW_GEMM_GEGLU) a.mode = MM_MODE_GEGLU;

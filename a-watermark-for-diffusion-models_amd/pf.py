@@ -183,7 +183,7 @@ def conv_pf(x: PF, w_packed: torch.Tensor, bias: Optional[torch.Tensor], *, ksiz
     Ho, Wo = x.H // stride, x.W // stride
     _same(w_packed, x.buf, "conv weight", Nn * ksize * ksize * C)
     _same(bias, x.buf, "conv bias", Nn)
-    _same(rowbias, x.buf, "rowbias", x.B * Nn)
+    ldrb = _rowbias_ld(rowbias, x.buf, x.B, Nn)
     if resid is not None:
         _same(resid.buf, x.buf, "resid")
         if (resid.B, resid.H, resid.W, resid.C) != (x.B, Ho, Wo, Nn):
@@ -198,13 +198,25 @@ def conv_pf(x: PF, w_packed: torch.Tensor, bias: Optional[torch.Tensor], *, ksiz
         _ensure_workspace(x.buf.device)
         e0 = tm.start() if tm is not None else None
         N.check(N.lib().gsw_conv_pf(xp, w_packed.data_ptr(), bias.data_ptr() if bias is not None else None,
-                                    rowbias.data_ptr() if rowbias is not None else None,
+                                    rowbias.data_ptr() if rowbias is not None else None, ldrb,
                                     resid.rows.data_ptr() if resid is not None else None, y.rows.data_ptr(),
                                     x.B, Ho, Wo, C, Nn, ksize, stride, x.C, _dt(x.buf.dtype), _stream_ptr()))
         if tm is not None:
             name = _conv_kernel_name(Wo, Nn, ksize, stride)
             tm.stop(e0, (name, x.B, Ho, Wo, ksize * ksize * C, Nn, stride) if tm.by_shape else name, 2.0 * x.B * Ho * Wo * Nn * ksize * ksize * C)
     return y
+
+
+def _rowbias_ld(rb: Optional[torch.Tensor], like: torch.Tensor, B: int, Nn: int) -> int:
+    """Per-image row bias [B, N]: contiguous, or a column slice of a wider row-major matrix (the time-embedding projections of every resnet
+    come out of ONE GEMM).  Returns the row stride in elements (0 when there is no row bias)."""
+    if rb is None:
+        return 0
+    if not rb.is_cuda or rb.device != like.device or rb.dtype != like.dtype:
+        raise ValueError(f"rowbias must be a {like.dtype} tensor on {like.device}")
+    if tuple(rb.shape) != (B, Nn) or rb.stride(1) != 1 or rb.data_ptr() % 16 or (B > 1 and (rb.stride(0) % 8 or rb.stride(0) < Nn)):
+        raise ValueError(f"rowbias must be [{B}, {Nn}] with contiguous, 16-byte aligned rows a multiple of 8 elements apart")
+    return rb.stride(0) if B > 1 else Nn
 
 
 def _rows2d(t: torch.Tensor, like: torch.Tensor, name: str):
@@ -416,7 +428,7 @@ def conv3x3_res_pf(x: PF, w_cat: torch.Tensor, bias: Optional[torch.Tensor], *, 
     Nn = w_cat.shape[0]
     _same(w_cat, x.buf, "w_cat", Nn * (9 * x.C + (x1.C if x1 is not None else 0) + (x2.C if x2 is not None else 0)))
     _same(bias, x.buf, "bias", Nn)
-    _same(rowbias, x.buf, "rowbias", x.B * Nn)
+    ldrb = _rowbias_ld(rowbias, x.buf, x.B, Nn)
     for t_, nm in ((resid, "resid"), (x1, "x1"), (x2, "x2")):
         if t_ is not None:
             _same(t_.buf, x.buf, nm)
@@ -426,7 +438,7 @@ def conv3x3_res_pf(x: PF, w_cat: torch.Tensor, bias: Optional[torch.Tensor], *, 
         _ensure_workspace(x.buf.device)
         e0 = tm.start() if tm is not None else None
         N.check(N.lib().gsw_conv3x3_res_pf(x.rows.data_ptr(), w_cat.data_ptr(), bias.data_ptr() if bias is not None else None,
-                                           rowbias.data_ptr() if rowbias is not None else None,
+                                           rowbias.data_ptr() if rowbias is not None else None, ldrb,
                                            resid.rows.data_ptr() if resid is not None else None, y.rows.data_ptr(),
                                            x.B, x.H, x.W, x.C, Nn,
                                            x1.rows.data_ptr() if x1 is not None else None, x1.C if x1 is not None else 0,

@@ -146,6 +146,15 @@ class TimestepEmbedding(nn.Module):
         return _lin(F.silu(_lin(x, self.linear_1)), self.linear_2)
 
 
+class TembRows:
+    """silu(time embedding) [B, temb] and, per resnet, its time_emb_proj output as a column slice [B, cout] of ONE GEMM over the concatenated
+    projection weights (22 resnets -> one launch instead of 22; the convolution epilogue reads the slice through its row stride)."""
+    __slots__ = ("act", "rows")
+
+    def __init__(self, act, rows):
+        self.act, self.rows = act, rows
+
+
 class ResnetBlock2D(nn.Module):
     def __init__(self, cin, cout, temb_dim, groups=32, eps=1e-5):
         super().__init__()
@@ -170,7 +179,8 @@ class ResnetBlock2D(nn.Module):
         if x2 is not None and not fuse:
             x, x2 = PF(torch.cat([x.buf, x2.buf], dim=1), x.B, x.H, x.W, x.C + x2.C), None
         n1 = groupnorm_pf2(x, x2, self.norm1.weight, self.norm1.bias, self.norm1.num_groups, self.norm1.eps, act=True)
-        h = conv_pf(n1, _pw(self.conv1), self.conv1.bias, rowbias=_lin(temb_act, self.time_emb_proj).contiguous())
+        rowbias = temb_act.rows[id(self)] if isinstance(temb_act, TembRows) else _lin(temb_act, self.time_emb_proj).contiguous()
+        h = conv_pf(n1, _pw(self.conv1), self.conv1.bias, rowbias=rowbias)
         h = _gn_pf(h, self.norm2)
         if self.conv_shortcut is None:
             return conv_pf(h, _pw(self.conv2), self.conv2.bias, resid=x)                 # residual add in the GEMM epilogue
@@ -557,8 +567,32 @@ def _edge_conv_weights(self):
     return cached(self, "_gsw_edge", (w_in, w_out, self.conv_out.bias), build)
 
 
+def _temb_rows(self, temb: torch.Tensor):
+    """Every resnet's time_emb_proj(temb) from one GEMM over the row-concatenated weights -> TembRows (or temb itself off the engine)."""
+    resnets = getattr(self, "_gsw_resnets", None)
+    if resnets is None:
+        resnets = self._gsw_resnets = [m for m in self.modules() if isinstance(m, ResnetBlock2D)]
+    n_tot = sum(r.time_emb_proj.out_features for r in resnets)
+    if not resnets or not _own_gemm_ok(temb, temb.shape[-1], n_tot) or any(r.time_emb_proj.out_features % 8 for r in resnets):
+        return temb
+    from .pf import cached, gemm
+    params = tuple(p for r in resnets for p in (r.time_emb_proj.weight, r.time_emb_proj.bias))
+    wcat, bcat = cached(self, "_gsw_temb_cat", params, lambda: (torch.cat([r.time_emb_proj.weight.detach() for r in resnets], dim=0).contiguous(),
+                                                                  torch.cat([r.time_emb_proj.bias.detach() for r in resnets], dim=0).contiguous()))
+    if wcat.dtype != temb.dtype:
+        return temb
+    rb = gemm(temb.contiguous(), wcat, bcat)
+    rows, off = {}, 0
+    for r in resnets:
+        n = r.time_emb_proj.out_features
+        rows[id(r)] = rb[:, off:off + n]
+        off += n
+    return TembRows(temb, rows)
+
+
 def _unet_forward_pf(self, x: torch.Tensor, temb: torch.Tensor, ctx: torch.Tensor) -> torch.Tensor:
     from .pf import PF, conv_pf
+    temb = _temb_rows(self, temb)
     w_in, w_out, b_out = _edge_conv_weights(self)
     B, cin, H, W = x.shape
     xin = PF.zeros(B, H, W, 64, x.dtype, x.device)

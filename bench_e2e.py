@@ -108,7 +108,9 @@ def run_e2e(args, rank, world, local_rank):
         model = model.to(memory_format=torch.channels_last)
     h, w = args.height // 8, args.width // 8
     flops_row = U.count_flops_per_image(model, h, w)
-    tm = TimedModel(model, flops_row)
+    from gswm_amd.graph import graphed
+    eps = graphed(model)                                    # forwards of <= 32 rows replay a captured HIP graph (GSW_GRAPH=never: eager A/B)
+    tm = TimedModel(eps, flops_row)
     g = torch.Generator(device="cpu").manual_seed(1)
     ctx_uncond = (torch.randn(1, 77, ctx_dim, generator=g) * 1.0).to(dev, dtype)        # stands for CLIP("")
     ctx_text = (torch.randn(B, 77, ctx_dim, generator=g) * 1.0).to(dev, dtype)          # stands for CLIP(prompt)
@@ -209,7 +211,8 @@ def run_e2e(args, rank, world, local_rank):
             "bit_accuracy": bit_acc, "lossless": bit_acc == 1.0 and int(flagged.item()) == 0, "flagged_images": int(flagged.item()),
             # latency of one step = one batch through embed -> sampling -> image stages -> inversion -> vote (device time between step marks)
             "latency": {"unit": "s per batch of %d" % B, "p50": step_ms[len(step_ms) // 2] * 1e-3, "min": step_ms[0] * 1e-3, "max": step_ms[-1] * 1e-3,
-                        "steps": len(step_ms)},
+                        "steps": len(step_ms), "p50_per_image_s": step_ms[len(step_ms) // 2] * 1e-3 / B},
+            "eps_model_launch_path": {"mode": eps.mode, "graph_max_rows": eps.max_rows, **eps.stats},
         }
         cs = conv_timer.summary()
         out["fallbacks_off_the_hand_written_path"] = fallbacks

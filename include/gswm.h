@@ -33,7 +33,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define GSW_VERSION 200 /* 0.2.0: GEGLU weights packed per 16-row block (see gsw_gemm) */
+#define GSW_VERSION 300 /* 0.3.0: gsw_conv_pf / gsw_conv3x3_res_pf take ld_rowbias; gsw_mm_set_workspace (split-K).  0.2.0: GEGLU weights packed per 16-row block (see gsw_gemm) */
 
 #define GSW_MSG_INLINE_MAX 256 /* message bytes carried inside the kernel arguments (2048 bit) */
 
@@ -139,8 +139,9 @@ int gsw_geglu(const void* in_dev, void* out_dev, int64_t rows, int inner, int dt
  *   w_dev: [N][ksize*ksize*C] (tap-major, channel-minor), ksize 1 or 3, stride 1 or 2 (3x3 only); H, W = OUTPUT size;
  *   ldx: row stride of x in elements; C % 64 == 0; N % 8 == 0 from 128 channels up (the matmul engine, csrc/gswm_mm.hip; a partial last 160-column
  *   tile costs a full one), N % 64 == 0 below that (the 64-column kernel of round 1: the 4-channel edges padded to one tile);
- *   dtype GSW_F16 / GSW_BF16; bias / rowbias / resid optional. */
-int gsw_conv_pf(const void* x_dev, const void* w_dev, const void* bias_dev, const void* rowbias_dev, const void* resid_dev, void* y_dev,
+ *   dtype GSW_F16 / GSW_BF16; bias / rowbias / resid optional.  rowbias: [B] rows, ld_rowbias elements apart (0 = N; else >= N and a
+ *   multiple of 8): the time-embedding projections of ALL resnets come out of one GEMM, each convolution reads its column slice. */
+int gsw_conv_pf(const void* x_dev, const void* w_dev, const void* bias_dev, const void* rowbias_dev, int ld_rowbias, const void* resid_dev, void* y_dev,
                 int B, int H, int W, int C, int N, int ksize, int stride, int ldx, int dtype, void* stream);
 
 /* GroupNorm (+SiLU) on a PF tensor: out = act(GroupNorm(x) * gamma + beta); out is a PF tensor (zero border) or, with out_tokens = 1,
@@ -155,7 +156,7 @@ int gsw_groupnorm_pf2(const void* x_dev, const void* x2_dev, int Ca, const void*
 
 /* ResnetBlock2D tail in ONE GEMM: y = conv3x3(x) + conv1x1([x1 | x2]) + bias + rowbias + resid on PF tensors.
  * w_dev: [N][9*C + C1 + C2] (3x3 taps first, then the shortcut's columns), x1 / x2 optional (x2 requires x1). */
-int gsw_conv3x3_res_pf(const void* x_dev, const void* w_dev, const void* bias_dev, const void* rowbias_dev, const void* resid_dev, void* y_dev,
+int gsw_conv3x3_res_pf(const void* x_dev, const void* w_dev, const void* bias_dev, const void* rowbias_dev, int ld_rowbias, const void* resid_dev, void* y_dev,
                        int B, int H, int W, int C, int N, const void* x1_dev, int C1, const void* x2_dev, int C2, int dtype, void* stream);
 
 /* Transformer blocks of the eps model: xnew = x + delta (skipped when delta_dev is NULL), y = LayerNorm(xnew) * gamma + beta;
@@ -203,9 +204,10 @@ int gsw_mm_config(int tile_rows, int split_mask);
 /* Split-K workspace of the CALLING THREAD (caller-owned device memory on the device of the streams it launches on; 16-byte aligned).
  * Small-batch launches of the eps model -- one image's 8 x 8 level is a single 64-row tile against 180-360 K stages (the reference's own use:
  * extract.py:112-117 inverts ONE latent per call) -- cannot fill 256 CUs with output tiles.  When a workspace is set, a launch whose 128-row
- * tiling has <= 128 tiles and >= 8 K stages lets up to 16 workgroups share a tile's stages: each dumps its fp32 accumulators into a slab
- * ([splits][tiles][8 waves][10 accumulators][64 lanes] float4), and a second kernel adds the slabs in split order (deterministic) and runs
- * the epilogue of the launch's mode.  bytes = 0 removes it (launches run unsplit).  20 MiB covers every launch (256 slabs of 80 KiB).
+ * tiling has <= 128 tiles lets up to 16 workgroups share a tile's K stages whenever a small cost model (fitted to tools/splitk_sweep.py) predicts
+ * a gain of 20 % or more: each workgroup dumps its fp32 accumulators into a slab ([splits][tiles][8 waves][10 accumulators][64 lanes] float4), and
+ * a second kernel adds the slabs in split order (deterministic) and runs the epilogue of the launch's mode.  bytes = 0 removes the workspace
+ * (launches run unsplit).  20 MiB covers every launch (256 slabs of 80 KiB).
  * The workspace is scratch between a launch and its reduce kernel, both on the launch's stream: launches on ONE stream may share it, launches
  * on different streams need different workspaces (set one per stream before launching there).
  *   max_splits : 0 = automatic, 1 = never split, k > 1 = split every launch min(k, stages, 256 / tiles) ways (parity tests) */

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"libgswm.so does not export {s}"
     assert sorted(N.exported_symbols()) == syms            # the ctypes prototypes cover the whole header
-    assert lib.gsw_version() == 200
+    assert lib.gsw_version() == 300
     assert lib.gsw_strerror(0) == b"ok" and b"IndexError" in lib.gsw_strerror(N.GSW_ERR_RAGGED)
 
 
@@ -174,9 +174,10 @@ def test_argument_validation_of_eps_model_and_image_entry_points():
     assert lib.gsw_attention(p, p, p, p, 1, 5, 64, 256, 128, 77, 316, 320, 320, 0.125, 1, None) == UNS           # row stride < H * d
     assert lib.gsw_attention(p, p, p, p, 1, 5, 64, 256, 128, 77, 320, 320, 320, 0.125, 0, None) == BAD           # fp32
     # convolutions on padded-flat activations
-    assert lib.gsw_conv_pf(p, p, None, None, None, p, 1, 8, 8, 60, 64, 3, 1, 60, 1, None) == UNS                 # C % 64
-    assert lib.gsw_conv_pf(p, p, None, None, None, p, 1, 8, 8, 64, 64, 5, 1, 64, 1, None) == BAD                 # 5x5
-    assert lib.gsw_conv3x3_res_pf(p, p, None, None, None, p, 1, 8, 8, 64, 64, p, 64, None, 0, 1, None) == UNS    # N % 160
+    assert lib.gsw_conv_pf(p, p, None, None, 0, None, p, 1, 8, 8, 60, 64, 3, 1, 60, 1, None) == UNS                 # C % 64
+    assert lib.gsw_conv_pf(p, p, None, None, 0, None, p, 1, 8, 8, 64, 64, 5, 1, 64, 1, None) == BAD                 # 5x5
+    assert lib.gsw_conv_pf(p, p, None, p, 60, None, p, 1, 8, 8, 64, 64, 3, 1, 64, 1, None) == BAD                  # rowbias stride < N
+    assert lib.gsw_conv3x3_res_pf(p, p, None, None, 0, None, p, 1, 8, 8, 64, 64, p, 64, None, 0, 1, None) == UNS    # N % 160
     assert lib.gsw_conv_up2x_pf(p, p, None, p, 1, 8, 8, 64, 64, 1, None) == UNS                                  # N % 160
     assert lib.gsw_conv_up2x_pf(None, p, None, p, 1, 8, 8, 64, 160, 1, None) == BAD
     # the matmul engine and the row softmax
