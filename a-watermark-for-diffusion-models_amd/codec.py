@@ -102,7 +102,7 @@ def embed_batch(key: bytes, nonce: bytes, k: bytes, batch: int, shape: Sequence[
     """Watermarked initial latents Z_s_T, shape [batch, *shape] (shape = (4, H/8, W/8)).
 
     u: optional float64 device tensor [batch, prod(shape)] of uniforms (the reference's np.random.uniform draws) for
-       bit-parity with gs_insert.py:62-64; None -> in-kernel Philox4x32-10 keyed by (seed, image_index0 + b, element).
+       bit-parity with gs_insert.py:62-64; None -> in-kernel Philox4x32-7 keyed by (seed, image_index0 + b, element).
     fast: fp32 inverse-CDF core (|dz| <= 1e-5) instead of Cephes fp64.
     """
     _check_key_nonce(key, nonce)

@@ -57,6 +57,12 @@ template <> struct MM<_Float16> {
         typedef float f2 __attribute__((ext_vector_type(2)));
         return __builtin_bit_cast(uint32_t, __builtin_convertvector(f2{lo, hi}, h2));
     }
+    static __device__ __forceinline__ float up_lo(uint32_t p) { typedef _Float16 h2 __attribute__((ext_vector_type(2))); return (float)__builtin_bit_cast(h2, p)[0]; }
+    static __device__ __forceinline__ float up_hi(uint32_t p) { typedef _Float16 h2 __attribute__((ext_vector_type(2))); return (float)__builtin_bit_cast(h2, p)[1]; }
+    static __device__ __forceinline__ uint32_t mul2(uint32_t a, uint32_t b) {  // v_pk_mul_f16: the correctly rounded fp16 product of fp16 operands, two at a time
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        return __builtin_bit_cast(uint32_t, __builtin_bit_cast(h2, a) * __builtin_bit_cast(h2, b));
+    }
 };
 template <> struct MM<__bf16> {
     typedef mm_b8 frag;
@@ -69,6 +75,11 @@ template <> struct MM<__bf16> {
         typedef __bf16 b2 __attribute__((ext_vector_type(2)));
         typedef float f2 __attribute__((ext_vector_type(2)));
         return __builtin_bit_cast(uint32_t, __builtin_convertvector(f2{lo, hi}, b2));
+    }
+    static __device__ __forceinline__ float up_lo(uint32_t p) { return __uint_as_float(p << 16); }
+    static __device__ __forceinline__ float up_hi(uint32_t p) { return __uint_as_float(p & 0xFFFF0000u); }
+    static __device__ __forceinline__ uint32_t mul2(uint32_t a, uint32_t b) {  // bf16 x bf16 is exact in fp32: one rounding, like a bf16 multiply
+        return cvt2(up_lo(a) * up_lo(b), up_hi(a) * up_hi(b));
     }
 };
 
@@ -93,18 +104,21 @@ __device__ unsigned long long* g_mm_trace_buf;
 
 // EPI: epilogue class the kernel is compiled for -- 0 dense rows (bias, optional residual), 1 generic (PF border / row bias / token scatter /
 // sub-pixel scatter), 2 GEGLU, 3 transposed output (MFMA operands swapped)
-// erf for the GEGLU epilogue: Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7 (three orders below the fp16 / bf16 rounding of the gelu it
-// feeds), branch-free: 1 v_rcp + 1 v_exp + 9 VALU instead of the ~40 of the library erff, whose two polynomial branches both execute in a
-// wave.  The epilogue of the L0 feed-forward projection (K = 320: five K slices per tile) is VALU-bound on exactly this.
-__device__ __forceinline__ float mm_erf(float x) {
-    const float ax = fabsf(x);
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
-    float pl = fmaf(1.061405429f, t, -1.453152027f);
-    pl = fmaf(pl, t, 1.421413741f);
-    pl = fmaf(pl, t, -0.284496736f);
-    pl = fmaf(pl, t, 0.254829592f);
-    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);       // exp(-x^2); underflows to 0 for |x| > 9.3, erf -> 1
-    return copysignf(fmaf(-pl * t, e, 1.0f), x);
+// Abramowitz & Stegun 7.1.26 for the GEGLU epilogue: erfc(x) = (a1 t + ... + a5 t^5) exp(-x^2), t = 1 / (1 + p x), |error| <= 1.5e-7 (three orders below the
+// fp16 / bf16 rounding of the gelu it feeds), branch-free.  The library erff (two polynomial branches, both executed in a wave) made the epilogue of the
+// L0 feed-forward projection (K = 320: five K slices per tile) VALU-bound.
+// gelu(g) = g Phi(g) for the GEGLU epilogue, from h = erfc(|g| / sqrt 2) / 2 (the same 7.1.26 polynomial with the 1/2 and the 1/sqrt 2 folded into
+// its constants): gelu = max(g, 0) - |g| h -- no sign transfer, no 1 + erf, 13 instructions with the v_rcp and the v_exp.
+__device__ __forceinline__ float mm_gelu(float g) {
+    const float ag = fabsf(g);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752f, ag, 1.0f));
+    float pl = fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
+    pl = fmaf(pl, t, 0.5f * 1.421413741f);
+    pl = fmaf(pl, t, 0.5f * -0.284496736f);
+    pl = fmaf(pl, t, 0.5f * 0.254829592f);
+    const float y = 0.84932180028801904f * g;                          // sqrt(log2(e) / 2) g: exp(-g^2 / 2) = exp2(-y^2)
+    const float e = __builtin_amdgcn_exp2f(-y * y);
+    return fmaf(-ag, pl * t * e, fmaxf(g, 0.0f));
 }
 
 // SPLIT: 12 waves -- waves 0-7 only read fragments and multiply, waves 8-11 (one per SIMD) own ALL the LDS-DMA: a global_load_lds holds
@@ -584,41 +598,32 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
                 }
             }
         } else if (EPI == 2) {
-            // GEGLU: accumulator columns of an n-tile are [8 value | 8 gate] of outputs 8 in .. 8 in + 7 (within the group's 40 outputs)
+            // GEGLU: accumulator columns of an n-tile are [8 value | 8 gate] of outputs 8 in .. 8 in + 7 (within the group's 40 outputs): lanes < 32
+            // hold values, lanes >= 32 the gates of the same four outputs 4 qv .. 4 qv + 3.  The projection is rounded to the storage dtype as torch
+            // materialises it -- two at a time by v_cvt_pk, which is also the packing: ONE v_permlane32_swap of the packed pairs then leaves every lane
+            // with (values, gates) of two outputs, the gate pair goes through gelu in fp32, is rounded like torch's F.gelu output, and the product is
+            // one packed multiply (v_pk_mul_f16: the correctly rounded product of the two rounded operands).  33 instead of 52 instructions per accumulator.
             const uint32_t qv = q & 1u;
             uint32_t D[5][2][2];                              // [in][row pair][2 registers]: 4 consecutive outputs 4 qv .. of row tile 2p + (lane >> 5)
 #pragma unroll
             for (int in = 0; in < 5; ++in) {
                 float bq[4];
                 bias4(in, bq);
-                uint32_t Wv[MT];                              // per row tile im: (out j = lane >> 5 ? 1 : 0) | (out j + 2) << 16
+                uint32_t Wv[MT];                              // per row tile im: outputs 4 qv + 2 (lane >> 5) + {0, 1}, packed
 #pragma unroll
                 for (int im = 0; im < MT; ++im) {
-                    // the projection as torch materialises it (rounded to the storage dtype), kept as fp32 bit patterns for the swaps
-                    uint32_t f[4];
-#pragma unroll
-#ifdef MM_GEGLU_NO_PROJ_ROUNDING                               // measured: ff1 +3-5 %, forward +0.8 % -- not worth leaving the reference's rounding points
-                    for (int j = 0; j < 4; ++j) f[j] = __float_as_uint(acc[in][im][j] + bq[j]);
-#else
-                    for (int j = 0; j < 4; ++j) f[j] = __float_as_uint(MM<T>::up(MM<T>::cvt(acc[in][im][j] + bq[j])));
-#endif
-                    swap32(f[0], f[1]);                       // lanes < 32: (value_0, gate_0); lanes >= 32: (value_1, gate_1)
-                    swap32(f[2], f[3]);                       // lanes < 32: (value_2, gate_2); lanes >= 32: (value_3, gate_3)
-                    uint16_t h[2];
-#pragma unroll
-                    for (int k = 0; k < 2; ++k) {
-                        const float v = __uint_as_float(f[2 * k]), g = __uint_as_float(f[2 * k + 1]);
-                        const float ge = MM<T>::up(MM<T>::cvt(0.5f * g * (1.0f + mm_erf(g * 0.70710678118654752f))));     // F.gelu(gate), rounded like torch's
-                        h[k] = MM<T>::cvt(v * ge);
-                    }
-                    Wv[im] = (uint32_t)h[0] | ((uint32_t)h[1] << 16);
+                    uint32_t A = MM<T>::cvt2(acc[in][im][0] + bq[0], acc[in][im][1] + bq[1]);
+                    uint32_t Bp = MM<T>::cvt2(acc[in][im][2] + bq[2], acc[in][im][3] + bq[3]);
+                    swap32(A, Bp);                            // lanes < 32: A = values 0, 1, Bp = gates 0, 1; lanes >= 32: values 2, 3 and gates 2, 3
+                    const uint32_t G = MM<T>::cvt2(mm_gelu(MM<T>::up_lo(Bp)), mm_gelu(MM<T>::up_hi(Bp)));
+                    Wv[im] = MM<T>::mul2(A, G);
                 }
 #pragma unroll
                 for (int pr = 0; pr < NPR; ++pr) {
                     uint32_t a = Wv[2 * pr], b = Wv[2 * pr + 1];
-                    swap32(a, b);                             // lanes < 32: outputs (0,2 | 1,3) of row tile 2p; lanes >= 32: of row tile 2p + 1
-                    D[in][pr][0] = (a & 0xFFFFu) | (b << 16);             // outputs 4 qv + 0, 1
-                    D[in][pr][1] = (a >> 16) | (b & 0xFFFF0000u);         // outputs 4 qv + 2, 3
+                    swap32(a, b);                             // lanes < 32: outputs (0, 1 | 2, 3) of row tile 2p; lanes >= 32: of row tile 2p + 1
+                    D[in][pr][0] = a;
+                    D[in][pr][1] = b;
                 }
             }
             const int64_t obase = (int64_t)tile_n * (BN / 2) + grp * 40u;
@@ -811,7 +816,7 @@ __global__ __launch_bounds__(256) void gsw_mm_reduce_kernel(const MMArgs p, cons
             for (int j = 0; j < 4; ++j) {
                 const float gb = bias ? MM<T>::up(bias[n + 8 + j]) : 0.f;
                 const float gg = MM<T>::up(MM<T>::cvt(g[j] + gb));
-                const float ge = MM<T>::up(MM<T>::cvt(0.5f * gg * (1.0f + mm_erf(gg * 0.70710678118654752f))));
+                const float ge = MM<T>::up(MM<T>::cvt(mm_gelu(gg)));
                 h[j] = MM<T>::cvt(MM<T>::up(h[j]) * ge);
             }
             const int64_t ocol = (int64_t)tile_n * 80 + grp * 40u + in * 8u + q * 4u;

@@ -74,7 +74,7 @@ int gsw_keystream(const uint8_t key[32], const uint8_t nonce16[16], uint8_t* out
  *   msg/msg_bytes : the padded watermark k (gs_insert.py:9-20); plaintext = k repeated floor(n_elems/(8*msg_bytes))
  *                   times then zeros (nodes.py:79-87)
  *   u_dev         : optional [B, n_elems] float64 uniforms in [0,1) (the reference's np.random.uniform draws,
- *                   gs_insert.py:62) -- bit-parity mode.  NULL => in-kernel Philox4x32-10 keyed by `seed`,
+ *                   gs_insert.py:62) -- bit-parity mode.  NULL => in-kernel Philox4x32-7 (Random123 philox4x32_R(7)) keyed by `seed`,
  *                   counter = (element index >> 2, image_index0 + b), one 32-bit word per element, u = (w + 1/2) 2^-32:
  *                   results do not depend on batch split
  *                   or GPU count.

@@ -385,7 +385,8 @@ def dpms_invert_reference(eps_fn, x0, num_inference_steps, num_train_timesteps=1
 
 
 # ----------------------------------------------------------------------------------------------
-# In-kernel RNG of the build (NOT reference behaviour): Philox4x32-10, restated so tests can check the HIP
+# In-kernel RNG of the build (NOT reference behaviour): Philox4x32-7 (Random123's philox4x32_R(7); the 10-round
+# default is kept for its published known answers), restated so tests can check the HIP
 # kernel's `u` stream.  Group g = e >> 2 of image `img` draws Philox(counter = (g, 0, img_lo, img_hi),
 # key = 64-bit seed); element e takes word e & 3; u = (w + 0.5) * 2^-32, exactly representable in fp64.
 # ----------------------------------------------------------------------------------------------
@@ -393,11 +394,14 @@ _PH_M0, _PH_M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
 _PH_W0, _PH_W1 = np.uint32(0x9E3779B9), np.uint32(0xBB67AE85)
 
 
-def philox4x32_10(c0, c1, c2, c3, k0, k1):
+PHILOX_ROUNDS = 7        # rounds of the build's throughput stream (csrc/gswm_kernels.hip: GSW_PHILOX_ROUNDS)
+
+
+def philox4x32(c0, c1, c2, c3, k0, k1, rounds=10):
     c0, c1, c2, c3 = (np.asarray(x, dtype=np.uint32) for x in (c0, c1, c2, c3))
     k0 = np.uint32(k0); k1 = np.uint32(k1)
     with np.errstate(over="ignore"):
-        for _ in range(10):
+        for _ in range(rounds):
             p0 = _PH_M0 * c0.astype(np.uint64)
             p1 = _PH_M1 * c2.astype(np.uint64)
             n0 = (p1 >> np.uint64(32)).astype(np.uint32) ^ c1 ^ k0
@@ -409,6 +413,10 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
     return c0, c1, c2, c3
 
 
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    return philox4x32(c0, c1, c2, c3, k0, k1, 10)
+
+
 def philox_uniform(seed: int, image_index0: int, batch: int, n_elems: int) -> np.ndarray:
     """u[b, e] of the build's in-kernel RNG (float64 in (0,1))."""
     ngroups = (n_elems + 3) // 4
@@ -417,8 +425,8 @@ def philox_uniform(seed: int, image_index0: int, batch: int, n_elems: int) -> np
     k0, k1 = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
     for b in range(batch):
         img = image_index0 + b
-        w = philox4x32_10(g, np.zeros(ngroups, np.uint32), np.full(ngroups, img & 0xFFFFFFFF, np.uint32),
-                          np.full(ngroups, (img >> 32) & 0xFFFFFFFF, np.uint32), k0, k1)
+        w = philox4x32(g, np.zeros(ngroups, np.uint32), np.full(ngroups, img & 0xFFFFFFFF, np.uint32),
+                       np.full(ngroups, (img >> 32) & 0xFFFFFFFF, np.uint32), k0, k1, PHILOX_ROUNDS)
         words = np.stack(w, axis=1).reshape(-1)[:n_elems]
         out[b] = (words.astype(np.float64) + 0.5) * 2.0 ** -32
     return out

@@ -219,5 +219,12 @@ def test_philox_reference_vectors():
     assert [int(v) for v in r] == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
     r = O.philox4x32_10(np.uint32(0x243f6a88), np.uint32(0x85a308d3), np.uint32(0x13198a2e), np.uint32(0x03707344), 0xa4093822, 0x299f31d0)
     assert [int(v) for v in r] == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+    # ... and for philox4x32_R(7), the variant the build's throughput stream runs (Random123 kat_vectors)
+    kat7 = [((0, 0, 0, 0), (0, 0), [0x5f6fb709, 0x0d893f64, 0x4f121f81, 0x4f730a48]),
+            ((0xffffffff,) * 4, (0xffffffff,) * 2, [0x5207ddc2, 0x45165e59, 0x4d8ee751, 0x8c52f662]),
+            ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), [0x4dfccaba, 0x190a87f0, 0xc47362ba, 0xb6b5242a])]
+    for c, k, want in kat7:
+        assert [int(v) for v in O.philox4x32(*(np.uint32(x) for x in c), k[0], k[1], rounds=7)] == want
+    assert O.PHILOX_ROUNDS == 7
     u = O.philox_uniform(7, 3, 2, 100)
     assert u.shape == (2, 100) and (u >= 0).all() and (u < 1).all()
