@@ -212,7 +212,12 @@ class _Up(nn.Module):
         return self.conv(F.interpolate(x, scale_factor=2.0, mode="nearest"))
 
     def forward_pf(self, x):
-        from .pf import PF, conv_pf
+        from .pf import PF, cached, conv_pf, conv_up2x_fusable, conv_up2x_pf, pack_upsample_weight
+        if conv_up2x_fusable(x, self.conv.out_channels):
+            # sub-pixel form (gsw_conv_up2x_pf, as in the UNet): four 2x2 convolutions of the LOW-resolution tensor -- 2.25x fewer FLOPs, no upsampled
+            # intermediate, no copy kernels.  The three upsamplers are 56 % of the decoder's FLOPs in the 3x3-on-upsampled form.
+            w4 = cached(self, "_gsw_up4", (self.conv.weight,), lambda: pack_upsample_weight(self.conv.weight))
+            return conv_up2x_pf(x, w4, self.conv.bias)
         up = PF.zeros(x.B, 2 * x.H, 2 * x.W, x.C, x.buf.dtype, x.buf.device)
         xi, g = x.interior, up.grid
         for dy in (0, 1):
