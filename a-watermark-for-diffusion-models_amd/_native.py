@@ -75,6 +75,11 @@ _PROTOTYPES = {
     "gsw_softmax_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_float, C.c_int, C.c_void_p]),
     "gsw_mm_config": (C.c_int, [C.c_int, C.c_int]),
     "gsw_mm_set_workspace": (C.c_int, [C.c_void_p, C.c_int64, C.c_int]),
+    "gsw_mm_next_colstats": (C.c_int, [C.c_void_p, C.c_int64]),
+    "gsw_mm_last_colstats": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "gsw_groupnorm_pf_cs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int,
+                                      C.c_int, C.c_void_p]),
     "gsw_linear": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
                              C.c_void_p]),
 }

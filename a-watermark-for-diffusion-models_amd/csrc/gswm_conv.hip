@@ -344,6 +344,10 @@ __global__ __launch_bounds__(512) void gsw_gn_pf_apply_kernel(const uint16_t* __
             const float* o = partial + (((int64_t)b * nslab_stats + k) * G + tid) * 2;
             sm += o[0]; sq += o[1];
         }
+        if (nslab_stats == 0) {                  // statistics as per-column-PAIR sums [B][C / 2][2] (gsw_gn_colstats_finish_kernel): fold this group's pairs in order
+            const float2* o = reinterpret_cast<const float2*>(partial) + (int64_t)b * (C >> 1) + tid * (cpg >> 1);
+            for (int32_t k = 0; k < (cpg >> 1); ++k) { sm += o[k].x; sq += o[k].y; }
+        }
         const float n = (float)(H * W * cpg);
         const float mean = sm / n;
         const float var = fmaxf(sq / n - mean * mean, 0.f);
@@ -555,7 +559,7 @@ static int launch_engine(const ConvArgs& a, int64_t M, int N, int dtype, void* s
     const bool whole = !a.up && a.stride == 1 && M <= 8192;
     m.M = whole ? (int32_t)M : B * (a.Hp - 2) * (a.Wp - 2); m.N = N;
     m.flags = whole ? MM_FLAG_NONE : MM_FLAG_COMPACT;
-    m.bias = a.bias; m.rowbias = a.rowbias; m.resid = a.resid; m.y = a.y;
+    m.bias = a.bias; m.rowbias = a.rowbias; m.resid = a.resid; m.y = a.y; m.colstats = nullptr;
     m.ldy = N; m.ldr = N; m.ldrb = a.ldrb;
     m.mode = a.up ? MM_MODE_UP2X : MM_MODE_PF;
     m.Hp = a.Hp; m.Wp = a.Wp; m.in_Hp = a.in_Hp; m.in_Wp = a.in_Wp; m.stride = a.stride; m.S = 1; m.Wimg = 1; m.up = a.up;
@@ -609,6 +613,77 @@ static int launch_conv_gemm(ConvArgs& a, int64_t M, int N, int dtype, void* stre
     const uint32_t grid = (uint32_t)(((M + CV_BM - 1) / CV_BM) * (N / CV_BN));
     if (dtype == GSW_F16) hipLaunchKernelGGL((gsw_conv_gemm_kernel<_Float16>), dim3(grid), dim3(CV_THREADS), 0, st, a);
     else hipLaunchKernelGGL((gsw_conv_gemm_kernel<__bf16>), dim3(grid), dim3(CV_THREADS), 0, st, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { g_conv_hip_error = (int)e; return GSW_ERR_HIP; }
+    return GSW_OK;
+}
+
+// GroupNorm statistics from the column records the producing engine launches left behind (MMArgs::colstats): per image, fold the image's row
+// blocks (and the four parity launches of a sub-pixel upsampler) per column in a fixed order, then the columns of every group -> the
+// [B][1][groups][2] (sum, sum of squares) record the apply kernel reads.  Two sources = the channel concatenation [x | x2].
+struct GnColSrc { const float* cs; int32_t C, npar, bpi, nblk; };      // records [npar][nblk][2 planes: sums | sums of squares][C / 2 column pairs]
+// grid (B, ceil(C / 2 / 64)), 512 threads = 64 column pairs x 8 block lanes: lane j adds blocks j, j + 8, ... (independent loads in flight), the eight
+// lanes are folded in a fixed order -> pairsum[b][cp] = (sum, sum of squares) of columns 2 cp, 2 cp + 1 over image b.  The apply kernel folds the
+// pairs of a group (groups are an even number of channels wide).
+__global__ __launch_bounds__(512) void gsw_gn_colstats_finish_kernel(GnColSrc s1, GnColSrc s2, float2* __restrict__ pairsum, int32_t C) {
+    __shared__ float2 part[8][64];
+    const int32_t b = blockIdx.x, tid = threadIdx.x, cl = tid & 63, lane = tid >> 6;
+    const int32_t cp = blockIdx.y * 64 + cl, np = C >> 1;
+    float a = 0.f, q = 0.f;
+    if (cp < np) {
+        const bool first = cp < (s1.C >> 1);
+        const GnColSrc& s = first ? s1 : s2;
+        const int32_t cc = first ? cp : cp - (s1.C >> 1), h = s.C >> 1;
+        for (int32_t par = 0; par < s.npar; ++par) {
+            const float* rec = s.cs + ((int64_t)par * s.nblk + (int64_t)b * s.bpi) * s.C + cc;      // block stride: 2 planes x C / 2 = C floats
+#pragma unroll 4
+            for (int32_t k = lane; k < s.bpi; k += 8) { a += rec[(int64_t)k * s.C]; q += rec[(int64_t)k * s.C + h]; }
+        }
+    }
+    part[lane][cl] = make_float2(a, q);
+    __syncthreads();
+    if (lane == 0 && cp < np) {
+        float2 t = part[0][cl];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) { t.x += part[j][cl].x; t.y += part[j][cl].y; }
+        pairsum[(int64_t)b * np + cp] = t;
+    }
+}
+
+int gsw_groupnorm_pf_cs(const void* x_dev, const void* x2_dev, int Ca, const float* cs1_dev, int cs1_rows, int cs1_npar, int cs1_blocks,
+                        const float* cs2_dev, int cs2_rows, int cs2_npar, int cs2_blocks, const void* gamma_dev, const void* beta_dev, void* out_dev,
+                        float* workspace_dev, int B, int H, int W, int C, int groups, float eps, int act, int out_tokens, int dtype, void* stream) {
+    // like gsw_groupnorm_pf2, with the statistics taken from column records instead of a pass over the tensor(s).
+    // csN_rows: rows per record block (32 / 64), csN_npar: 1, or 4 for the output of gsw_conv_up2x_pf (records per parity launch over the
+    // LOW-resolution pixels), csN_blocks: blocks per parity buffer.  H * W (per parity: H/2 * W/2) must be a multiple of csN_rows.
+    if (x2_dev && (Ca <= 0 || Ca >= C || (Ca & 7) || !cs2_dev)) return GSW_ERR_BAD_ARG;
+    if (!x_dev || !cs1_dev || !gamma_dev || !beta_dev || !out_dev || !workspace_dev || B <= 0 || H <= 0 || W <= 0 || C <= 0 || groups <= 0) return GSW_ERR_BAD_ARG;
+    if ((C & 7) || C % groups || groups > GN_MAX_GROUPS || (C >> 3) > 512 || C > 4096 || ((C / groups) & 1)) return GSW_ERR_UNSUPPORTED;      // column pairs: even group width
+    if (dtype != GSW_F16 && dtype != GSW_BF16) return GSW_ERR_BAD_ARG;
+    const int C1 = x2_dev ? Ca : C;
+    auto src = [&](const float* cs, int Cs, int rows, int npar, int blocks, GnColSrc& o) -> int {
+        if (rows <= 0 || (npar != 1 && npar != 4) || blocks <= 0) return GSW_ERR_BAD_ARG;
+        const int64_t pix = npar == 4 ? ((H & 1) || (W & 1) ? -1 : (int64_t)(H / 2) * (W / 2)) : (int64_t)H * W;
+        if (pix <= 0 || pix % rows || (int64_t)B * (pix / rows) > blocks) return GSW_ERR_UNSUPPORTED;
+        o = GnColSrc{cs, Cs, npar, (int32_t)(pix / rows), blocks};
+        return GSW_OK;
+    };
+    GnColSrc s1, s2 = GnColSrc{nullptr, 0, 0, 0, 0};
+    { const int rc = src(cs1_dev, C1, cs1_rows, cs1_npar, cs1_blocks, s1); if (rc != GSW_OK) return rc; }
+    if (x2_dev) { const int rc = src(cs2_dev, C - Ca, cs2_rows, cs2_npar, cs2_blocks, s2); if (rc != GSW_OK) return rc; }
+    const int cv = C >> 3;
+    const int P = std::max(1, 320 / cv);
+    const int threads = cv * P;
+    const int HpWp = (H + 2) * (W + 2);
+    int nslab = std::max(1, std::min(64, std::min((2048 + B - 1) / B, (HpWp + P - 1) / P)));
+    const int slab_len = (HpWp + nslab - 1) / nslab;
+    nslab = (HpWp + slab_len - 1) / slab_len;
+    hipStream_t st = (hipStream_t)stream;
+    const int bf = dtype == GSW_BF16;
+    // workspace_dev: >= B * C floats here (the column-pair sums)
+    hipLaunchKernelGGL(gsw_gn_colstats_finish_kernel, dim3(B, (C / 2 + 63) / 64), dim3(512), 0, st, s1, s2, reinterpret_cast<float2*>(workspace_dev), C);
+    hipLaunchKernelGGL(gsw_gn_pf_apply_kernel, dim3(nslab, B), dim3(threads), 0, st, (const uint16_t*)x_dev, (const uint16_t*)x2_dev, Ca, (const float*)workspace_dev, (const uint16_t*)gamma_dev,
+                       (const uint16_t*)beta_dev, (uint16_t*)out_dev, C, groups, H + 2, W + 2, 0, slab_len, P, eps, act, out_tokens, bf);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g_conv_hip_error = (int)e; return GSW_ERR_HIP; }
     return GSW_OK;
@@ -716,7 +791,11 @@ int gsw_conv_up2x_pf(const void* x_dev, const void* w4_dev, const void* bias_dev
     a.stride = 1; a.dense = 0; a.up = 1;
     zero_border(y_dev, B, 2 * H + 2, 2 * W + 2, N, (hipStream_t)stream);
     const size_t esz = 2;
+    // a pending column-statistics request covers the whole output: each parity launch fills its quarter of the buffer ([4][blocks][N][2])
+    int64_t cs_cap = 0;
+    float* cs_base = gsw_mm_take_colstats(&cs_cap);
     for (int par = 0; par < 4; ++par) {
+        if (cs_base) gsw_mm_give_colstats(cs_base + (size_t)par * (size_t)(cs_cap / 4), cs_cap / 4);
         const int dy = par >> 1, dx = par & 1;
         for (int i = 0; i < 9; ++i) a.tap_off[i] = 0;
         for (int ta = 0; ta < 2; ++ta)

@@ -39,9 +39,15 @@ struct MMArgs {
     int32_t up;           // UP2X: 1 + dy * 2 + dx
     int32_t flags;        // MM_FLAG_*
     int32_t splits;       // filled by gsw_mm_launch: > 1 = split-K (the K stages of a tile are shared by `splits` workgroups, fp32 partials in ws)
+    float* colstats;      // EPI 1 only, or null: per 16 MT-row block and output column PAIR the sum and the sum of squares of the STORED values,
+                          // [blocks = 4 tiles_m][2 planes][N / 2] floats -- GroupNorm statistics of the output without another pass over it
     float* ws;            // filled by gsw_mm_launch: split-K workspace, [splits][ntiles][8 waves][5 * MT accumulators][64 lanes] float4
 };
 
 int gsw_mm_launch(MMArgs& a, int dtype, void* stream);
+
+// one-shot column-statistics request of the calling thread (gsw_mm_next_colstats): take it (clears it) / hand a (sub-)buffer to the next launch
+float* gsw_mm_take_colstats(int64_t* capacity_floats);
+void gsw_mm_give_colstats(float* dev, int64_t capacity_floats);
 
 #endif

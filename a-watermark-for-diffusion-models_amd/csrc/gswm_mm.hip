@@ -63,6 +63,13 @@ template <> struct MM<_Float16> {
         typedef _Float16 h2 __attribute__((ext_vector_type(2)));
         return __builtin_bit_cast(uint32_t, __builtin_bit_cast(h2, a) * __builtin_bit_cast(h2, b));
     }
+    // (sum, sum of squares) of a packed pair into fp32 accumulators: two v_dot2_f32_f16 (exact products, fp32 accumulation)
+    static __device__ __forceinline__ void stat2(uint32_t w, float& sm, float& sq) {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        const h2 v = __builtin_bit_cast(h2, w);
+        sm = __builtin_amdgcn_fdot2(v, h2{(_Float16)1.0f, (_Float16)1.0f}, sm, false);
+        sq = __builtin_amdgcn_fdot2(v, v, sq, false);
+    }
 };
 template <> struct MM<__bf16> {
     typedef mm_b8 frag;
@@ -80,6 +87,11 @@ template <> struct MM<__bf16> {
     static __device__ __forceinline__ float up_hi(uint32_t p) { return __uint_as_float(p & 0xFFFF0000u); }
     static __device__ __forceinline__ uint32_t mul2(uint32_t a, uint32_t b) {  // bf16 x bf16 is exact in fp32: one rounding, like a bf16 multiply
         return cvt2(up_lo(a) * up_lo(b), up_hi(a) * up_hi(b));
+    }
+    static __device__ __forceinline__ void stat2(uint32_t w, float& sm, float& sq) {
+        const float lo = up_lo(w), hi = up_hi(w);
+        sm += lo + hi;
+        sq = fmaf(lo, lo, fmaf(hi, hi, sq));
     }
 };
 
@@ -119,6 +131,12 @@ __device__ __forceinline__ float mm_gelu(float g) {
     const float y = 0.84932180028801904f * g;                          // sqrt(log2(e) / 2) g: exp(-g^2 / 2) = exp2(-y^2)
     const float e = __builtin_amdgcn_exp2f(-y * y);
     return fmaf(-ag, pl * t * e, fmaxf(g, 0.0f));
+}
+
+// x + (the DPP-selected x of another lane; 0 where the selection has no source or the row is masked out)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float mm_dpp_add(float x) {
+    return x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, ROW_MASK, 0xf, false));
 }
 
 // SPLIT: 12 waves -- waves 0-7 only read fragments and multiply, waves 8-11 (one per SIMD) own ALL the LDS-DMA: a global_load_lds holds
@@ -567,11 +585,17 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
                     orow[pr] = (int64_t)b * HpWp + (int64_t)(yy + 1) * p.Wp + (xx + 1);
                 }
             }
+            // Column statistics for the GroupNorm that consumes this output (p.colstats): every lane adds the values it STORES -- as packed column pairs,
+            // two v_dot2_f32_f16 per pair -- into 4 (sum, sum of squares) pairs; one v_permlane16_swap + add folds the two row tiles and leaves the sums
+            // in even 16-lane rows and the sums of squares in odd ones, four row_shr steps fold the 16 rows of a lane row -- a fixed order, so the result
+            // is reproducible -- and lanes 15 / 31 / 47 / 63 each write one 16-byte record (4 column pairs of one plane) for this wave's block of 16 MT rows.
+            const bool cstat = p.colstats != nullptr;
 #pragma unroll
             for (int in = 0; in < 5; ++in) {
                 float bq[4];
                 bias4(in, bq);
                 const int64_t col = (int64_t)n0 + grp * (uint32_t)HC + (uint32_t)in * 16u + (q >> 1) * 8u;
+                float cs_s[4] = {0.f, 0.f, 0.f, 0.f}, cs_q[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int pr = 0; pr < NPR; ++pr) {
                     uint32_t a0, a1, b0, b1;
@@ -595,6 +619,29 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
                         }
                     }
                     *reinterpret_cast<uint4*>(Y + orow[pr] * p.ldy + col) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+                    if (cstat && !border[pr]) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) MM<T>::stat2(w4[k], cs_s[k], cs_q[k]);
+                    }
+                }
+                if (cstat) {
+                    float rec[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        uint32_t a = __float_as_uint(cs_s[k]), b = __float_as_uint(cs_q[k]);
+                        swap16(a, b);                                                // a: (sum r0, sq r0, sum r2, sq r2), b: (sum r1, sq r1, sum r3, sq r3)
+                        float t = __uint_as_float(a) + __uint_as_float(b);           // rows 0 / 2: sums of both row tiles, rows 1 / 3: their sums of squares
+                        t = mm_dpp_add<0x111, 0xf>(t);                               // row_shr:1, 2, 4, 8: lane 15 of every 16-lane row = the row's total
+                        t = mm_dpp_add<0x112, 0xf>(t);
+                        t = mm_dpp_add<0x114, 0xf>(t);
+                        t = mm_dpp_add<0x118, 0xf>(t);
+                        rec[k] = t;
+                    }
+                    if (li == 15u && col < p.N) {
+                        // records [block][plane: sums | sums of squares][N / 2 column pairs]
+                        float* dst = p.colstats + (((int64_t)tile_m * 4 + wm) * 2 + (q & 1u)) * (int64_t)(p.N >> 1) + (col >> 1);
+                        *reinterpret_cast<mm_f4*>(dst) = mm_f4{rec[0], rec[1], rec[2], rec[3]};
+                    }
                 }
             }
         } else if (EPI == 2) {
@@ -929,6 +976,33 @@ int gsw_mm_set_workspace(void* ws_dev, int64_t bytes, int max_splits) {
     return GSW_OK;
 }
 
+// Column statistics (MMArgs::colstats): a one-shot request of the calling thread, consumed (and cleared) by its next engine launch
+static thread_local float* t_cs_next = nullptr;
+static thread_local int64_t t_cs_cap = 0;
+static thread_local int t_cs_rows = 0, t_cs_blocks = 0;      // what the last launch produced: rows per block (0 = nothing), blocks
+
+float* gsw_mm_take_colstats(int64_t* capacity_floats) {
+    float* q = t_cs_next;
+    if (capacity_floats) *capacity_floats = t_cs_cap;
+    t_cs_next = nullptr; t_cs_cap = 0;
+    return q;
+}
+void gsw_mm_give_colstats(float* dev, int64_t capacity_floats) { t_cs_next = dev; t_cs_cap = dev ? capacity_floats : 0; }
+
+int gsw_mm_next_colstats(float* stats_dev, int64_t capacity_floats) {
+    if (capacity_floats < 0 || (capacity_floats > 0 && !stats_dev) || ((uintptr_t)stats_dev & 15)) return GSW_ERR_BAD_ARG;
+    gsw_mm_give_colstats(capacity_floats > 0 ? stats_dev : nullptr, capacity_floats);
+    t_cs_rows = 0; t_cs_blocks = 0;
+    return GSW_OK;
+}
+
+int gsw_mm_last_colstats(int* rows_per_block, int* blocks) {
+    if (rows_per_block) *rows_per_block = t_cs_rows;
+    if (blocks) *blocks = t_cs_blocks;
+    gsw_mm_give_colstats(nullptr, 0);          // a request the launch never saw (a kernel off the engine) must not reach a later launch
+    return GSW_OK;
+}
+
 int gsw_mm_config(int tile_rows, int split_mask) {
     if (tile_rows != 0 && tile_rows != 128 && tile_rows != 256 && tile_rows != -1) return GSW_ERR_BAD_ARG;
     if (split_mask < -1 || split_mask > 15) return GSW_ERR_BAD_ARG;
@@ -952,6 +1026,10 @@ int gsw_mm_launch(MMArgs& a, int dtype, void* stream) {
     if (bm_env == 128 || bm_env == 256) BM = bm_env;
     hipStream_t st = (hipStream_t)stream;
     a.splits = 1; a.ws = nullptr;
+    int64_t cs_cap = 0;
+    float* cs_req = gsw_mm_take_colstats(&cs_cap);
+    a.colstats = nullptr;
+    t_cs_rows = 0; t_cs_blocks = 0;
     // Split-K for launches that cannot fill the chip with output tiles (the deep levels at small batch: 8 x 8 pixels of one image are ONE row tile
     // against 180-360 K stages): `splits` workgroups share a tile's stages, fp32 partials go through the caller's workspace, a second small kernel
     // adds them in a fixed order and runs the epilogue.  Needs a workspace (gsw_mm_set_workspace); without one the launch runs unsplit.
@@ -987,6 +1065,12 @@ int gsw_mm_launch(MMArgs& a, int dtype, void* stream) {
     a.tiles_n = (int32_t)tiles_n;
     a.ntiles = (int32_t)(tiles_m * tiles_n);
     const uint32_t grid = (uint32_t)std::min<int64_t>(256, (a.ntiles + 7) / 8 * 8);
+    // column statistics: EPI 1 launches whose M dimension enumerates real pixels / tokens (interior enumeration or the token scatter), unsplit
+    if (cs_req && (a.mode == MM_MODE_TOK2PF || ((a.mode == MM_MODE_PF || a.mode == MM_MODE_UP2X) && (a.flags & MM_FLAG_COMPACT)))
+        && tiles_m * 4 * (int64_t)a.N <= cs_cap) {
+        a.colstats = cs_req;
+        t_cs_rows = BM / 4; t_cs_blocks = (int)(tiles_m * 4);
+    }
     const int epi = a.mode == MM_MODE_TRANS ? 3 : a.mode == MM_MODE_GEGLU ? 2 : (a.mode == MM_MODE_DENSE && !a.rowbias) ? 0 : 1;
     const int e = dtype == GSW_F16 ? mm_launch_e<_Float16>(a, epi, grid, BM / 64, st) : mm_launch_e<__bf16>(a, epi, grid, BM / 64, st);
     if (e != 0) { g_last_hip_error = e; return GSW_ERR_HIP; }
@@ -1010,7 +1094,7 @@ int gsw_gemm_strided(const void* x_dev, int64_t ldx, const void* w_dev, int64_t 
     a.nseg = 1; a.P = K / 64;
     a.w = w_dev; a.ldw = (int32_t)ldw;
     a.M = (int32_t)M; a.N = N;
-    a.bias = bias_dev; a.rowbias = nullptr; a.resid = resid_dev; a.y = y_dev;
+    a.bias = bias_dev; a.rowbias = nullptr; a.resid = resid_dev; a.y = y_dev; a.colstats = nullptr;
     a.ldy = (int32_t)ldy; a.ldr = (int32_t)ldr; a.ldrb = N;
     a.Hp = 1; a.Wp = 1; a.in_Hp = 1; a.in_Wp = 1; a.stride = 1; a.S = S > 0 ? S : 1; a.Wimg = Wimg > 0 ? Wimg : 1; a.up = 0; a.flags = MM_FLAG_NONE;
     a.mode = MM_MODE_DENSE;

@@ -14,10 +14,13 @@ from .codec import _dt, _stream_ptr
 
 
 class PF:
-    __slots__ = ("buf", "B", "H", "W", "C")
+    __slots__ = ("buf", "B", "H", "W", "C", "stats")
 
     def __init__(self, buf: torch.Tensor, B: int, H: int, W: int, C: int):
         self.buf, self.B, self.H, self.W, self.C = buf, B, H, W, C
+        # column records of the launch that produced the payload (ColStats) -- GroupNorm statistics without a pass over the tensor; anything
+        # that writes the payload by other means must leave it None
+        self.stats: Optional["ColStats"] = None
 
     @property
     def G(self) -> int:
@@ -113,6 +116,48 @@ class splitk_workspace:
         return False
 
 
+
+# ---- GroupNorm statistics from the producing launch (gsw_mm_next_colstats / gsw_groupnorm_pf_cs): the engine's convolution / token-scatter
+# epilogue also writes per-block, per-column (sum, sum of squares) records of what it stores; the GroupNorm that consumes the tensor folds
+# them instead of reading the tensor once more (that pass was 2.6 % of the end-to-end run).
+FUSE_GN_STATS = True
+
+
+class ColStats:
+    __slots__ = ("buf", "rows", "npar", "blocks")
+
+    def __init__(self, buf: torch.Tensor, rows: int, npar: int, blocks: int):
+        self.buf, self.rows, self.npar, self.blocks = buf, rows, npar, blocks      # blocks: per parity buffer (the buffer's stride)
+
+
+def _colstats_arm(M: int, Nn: int, device, npar: int = 1):
+    """Arm the one-shot request for a launch with M output pixels (per parity launch) and Nn columns -> (buffer, block capacity) or None."""
+    if not FUSE_GN_STATS:
+        return None
+    cap_blocks = (M + 127) // 128 * 4                 # 32-row blocks of 128-row tiles (64-row blocks of 256-row tiles need fewer)
+    buf = torch.empty(npar * cap_blocks * Nn, dtype=torch.float32, device=device)      # [npar][blocks][2 planes][Nn / 2]
+    N.check(N.lib().gsw_mm_next_colstats(buf.data_ptr(), buf.numel()))
+    return buf, cap_blocks
+
+
+def _colstats_collect(armed, npar: int = 1) -> Optional[ColStats]:
+    """What the launch produced (None when it could not: split-K, whole-tensor enumeration, a kernel off the engine); clears the request."""
+    if armed is None:
+        return None
+    import ctypes as C
+    rows, blocks = C.c_int(0), C.c_int(0)
+    N.check(N.lib().gsw_mm_last_colstats(C.byref(rows), C.byref(blocks)))
+    return ColStats(armed[0], rows.value, npar, armed[1]) if rows.value > 0 else None
+
+
+def _stats_usable(x: "PF") -> bool:
+    st = x.stats
+    if st is None:
+        return False
+    pix = x.H * x.W if st.npar == 1 else (x.H // 2) * (x.W // 2)
+    return pix % st.rows == 0 and (st.npar == 1 or (x.H % 2 == 0 and x.W % 2 == 0))
+
+
 def cached(owner, name: str, params, build):
     """Derived-weight cache on a module attribute, keyed by the source parameters' storage, version counter, device and dtype, so
     that `.to()`, `load_state_dict` or any in-place edit of the weights rebuilds the packed copy."""
@@ -197,10 +242,12 @@ def conv_pf(x: PF, w_packed: torch.Tensor, bias: Optional[torch.Tensor], *, ksiz
     with torch.cuda.device(x.buf.device):
         _ensure_workspace(x.buf.device)
         e0 = tm.start() if tm is not None else None
+        armed = _colstats_arm(x.B * Ho * Wo, Nn, x.buf.device) if Nn >= 128 else None
         N.check(N.lib().gsw_conv_pf(xp, w_packed.data_ptr(), bias.data_ptr() if bias is not None else None,
                                     rowbias.data_ptr() if rowbias is not None else None, ldrb,
                                     resid.rows.data_ptr() if resid is not None else None, y.rows.data_ptr(),
                                     x.B, Ho, Wo, C, Nn, ksize, stride, x.C, _dt(x.buf.dtype), _stream_ptr()))
+        y.stats = _colstats_collect(armed)
         if tm is not None:
             name = _conv_kernel_name(Wo, Nn, ksize, stride)
             tm.stop(e0, (name, x.B, Ho, Wo, ksize * ksize * C, Nn, stride) if tm.by_shape else name, 2.0 * x.B * Ho * Wo * Nn * ksize * ksize * C)
@@ -282,8 +329,8 @@ def attention_single_head(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor) ->
 _GN_WS = {}
 
 
-def _gn_workspace(device, B, groups):
-    k = (str(device), B * 64 * groups * 2)
+def _gn_workspace(device, B, groups, C=0):
+    k = (str(device), max(B * 64 * groups * 2, B * C * 2))        # slab records of the statistics pass, or per-column sums (gsw_groupnorm_pf_cs)
     if k not in _GN_WS:
         _GN_WS[k] = torch.empty(k[1], dtype=torch.float32, device=device)
     return _GN_WS[k]
@@ -294,13 +341,20 @@ def groupnorm_pf(x: PF, gamma: torch.Tensor, beta: torch.Tensor, groups: int, ep
     dev = x.buf.device
     _same(gamma, x.buf, "gamma", x.C)
     _same(beta, x.buf, "beta", x.C)
-    ws = _gn_workspace(dev, x.B, groups)
+    ws = _gn_workspace(dev, x.B, groups, x.C)
     if tokens:
         out = torch.empty((x.B, x.H * x.W, x.C), dtype=x.buf.dtype, device=dev)
         optr, res = out.data_ptr(), out
     else:
         y = PF.empty(x.B, x.H, x.W, x.C, x.buf.dtype, dev)
         optr, res = y.rows.data_ptr(), y
+    if FUSE_GN_STATS and _stats_usable(x) and x.C <= 4096 and (x.C // groups) % 2 == 0:
+        st = x.stats
+        with torch.cuda.device(dev):
+            N.check(N.lib().gsw_groupnorm_pf_cs(x.rows.data_ptr(), None, 0, st.buf.data_ptr(), st.rows, st.npar, st.blocks, None, 0, 0, 0,
+                                                gamma.data_ptr(), beta.data_ptr(), optr, ws.data_ptr(), x.B, x.H, x.W, x.C, groups, eps,
+                                                1 if act else 0, 1 if tokens else 0, _dt(x.buf.dtype), _stream_ptr()))
+        return res
     with torch.cuda.device(dev):
         N.check(N.lib().gsw_groupnorm_pf(x.rows.data_ptr(), gamma.data_ptr(), beta.data_ptr(), optr, ws.data_ptr(), x.B, x.H, x.W, x.C, groups,
                                          eps, 1 if act else 0, 1 if tokens else 0, _dt(x.buf.dtype), _stream_ptr()))
@@ -353,7 +407,7 @@ def _same(t: Optional[torch.Tensor], like: torch.Tensor, name: str, numel: Optio
 
 
 def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, resid: Optional[torch.Tensor] = None, mode: str = "plain",
-         tokens: int = 0, width: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+         tokens: int = 0, width: int = 0, out: Optional[torch.Tensor] = None, stats_for: Optional["PF"] = None) -> torch.Tensor:
     """x[..., K] @ w[N, K]^T + bias on the matmul engine (csrc/gswm_mm.hip).
     mode "plain":  -> [..., N] (+ resid[..., N]);  "geglu": pf.pack_geglu_weight operands -> [..., N/2] = value * gelu(gate);
     "trans": x is [B, S, K] -> [B, N, S] (tokens = S);  "tok2pf": rows are tokens of `tokens`-pixel images of width `width`, `out` is the
@@ -392,9 +446,13 @@ def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     with torch.cuda.device(x.device):
         _ensure_workspace(x.device)
         e0 = tm.start() if tm is not None else None
+        # stats_for (tok2pf): the PF tensor whose payload this launch writes -- it gets the launch's column records (or None)
+        armed = _colstats_arm(M, Nn, x.device) if (stats_for is not None and mode == "tok2pf") else None
         N.check(N.lib().gsw_gemm(x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None,
                                  resid.data_ptr() if resid is not None else None, y.data_ptr(), M, K, Nn, m, tokens, width,
                                  _dt(x.dtype), _stream_ptr()))
+        if stats_for is not None:
+            stats_for.stats = _colstats_collect(armed)
         if tm is not None:
             tm.stop(e0, ("gsw_mm_kernel", M, K, Nn, mode) if tm.by_shape else "gsw_mm_kernel", 2.0 * M * K * Nn)
     return y
@@ -409,8 +467,15 @@ def groupnorm_pf2(x: PF, x2: Optional[PF], gamma: torch.Tensor, beta: torch.Tens
     _same(x2.buf, x.buf, "x2")
     _same(gamma, x.buf, "gamma", C)
     _same(beta, x.buf, "beta", C)
-    ws = _gn_workspace(dev, x.B, groups)
+    ws = _gn_workspace(dev, x.B, groups, C)
     y = PF.empty(x.B, x.H, x.W, C, x.buf.dtype, dev)
+    if FUSE_GN_STATS and _stats_usable(x) and _stats_usable(x2) and C <= 4096 and (C // groups) % 2 == 0 and x.C % 2 == 0:
+        s1, s2 = x.stats, x2.stats
+        with torch.cuda.device(dev):
+            N.check(N.lib().gsw_groupnorm_pf_cs(x.rows.data_ptr(), x2.rows.data_ptr(), x.C, s1.buf.data_ptr(), s1.rows, s1.npar, s1.blocks,
+                                                s2.buf.data_ptr(), s2.rows, s2.npar, s2.blocks, gamma.data_ptr(), beta.data_ptr(), y.rows.data_ptr(),
+                                                ws.data_ptr(), x.B, x.H, x.W, C, groups, eps, 1 if act else 0, 0, _dt(x.buf.dtype), _stream_ptr()))
+        return y
     with torch.cuda.device(dev):
         N.check(N.lib().gsw_groupnorm_pf2(x.rows.data_ptr(), x2.rows.data_ptr(), x.C, gamma.data_ptr(), beta.data_ptr(), y.rows.data_ptr(),
                                           ws.data_ptr(), x.B, x.H, x.W, C, groups, eps, 1 if act else 0, 0, _dt(x.buf.dtype), _stream_ptr()))
@@ -437,6 +502,7 @@ def conv3x3_res_pf(x: PF, w_cat: torch.Tensor, bias: Optional[torch.Tensor], *, 
     with torch.cuda.device(x.buf.device):
         _ensure_workspace(x.buf.device)
         e0 = tm.start() if tm is not None else None
+        armed = _colstats_arm(x.B * x.H * x.W, Nn, x.buf.device)
         N.check(N.lib().gsw_conv3x3_res_pf(x.rows.data_ptr(), w_cat.data_ptr(), bias.data_ptr() if bias is not None else None,
                                            rowbias.data_ptr() if rowbias is not None else None, ldrb,
                                            resid.rows.data_ptr() if resid is not None else None, y.rows.data_ptr(),
@@ -444,6 +510,7 @@ def conv3x3_res_pf(x: PF, w_cat: torch.Tensor, bias: Optional[torch.Tensor], *, 
                                            x1.rows.data_ptr() if x1 is not None else None, x1.C if x1 is not None else 0,
                                            x2.rows.data_ptr() if x2 is not None else None, x2.C if x2 is not None else 0,
                                            _dt(x.buf.dtype), _stream_ptr()))
+        y.stats = _colstats_collect(armed)
         if tm is not None:
             k = 9 * x.C + (x1.C if x1 is not None else 0) + (x2.C if x2 is not None else 0)
             name = _conv_kernel_name(x.W, Nn, 3, 1)
@@ -525,8 +592,10 @@ def conv_up2x_pf(x: PF, w4: torch.Tensor, bias: Optional[torch.Tensor]) -> PF:
     with torch.cuda.device(x.buf.device):
         _ensure_workspace(x.buf.device)
         e0 = tm.start() if tm is not None else None
+        armed = _colstats_arm(x.B * x.H * x.W, Nn, x.buf.device, npar=4)
         N.check(N.lib().gsw_conv_up2x_pf(x.rows.data_ptr(), w4.data_ptr(), bias.data_ptr() if bias is not None else None, y.rows.data_ptr(),
                                          x.B, x.H, x.W, x.C, Nn, _dt(x.buf.dtype), _stream_ptr()))
+        y.stats = _colstats_collect(armed, npar=4)
         if tm is not None:      # EXECUTED FLOPs (16 C MACs per output: four 2x2 convolutions); the 3x3-on-upsampled form it replaces is 2.25x that
             name = "gsw_mm_kernel(up2x)"
             tm.stop(e0, (name, x.B, 2 * x.H, 2 * x.W, 4 * x.C, Nn, 1) if tm.by_shape else name,

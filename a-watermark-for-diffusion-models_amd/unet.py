@@ -360,9 +360,10 @@ class Transformer2DModel(nn.Module):
         if _own_gemm_ok(y, self.proj_out.in_features, self.proj_out.out_features):
             from .pf import gemm        # proj_out + residual written straight into the PF tensor's interior rows (x has no other reader)
             w, b = _wb(self.proj_out, y)
-            gemm(y.contiguous(), w, b, resid=x.rows, mode="tok2pf", tokens=x.H * x.W, width=x.W, out=x.rows)
+            gemm(y.contiguous(), w, b, resid=x.rows, mode="tok2pf", tokens=x.H * x.W, width=x.W, out=x.rows, stats_for=x)
         else:
             x.interior.add_(_lin(y, self.proj_out).view(x.B, x.H, x.W, x.C))
+            x.stats = None
         return x
 
 

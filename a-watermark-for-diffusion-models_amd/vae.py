@@ -173,7 +173,7 @@ class VaeAttention(nn.Module):
         qk = gemm(y, wqk, bqk)
         vt = gemm(y, self.to_v.weight.detach(), self.to_v.bias.detach(), mode="trans", tokens=S)
         o = attention_single_head(qk[..., :C], qk[..., C:], vt)
-        gemm(o, self.to_out[0].weight.detach(), self.to_out[0].bias.detach(), resid=x.rows, mode="tok2pf", tokens=S, width=x.W, out=x.rows)
+        gemm(o, self.to_out[0].weight.detach(), self.to_out[0].bias.detach(), resid=x.rows, mode="tok2pf", tokens=S, width=x.W, out=x.rows, stats_for=x)
         return x
 
 

@@ -154,6 +154,22 @@ int gsw_groupnorm_pf(const void* x_dev, const void* gamma_dev, const void* beta_
 int gsw_groupnorm_pf2(const void* x_dev, const void* x2_dev, int Ca, const void* gamma_dev, const void* beta_dev, void* out_dev, float* workspace_dev,
                       int B, int H, int W, int C, int groups, float eps, int act, int out_tokens, int dtype, void* stream);
 
+/* GroupNorm statistics without a pass over the tensor.  gsw_mm_next_colstats arms a ONE-SHOT request of the calling thread: the next convolution /
+ * token-scatter launch of the matmul engine (gsw_conv_pf, gsw_conv3x3_res_pf, gsw_conv_up2x_pf, gsw_gemm with GSW_GEMM_TOK2PF) also writes, per
+ * block of 32 or 64 consecutive output pixels and per PAIR of output columns (2c, 2c + 1), the sum and the sum of squares of the values it stores:
+ *   stats_dev [npar][blocks][2 planes: sums | sums of squares][N / 2] floats, npar = 1 (4 for gsw_conv_up2x_pf: one quarter of the buffer per parity
+ *   launch, records over the low-resolution pixels); capacity_floats >= npar * ceil(M / 128) * 4 * N covers either tile height (M = output pixels
+ *   of ONE launch).
+ * gsw_mm_last_colstats reports what the launch produced -- rows per block (0: nothing, e.g. a split-K or whole-tensor launch, or a kernel off the
+ * engine) and blocks written -- and clears a request no launch consumed.  gsw_groupnorm_pf_cs is gsw_groupnorm_pf2 with the statistics folded from
+ * such records (cs*_blocks = blocks per parity buffer, i.e. the buffer's stride): pixels per image must be a multiple of the block rows and the
+ * groups an even number of channels wide; workspace_dev >= max(B * 64 * groups * 2, B * C) floats. */
+int gsw_mm_next_colstats(float* stats_dev, int64_t capacity_floats);
+int gsw_mm_last_colstats(int* rows_per_block, int* blocks);
+int gsw_groupnorm_pf_cs(const void* x_dev, const void* x2_dev, int Ca, const float* cs1_dev, int cs1_rows, int cs1_npar, int cs1_blocks,
+                        const float* cs2_dev, int cs2_rows, int cs2_npar, int cs2_blocks, const void* gamma_dev, const void* beta_dev, void* out_dev,
+                        float* workspace_dev, int B, int H, int W, int C, int groups, float eps, int act, int out_tokens, int dtype, void* stream);
+
 /* ResnetBlock2D tail in ONE GEMM: y = conv3x3(x) + conv1x1([x1 | x2]) + bias + rowbias + resid on PF tensors.
  * w_dev: [N][9*C + C1 + C2] (3x3 taps first, then the shortcut's columns), x1 / x2 optional (x2 requires x1). */
 int gsw_conv3x3_res_pf(const void* x_dev, const void* w_dev, const void* bias_dev, const void* rowbias_dev, int ld_rowbias, const void* resid_dev, void* y_dev,

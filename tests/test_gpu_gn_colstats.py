@@ -1,0 +1,147 @@
+"""GPU: GroupNorm statistics from the producing launch's column records (gsw_mm_next_colstats -> gsw_groupnorm_pf_cs) against the separate
+statistics pass and against fp32 torch GroupNorm of the same tensor: every producer (3x3 / stride-2 / 1x1 convolution, the three-segment resnet
+launch, the sub-pixel upsampler's four parity launches, the token scatter), both tile heights, images smaller than a tile (8 x 8: four images per
+256-row tile), the channel concatenation of two producers (a skip connection), and the fall-back when a launch cannot produce records."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def G():
+    import types
+    import gswm_amd
+    from gswm_amd import pf, _native
+    return types.SimpleNamespace(pf=pf, lib=_native.lib())
+
+
+@pytest.fixture(params=[0, 128, 256], ids=["auto", "BM128", "BM256"])
+def tile_rows(request, G):
+    assert G.lib.gsw_mm_config(request.param, -1) == 0
+    yield request.param
+    assert G.lib.gsw_mm_config(0, -1) == 0
+
+
+def _gn_ref(x_nchw, gamma, beta, groups, eps, act):
+    y = F.group_norm(x_nchw.float(), groups, gamma.float(), beta.float(), eps)
+    return F.silu(y) if act else y
+
+
+def _check_records(st, y_nchw):
+    """the records themselves: folded over blocks they are the per-image, per-channel sums of the stored tensor"""
+    B, C, H, W = y_nchw.shape
+    rec = st.buf.view(st.npar, st.blocks, 2, C // 2).double()                        # [parity][block][sums | sums of squares][column pair]
+    pix = H * W if st.npar == 1 else (H // 2) * (W // 2)
+    bpi = pix // st.rows
+    tot = rec[:, : B * bpi].reshape(st.npar, B, bpi, 2, C // 2).sum(dim=(0, 2))      # [B, 2, C / 2]
+    yf = y_nchw.double().view(B, C // 2, 2, H, W)
+    assert torch.allclose(tot[:, 0], yf.sum(dim=(2, 3, 4)), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(tot[:, 1], (yf * yf).sum(dim=(2, 3, 4)), rtol=1e-4, atol=1e-2)
+
+
+def _gn_both(G, y, gamma, beta, groups, eps, act, x2=None):
+    pf = G.pf
+    assert y.stats is not None and pf._stats_usable(y)
+    a = pf.groupnorm_pf2(y, x2, gamma, beta, groups, eps, act=act)
+    prev = pf.FUSE_GN_STATS
+    pf.FUSE_GN_STATS = False
+    try:
+        b = pf.groupnorm_pf2(y, x2, gamma, beta, groups, eps, act=act)
+    finally:
+        pf.FUSE_GN_STATS = prev
+    return a, b
+
+
+@pytest.mark.parametrize("B,C,N,H,W,ks,stride", [(8, 320, 320, 32, 32, 3, 1), (84, 1280, 640, 8, 8, 3, 1), (40, 640, 1280, 32, 32, 3, 2), (30, 640, 320, 16, 16, 1, 1),
+                                                  (2, 128, 256, 64, 64, 3, 1), (3, 320, 320, 32, 32, 3, 1)])
+def test_conv_records_and_groupnorm(G, tile_rows, B, C, N, H, W, ks, stride):
+    dt = torch.float16
+    g = torch.Generator().manual_seed(B + C + N + H)
+    x = torch.randn(B, C, H, W, generator=g).to(dt).cuda()
+    w = (torch.randn(N, C, ks, ks, generator=g) * (1.0 / (C * ks * ks)) ** 0.5).to(dt).cuda()
+    b = torch.randn(N, generator=g).to(dt).cuda()
+    rb = torch.randn(B, N, generator=g).to(dt).cuda()
+    P = G.pf.PF.from_nchw
+    y = G.pf.conv_pf(P(x), G.pf.pack_conv_weight(w), b, ksize=ks, stride=stride, rowbias=rb)
+    if y.B * (y.H + 2) * (y.W + 2) <= 8192 and stride == 1:
+        assert y.stats is None           # small tensors enumerate all padded rows (no records): GroupNorm takes the separate pass
+        return
+    _check_records(y.stats, y.to_nchw())
+    gamma, beta = torch.randn(N, generator=g).to(dt).cuda(), torch.randn(N, generator=g).to(dt).cuda()
+    a, bb = _gn_both(G, y, gamma, beta, 32, 1e-5, True)
+    ref = _gn_ref(y.to_nchw(), gamma, beta, 32, 1e-5, True)
+    assert (a.to_nchw().float() - ref).abs().max().item() <= 4e-3 * max(1.0, ref.abs().max().item())
+    assert (a.to_nchw().float() - bb.to_nchw().float()).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item())
+    assert a.grid[:, 0].abs().max() == 0 and a.grid[:, :, -1].abs().max() == 0
+
+
+def test_resnet_tail_upsampler_and_concatenation(G, tile_rows):
+    dt = torch.float16
+    g = torch.Generator().manual_seed(11)
+    rnd = lambda *s: torch.randn(*s, generator=g)
+    B, C, N, H, W = 28, 640, 640, 16, 16
+    P = G.pf.PF.from_nchw
+    x, x1, x2 = (rnd(B, C, H, W).to(dt).cuda() for _ in range(3))
+    w3 = (rnd(N, C, 3, 3) * (1.0 / (9 * C)) ** 0.5).to(dt).cuda()
+    w1 = (rnd(N, 2 * C) * (1.0 / (2 * C)) ** 0.5).to(dt).cuda()
+    bias = rnd(N).to(dt).cuda()
+    tail = G.pf.conv3x3_res_pf(P(x), torch.cat([G.pf.pack_conv_weight(w3), w1], dim=1).contiguous(), bias, x1=P(x1), x2=P(x2))
+    _check_records(tail.stats, tail.to_nchw())
+    # sub-pixel upsampler: four parity launches, records over the low-resolution pixels
+    wu = (rnd(N, N, 3, 3) * (1.0 / (9 * N)) ** 0.5).to(dt).cuda()
+    up = G.pf.conv_up2x_pf(tail, G.pf.pack_upsample_weight(wu), bias)
+    assert up.stats is not None and up.stats.npar == 4
+    _check_records(up.stats, up.to_nchw())
+    # a skip tensor at the upsampled resolution from a plain convolution; GroupNorm over the concatenation [up | skip] with 32 groups of
+    # (640 + 320) / 32 = 30 channels: groups straddle the boundary between the two tensors
+    xs = rnd(B, 320, 2 * H, 2 * W).to(dt).cuda()
+    ws = (rnd(320, 320, 3, 3) * (1.0 / (9 * 320)) ** 0.5).to(dt).cuda()
+    skip = G.pf.conv_pf(P(xs), G.pf.pack_conv_weight(ws), None)
+    Ct = N + 320
+    gamma, beta = rnd(Ct).to(dt).cuda(), rnd(Ct).to(dt).cuda()
+    a, bb = _gn_both(G, up, gamma, beta, 32, 1e-5, True, x2=skip)
+    ref = _gn_ref(torch.cat([up.to_nchw(), skip.to_nchw()], dim=1), gamma, beta, 32, 1e-5, True)
+    assert (a.to_nchw().float() - ref).abs().max().item() <= 4e-3 * max(1.0, ref.abs().max().item())
+    assert (a.to_nchw().float() - bb.to_nchw().float()).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item())
+
+
+def test_token_scatter_replaces_the_records_and_tokens_output(G, tile_rows):
+    dt = torch.float16
+    g = torch.Generator().manual_seed(5)
+    B, H, W, C = 8, 32, 32, 320
+    base = torch.randn(B, C, H, W, generator=g).to(dt).cuda()
+    wc = (torch.randn(C, C, 3, 3, generator=g) * (1.0 / (9 * C)) ** 0.5).to(dt).cuda()
+    x = G.pf.conv_pf(G.pf.PF.from_nchw(base), G.pf.pack_conv_weight(wc), None)
+    old = x.stats
+    tok = torch.randn(B, H * W, C, generator=g).to(dt).cuda()
+    w = (torch.randn(C, C, generator=g) * C ** -0.5).to(dt).cuda()
+    b = torch.randn(C, generator=g).to(dt).cuda()
+    G.pf.gemm(tok, w, b, resid=x.rows, mode="tok2pf", tokens=H * W, width=W, out=x.rows, stats_for=x)
+    assert x.stats is not None and x.stats is not old
+    _check_records(x.stats, x.to_nchw())
+    gamma, beta = torch.randn(C, generator=g).to(dt).cuda(), torch.randn(C, generator=g).to(dt).cuda()
+    t_cs = G.pf.groupnorm_pf(x, gamma, beta, 32, 1e-6, act=False, tokens=True)
+    ref = _gn_ref(x.to_nchw(), gamma, beta, 32, 1e-6, False).permute(0, 2, 3, 1).reshape(B, H * W, C)
+    assert (t_cs.float() - ref).abs().max().item() <= 4e-3 * max(1.0, ref.abs().max().item())
+
+
+def test_a_request_no_launch_consumed_does_not_leak(G):
+    """a convolution off the engine (64 output columns) never sees the request; the next engine launch must not write into it"""
+    buf = torch.zeros(1 << 16, dtype=torch.float32, device="cuda")
+    assert G.lib.gsw_mm_next_colstats(buf.data_ptr(), buf.numel()) == 0
+    import ctypes as C
+    rows, blocks = C.c_int(-1), C.c_int(-1)
+    assert G.lib.gsw_mm_last_colstats(C.byref(rows), C.byref(blocks)) == 0 and rows.value == 0
+    x = torch.randn(2, 64, 16, 16, device="cuda").half()
+    w = torch.randn(128, 64, 3, 3, device="cuda").half() * 0.05
+    prev = G.pf.FUSE_GN_STATS
+    G.pf.FUSE_GN_STATS = False
+    try:
+        y = G.pf.conv_pf(G.pf.PF.from_nchw(x), G.pf.pack_conv_weight(w), None)
+    finally:
+        G.pf.FUSE_GN_STATS = prev
+    torch.cuda.synchronize()
+    assert y.stats is None and float(buf.abs().sum()) == 0.0
+    assert G.lib.gsw_mm_next_colstats(buf.data_ptr() + 4, 16) != 0          # alignment
