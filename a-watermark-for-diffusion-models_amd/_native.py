@@ -70,6 +70,7 @@ _PROTOTYPES = {
                                       C.c_void_p, C.c_void_p]),
     "gsw_gemm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                            C.c_int, C.c_void_p]),
+    "gsw_gemm_qkv": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "gsw_gemm_strided": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64,
                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "gsw_softmax_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_float, C.c_int, C.c_void_p]),

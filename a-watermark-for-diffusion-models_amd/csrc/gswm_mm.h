@@ -14,7 +14,7 @@ struct MMSeg {
     int32_t wk0;         // offset of this segment inside a weight row; inside it K runs tap-major, channel-minor
 };
 
-enum { MM_MODE_DENSE = 0, MM_MODE_PF = 1, MM_MODE_TOK2PF = 2, MM_MODE_UP2X = 3, MM_MODE_GEGLU = 4, MM_MODE_TRANS = 5 };
+enum { MM_MODE_DENSE = 0, MM_MODE_PF = 1, MM_MODE_TOK2PF = 2, MM_MODE_UP2X = 3, MM_MODE_GEGLU = 4, MM_MODE_TRANS = 5, MM_MODE_QKV = 6 };
 enum { MM_FLAG_NONE = 0, MM_FLAG_COMPACT = 1 };   // COMPACT (MM_MODE_PF / UP2X): M enumerates interior pixels, borders are not written
 
 struct MMArgs {
@@ -29,6 +29,8 @@ struct MMArgs {
     const void* rowbias;  // [images][ldrb] or null (MM_MODE_PF): per-image row bias, rows ldrb elements apart (a column slice of a wider matrix)
     const void* resid;    // [rows][ldr] or null, addressed like the output
     void* y;
+    void* y2;             // MM_MODE_QKV: the transposed part [images][N - n_rows][S] (columns >= n_rows); y takes columns < n_rows as dense rows
+    int32_t n_rows;       // MM_MODE_QKV: columns of the row-major part (a multiple of the 160-column tile)
     int32_t ldy, ldr;
     int32_t ldrb;         // row stride of rowbias (>= N, multiple of 8)
     int32_t mode;

@@ -31,6 +31,7 @@
 #include <stdlib.h>
 #include <algorithm>
 #include <atomic>
+#include <type_traits>
 
 #include "../../include/gswm.h"
 #include "gswm_mm.h"
@@ -151,6 +152,9 @@ __device__ __forceinline__ float mm_dpp_add(float x) {
 template <typename T, int EPI, bool SPLIT, int MT>
 __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kernel(const MMArgs p) {
     constexpr bool SWAP = EPI == 3;
+    // EPI 5 (self-attention q | k | v from ONE pass over the tokens): column tiles below p.n_rows are dense rows (EPI 0), the others the transposed value
+    // projection (EPI 3: MFMA operands swapped) -- decided per tile, the step loop exists in both forms
+    constexpr bool QKV = EPI == 5;
     // EPI 4 (split-K, always the 12-wave variant): the workgroup multiplies a RANGE of its tile's K stages and dumps the fp32 accumulators into a
     // workspace slab; gsw_mm_reduce_kernel sums the slabs of a tile in a fixed order and runs the epilogue of the launch's mode
     constexpr bool PART = EPI == 4;
@@ -463,6 +467,8 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
         decode_tile(PART ? slotx % ntiles : c_it * G + slotx, tile_m, tile_n);
         const int32_t m0 = tile_m * BM, n0 = tile_n * BN;
         const uint32_t q = lane >> 4, li = lane & 15u;
+        const bool vtile = QKV && n0 >= p.n_rows;                 // (wave-uniform) this tile belongs to the transposed part
+        const bool transposed = SWAP || vtile;
         if constexpr (PART) {
             // slab of virtual tile v: [wave][5 * MT accumulators][lane] float4 -- one coalesced 1 KiB store per accumulator; 16-row blocks past M are
             // neither stored nor read back
@@ -486,7 +492,7 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
         for (int in = 0; in < 5; ++in) {
             bq_raw[in] = make_uint2(0, 0);
             const int32_t nb = n0 + (int32_t)(grp * HC + (uint32_t)in * 16u + q * 4u);       // N % 8 == 0: a 4-column group is inside N or outside
-            if (!SWAP && bias && nb < p.N) bq_raw[in] = *reinterpret_cast<const uint2*>(bias + nb);
+            if (!transposed && bias && nb < p.N) bq_raw[in] = *reinterpret_cast<const uint2*>(bias + nb);
         }
         auto bias4 = [&](int in, float (&bq)[4]) {
             bq[0] = MM<T>::up((uint16_t)bq_raw[in].x); bq[1] = MM<T>::up((uint16_t)(bq_raw[in].x >> 16));
@@ -500,7 +506,7 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
             const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
             a = r[0]; b = r[1];
         };
-        if (EPI == 0) {
+        if (EPI == 0 || (QKV && !vtile)) {
             // dense rows: out[m, n] (+ resid[m, n]); row pointers hoisted, ten 16-byte stores per lane at immediate column offsets
             uint16_t* yrow[2];
             const uint16_t* rrow[2];
@@ -693,11 +699,15 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
             }
         } else {
             // transposed output Y[image][n][token]: lane (q, i) holds tokens 16 im + 4 q + j of output row 16 in + i
+            // (QKV: the value part -- output rows counted from column n_rows, written to y2)
+            const int32_t nbase = QKV ? p.n_rows : 0, Nt = p.N - nbase;
+            uint16_t* Yt = QKV ? reinterpret_cast<uint16_t*>(p.y2) : Y;
 #pragma unroll
             for (int in = 0; in < 5; ++in) {
-                const int32_t nrow = n0 + (int32_t)(grp * HC + (uint32_t)in * 16u + li);
-                const bool nok = nrow < p.N;
-                const float bv = bias && nok ? MM<T>::up(bias[nrow]) : 0.f;
+                const int32_t ncol = n0 + (int32_t)(grp * HC + (uint32_t)in * 16u + li);
+                const int32_t nrow = ncol - nbase;
+                const bool nok = ncol < p.N;
+                const float bv = bias && nok ? MM<T>::up(bias[ncol]) : 0.f;
                 const float bq[4] = {bv, bv, bv, bv};
 #pragma unroll
                 for (int pr = 0; pr < NPR; ++pr) {
@@ -709,7 +719,7 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
                     const int32_t m = m0 + (int32_t)(wm * (16u * MT) + (uint32_t)(2 * pr + (int)(q & 1u)) * 16u + (q >> 1) * 8u);      // first of 8 consecutive tokens
                     if (m >= p.M || !nok) continue;
                     const int32_t b = m / p.S, sidx = m - b * p.S;
-                    *reinterpret_cast<uint4*>(Y + ((int64_t)b * p.N + nrow) * p.S + sidx) = make_uint4(a0, a1, b0, b1);
+                    *reinterpret_cast<uint4*>(Yt + ((int64_t)b * Nt + nrow) * p.S + sidx) = make_uint4(a0, a1, b0, b1);
                 }
             }
         }
@@ -720,12 +730,13 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
         ++c_it;
     };
 
-    auto mfma20 = [&](frag (&xc)[MT], frag (&wc)[5]) {
+    auto mfma20 = [&](auto swap_tag, frag (&xc)[MT], frag (&wc)[5]) {
+        constexpr bool SW = decltype(swap_tag)::value;
 #pragma unroll
         for (int in = 0; in < 5; ++in)
 #pragma unroll
             for (int im = 0; im < MT; ++im)
-                acc[in][im] = SWAP ? MM<T>::mma(xc[im], wc[in], acc[in][im]) : MM<T>::mma(wc[in], xc[im], acc[in][im]);
+                acc[in][im] = SW ? MM<T>::mma(xc[im], wc[in], acc[in][im]) : MM<T>::mma(wc[in], xc[im], acc[in][im]);
     };
     // issue order of a phase's main block: three DMA pieces, each behind three MFMAs, then the nine fragment reads one per MFMA
     auto pin_order = [&]() {
@@ -756,7 +767,7 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
         }
     };
     // X holds the fragments of (stage s, k-half 0) on entry; Y is filled with (s, k-half 1), then X with (s+1, k-half 0)
-    auto step = [&](frag (&xX)[MT], frag (&wX)[5], frag (&xY)[MT], frag (&wY)[5]) {
+    auto step = [&](auto swap_tag, frag (&xX)[MT], frag (&wX)[5], frag (&xY)[MT], frag (&wY)[5]) {
         const uint32_t nx_slot = rd_slot + STAGE == RING ? 0u : rd_slot + STAGE;
         // ---- even phase: second half of stage s+2 (its slot held stage s-1, whose last reads completed before the previous barrier)
         MM_STAMP(0);
@@ -765,7 +776,7 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
         read_frags(xY, wY, rd_slot, 1u);
 #endif
 #ifndef MM_ABL_NOMFMA
-        mfma20(xX, wX);
+        mfma20(swap_tag, xX, wX);
 #endif
         pin_order();
         if constexpr (!SPLIT) { if (--pr_run == 0) end_run(); }
@@ -782,7 +793,7 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
         read_frags(xX, wX, nx_slot, 0u);
 #endif
 #ifndef MM_ABL_NOMFMA
-        mfma20(xY, wY);
+        mfma20(swap_tag, xY, wY);
 #endif
         pin_order();
         MM_STAMP(4);
@@ -806,7 +817,14 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
     read_frags(xa, wa, 0u, 0u);                               // (stage 0, k-half 0)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     for (uint32_t it = 0; it < nt_mine; ++it) {
-        for (int32_t i = 0; i < P_mine; ++i) step(xa, wa, xb, wb);
+        if constexpr (QKV) {
+            int32_t tm_, tn_;
+            decode_tile(it * G + slotx, tm_, tn_);
+            if (tn_ * BN >= p.n_rows) { for (int32_t i = 0; i < P_mine; ++i) step(std::true_type{}, xa, wa, xb, wb); }
+            else { for (int32_t i = 0; i < P_mine; ++i) step(std::false_type{}, xa, wa, xb, wb); }
+        } else {
+            for (int32_t i = 0; i < P_mine; ++i) step(std::integral_constant<bool, SWAP>{}, xa, wa, xb, wb);
+        }
         epilogue();
         MM_STAMP(6);
     }
@@ -870,9 +888,11 @@ __global__ __launch_bounds__(256) void gsw_mm_reduce_kernel(const MMArgs p, cons
             *reinterpret_cast<uint2*>(Y + (int64_t)m * p.ldy + ocol) = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
             continue;
         }
-        if (p.mode == MM_MODE_TRANS) {
+        if (p.mode == MM_MODE_TRANS || (p.mode == MM_MODE_QKV && n >= p.n_rows)) {
+            const int32_t nbase = p.mode == MM_MODE_QKV ? p.n_rows : 0;
+            uint16_t* Yt = p.mode == MM_MODE_QKV ? reinterpret_cast<uint16_t*>(p.y2) : Y;
             const int32_t b = m / p.S, sidx = m - b * p.S;
-            for (int j = 0; j < 4; ++j) Y[((int64_t)b * p.N + n + j) * p.S + sidx] = h[j];
+            for (int j = 0; j < 4; ++j) Yt[((int64_t)b * (p.N - nbase) + (n - nbase) + j) * p.S + sidx] = h[j];
             continue;
         }
         int64_t orow = m;
@@ -932,10 +952,13 @@ int mm_launch_k(const MMArgs& a, uint32_t grid, hipStream_t st) {
 }
 template <typename T, int EPI>
 int mm_launch_t(const MMArgs& a, uint32_t grid, int mt, hipStream_t st) {
+    if constexpr (EPI == 5) return mt == 4 ? mm_launch_k<T, 5, false, 4>(a, grid, st) : mm_launch_k<T, 5, false, 2>(a, grid, st);      // dense epilogues: 8-wave form
+    else {
     // bit e of the split mask set = epilogue kind e runs the 12-wave variant whose waves 8-11 own the LDS-DMA (gsw_mm_config / GSW_MM_SPLIT: A/B switch)
     const bool split = (g_mm_split_mask.load(std::memory_order_relaxed) >> EPI) & 1;
     if (mt == 4) return split ? mm_launch_k<T, EPI, true, 4>(a, grid, st) : mm_launch_k<T, EPI, false, 4>(a, grid, st);
     return split ? mm_launch_k<T, EPI, true, 2>(a, grid, st) : mm_launch_k<T, EPI, false, 2>(a, grid, st);
+    }
 }
 template <typename T>
 int mm_launch_splitk(const MMArgs& a, uint32_t grid, int mt, hipStream_t st) {
@@ -954,6 +977,7 @@ int mm_launch_e(const MMArgs& a, int epi, uint32_t grid, int mt, hipStream_t st)
         case 0: return mm_launch_t<T, 0>(a, grid, mt, st);
         case 1: return mm_launch_t<T, 1>(a, grid, mt, st);
         case 2: return mm_launch_t<T, 2>(a, grid, mt, st);
+        case 5: return mm_launch_t<T, 5>(a, grid, mt, st);
         default: return mm_launch_t<T, 3>(a, grid, mt, st);
     }
 }
@@ -1016,6 +1040,7 @@ int gsw_mm_launch(MMArgs& a, int dtype, void* stream) {
     if (dtype != GSW_F16 && dtype != GSW_BF16) return GSW_ERR_BAD_ARG;
     // N: any multiple of 8 (the last 160-column tile may be partial: weight rows are clamped, stores masked); GEGLU pairs columns inside a tile
     if (a.N % 8 || (a.mode == MM_MODE_GEGLU && a.N % 160) || a.M <= 0 || a.P <= 0) return GSW_ERR_UNSUPPORTED;
+    if (a.mode == MM_MODE_QKV && (a.n_rows <= 0 || a.n_rows % 160 || a.n_rows >= a.N || !a.y2)) return GSW_ERR_UNSUPPORTED;
     constexpr int BN = 160;
     const int64_t tiles_n = (a.N + BN - 1) / BN;
     // 256-row tiles unless they would leave CUs without one: then 128-row tiles (GSW_MM_BM=128 / 256 forces one for A/B runs)
@@ -1071,7 +1096,7 @@ int gsw_mm_launch(MMArgs& a, int dtype, void* stream) {
         a.colstats = cs_req;
         t_cs_rows = BM / 4; t_cs_blocks = (int)(tiles_m * 4);
     }
-    const int epi = a.mode == MM_MODE_TRANS ? 3 : a.mode == MM_MODE_GEGLU ? 2 : (a.mode == MM_MODE_DENSE && !a.rowbias) ? 0 : 1;
+    const int epi = a.mode == MM_MODE_QKV ? 5 : a.mode == MM_MODE_TRANS ? 3 : a.mode == MM_MODE_GEGLU ? 2 : (a.mode == MM_MODE_DENSE && !a.rowbias) ? 0 : 1;
     const int e = dtype == GSW_F16 ? mm_launch_e<_Float16>(a, epi, grid, BM / 64, st) : mm_launch_e<__bf16>(a, epi, grid, BM / 64, st);
     if (e != 0) { g_last_hip_error = e; return GSW_ERR_HIP; }
     return GSW_OK;
@@ -1094,13 +1119,31 @@ int gsw_gemm_strided(const void* x_dev, int64_t ldx, const void* w_dev, int64_t 
     a.nseg = 1; a.P = K / 64;
     a.w = w_dev; a.ldw = (int32_t)ldw;
     a.M = (int32_t)M; a.N = N;
-    a.bias = bias_dev; a.rowbias = nullptr; a.resid = resid_dev; a.y = y_dev; a.colstats = nullptr;
+    a.bias = bias_dev; a.rowbias = nullptr; a.resid = resid_dev; a.y = y_dev; a.colstats = nullptr; a.y2 = nullptr; a.n_rows = 0;
     a.ldy = (int32_t)ldy; a.ldr = (int32_t)ldr; a.ldrb = N;
     a.Hp = 1; a.Wp = 1; a.in_Hp = 1; a.in_Wp = 1; a.stride = 1; a.S = S > 0 ? S : 1; a.Wimg = Wimg > 0 ? Wimg : 1; a.up = 0; a.flags = MM_FLAG_NONE;
     a.mode = MM_MODE_DENSE;
     if (mode == GSW_GEMM_GEGLU) a.mode = MM_MODE_GEGLU;
     else if (mode == GSW_GEMM_TRANS) a.mode = MM_MODE_TRANS;
     else if (mode == GSW_GEMM_TOK2PF) { a.mode = MM_MODE_TOK2PF; a.Wp = Wimg + 2; a.Hp = S / Wimg + 2; }
+    return gsw_mm_launch(a, dtype, stream);
+}
+
+int gsw_gemm_qkv(const void* x_dev, const void* w_dev, const void* bias_dev, void* rows_dev, void* trans_dev, int64_t M, int K, int N_rows, int N,
+                 int S, int dtype, void* stream) {
+    // one pass over x [M, K]: columns [0, N_rows) of x w^T (+ bias) -> rows_dev [M, N_rows] (self-attention's q | k), columns [N_rows, N) -> trans_dev
+    // [M / S][N - N_rows][S] (the value projection transposed, what gsw_attention consumes).  w [N][K]; N_rows % 160 == 0; S % 8 == 0; M % S == 0.
+    if (!x_dev || !w_dev || !rows_dev || !trans_dev || M <= 0 || K <= 0 || N <= 0 || N_rows <= 0 || N_rows >= N || S <= 0) return GSW_ERR_BAD_ARG;
+    if (K % 64 || N % 8 || N_rows % 160 || (S & 7) || M % S || M > 0x7FFFFF00 || M * (int64_t)K >= ((int64_t)1 << 40) || (int64_t)N * K >= ((int64_t)1 << 31)) return GSW_ERR_UNSUPPORTED;
+    MMArgs a;
+    for (int i = 0; i < 3; ++i) a.seg[i] = MMSeg{x_dev, K, K / 64, 1, 1, 0, 0, 0};
+    a.nseg = 1; a.P = K / 64;
+    a.w = w_dev; a.ldw = K;
+    a.M = (int32_t)M; a.N = N;
+    a.bias = bias_dev; a.rowbias = nullptr; a.resid = nullptr; a.y = rows_dev; a.colstats = nullptr; a.y2 = trans_dev; a.n_rows = N_rows;
+    a.ldy = N_rows; a.ldr = N_rows; a.ldrb = N;
+    a.Hp = 1; a.Wp = 1; a.in_Hp = 1; a.in_Wp = 1; a.stride = 1; a.S = S; a.Wimg = 1; a.up = 0; a.flags = MM_FLAG_NONE;
+    a.mode = MM_MODE_QKV;
     return gsw_mm_launch(a, dtype, stream);
 }
 

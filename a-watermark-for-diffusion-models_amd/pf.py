@@ -458,6 +458,31 @@ def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     return y
 
 
+def gemm_qkv(x: torch.Tensor, w: torch.Tensor, n_rows: int, bias: Optional[torch.Tensor] = None):
+    """Self-attention's three projections from ONE pass over the tokens (gsw_gemm_qkv): x [B, S, K], w [N, K] = [to_q | to_k | to_v] rows ->
+    (rows [B, S, n_rows] = q | k as the attention kernel reads them, vt [B, N - n_rows, S] = V transposed).  n_rows % 160 == 0, S % 8 == 0."""
+    if x.dtype not in (torch.float16, torch.bfloat16) or x.dim() != 3:
+        raise ValueError("gemm_qkv: fp16 / bf16 tokens [B, S, K]")
+    B, S, K = x.shape
+    Nn = w.shape[0]
+    _same(x, x, "x")
+    _same(w, x, "w", Nn * K)
+    _same(bias, x, "bias", Nn)
+    if n_rows <= 0 or n_rows >= Nn or n_rows % 160 or S % 8:
+        raise ValueError("gemm_qkv: n_rows must be a multiple of 160 inside (0, N), S a multiple of 8")
+    rows = torch.empty((B, S, n_rows), dtype=x.dtype, device=x.device)
+    vt = torch.empty((B, Nn - n_rows, S), dtype=x.dtype, device=x.device)
+    tm = CONV_TIMER
+    with torch.cuda.device(x.device):
+        _ensure_workspace(x.device)
+        e0 = tm.start() if tm is not None else None
+        N.check(N.lib().gsw_gemm_qkv(x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None, rows.data_ptr(), vt.data_ptr(),
+                                     B * S, K, n_rows, Nn, S, _dt(x.dtype), _stream_ptr()))
+        if tm is not None:
+            tm.stop(e0, ("gsw_mm_kernel", B * S, K, Nn, "qkv") if tm.by_shape else "gsw_mm_kernel", 2.0 * B * S * K * Nn)
+    return rows, vt
+
+
 def groupnorm_pf2(x: PF, x2: Optional[PF], gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float, *, act: bool = True) -> PF:
     """act(GroupNorm(cat([x, x2], channels))) -> one PF tensor, without materialising the concatenation."""
     if x2 is None:

@@ -62,6 +62,10 @@ CACHE_CONTEXT_KV = True   # cross-attention K / V^T of a context tensor are comp
 
 FUSED_QK = True       # self-attention: q and k projections as one GEMM (own attention kernel reads them as column slices)
 
+FUSED_QKV = False     # ... and the transposed value projection from the same launch (gsw_gemm_qkv: the tokens are read once).  Measured: no gain --
+                      # forward 113.6 vs 113.3 ms at 128 rows, 60.5 vs 60.2 at 64 (the value part loses the 12-wave form, the launch runs at 235 registers);
+                      # kept as an A/B switch, bit-identical to the two launches (tests/test_gpu_qkv.py)
+
 OWN_ATTENTION = True  # attention with head_dim 40 / 64 / 80 / 160, any query count, keys % 8 == 0 runs on gsw_attention instead of torch SDPA
 
 OWN_GEMM = True       # every dense linear layer (q / k / v / out projections, proj_in / proj_out, feed-forward, time embedding) on the
@@ -256,6 +260,16 @@ class Attention(nn.Module):
                     k_ctx, vt_ctx = self.context_kv(src)
                     o = attention(_lin(x, self.to_q), k_ctx, vt_ctx, self.heads, valid_keys=valid)
                     return _lin(o, self.to_out[0], resid)
+                inner = self.to_q.out_features
+                if (ctx is None and FUSED_QK and FUSED_QKV and self.to_q.bias is None and self.to_k.bias is None and self.to_v.bias is None
+                        and (2 * inner) % 160 == 0 and n % 8 == 0 and _own_gemm_ok(x, self.to_q.in_features, 3 * inner)):
+                    from .pf import cached, gemm_qkv
+                    wqkv = cached(self, "_gsw_wqkv", (self.to_q.weight, self.to_k.weight, self.to_v.weight),
+                                  lambda: torch.cat([self.to_q.weight.detach(), self.to_k.weight.detach(), self.to_v.weight.detach()], dim=0).contiguous())
+                    if wqkv.dtype == x.dtype:
+                        qk, vt = gemm_qkv(x.contiguous(), wqkv, 2 * inner)
+                        o = attention(qk[..., :inner], qk[..., inner:], vt, self.heads, valid_keys=valid)
+                        return _lin(o, self.to_out[0], resid)
                 vt = _lin_t(src, self.to_v)
                 if ctx is None and FUSED_QK:
                     # self-attention: q and k from ONE GEMM over x (x is read once); the kernel takes them as column slices

@@ -205,6 +205,12 @@ int gsw_linear(const void* x_dev, const void* w_dev, const void* bias_dev, const
 #define GSW_GEMM_TOK2PF 3
 int gsw_gemm(const void* x_dev, const void* w_dev, const void* bias_dev, const void* resid_dev, void* y_dev, int64_t M, int K, int N,
              int mode, int S, int Wimg, int dtype, void* stream);
+/* Self-attention's q | k | v projections from ONE pass over the tokens (diffusers Attention.to_q / to_k / to_v behind extract.py:66-69): w = the three
+ * weights row-concatenated [N][K]; columns [0, N_rows) of x w^T (+ bias) -> rows_dev [M, N_rows] (q | k, read by gsw_attention as column slices),
+ * columns [N_rows, N) -> trans_dev [M / S][N - N_rows][S] (V transposed).  N_rows % 160 == 0 (a column tile is either kind); K % 64, N % 8, S % 8 == 0. */
+int gsw_gemm_qkv(const void* x_dev, const void* w_dev, const void* bias_dev, void* rows_dev, void* trans_dev, int64_t M, int K, int N_rows, int N,
+                 int S, int dtype, void* stream);
+
 /* The same with explicit row strides (elements, multiples of 8): x rows ldx >= K, w rows ldw >= K, resid rows ldr, y rows ldy -- operands may be
  * column slices of wider matrices (the per-image Q K^T and P V products of the VAE's single-head attention). */
 int gsw_gemm_strided(const void* x_dev, int64_t ldx, const void* w_dev, int64_t ldw, const void* bias_dev, const void* resid_dev, int64_t ldr,
