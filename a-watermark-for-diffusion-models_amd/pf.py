@@ -150,6 +150,21 @@ def _colstats_collect(armed, npar: int = 1) -> Optional[ColStats]:
     return ColStats(armed[0], rows.value, npar, armed[1]) if rows.value > 0 else None
 
 
+class _colstats_scope:
+    """A launch that raises (bad arguments on either side of the ABI) must not leave its one-shot request armed for a later launch."""
+
+    def __init__(self, armed):
+        self.armed = armed
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, et, ev, tb):
+        if et is not None and self.armed is not None:
+            N.lib().gsw_mm_last_colstats(None, None)
+        return False
+
+
 def _stats_usable(x: "PF") -> bool:
     st = x.stats
     if st is None:
@@ -243,10 +258,11 @@ def conv_pf(x: PF, w_packed: torch.Tensor, bias: Optional[torch.Tensor], *, ksiz
         _ensure_workspace(x.buf.device)
         e0 = tm.start() if tm is not None else None
         armed = _colstats_arm(x.B * Ho * Wo, Nn, x.buf.device) if Nn >= 128 else None
-        N.check(N.lib().gsw_conv_pf(xp, w_packed.data_ptr(), bias.data_ptr() if bias is not None else None,
-                                    rowbias.data_ptr() if rowbias is not None else None, ldrb,
-                                    resid.rows.data_ptr() if resid is not None else None, y.rows.data_ptr(),
-                                    x.B, Ho, Wo, C, Nn, ksize, stride, x.C, _dt(x.buf.dtype), _stream_ptr()))
+        with _colstats_scope(armed):
+            N.check(N.lib().gsw_conv_pf(xp, w_packed.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                        rowbias.data_ptr() if rowbias is not None else None, ldrb,
+                                        resid.rows.data_ptr() if resid is not None else None, y.rows.data_ptr(),
+                                        x.B, Ho, Wo, C, Nn, ksize, stride, x.C, _dt(x.buf.dtype), _stream_ptr()))
         y.stats = _colstats_collect(armed)
         if tm is not None:
             name = _conv_kernel_name(Wo, Nn, ksize, stride)
@@ -448,9 +464,10 @@ def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
         e0 = tm.start() if tm is not None else None
         # stats_for (tok2pf): the PF tensor whose payload this launch writes -- it gets the launch's column records (or None)
         armed = _colstats_arm(M, Nn, x.device) if (stats_for is not None and mode == "tok2pf") else None
-        N.check(N.lib().gsw_gemm(x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None,
-                                 resid.data_ptr() if resid is not None else None, y.data_ptr(), M, K, Nn, m, tokens, width,
-                                 _dt(x.dtype), _stream_ptr()))
+        with _colstats_scope(armed):
+            N.check(N.lib().gsw_gemm(x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                     resid.data_ptr() if resid is not None else None, y.data_ptr(), M, K, Nn, m, tokens, width,
+                                     _dt(x.dtype), _stream_ptr()))
         if stats_for is not None:
             stats_for.stats = _colstats_collect(armed)
         if tm is not None:
@@ -528,13 +545,14 @@ def conv3x3_res_pf(x: PF, w_cat: torch.Tensor, bias: Optional[torch.Tensor], *, 
         _ensure_workspace(x.buf.device)
         e0 = tm.start() if tm is not None else None
         armed = _colstats_arm(x.B * x.H * x.W, Nn, x.buf.device)
-        N.check(N.lib().gsw_conv3x3_res_pf(x.rows.data_ptr(), w_cat.data_ptr(), bias.data_ptr() if bias is not None else None,
-                                           rowbias.data_ptr() if rowbias is not None else None, ldrb,
-                                           resid.rows.data_ptr() if resid is not None else None, y.rows.data_ptr(),
-                                           x.B, x.H, x.W, x.C, Nn,
-                                           x1.rows.data_ptr() if x1 is not None else None, x1.C if x1 is not None else 0,
-                                           x2.rows.data_ptr() if x2 is not None else None, x2.C if x2 is not None else 0,
-                                           _dt(x.buf.dtype), _stream_ptr()))
+        with _colstats_scope(armed):
+            N.check(N.lib().gsw_conv3x3_res_pf(x.rows.data_ptr(), w_cat.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                               rowbias.data_ptr() if rowbias is not None else None, ldrb,
+                                               resid.rows.data_ptr() if resid is not None else None, y.rows.data_ptr(),
+                                               x.B, x.H, x.W, x.C, Nn,
+                                               x1.rows.data_ptr() if x1 is not None else None, x1.C if x1 is not None else 0,
+                                               x2.rows.data_ptr() if x2 is not None else None, x2.C if x2 is not None else 0,
+                                               _dt(x.buf.dtype), _stream_ptr()))
         y.stats = _colstats_collect(armed)
         if tm is not None:
             k = 9 * x.C + (x1.C if x1 is not None else 0) + (x2.C if x2 is not None else 0)
@@ -618,8 +636,9 @@ def conv_up2x_pf(x: PF, w4: torch.Tensor, bias: Optional[torch.Tensor]) -> PF:
         _ensure_workspace(x.buf.device)
         e0 = tm.start() if tm is not None else None
         armed = _colstats_arm(x.B * x.H * x.W, Nn, x.buf.device, npar=4)
-        N.check(N.lib().gsw_conv_up2x_pf(x.rows.data_ptr(), w4.data_ptr(), bias.data_ptr() if bias is not None else None, y.rows.data_ptr(),
-                                         x.B, x.H, x.W, x.C, Nn, _dt(x.buf.dtype), _stream_ptr()))
+        with _colstats_scope(armed):
+            N.check(N.lib().gsw_conv_up2x_pf(x.rows.data_ptr(), w4.data_ptr(), bias.data_ptr() if bias is not None else None, y.rows.data_ptr(),
+                                             x.B, x.H, x.W, x.C, Nn, _dt(x.buf.dtype), _stream_ptr()))
         y.stats = _colstats_collect(armed, npar=4)
         if tm is not None:      # EXECUTED FLOPs (16 C MACs per output: four 2x2 convolutions); the 3x3-on-upsampled form it replaces is 2.25x that
             name = "gsw_mm_kernel(up2x)"

@@ -187,6 +187,21 @@ def test_argument_validation_of_eps_model_and_image_entry_points():
     assert lib.gsw_gemm_strided(p, 64, p, 64, None, None, 160, p, 100, 4, 64, 160, 0, 0, 0, 1, None) == UNS      # ldy % 8
     assert lib.gsw_gemm_strided(p, 64, p, 64, None, None, 160, p, 96, 4, 64, 160, 0, 0, 0, 1, None) == BAD       # ldy < N
     assert lib.gsw_gemm(None, p, None, None, p, 4, 64, 160, 0, 0, 0, 1, None) == BAD
+    assert lib.gsw_gemm_qkv(p, p, None, p, p, 256, 320, 600, 960, 128, 1, None) == UNS                           # a column tile must be of one kind
+    assert lib.gsw_gemm_qkv(p, p, None, p, None, 256, 320, 640, 960, 128, 1, None) == BAD                        # no transposed output
+    assert lib.gsw_gemm_qkv(p, p, None, p, p, 256, 320, 640, 960, 100, 1, None) == UNS                           # S % 8
+    # split-K workspace / column-statistics requests: per-thread state, validated without touching the device
+    assert lib.gsw_mm_set_workspace(None, 16, 0) == BAD and lib.gsw_mm_set_workspace(p, -1, 0) == BAD and lib.gsw_mm_set_workspace(p, 16, 65) == BAD
+    assert lib.gsw_mm_set_workspace(ctypes.c_void_p(72), 1024, 0) == BAD                                         # 16-byte alignment
+    assert lib.gsw_mm_set_workspace(p, 1 << 20, 0) == N.GSW_OK and lib.gsw_mm_set_workspace(None, 0, 0) == N.GSW_OK
+    assert lib.gsw_mm_next_colstats(None, 16) == BAD and lib.gsw_mm_next_colstats(ctypes.c_void_p(68), 16) == BAD
+    rows, blocks = ctypes.c_int(-1), ctypes.c_int(-1)
+    assert lib.gsw_mm_next_colstats(p, 1 << 10) == N.GSW_OK
+    assert lib.gsw_mm_last_colstats(ctypes.byref(rows), ctypes.byref(blocks)) == N.GSW_OK and rows.value == 0 and blocks.value == 0   # nothing launched; request cleared
+    assert lib.gsw_groupnorm_pf_cs(p, None, 0, p, 64, 1, 4, None, 0, 0, 0, p, p, p, p, 1, 8, 8, 330, 33, 1e-5, 1, 0, 1, None) == UNS  # C % 8
+    assert lib.gsw_groupnorm_pf_cs(p, None, 0, p, 64, 1, 4, None, 0, 0, 0, p, p, p, p, 1, 8, 8, 96, 32, 1e-5, 1, 0, 1, None) == UNS   # odd group width (column pairs)
+    assert lib.gsw_groupnorm_pf_cs(p, None, 0, p, 48, 1, 4, None, 0, 0, 0, p, p, p, p, 1, 8, 8, 320, 32, 1e-5, 1, 0, 1, None) == UNS  # 64 pixels per image, 48-row blocks
+    assert lib.gsw_groupnorm_pf_cs(p, None, 0, p, 64, 3, 4, None, 0, 0, 0, p, p, p, p, 1, 8, 8, 320, 32, 1e-5, 1, 0, 1, None) == BAD  # parity count
     assert lib.gsw_softmax_rows(p, 4, 100, 104, 1.0, 1, None) == UNS                                             # cols % 8
     assert lib.gsw_softmax_rows(p, 4, 128, 64, 1.0, 1, None) == BAD                                              # ld < cols
     assert lib.gsw_softmax_rows(p, 0, 128, 128, 1.0, 1, None) == N.GSW_OK
