@@ -621,6 +621,14 @@ static int launch_conv_gemm(ConvArgs& a, int64_t M, int N, int dtype, void* stre
 // GroupNorm statistics from the column records the producing engine launches left behind (MMArgs::colstats): per image, fold the image's row
 // blocks (and the four parity launches of a sub-pixel upsampler) per column in a fixed order, then the columns of every group -> the
 // [B][1][groups][2] (sum, sum of squares) record the apply kernel reads.  Two sources = the channel concatenation [x | x2].
+// Work split of the apply kernel: slabs of >= 4 P rows (one iteration of its four-rows-in-flight loop), ~2048 workgroups in total at most.  With one image
+// the 64-slab split of the statistics pass left 3/4 of the chip idle and every workgroup two dependent iterations long (18.8 us per launch at 64 x 64).
+static void gn_apply_slabs(int B, int HpWp, int P, int& nslab, int& slab_len) {
+    nslab = std::max(1, std::min((2048 + B - 1) / B, (HpWp + 4 * P - 1) / (4 * P)));
+    slab_len = (HpWp + nslab - 1) / nslab;
+    nslab = (HpWp + slab_len - 1) / slab_len;
+}
+
 struct GnColSrc { const float* cs; int32_t C, npar, bpi, nblk; };      // records [npar][nblk][2 planes: sums | sums of squares][C / 2 column pairs]
 // grid (B, ceil(C / 2 / 64)), 512 threads = 64 column pairs x 8 block lanes: lane j adds blocks j, j + 8, ... (independent loads in flight), the eight
 // lanes are folded in a fixed order -> pairsum[b][cp] = (sum, sum of squares) of columns 2 cp, 2 cp + 1 over image b.  The apply kernel folds the
@@ -675,9 +683,8 @@ int gsw_groupnorm_pf_cs(const void* x_dev, const void* x2_dev, int Ca, const flo
     const int P = std::max(1, 320 / cv);
     const int threads = cv * P;
     const int HpWp = (H + 2) * (W + 2);
-    int nslab = std::max(1, std::min(64, std::min((2048 + B - 1) / B, (HpWp + P - 1) / P)));
-    const int slab_len = (HpWp + nslab - 1) / nslab;
-    nslab = (HpWp + slab_len - 1) / slab_len;
+    int nslab, slab_len;
+    gn_apply_slabs(B, HpWp, P, nslab, slab_len);
     hipStream_t st = (hipStream_t)stream;
     const int bf = dtype == GSW_BF16;
     // workspace_dev: >= B * C floats here (the column-pair sums)
@@ -701,15 +708,17 @@ int gsw_groupnorm_pf2(const void* x_dev, const void* x2_dev, int Ca, const void*
     const int P = std::max(1, 320 / cv);
     const int threads = cv * P;
     const int HpWp = (H + 2) * (W + 2);
-    // enough workgroups to fill the chip: ~2048 in total, at most 64 slabs per image (workspace bound)
+    // statistics pass: enough workgroups to fill the chip (~2048 in total), at most 64 slabs per image (workspace bound)
     int nslab = std::max(1, std::min(64, std::min((2048 + B - 1) / B, (HpWp + P - 1) / P)));
     const int slab_len = (HpWp + nslab - 1) / nslab;
     nslab = (HpWp + slab_len - 1) / slab_len;
+    int nslab_a, slab_len_a;                 // the apply pass splits the image on its own (one image: up to ~140 workgroups of one iteration each)
+    gn_apply_slabs(B, HpWp, P, nslab_a, slab_len_a);
     hipStream_t st = (hipStream_t)stream;
     const int bf = dtype == GSW_BF16;
     hipLaunchKernelGGL(gsw_gn_pf_stats_kernel, dim3(nslab, B), dim3(threads), 0, st, (const uint16_t*)x_dev, (const uint16_t*)x2_dev, Ca, workspace_dev, C, groups, HpWp, slab_len, P, bf);
-    hipLaunchKernelGGL(gsw_gn_pf_apply_kernel, dim3(nslab, B), dim3(threads), 0, st, (const uint16_t*)x_dev, (const uint16_t*)x2_dev, Ca, (const float*)workspace_dev, (const uint16_t*)gamma_dev,
-                       (const uint16_t*)beta_dev, (uint16_t*)out_dev, C, groups, H + 2, W + 2, nslab, slab_len, P, eps, act, out_tokens, bf);
+    hipLaunchKernelGGL(gsw_gn_pf_apply_kernel, dim3(nslab_a, B), dim3(threads), 0, st, (const uint16_t*)x_dev, (const uint16_t*)x2_dev, Ca, (const float*)workspace_dev, (const uint16_t*)gamma_dev,
+                       (const uint16_t*)beta_dev, (uint16_t*)out_dev, C, groups, H + 2, W + 2, nslab, slab_len_a, P, eps, act, out_tokens, bf);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g_conv_hip_error = (int)e; return GSW_ERR_HIP; }
     return GSW_OK;
