@@ -64,6 +64,10 @@ template <> struct MM<_Float16> {
         typedef _Float16 h2 __attribute__((ext_vector_type(2)));
         return __builtin_bit_cast(uint32_t, __builtin_bit_cast(h2, a) * __builtin_bit_cast(h2, b));
     }
+    static __device__ __forceinline__ uint32_t add2(uint32_t a, uint32_t b) {  // v_pk_add_f16: the correctly rounded sum of two fp16 values = cvt(up(a) + up(b)), two at a time
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        return __builtin_bit_cast(uint32_t, __builtin_bit_cast(h2, a) + __builtin_bit_cast(h2, b));
+    }
     // (sum, sum of squares) of a packed pair into fp32 accumulators: two v_dot2_f32_f16 (exact products, fp32 accumulation)
     static __device__ __forceinline__ void stat2(uint32_t w, float& sm, float& sq) {
         typedef _Float16 h2 __attribute__((ext_vector_type(2)));
@@ -89,6 +93,7 @@ template <> struct MM<__bf16> {
     static __device__ __forceinline__ uint32_t mul2(uint32_t a, uint32_t b) {  // bf16 x bf16 is exact in fp32: one rounding, like a bf16 multiply
         return cvt2(up_lo(a) * up_lo(b), up_hi(a) * up_hi(b));
     }
+    static __device__ __forceinline__ uint32_t add2(uint32_t a, uint32_t b) { return cvt2(up_lo(a) + up_lo(b), up_hi(a) + up_hi(b)); }
     static __device__ __forceinline__ void stat2(uint32_t w, float& sm, float& sq) {
         const float lo = up_lo(w), hi = up_hi(w);
         sm += lo + hi;
@@ -551,9 +556,7 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
                     if (resid) {
                         const uint32_t rsw[4] = {rs[in][pr].x, rs[in][pr].y, rs[in][pr].z, rs[in][pr].w};
 #pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            w4[k] = MM<T>::cvt2(MM<T>::up((uint16_t)w4[k]) + MM<T>::up((uint16_t)rsw[k]),
-                                                MM<T>::up((uint16_t)(w4[k] >> 16)) + MM<T>::up((uint16_t)(rsw[k] >> 16)));
+                        for (int k = 0; k < 4; ++k) w4[k] = MM<T>::add2(w4[k], rsw[k]);           // one rounding of the exact sum, as before
                     }
                     if (live[pr] && colb + in * 16 < p.N) *reinterpret_cast<uint4*>(yrow[pr] + in * 16) = make_uint4(w4[0], w4[1], w4[2], w4[3]);      // the last N tile may be partial
                 }
@@ -617,6 +620,10 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
                         if (rowbias) rb = *reinterpret_cast<const uint4*>(rowbias + (int64_t)img_b[pr] * p.ldrb + col);
                         if (resid) rs = *reinterpret_cast<const uint4*>(resid + orow[pr] * p.ldr + col);
                         const uint32_t rbw[4] = {rb.x, rb.y, rb.z, rb.w}, rsw[4] = {rs.x, rs.y, rs.z, rs.w};
+                        if (!(rowbias && resid)) {      // one addend (the usual case: conv1 has the row bias, conv2 / the token scatter the residual): a packed add
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) w4[k] = MM<T>::add2(w4[k], rowbias ? rbw[k] : rsw[k]);
+                        } else
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             const float f0 = MM<T>::up((uint16_t)w4[k]) + MM<T>::up((uint16_t)rbw[k]) + MM<T>::up((uint16_t)rsw[k]);
