@@ -559,7 +559,7 @@ static int launch_engine(const ConvArgs& a, int64_t M, int N, int dtype, void* s
     const bool whole = !a.up && a.stride == 1 && M <= 8192;
     m.M = whole ? (int32_t)M : B * (a.Hp - 2) * (a.Wp - 2); m.N = N;
     m.flags = whole ? MM_FLAG_NONE : MM_FLAG_COMPACT;
-    m.bias = a.bias; m.rowbias = a.rowbias; m.resid = a.resid; m.y = a.y; m.colstats = nullptr; m.y2 = nullptr; m.n_rows = 0;
+    m.bias = a.bias; m.rowbias = a.rowbias; m.resid = a.resid; m.y = a.y; m.colstats = nullptr; m.y2 = nullptr; m.n_rows = 0; m.ln_stat = nullptr; m.ln_u = nullptr; m.ln_v = nullptr;
     m.ldy = N; m.ldr = N; m.ldrb = a.ldrb;
     m.mode = a.up ? MM_MODE_UP2X : MM_MODE_PF;
     m.Hp = a.Hp; m.Wp = a.Wp; m.in_Hp = a.in_Hp; m.in_Wp = a.in_Wp; m.stride = a.stride; m.S = 1; m.Wimg = 1; m.up = a.up;

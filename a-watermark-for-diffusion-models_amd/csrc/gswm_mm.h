@@ -43,6 +43,12 @@ struct MMArgs {
     int32_t splits;       // filled by gsw_mm_launch: > 1 = split-K (the K stages of a tile are shared by `splits` workgroups, fp32 partials in ws)
     float* colstats;      // EPI 1 only, or null: per 16 MT-row block and output column PAIR the sum and the sum of squares of the STORED values,
                           // [blocks = 4 tiles_m][2 planes][N / 2] floats -- GroupNorm statistics of the output without another pass over it
+    // LayerNorm folded into the GEMM (LNF kernels; dense / GEGLU / transposed modes): y = rstd_m (x W'^T)_mn + nrm_m u_n + v_n with W' = W diag(gamma),
+    // u = W' 1, v = W beta + bias, (rstd_m, nrm_m = -rstd_m mean_m) per row of x
+    const void* ln_stat;  // float2 [M] or null
+    const float* ln_u;    // [N]
+    const float* ln_v;    // [N]
+    float* rowstats;      // EPI 0 only, or null: per output row and 80-column half tile the (sum, sum of squares) of the STORED values, [M][2 tiles_n][2] floats
     float* ws;            // filled by gsw_mm_launch: split-K workspace, [splits][ntiles][8 waves][5 * MT accumulators][64 lanes] float4
 };
 

@@ -154,8 +154,9 @@ __device__ __forceinline__ float mm_dpp_add(float x) {
 // multiplying wave's stream costs more than the relief it gives the producers.)
 // MT: 16-row MFMA tiles per wave along M: 4 -> the 256 x 160 tile; 2 -> a 128 x 160 tile for launches whose 256-row tiling would leave CUs without
 // a tile (the 8 x 8 level at batch 64, everything deep at batch 8).
-template <typename T, int EPI, bool SPLIT, int MT>
+template <typename T, int EPI, bool SPLIT, int MT, bool LNF = false>
 __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kernel(const MMArgs p) {
+    static_assert(!LNF || (!SPLIT && (EPI == 0 || EPI == 2 || EPI == 3)), "LayerNorm-folded epilogues: dense rows, GEGLU, transposed; 8-wave form");
     constexpr bool SWAP = EPI == 3;
     // EPI 5 (self-attention q | k | v from ONE pass over the tokens): column tiles below p.n_rows are dense rows (EPI 0), the others the transposed value
     // projection (EPI 3: MFMA operands swapped) -- decided per tile, the step loop exists in both forms
@@ -487,9 +488,70 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
             ++c_it;
             return;
         }
-        auto pack4 = [&](const mm_f4& a, const float (&b)[4], uint32_t& lo, uint32_t& hi) {
-            lo = MM<T>::cvt2(a[0] + b[0], a[1] + b[1]);
-            hi = MM<T>::cvt2(a[2] + b[2], a[3] + b[3]);
+        // LNF: per-row (rstd, nrm) of this lane's rows and the fp32 column vectors u, v replace the bias: value = rstd acc + nrm u + v
+        float ln_r[SWAP ? 4 * MT : MT], ln_n[SWAP ? 4 * MT : MT];
+        mm_f4 ln_u4[5], ln_v4[5];
+        if constexpr (LNF) {
+            const float2* st = reinterpret_cast<const float2*>(p.ln_stat);
+            if constexpr (!SWAP) {
+#pragma unroll
+                for (int im = 0; im < MT; ++im) {
+                    const int32_t m = m0 + (int32_t)(wm * (16u * MT) + (uint32_t)im * 16u + li);
+                    const float2 v = st[m < p.M ? m : p.M - 1];
+                    ln_r[im] = v.x; ln_n[im] = v.y;
+                }
+#pragma unroll
+                for (int in = 0; in < 5; ++in) {
+                    const int32_t nb = n0 + (int32_t)(grp * HC + (uint32_t)in * 16u + q * 4u);
+                    const int32_t nc = nb < p.N ? nb : 0;
+                    ln_u4[in] = *reinterpret_cast<const mm_f4*>(p.ln_u + nc);
+                    ln_v4[in] = *reinterpret_cast<const mm_f4*>(p.ln_v + nc);
+                }
+            } else {
+#pragma unroll
+                for (int im = 0; im < MT; ++im) {
+                    const int32_t m = m0 + (int32_t)(wm * (16u * MT) + (uint32_t)im * 16u + q * 4u);       // four consecutive tokens (M % 8 == 0)
+                    const int32_t mc = m + 3 < p.M ? m : 0;
+                    const mm_f4 a = *reinterpret_cast<const mm_f4*>(st + mc), b = *reinterpret_cast<const mm_f4*>(st + mc + 2);
+                    ln_r[4 * im] = a[0]; ln_n[4 * im] = a[1]; ln_r[4 * im + 1] = a[2]; ln_n[4 * im + 1] = a[3];
+                    ln_r[4 * im + 2] = b[0]; ln_n[4 * im + 2] = b[1]; ln_r[4 * im + 3] = b[2]; ln_n[4 * im + 3] = b[3];
+                }
+#pragma unroll
+                for (int in = 0; in < 5; ++in) {
+                    const int32_t ncol = n0 + (int32_t)(grp * HC + (uint32_t)in * 16u + li);
+                    const int32_t nc = ncol < p.N ? ncol : 0;
+                    ln_u4[in] = mm_f4{p.ln_u[nc], 0.f, 0.f, 0.f};
+                    ln_v4[in] = mm_f4{p.ln_v[nc], 0.f, 0.f, 0.f};
+                }
+            }
+        }
+        // the four values of accumulator (in, im) as they are rounded and stored: acc + bias, or the LayerNorm-folded form
+        auto vals4 = [&](int in, int im, const float (&b)[4], float (&o)[4]) {
+            const mm_f4& a = acc[in][im];
+            if constexpr (LNF) {
+                if constexpr (!SWAP) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = fmaf(a[j], ln_r[im], fmaf(ln_n[im], ln_u4[in][j], ln_v4[in][j]));
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = fmaf(a[j], ln_r[4 * im + j], fmaf(ln_n[4 * im + j], ln_u4[in][0], ln_v4[in][0]));
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = a[j] + b[j];
+            }
+        };
+        auto pack4 = [&](int in, int im, const float (&b)[4], uint32_t& lo, uint32_t& hi) {
+            if constexpr (LNF) {
+                float o[4];
+                vals4(in, im, b, o);
+                lo = MM<T>::cvt2(o[0], o[1]);
+                hi = MM<T>::cvt2(o[2], o[3]);
+            } else {
+                const mm_f4& a = acc[in][im];
+                lo = MM<T>::cvt2(a[0] + b[0], a[1] + b[1]);
+                hi = MM<T>::cvt2(a[2] + b[2], a[3] + b[3]);
+            }
         };
         // bias of this lane's own accumulator columns, all five column blocks up front (one wait, not one per block)
         uint2 bq_raw[5];
@@ -497,7 +559,7 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
         for (int in = 0; in < 5; ++in) {
             bq_raw[in] = make_uint2(0, 0);
             const int32_t nb = n0 + (int32_t)(grp * HC + (uint32_t)in * 16u + q * 4u);       // N % 8 == 0: a 4-column group is inside N or outside
-            if (!transposed && bias && nb < p.N) bq_raw[in] = *reinterpret_cast<const uint2*>(bias + nb);
+            if (!LNF && !transposed && bias && nb < p.N) bq_raw[in] = *reinterpret_cast<const uint2*>(bias + nb);
         }
         auto bias4 = [&](int in, float (&bq)[4]) {
             bq[0] = MM<T>::up((uint16_t)bq_raw[in].x); bq[1] = MM<T>::up((uint16_t)(bq_raw[in].x >> 16));
@@ -527,6 +589,8 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
             }
             // residual chunks are fetched RSD column blocks ahead of their use: all five up front on the 8-wave variant, two on the 12-wave one
             // (168 registers: 80 accumulators + the next tile's 36 fragment registers are live here)
+            const bool rstat = EPI == 0 && p.rowstats != nullptr;
+            float rs_s[2] = {0.f, 0.f}, rs_q[2] = {0.f, 0.f};
             constexpr int RSD = SPLIT ? 2 : 5;
             uint4 rs[5][2];
             auto load_rs = [&](int in) {
@@ -548,8 +612,8 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
 #pragma unroll
                 for (int pr = 0; pr < NPR; ++pr) {
                     uint32_t a0, a1, b0, b1;
-                    pack4(acc[in][2 * pr], bq, a0, a1);
-                    pack4(acc[in][2 * pr + 1], bq, b0, b1);
+                    pack4(in, 2 * pr, bq, a0, a1);
+                    pack4(in, 2 * pr + 1, bq, b0, b1);
                     swap16(a0, b0);
                     swap16(a1, b1);
                     uint32_t w4[4] = {a0, a1, b0, b1};
@@ -558,7 +622,25 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
 #pragma unroll
                         for (int k = 0; k < 4; ++k) w4[k] = MM<T>::add2(w4[k], rsw[k]);           // one rounding of the exact sum, as before
                     }
-                    if (live[pr] && colb + in * 16 < p.N) *reinterpret_cast<uint4*>(yrow[pr] + in * 16) = make_uint4(w4[0], w4[1], w4[2], w4[3]);      // the last N tile may be partial
+                    if (live[pr] && colb + in * 16 < p.N) {
+                        *reinterpret_cast<uint4*>(yrow[pr] + in * 16) = make_uint4(w4[0], w4[1], w4[2], w4[3]);      // the last N tile may be partial
+                        if (rstat) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) MM<T>::stat2(w4[k], rs_s[pr], rs_q[pr]);
+                        }
+                    }
+                }
+            }
+            // Row statistics for the LayerNorm that consumes this output (p.rowstats): (sum, sum of squares) of the stored values of each row over this
+            // wave's 80 columns; one v_permlane32_swap + add folds the two 8-column halves of a lane pair, lanes < 32 then hold sums, lanes >= 32 squares
+            if (rstat) {
+#pragma unroll
+                for (int pr = 0; pr < NPR; ++pr) {
+                    uint32_t a = __float_as_uint(rs_s[pr]), b = __float_as_uint(rs_q[pr]);
+                    swap32(a, b);
+                    const float t = __uint_as_float(a) + __uint_as_float(b);
+                    const int32_t m = m0 + (int32_t)(wm * (16u * MT) + (uint32_t)(2 * pr + (int)(q & 1u)) * 16u + li);
+                    if (m < p.M) p.rowstats[((int64_t)m * (2 * p.tiles_n) + 2 * tile_n + (int32_t)grp) * 2 + (int32_t)(lane >> 5)] = t;
                 }
             }
         } else if (EPI == 1) {
@@ -608,8 +690,8 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
 #pragma unroll
                 for (int pr = 0; pr < NPR; ++pr) {
                     uint32_t a0, a1, b0, b1;
-                    pack4(acc[in][2 * pr], bq, a0, a1);
-                    pack4(acc[in][2 * pr + 1], bq, b0, b1);
+                    pack4(in, 2 * pr, bq, a0, a1);
+                    pack4(in, 2 * pr + 1, bq, b0, b1);
                     swap16(a0, b0);
                     swap16(a1, b1);
                     if (!live[pr] || col >= p.N) continue;
@@ -620,15 +702,11 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
                         if (rowbias) rb = *reinterpret_cast<const uint4*>(rowbias + (int64_t)img_b[pr] * p.ldrb + col);
                         if (resid) rs = *reinterpret_cast<const uint4*>(resid + orow[pr] * p.ldr + col);
                         const uint32_t rbw[4] = {rb.x, rb.y, rb.z, rb.w}, rsw[4] = {rs.x, rs.y, rs.z, rs.w};
-                        if (!(rowbias && resid)) {      // one addend (the usual case: conv1 has the row bias, conv2 / the token scatter the residual): a packed add
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) w4[k] = MM<T>::add2(w4[k], rowbias ? rbw[k] : rsw[k]);
-                        } else
+                        // packed adds, rounded like the separate tensor adds they replace (conv1 has the row bias, conv2 / the token scatter the residual)
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
-                            const float f0 = MM<T>::up((uint16_t)w4[k]) + MM<T>::up((uint16_t)rbw[k]) + MM<T>::up((uint16_t)rsw[k]);
-                            const float f1 = MM<T>::up((uint16_t)(w4[k] >> 16)) + MM<T>::up((uint16_t)(rbw[k] >> 16)) + MM<T>::up((uint16_t)(rsw[k] >> 16));
-                            w4[k] = (uint32_t)MM<T>::cvt(f0) | ((uint32_t)MM<T>::cvt(f1) << 16);
+                            if (rowbias) w4[k] = MM<T>::add2(w4[k], rbw[k]);
+                            if (resid) w4[k] = MM<T>::add2(w4[k], rsw[k]);
                         }
                     }
                     *reinterpret_cast<uint4*>(Y + orow[pr] * p.ldy + col) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
@@ -672,8 +750,8 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
                 uint32_t Wv[MT];                              // per row tile im: outputs 4 qv + 2 (lane >> 5) + {0, 1}, packed
 #pragma unroll
                 for (int im = 0; im < MT; ++im) {
-                    uint32_t A = MM<T>::cvt2(acc[in][im][0] + bq[0], acc[in][im][1] + bq[1]);
-                    uint32_t Bp = MM<T>::cvt2(acc[in][im][2] + bq[2], acc[in][im][3] + bq[3]);
+                    uint32_t A, Bp;
+                    pack4(in, im, bq, A, Bp);
                     swap32(A, Bp);                            // lanes < 32: A = values 0, 1, Bp = gates 0, 1; lanes >= 32: values 2, 3 and gates 2, 3
                     const uint32_t G = MM<T>::cvt2(mm_gelu(MM<T>::up_lo(Bp)), mm_gelu(MM<T>::up_hi(Bp)));
                     Wv[im] = MM<T>::mul2(A, G);
@@ -714,13 +792,13 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
                 const int32_t ncol = n0 + (int32_t)(grp * HC + (uint32_t)in * 16u + li);
                 const int32_t nrow = ncol - nbase;
                 const bool nok = ncol < p.N;
-                const float bv = bias && nok ? MM<T>::up(bias[ncol]) : 0.f;
+                const float bv = !LNF && bias && nok ? MM<T>::up(bias[ncol]) : 0.f;
                 const float bq[4] = {bv, bv, bv, bv};
 #pragma unroll
                 for (int pr = 0; pr < NPR; ++pr) {
                     uint32_t a0, a1, b0, b1;
-                    pack4(acc[in][2 * pr], bq, a0, a1);
-                    pack4(acc[in][2 * pr + 1], bq, b0, b1);
+                    pack4(in, 2 * pr, bq, a0, a1);
+                    pack4(in, 2 * pr + 1, bq, b0, b1);
                     swap16(a0, b0);
                     swap16(a1, b1);
                     const int32_t m = m0 + (int32_t)(wm * (16u * MT) + (uint32_t)(2 * pr + (int)(q & 1u)) * 16u + (q >> 1) * 8u);      // first of 8 consecutive tokens
@@ -945,22 +1023,27 @@ __global__ __launch_bounds__(256) void gsw_mm_reduce_kernel(const MMArgs p, cons
 }
 
 // host ---------------------------------------------------------------------------------------------
-template <typename T, int EPI, bool SPLIT, int MT>
+template <typename T, int EPI, bool SPLIT, int MT, bool LNF = false>
 int mm_launch_k(const MMArgs& a, uint32_t grid, hipStream_t st) {
     static bool attr_done = false;          // benign race: setting the attribute twice is harmless
     constexpr size_t ldsb = 3u * (size_t)(64 * MT + 160) * 128u;       // the three-stage ring
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)gsw_mm_kernel<T, EPI, SPLIT, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)gsw_mm_kernel<T, EPI, SPLIT, MT, LNF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((gsw_mm_kernel<T, EPI, SPLIT, MT>), dim3(grid), dim3(SPLIT ? 768 : 512), ldsb, st, a);
+    hipLaunchKernelGGL((gsw_mm_kernel<T, EPI, SPLIT, MT, LNF>), dim3(grid), dim3(SPLIT ? 768 : 512), ldsb, st, a);
     return (int)hipGetLastError();
 }
 template <typename T, int EPI>
 int mm_launch_t(const MMArgs& a, uint32_t grid, int mt, hipStream_t st) {
     if constexpr (EPI == 5) return mt == 4 ? mm_launch_k<T, 5, false, 4>(a, grid, st) : mm_launch_k<T, 5, false, 2>(a, grid, st);      // dense epilogues: 8-wave form
     else {
+    if (a.ln_stat) {                      // LayerNorm folded into the epilogue: dense rows / GEGLU / transposed, 8-wave form
+        if constexpr (EPI == 0 || EPI == 2 || EPI == 3)
+            return mt == 4 ? mm_launch_k<T, EPI, false, 4, true>(a, grid, st) : mm_launch_k<T, EPI, false, 2, true>(a, grid, st);
+        else return (int)hipErrorInvalidValue;
+    }
     // bit e of the split mask set = epilogue kind e runs the 12-wave variant whose waves 8-11 own the LDS-DMA (gsw_mm_config / GSW_MM_SPLIT: A/B switch)
     const bool split = (g_mm_split_mask.load(std::memory_order_relaxed) >> EPI) & 1;
     if (mt == 4) return split ? mm_launch_k<T, EPI, true, 4>(a, grid, st) : mm_launch_k<T, EPI, false, 4>(a, grid, st);
@@ -1020,6 +1103,25 @@ float* gsw_mm_take_colstats(int64_t* capacity_floats) {
 }
 void gsw_mm_give_colstats(float* dev, int64_t capacity_floats) { t_cs_next = dev; t_cs_cap = dev ? capacity_floats : 0; }
 
+// Row statistics (MMArgs::rowstats): the same one-shot protocol for the dense-row launches whose output a LayerNorm consumes
+static thread_local float* t_rs_next = nullptr;
+static thread_local int64_t t_rs_cap = 0;
+static thread_local int t_rs_slots = 0;
+
+int gsw_mm_next_rowstats(float* stats_dev, int64_t capacity_floats) {
+    if (capacity_floats < 0 || (capacity_floats > 0 && !stats_dev) || ((uintptr_t)stats_dev & 7)) return GSW_ERR_BAD_ARG;
+    t_rs_next = capacity_floats > 0 ? stats_dev : nullptr;
+    t_rs_cap = t_rs_next ? capacity_floats : 0;
+    t_rs_slots = 0;
+    return GSW_OK;
+}
+
+int gsw_mm_last_rowstats(int* slots) {
+    if (slots) *slots = t_rs_slots;
+    t_rs_next = nullptr; t_rs_cap = 0;
+    return GSW_OK;
+}
+
 int gsw_mm_next_colstats(float* stats_dev, int64_t capacity_floats) {
     if (capacity_floats < 0 || (capacity_floats > 0 && !stats_dev) || ((uintptr_t)stats_dev & 15)) return GSW_ERR_BAD_ARG;
     gsw_mm_give_colstats(capacity_floats > 0 ? stats_dev : nullptr, capacity_floats);
@@ -1062,10 +1164,16 @@ int gsw_mm_launch(MMArgs& a, int dtype, void* stream) {
     float* cs_req = gsw_mm_take_colstats(&cs_cap);
     a.colstats = nullptr;
     t_cs_rows = 0; t_cs_blocks = 0;
+    float* rs_req = t_rs_next;
+    const int64_t rs_cap = t_rs_cap;
+    t_rs_next = nullptr; t_rs_cap = 0; t_rs_slots = 0;
+    a.rowstats = nullptr;
+    if (a.ln_stat && (a.mode != MM_MODE_DENSE && a.mode != MM_MODE_GEGLU && a.mode != MM_MODE_TRANS)) return GSW_ERR_UNSUPPORTED;
+    if (a.ln_stat && a.rowbias) return GSW_ERR_UNSUPPORTED;
     // Split-K for launches that cannot fill the chip with output tiles (the deep levels at small batch: 8 x 8 pixels of one image are ONE row tile
     // against 180-360 K stages): `splits` workgroups share a tile's stages, fp32 partials go through the caller's workspace, a second small kernel
     // adds them in a fixed order and runs the epilogue.  Needs a workspace (gsw_mm_set_workspace); without one the launch runs unsplit.
-    if (t_mm_ws && t_mm_max_splits != 1) {
+    if (t_mm_ws && t_mm_max_splits != 1 && !a.ln_stat) {
         const int bm_s = 128;
         const int64_t nt = (((int64_t)a.M + bm_s - 1) / bm_s) * tiles_n;
         int splits = 1;
@@ -1097,6 +1205,11 @@ int gsw_mm_launch(MMArgs& a, int dtype, void* stream) {
     a.tiles_n = (int32_t)tiles_n;
     a.ntiles = (int32_t)(tiles_m * tiles_n);
     const uint32_t grid = (uint32_t)std::min<int64_t>(256, (a.ntiles + 7) / 8 * 8);
+    // row statistics: plain dense-row launches (EPI 0), unsplit
+    if (rs_req && a.mode == MM_MODE_DENSE && !a.rowbias && !a.ln_stat && (int64_t)a.M * 2 * tiles_n * 2 <= rs_cap) {
+        a.rowstats = rs_req;
+        t_rs_slots = (int)(2 * tiles_n);
+    }
     // column statistics: EPI 1 launches whose M dimension enumerates real pixels / tokens (interior enumeration or the token scatter), unsplit
     if (cs_req && (a.mode == MM_MODE_TOK2PF || ((a.mode == MM_MODE_PF || a.mode == MM_MODE_UP2X) && (a.flags & MM_FLAG_COMPACT)))
         && tiles_m * 4 * (int64_t)a.N <= cs_cap) {
@@ -1127,6 +1240,7 @@ int gsw_gemm_strided(const void* x_dev, int64_t ldx, const void* w_dev, int64_t 
     a.w = w_dev; a.ldw = (int32_t)ldw;
     a.M = (int32_t)M; a.N = N;
     a.bias = bias_dev; a.rowbias = nullptr; a.resid = resid_dev; a.y = y_dev; a.colstats = nullptr; a.y2 = nullptr; a.n_rows = 0;
+    a.ln_stat = nullptr; a.ln_u = nullptr; a.ln_v = nullptr;
     a.ldy = (int32_t)ldy; a.ldr = (int32_t)ldr; a.ldrb = N;
     a.Hp = 1; a.Wp = 1; a.in_Hp = 1; a.in_Wp = 1; a.stride = 1; a.S = S > 0 ? S : 1; a.Wimg = Wimg > 0 ? Wimg : 1; a.up = 0; a.flags = MM_FLAG_NONE;
     a.mode = MM_MODE_DENSE;
@@ -1148,9 +1262,54 @@ int gsw_gemm_qkv(const void* x_dev, const void* w_dev, const void* bias_dev, voi
     a.w = w_dev; a.ldw = K;
     a.M = (int32_t)M; a.N = N;
     a.bias = bias_dev; a.rowbias = nullptr; a.resid = nullptr; a.y = rows_dev; a.colstats = nullptr; a.y2 = trans_dev; a.n_rows = N_rows;
+    a.ln_stat = nullptr; a.ln_u = nullptr; a.ln_v = nullptr;
     a.ldy = N_rows; a.ldr = N_rows; a.ldrb = N;
     a.Hp = 1; a.Wp = 1; a.in_Hp = 1; a.in_Wp = 1; a.stride = 1; a.S = S; a.Wimg = 1; a.up = 0; a.flags = MM_FLAG_NONE;
     a.mode = MM_MODE_QKV;
+    return gsw_mm_launch(a, dtype, stream);
+}
+
+// Row records [M][slots][2] (sum, sum of squares per 80-column half tile) -> (rstd, -rstd * mean) per row, the form the LayerNorm-folded epilogues read
+__global__ __launch_bounds__(256) void gsw_ln_rowstats_finish_kernel(const float2* __restrict__ rec, int32_t slots, int64_t M, float inv_c, float eps, float2* __restrict__ out) {
+    const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    float s = 0.f, q = 0.f;
+    for (int32_t k = 0; k < slots; ++k) { const float2 v = rec[m * slots + k]; s += v.x; q += v.y; }
+    const float mean = s * inv_c;
+    const float var = fmaxf(q * inv_c - mean * mean, 0.f);
+    const float rstd = rsqrtf(var + eps);
+    out[m] = make_float2(rstd, -rstd * mean);
+}
+
+int gsw_ln_rowstats_finish(const float* records_dev, int slots, int64_t M, int C, float eps, float* stat_dev, void* stream) {
+    if (!records_dev || !stat_dev || slots <= 0 || M <= 0 || C <= 0) return GSW_ERR_BAD_ARG;
+    hipLaunchKernelGGL(gsw_ln_rowstats_finish_kernel, dim3((uint32_t)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float2*>(records_dev), slots, M,
+                       1.0f / (float)C, eps, reinterpret_cast<float2*>(stat_dev));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { g_last_hip_error = (int)e; return GSW_ERR_HIP; }
+    return GSW_OK;
+}
+
+int gsw_gemm_ln(const void* x_dev, const float* ln_stat_dev, const void* w_dev, const float* u_dev, const float* v_dev, void* y_dev, int64_t M, int K, int N,
+                int mode, int S, int dtype, void* stream) {
+    // y = LayerNorm(x) W^T + b without materialising LayerNorm(x): w_dev = W diag(gamma) [N][K], u = (row sums of w_dev), v = W beta + b (fp32 [N]),
+    // ln_stat_dev float2 [M] = (rstd, -rstd * mean) of the rows of x (gsw_ln_rowstats_finish).  mode: GSW_GEMM_PLAIN / GEGLU (packed rows) / TRANS.
+    if (!x_dev || !ln_stat_dev || !w_dev || !u_dev || !v_dev || !y_dev || M <= 0 || K <= 0 || N <= 0) return GSW_ERR_BAD_ARG;
+    if (mode != GSW_GEMM_PLAIN && mode != GSW_GEMM_GEGLU && mode != GSW_GEMM_TRANS) return GSW_ERR_BAD_ARG;
+    if (K % 64 || N % 8 || (mode == GSW_GEMM_GEGLU && N % 160) || (M & 7) || M > 0x7FFFFF00 || M * (int64_t)K >= ((int64_t)1 << 40) || (int64_t)N * K >= ((int64_t)1 << 31)) return GSW_ERR_UNSUPPORTED;
+    if (mode == GSW_GEMM_TRANS && (S <= 0 || (S & 7) || M % S)) return GSW_ERR_UNSUPPORTED;
+    if (((uintptr_t)u_dev | (uintptr_t)v_dev | (uintptr_t)ln_stat_dev) & 15) return GSW_ERR_BAD_ARG;
+    MMArgs a;
+    for (int i = 0; i < 3; ++i) a.seg[i] = MMSeg{x_dev, K, K / 64, 1, 1, 0, 0, 0};
+    a.nseg = 1; a.P = K / 64;
+    a.w = w_dev; a.ldw = K;
+    a.M = (int32_t)M; a.N = N;
+    a.bias = nullptr; a.rowbias = nullptr; a.resid = nullptr; a.y = y_dev; a.colstats = nullptr; a.y2 = nullptr; a.n_rows = 0;
+    a.ln_stat = ln_stat_dev; a.ln_u = u_dev; a.ln_v = v_dev;
+    const int ncols = mode == GSW_GEMM_GEGLU ? N / 2 : N;
+    a.ldy = ncols; a.ldr = ncols; a.ldrb = N;
+    a.Hp = 1; a.Wp = 1; a.in_Hp = 1; a.in_Wp = 1; a.stride = 1; a.S = S > 0 ? S : 1; a.Wimg = 1; a.up = 0; a.flags = MM_FLAG_NONE;
+    a.mode = mode == GSW_GEMM_GEGLU ? MM_MODE_GEGLU : mode == GSW_GEMM_TRANS ? MM_MODE_TRANS : MM_MODE_DENSE;
     return gsw_mm_launch(a, dtype, stream);
 }
 

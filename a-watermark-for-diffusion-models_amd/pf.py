@@ -423,7 +423,8 @@ def _same(t: Optional[torch.Tensor], like: torch.Tensor, name: str, numel: Optio
 
 
 def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, resid: Optional[torch.Tensor] = None, mode: str = "plain",
-         tokens: int = 0, width: int = 0, out: Optional[torch.Tensor] = None, stats_for: Optional["PF"] = None) -> torch.Tensor:
+         tokens: int = 0, width: int = 0, out: Optional[torch.Tensor] = None, stats_for: Optional["PF"] = None,
+         rowstats: bool = False) -> torch.Tensor:
     """x[..., K] @ w[N, K]^T + bias on the matmul engine (csrc/gswm_mm.hip).
     mode "plain":  -> [..., N] (+ resid[..., N]);  "geglu": pf.pack_geglu_weight operands -> [..., N/2] = value * gelu(gate);
     "trans": x is [B, S, K] -> [B, N, S] (tokens = S);  "tok2pf": rows are tokens of `tokens`-pixel images of width `width`, `out` is the
@@ -464,14 +465,105 @@ def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
         e0 = tm.start() if tm is not None else None
         # stats_for (tok2pf): the PF tensor whose payload this launch writes -- it gets the launch's column records (or None)
         armed = _colstats_arm(M, Nn, x.device) if (stats_for is not None and mode == "tok2pf") else None
-        with _colstats_scope(armed):
+        rs_buf = None
+        if rowstats and mode == "plain" and FOLD_LN:
+            # row records for the LayerNorm that consumes this output (gsw_mm_next_rowstats): [M][2 * ceil(N / 160)][2] floats
+            rs_buf = torch.empty(M * 2 * ((Nn + 159) // 160) * 2, dtype=torch.float32, device=x.device)
+            N.check(N.lib().gsw_mm_next_rowstats(rs_buf.data_ptr(), rs_buf.numel()))
+        with _colstats_scope(armed), _rowstats_scope(rs_buf):
             N.check(N.lib().gsw_gemm(x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None,
                                      resid.data_ptr() if resid is not None else None, y.data_ptr(), M, K, Nn, m, tokens, width,
                                      _dt(x.dtype), _stream_ptr()))
         if stats_for is not None:
             stats_for.stats = _colstats_collect(armed)
+        if rs_buf is not None:
+            import ctypes as C
+            slots = C.c_int(0)
+            N.check(N.lib().gsw_mm_last_rowstats(C.byref(slots)))
+            if slots.value > 0:
+                y._gsw_rowstats = (rs_buf, slots.value)          # rides on the output tensor; in-place edits of y must drop it
         if tm is not None:
             tm.stop(e0, ("gsw_mm_kernel", M, K, Nn, mode) if tm.by_shape else "gsw_mm_kernel", 2.0 * M * K * Nn)
+    return y
+
+
+# ---- LayerNorm folded into the consuming GEMM (gsw_gemm_ln): LN(x) W^T + b = rstd (x W'^T) + nrm u + v, W' = W diag(gamma), u = W' 1, v = W beta + b
+FOLD_LN = True
+FOLD_LN_MIN_ROWS = 16384       # below that the consumers would rather take the split-K form, which the folded epilogue does not have
+
+
+class _rowstats_scope:
+    def __init__(self, buf):
+        self.buf = buf
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, et, ev, tb):
+        if et is not None and self.buf is not None:
+            N.lib().gsw_mm_last_rowstats(None)
+        return False
+
+
+def ln_stat(x: torch.Tensor, eps: float) -> Optional[torch.Tensor]:
+    """(rstd, -rstd * mean) per row of x [.., C] from the row records its producer left on it, or None when there are none."""
+    rs = getattr(x, "_gsw_rowstats", None)
+    if rs is None or not FOLD_LN:
+        return None
+    C = x.shape[-1]
+    M = x.numel() // C
+    if M % 8 or M < FOLD_LN_MIN_ROWS:
+        return None
+    out = torch.empty((M, 2), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        N.check(N.lib().gsw_ln_rowstats_finish(rs[0].data_ptr(), rs[1], M, C, float(eps), out.data_ptr(), _stream_ptr()))
+    return out
+
+
+def fold_ln_weights(w: torch.Tensor, b: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor, geglu: bool = False):
+    """(W' = W diag(gamma) in the activations' dtype, u = row sums of the ROUNDED W' (fp32), v = W beta + b (fp32)); geglu: packed like pack_geglu_weight."""
+    wf = w.detach().float()
+    wp = (wf * gamma.detach().float()[None, :]).to(w.dtype)
+    u = wp.float().sum(dim=1)
+    v = wf @ beta.detach().float()
+    if b is not None:
+        v = v + b.detach().float()
+    if geglu:
+        wp, u = pack_geglu_weight(wp, u)
+        _, v = pack_geglu_weight(wp, v)
+    return wp.contiguous(), u.contiguous(), v.contiguous()
+
+
+def gemm_ln(x: torch.Tensor, stat: torch.Tensor, wp: torch.Tensor, u: torch.Tensor, v: torch.Tensor, *, mode: str = "plain", tokens: int = 0) -> torch.Tensor:
+    """LayerNorm(x) W^T + b on the matmul engine without the normalised tensor (gsw_gemm_ln); operands from fold_ln_weights / ln_stat."""
+    K = x.shape[-1]
+    M = x.numel() // K
+    Nn = wp.shape[0]
+    _same(x, x, "x")
+    _same(wp, x, "w", Nn * K)
+    for t_, nm in ((stat, "stat"), (u, "u"), (v, "v")):
+        if t_.dtype != torch.float32 or t_.device != x.device or not t_.is_contiguous() or t_.data_ptr() % 16:
+            raise ValueError(f"gemm_ln: {nm} must be a contiguous, 16-byte aligned fp32 tensor on {x.device}")
+    if stat.numel() != 2 * M or u.numel() != Nn or v.numel() != Nn:
+        raise ValueError("gemm_ln: stat [M, 2], u [N], v [N]")
+    if mode == "plain":
+        y = torch.empty((*x.shape[:-1], Nn), dtype=x.dtype, device=x.device)
+    elif mode == "geglu":
+        y = torch.empty((*x.shape[:-1], Nn // 2), dtype=x.dtype, device=x.device)
+    elif mode == "trans":
+        if tokens <= 0 or M % tokens:
+            raise ValueError("gemm_ln: trans needs tokens = rows per image")
+        y = torch.empty((M // tokens, Nn, tokens), dtype=x.dtype, device=x.device)
+    else:
+        raise ValueError(mode)
+    tm = CONV_TIMER
+    with torch.cuda.device(x.device):
+        _ensure_workspace(x.device)
+        e0 = tm.start() if tm is not None else None
+        N.check(N.lib().gsw_gemm_ln(x.data_ptr(), stat.data_ptr(), wp.data_ptr(), u.data_ptr(), v.data_ptr(), y.data_ptr(), M, K, Nn,
+                                    GEMM_MODES[mode], tokens, _dt(x.dtype), _stream_ptr()))
+        if tm is not None:
+            tm.stop(e0, ("gsw_mm_kernel", M, K, Nn, mode + "+ln") if tm.by_shape else "gsw_mm_kernel", 2.0 * M * K * Nn)
     return y
 
 

@@ -104,12 +104,13 @@ def _wb(lin: nn.Linear, x: torch.Tensor):
     return lin.weight, lin.bias
 
 
-def _lin(x: torch.Tensor, lin: nn.Linear, resid: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Linear (+ residual in the epilogue) on the matmul engine, else torch.  out: written in place (same shape, contiguous)."""
+def _lin(x: torch.Tensor, lin: nn.Linear, resid: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, rowstats: bool = False) -> torch.Tensor:
+    """Linear (+ residual in the epilogue) on the matmul engine, else torch.  out: written in place (same shape, contiguous).
+    rowstats: the launch also leaves the row records a following LayerNorm can be folded from (pf.ln_stat) on the result."""
     if _own_gemm_ok(x, lin.in_features, lin.out_features):
         from .pf import gemm
         w, b = _wb(lin, x)
-        return gemm(x.contiguous(), w, b, resid=None if resid is None else resid.contiguous(), out=out)
+        return gemm(x.contiguous(), w, b, resid=None if resid is None else resid.contiguous(), out=out, rowstats=rowstats)
     y = lin(x)
     y = y if resid is None else y + resid
     return y if out is None else out.copy_(y)
@@ -246,6 +247,34 @@ class Attention(nn.Module):
             store[id(self)] = ent
         return ent[1], ent[2]
 
+    def forward_ln(self, x, stat, norm: nn.LayerNorm, ctx=None, resid=None):
+        """attn(LayerNorm(x)) + resid with the LayerNorm folded into the projections that consume it (pf.gemm_ln): x is the RAW residual stream,
+        stat its per-row (rstd, -rstd mean).  Self-attention: q | k and V^T; cross-attention: q (keys / values come from the context)."""
+        from .pf import attention, cached, fold_ln_weights, gemm_ln
+        b, n, _ = x.shape
+        inner = self.to_q.out_features
+        if ctx is None:
+            fq = cached(self, "_gsw_ln_qk", (self.to_q.weight, self.to_k.weight, norm.weight, norm.bias),
+                        lambda: fold_ln_weights(torch.cat([self.to_q.weight.detach(), self.to_k.weight.detach()], dim=0), None, norm.weight, norm.bias))
+            fv = cached(self, "_gsw_ln_v", (self.to_v.weight, norm.weight, norm.bias), lambda: fold_ln_weights(self.to_v.weight.detach(), None, norm.weight, norm.bias))
+            qk = gemm_ln(x, stat, *fq)
+            vt = gemm_ln(x, stat, *fv, mode="trans", tokens=n)
+            o = attention(qk[..., :inner], qk[..., inner:], vt, self.heads)
+        else:
+            src, valid = _padded_ctx(ctx)
+            fq = cached(self, "_gsw_ln_q", (self.to_q.weight, norm.weight, norm.bias), lambda: fold_ln_weights(self.to_q.weight.detach(), None, norm.weight, norm.bias))
+            k_ctx, vt_ctx = self.context_kv(src)
+            o = attention(gemm_ln(x, stat, *fq), k_ctx, vt_ctx, self.heads, valid_keys=valid)
+        return _lin(o, self.to_out[0], resid, rowstats=True)
+
+    def ln_foldable(self, x, ctx=None) -> bool:
+        from .pf import attention_ok
+        n = x.shape[1]
+        sk = n if ctx is None else (ctx.shape[1] + 63) // 64 * 64
+        return (OWN_ATTENTION and FUSED_KERNELS and n % 8 == 0 and self.to_q.bias is None and self.to_k.bias is None and self.to_v.bias is None
+                and attention_ok(x, self.heads, self.to_q.out_features // self.heads, n, sk) and (ctx is None or CACHE_CONTEXT_KV)
+                and _own_gemm_ok(x, self.to_q.in_features, self.to_q.out_features))
+
     def forward(self, x, ctx=None, resid=None):
         """resid: added to the output projection (in its GEMM epilogue on the own path): `x + attn(norm(x))` of the transformer block"""
         b, n, _ = x.shape
@@ -320,8 +349,15 @@ class FeedForward(nn.Module):
         super().__init__()
         self.net = nn.ModuleList([GEGLU(dim, dim * mult), nn.Identity(), nn.Linear(dim * mult, dim)])
 
-    def forward(self, x, resid=None):
-        return _lin(self.net[0](x), self.net[2], resid)
+    def forward(self, x, resid=None, rowstats: bool = False):
+        return _lin(self.net[0](x), self.net[2], resid, rowstats=rowstats)
+
+    def forward_ln(self, x, stat, norm: nn.LayerNorm, resid=None):
+        """ff(LayerNorm(x)) + resid with the LayerNorm folded into the GEGLU projection (pf.gemm_ln)"""
+        from .pf import cached, fold_ln_weights, gemm_ln
+        proj = self.net[0].proj
+        f = cached(self, "_gsw_ln_ff1", (proj.weight, proj.bias, norm.weight, norm.bias), lambda: fold_ln_weights(proj.weight.detach(), proj.bias, norm.weight, norm.bias, geglu=True))
+        return _lin(gemm_ln(x, stat, *f, mode="geglu"), self.net[2], resid, rowstats=True)
 
 
 class BasicTransformerBlock(nn.Module):
@@ -338,11 +374,26 @@ class BasicTransformerBlock(nn.Module):
         if FUSED_KERNELS and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and x.is_contiguous() and x.shape[-1] % 8 == 0 \
                 and x.shape[-1] <= 1536:
             from .codec import add_layernorm
-            # the residual adds ride in the output projections' GEMM epilogues; LayerNorm is then one read + one write
-            _, n = add_layernorm(x, None, self.norm1.weight, self.norm1.bias, self.norm1.eps)
-            x = self.attn1(n, resid=x)
-            _, n = add_layernorm(x, None, self.norm2.weight, self.norm2.bias, self.norm2.eps)
-            x = self.attn2(n, ctx, resid=x)
+            from .pf import ln_stat
+            # the residual adds ride in the output projections' GEMM epilogues.  Each LayerNorm is FOLDED into the projections that consume it when the
+            # launch that produced x left row records on it (large batches: pf.ln_stat) -- the normalised tensor is then never written; otherwise it is
+            # one read + one write (gsw_add_layernorm)
+            inner4 = self.ff.net[2].in_features
+            st = ln_stat(x, self.norm1.eps) if self.attn1.ln_foldable(x) else None
+            if st is not None:
+                x = self.attn1.forward_ln(x, st, self.norm1, resid=x)
+            else:
+                _, n = add_layernorm(x, None, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+                x = self.attn1(n, resid=x)
+            st = ln_stat(x, self.norm2.eps) if self.attn2.ln_foldable(x, ctx) else None
+            if st is not None:
+                x = self.attn2.forward_ln(x, st, self.norm2, ctx, resid=x)
+            else:
+                _, n = add_layernorm(x, None, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+                x = self.attn2(n, ctx, resid=x)
+            st = ln_stat(x, self.norm3.eps) if (inner4 % 80 == 0 and _own_gemm_ok(x, x.shape[-1], 2 * inner4)) else None
+            if st is not None:
+                return self.ff.forward_ln(x, st, self.norm3, resid=x)
             _, n = add_layernorm(x, None, self.norm3.weight, self.norm3.bias, self.norm3.eps)
             return self.ff(n, resid=x)
         x = x + self.attn1(self.norm1(x))
@@ -368,7 +419,7 @@ class Transformer2DModel(nn.Module):
         return x + y
 
     def forward_pf(self, x, ctx):
-        y = _lin(_gn_pf(x, self.norm, act=False, tokens=True), self.proj_in)      # GroupNorm writes dense tokens directly
+        y = _lin(_gn_pf(x, self.norm, act=False, tokens=True), self.proj_in, rowstats=True)      # GroupNorm writes dense tokens directly
         for blk in self.transformer_blocks:
             y = blk(y, ctx)
         if _own_gemm_ok(y, self.proj_out.in_features, self.proj_out.out_features):

@@ -211,6 +211,21 @@ int gsw_gemm(const void* x_dev, const void* w_dev, const void* bias_dev, const v
 int gsw_gemm_qkv(const void* x_dev, const void* w_dev, const void* bias_dev, void* rows_dev, void* trans_dev, int64_t M, int K, int N_rows, int N,
                  int S, int dtype, void* stream);
 
+/* LayerNorm folded into the GEMM that consumes it (diffusers BasicTransformerBlock: norm1 -> to_q | to_k | to_v, norm2 -> to_q, norm3 -> the GEGLU
+ * projection): LN(x) W^T + b = rstd_m (x W'^T)_mn - rstd_m mean_m u_n + v_n with W' = W diag(gamma), u = W' 1, v = W beta + b -- the normalised tensor
+ * is never written or read.
+ *   gsw_mm_next_rowstats : one-shot request (like gsw_mm_next_colstats): the next plain gsw_gemm (+ residual) also writes, per output row and 80-column
+ *                          half tile, the (sum, sum of squares) of what it stores: stats_dev [M][slots][2] floats, capacity >= M * 2 ceil(N / 160) * 2.
+ *   gsw_mm_last_rowstats : slots written per row (0: the launch produced none, e.g. split-K); clears an unconsumed request.
+ *   gsw_ln_rowstats_finish: records -> stat_dev float2 [M] = (rstd, -rstd * mean) over the C columns.
+ *   gsw_gemm_ln          : the consuming GEMM; w_dev = W' (GEGLU: packed like gsw_gemm), u_dev / v_dev fp32 [N] in the same row order, 16-byte aligned;
+ *                          mode GSW_GEMM_PLAIN / GSW_GEMM_GEGLU / GSW_GEMM_TRANS; M % 8 == 0. */
+int gsw_mm_next_rowstats(float* stats_dev, int64_t capacity_floats);
+int gsw_mm_last_rowstats(int* slots);
+int gsw_ln_rowstats_finish(const float* records_dev, int slots, int64_t M, int C, float eps, float* stat_dev, void* stream);
+int gsw_gemm_ln(const void* x_dev, const float* ln_stat_dev, const void* w_dev, const float* u_dev, const float* v_dev, void* y_dev, int64_t M, int K, int N,
+                int mode, int S, int dtype, void* stream);
+
 /* The same with explicit row strides (elements, multiples of 8): x rows ldx >= K, w rows ldw >= K, resid rows ldr, y rows ldy -- operands may be
  * column slices of wider matrices (the per-image Q K^T and P V products of the VAE's single-head attention). */
 int gsw_gemm_strided(const void* x_dev, int64_t ldx, const void* w_dev, int64_t ldw, const void* bias_dev, const void* resid_dev, int64_t ldr,
