@@ -202,6 +202,16 @@ def test_argument_validation_of_eps_model_and_image_entry_points():
     assert lib.gsw_groupnorm_pf_cs(p, None, 0, p, 64, 1, 4, None, 0, 0, 0, p, p, p, p, 1, 8, 8, 96, 32, 1e-5, 1, 0, 1, None) == UNS   # odd group width (column pairs)
     assert lib.gsw_groupnorm_pf_cs(p, None, 0, p, 48, 1, 4, None, 0, 0, 0, p, p, p, p, 1, 8, 8, 320, 32, 1e-5, 1, 0, 1, None) == UNS  # 64 pixels per image, 48-row blocks
     assert lib.gsw_groupnorm_pf_cs(p, None, 0, p, 64, 3, 4, None, 0, 0, 0, p, p, p, p, 1, 8, 8, 320, 32, 1e-5, 1, 0, 1, None) == BAD  # parity count
+    # LayerNorm folded into the consuming GEMM
+    assert lib.gsw_gemm_ln(p, None, p, p, p, p, 256, 320, 640, 0, 0, 1, None) == BAD                              # no row statistics
+    assert lib.gsw_gemm_ln(p, p, p, p, p, p, 252, 320, 640, 0, 0, 1, None) == UNS                                 # M % 8
+    assert lib.gsw_gemm_ln(p, p, p, p, p, p, 256, 320, 648, 1, 0, 1, None) == UNS                                 # GEGLU needs N % 160
+    assert lib.gsw_gemm_ln(p, p, p, p, p, p, 256, 320, 640, 3, 0, 1, None) == BAD                                 # no token scatter
+    assert lib.gsw_gemm_ln(p, p, p, ctypes.c_void_p(68), p, p, 256, 320, 640, 0, 0, 1, None) == BAD               # u alignment
+    assert lib.gsw_ln_rowstats_finish(None, 4, 256, 320, 1e-5, p, None) == BAD and lib.gsw_ln_rowstats_finish(p, 0, 256, 320, 1e-5, p, None) == BAD
+    slots = ctypes.c_int(-1)
+    assert lib.gsw_mm_next_rowstats(None, 16) == BAD and lib.gsw_mm_next_rowstats(p, 1 << 10) == N.GSW_OK
+    assert lib.gsw_mm_last_rowstats(ctypes.byref(slots)) == N.GSW_OK and slots.value == 0
     assert lib.gsw_softmax_rows(p, 4, 100, 104, 1.0, 1, None) == UNS                                             # cols % 8
     assert lib.gsw_softmax_rows(p, 4, 128, 64, 1.0, 1, None) == BAD                                              # ld < cols
     assert lib.gsw_softmax_rows(p, 0, 128, 128, 1.0, 1, None) == N.GSW_OK
