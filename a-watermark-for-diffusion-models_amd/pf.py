@@ -489,7 +489,7 @@ def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
 
 # ---- LayerNorm folded into the consuming GEMM (gsw_gemm_ln): LN(x) W^T + b = rstd (x W'^T) + nrm u + v, W' = W diag(gamma), u = W' 1, v = W beta + b
 FOLD_LN = True
-FOLD_LN_MIN_ROWS = 16384       # below that the consumers would rather take the split-K form, which the folded epilogue does not have
+FOLD_LN_MIN_ROWS = int(__import__("os").environ.get("GSW_FOLD_LN_MIN_ROWS", "1024"))       # below that the consumers would rather take the split-K form, which the folded epilogue does not have
 
 
 class _rowstats_scope:
