@@ -1156,7 +1156,11 @@ int gsw_mm_launch(MMArgs& a, int dtype, void* stream) {
     const int bm_env = g_mm_tile_rows.load(std::memory_order_relaxed);
     // (pricing a 128-row tile at 0.55 of a 256-row one and minimising rounds of 256 workgroups -- e.g. 384 tiles -> 768 half tiles -- measured slower:
     // the half tile re-fetches the weight tile twice as often)
-    int BM = (((int64_t)a.M + 255) / 256) * tiles_n < 256 && a.M > 128 ? 128 : 256;
+    // ... but not when the 256-row tiling still has 128 or more tiles: the deep levels at 4096 rows (8 x 8 at batch 64, 16 x 16 at batch 16) re-read a
+    // 30-60 MB weight matrix once per row tile through L2, and half as many row tiles on half the CUs beat twice as many on all of them
+    // (profiles/r03_splitk_sweep_256.txt: 155 vs 210 us, 141 vs 180, 295 vs 394)
+    const int64_t nt256_ = (((int64_t)a.M + 255) / 256) * tiles_n;
+    int BM = nt256_ < (a.P >= 64 ? 128 : 256) && a.M > 128 ? 128 : 256;       // (long K only: a short-K weight matrix stays in L2 and all CUs win)
     if (bm_env == 128 || bm_env == 256) BM = bm_env;
     hipStream_t st = (hipStream_t)stream;
     a.splits = 1; a.ws = nullptr;
