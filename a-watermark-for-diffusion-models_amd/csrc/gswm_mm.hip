@@ -114,11 +114,36 @@ __device__ unsigned long long* g_mm_trace_buf;
 // epilogue barrier: LDS image traffic only -- the DMA prefetch of the next tile stays in flight (no vmcnt wait)
 #define MM_LDS_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); MM_BARRIER(); } while (0)
 
-// LDS image traffic of the epilogue as inline asm: hipcc puts s_waitcnt vmcnt(0) in front of every LDS access it can see while an LDS-DMA
-// may be in flight (it cannot prove the image and the DMA destinations disjoint), which serialises the epilogue behind the prefetch of
-// the next tile and behind every one of its own stores (measured: 1800 cycles per put, 3600 per 5-chunk store, tools/ubench/mm_trace).
-// five 16-byte chunks (ten ds_read_b64) and their wait in ONE statement: the outputs are valid when it ends
-// four 8-byte cells and their wait in one statement (GEGLU: the value waves pick up the gate cells they multiply into)
+// LDS reads of the staged epilogue parameters as inline asm: hipcc puts s_waitcnt vmcnt(0) in front of every LDS access it can see while an
+// LDS-DMA may be in flight (it cannot prove the destinations disjoint from the read), which is exactly the wait the staging removes.  Each helper
+// ends with its own s_waitcnt lgkmcnt(0): the outputs are valid when the statement ends.
+typedef float mm_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t mm_lds_addr(const uint8_t* p) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t*)p; }
+// five 8-byte cells 32 bytes apart (the bias of a lane's four columns in each of the five column blocks)
+__device__ __forceinline__ void mm_lds_read5_b64(uint32_t a, uint2 (&o)[5]) {
+    uint64_t r0, r1, r2, r3, r4;
+    asm volatile("ds_read_b64 %0, %5\n\tds_read_b64 %1, %5 offset:32\n\tds_read_b64 %2, %5 offset:64\n\tds_read_b64 %3, %5 offset:96\n\tds_read_b64 %4, %5 offset:128\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4) : "v"(a) : "memory");
+    const uint64_t r[5] = {r0, r1, r2, r3, r4};
+#pragma unroll
+    for (int i = 0; i < 5; ++i) o[i] = make_uint2((uint32_t)r[i], (uint32_t)(r[i] >> 32));
+}
+// LayerNorm fold: u and v (1 KiB apart) of a lane's four columns in each of the five column blocks, and (rstd, nrm) of its MT rows (16 rows apart)
+__device__ __forceinline__ void mm_lds_read_uv(uint32_t a, mm_f4 (&u)[5], mm_f4 (&v)[5]) {
+    asm volatile("ds_read_b128 %0, %10\n\tds_read_b128 %1, %10 offset:64\n\tds_read_b128 %2, %10 offset:128\n\tds_read_b128 %3, %10 offset:192\n\tds_read_b128 %4, %10 offset:256\n\t"
+                 "ds_read_b128 %5, %10 offset:1024\n\tds_read_b128 %6, %10 offset:1088\n\tds_read_b128 %7, %10 offset:1152\n\tds_read_b128 %8, %10 offset:1216\n\t"
+                 "ds_read_b128 %9, %10 offset:1280\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(u[0]), "=&v"(u[1]), "=&v"(u[2]), "=&v"(u[3]), "=&v"(u[4]), "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]) : "v"(a) : "memory");
+}
+template <int MT>
+__device__ __forceinline__ void mm_lds_read_rows(uint32_t a, mm_f2 (&r)[MT]) {
+    if constexpr (MT == 4)
+        asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:128\n\tds_read_b64 %2, %4 offset:256\n\tds_read_b64 %3, %4 offset:384\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]) : "v"(a) : "memory");
+    else
+        asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:128\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r[0]), "=&v"(r[1]) : "v"(a) : "memory");
+}
 
 // EPI: epilogue class the kernel is compiled for -- 0 dense rows (bias, optional residual), 1 generic (PF border / row bias / token scatter /
 // sub-pixel scatter), 2 GEGLU, 3 transposed output (MFMA operands swapped)
@@ -177,6 +202,14 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
     constexpr uint32_t STAGE = (uint32_t)(BM + BN) * 128u;     // one stage = 64 k-values of every tile row: 52 KiB
     constexpr uint32_t RING = 3u * STAGE;
     constexpr int HC = BN / 2;                       // columns owned by a group
+    // STG (8-wave dense-row / GEGLU epilogues): the epilogue's per-column / per-row parameters (bias; LayerNorm fold: u, v, the rows' (rstd, nrm)) are
+    // staged in the 4 KiB of LDS behind the ring by LDS-DMA pieces wave 7 issues in the tile's first step.  Fetched by the epilogue itself they are
+    // vector-memory loads BEHIND the next tile's prefetched stages, i.e. the epilogue's arithmetic starts a full HBM latency late
+    // (profiles/r03w_epilogue_param_wait.txt: the GEGLU launches are 6-13 % faster without a bias vector).
+    // (not the LayerNorm-folded dense-row epilogue: it sits at the 256-register cap)
+    constexpr bool STG = !SPLIT && !SWAP && !QKV && (EPI == 2 || (EPI == 0 && !LNF));
+    constexpr uint32_t PARAM = RING;                 // [0, 1 KiB): bias (fp16) or u (fp32) of the tile's 160 columns; [1, 2): v; [2, 4): (rstd, nrm) of its rows
+    constexpr int NPAR = LNF ? 2 + (BM + 127) / 128 : 1;
     typedef typename MM<T>::frag frag;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 
@@ -185,6 +218,10 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
     const uint32_t grp = (wave >> 2) & 1u, wm = wave & 3u;
     const uint32_t pid = SPLIT ? (wave & 3u) : wave;          // index among the producing waves (SPLIT: waves 8..11)
     const bool extra = pid < (uint32_t)NEXTRA;
+    // (three steps: the pieces are issued in step 0 and published by the barrier of step 2)
+    // with fewer than three steps per tile the pieces are issued inside the epilogue, between two barriers
+    const bool stg = STG && p.P >= 3 && (LNF || p.bias != nullptr);
+    const bool stg7 = stg && wave == 7u;
 
     // LDS rows are 128 B (64 k-values); 16-byte chunks are XOR-swizzled with (row >> 1) & 7.
     // fragment read of k-half h: row = lane & 15 of a 16-row block, logical chunk = 4h + (lane >> 4); (row >> 1) & 7 = (lane >> 1) & 7
@@ -457,6 +494,26 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
         for (int in = 0; in < 5; ++in) wf[in] = *reinterpret_cast<const frag*>(wp + in * 2048);
     };
 
+    auto dma_params = [&]() {
+        int32_t tm, tn;
+        decode_tile(c_it * G + slotx, tm, tn);
+        const int32_t m0 = tm * BM, n0 = tn * BN;
+        auto piece = [&](const void* src, uint32_t k) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(lds + PARAM + k * 1024u), 16, 0, 0);
+        };
+        // lanes past the end of a vector / of the rows re-read its last 16 bytes: their LDS positions belong to columns / rows that are never stored
+        if constexpr (LNF) {
+            const int32_t nc = min(n0 + 4 * (int32_t)lane, p.N - 4);
+            piece(p.ln_u + nc, 0u);
+            piece(p.ln_v + nc, 1u);
+            const float2* st = reinterpret_cast<const float2*>(p.ln_stat);
+#pragma unroll
+            for (int k = 0; k < (BM + 127) / 128; ++k) piece(st + min(m0 + 128 * k + 2 * (int32_t)lane, p.M - 2), 2u + (uint32_t)k);
+        } else {
+            piece(reinterpret_cast<const uint16_t*>(p.bias) + min(n0 + 8 * (int32_t)lane, p.N - 8), 0u);
+        }
+    };
+
     // ---------------------------------------------------------------- epilogue: straight from the accumulators, no LDS image, no barrier.
     // MFMA layout (non-SWAP): lane (q = lane >> 4, i = lane & 15) holds columns 16 in + 4 q + j (j = 0..3) of row 16 im + i.  After
     // bias + rounding + packing (4 fp16 = 2 registers per (in, im)), ONE v_permlane16_swap per register between row tiles im = 2p and
@@ -494,6 +551,18 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
         if constexpr (LNF) {
             const float2* st = reinterpret_cast<const float2*>(p.ln_stat);
             if constexpr (!SWAP) {
+                if constexpr (STG) {                               // staged behind the ring by wave 7 (dma_params)
+                    if (!stg) {                                    // (short tiles: now)
+                        MM_BARRIER();
+                        if (wave == 7u) { dma_params(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+                        MM_BARRIER();
+                    }
+                    mm_f2 rw[MT];
+                    mm_lds_read_rows<MT>(mm_lds_addr(lds + PARAM + 2048u) + (wm * (16u * MT) + li) * 8u, rw);
+#pragma unroll
+                    for (int im = 0; im < MT; ++im) { ln_r[im] = rw[im][0]; ln_n[im] = rw[im][1]; }
+                    mm_lds_read_uv(mm_lds_addr(lds + PARAM) + (grp * HC + q * 4u) * 4u, ln_u4, ln_v4);
+                } else {
 #pragma unroll
                 for (int im = 0; im < MT; ++im) {
                     const int32_t m = m0 + (int32_t)(wm * (16u * MT) + (uint32_t)im * 16u + li);
@@ -506,6 +575,7 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
                     const int32_t nc = nb < p.N ? nb : 0;
                     ln_u4[in] = *reinterpret_cast<const mm_f4*>(p.ln_u + nc);
                     ln_v4[in] = *reinterpret_cast<const mm_f4*>(p.ln_v + nc);
+                }
                 }
             } else {
 #pragma unroll
@@ -555,6 +625,18 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
         };
         // bias of this lane's own accumulator columns, all five column blocks up front (one wait, not one per block)
         uint2 bq_raw[5];
+        if constexpr (STG && !LNF) {
+#pragma unroll
+            for (int in = 0; in < 5; ++in) bq_raw[in] = make_uint2(0, 0);
+            if (bias) {                                        // staged behind the ring by wave 7 (dma_params)
+                if (!stg) {                                    // (short tiles: now)
+                    MM_BARRIER();
+                    if (wave == 7u) { dma_params(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+                    MM_BARRIER();
+                }
+                mm_lds_read5_b64(mm_lds_addr(lds + PARAM) + (grp * HC + q * 4u) * 2u, bq_raw);
+            }
+        } else
 #pragma unroll
         for (int in = 0; in < 5; ++in) {
             bq_raw[in] = make_uint2(0, 0);
@@ -852,7 +934,7 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
         }
     };
     // X holds the fragments of (stage s, k-half 0) on entry; Y is filled with (s, k-half 1), then X with (s+1, k-half 0)
-    auto step = [&](auto swap_tag, frag (&xX)[MT], frag (&wX)[5], frag (&xY)[MT], frag (&wY)[5]) {
+    auto step = [&](auto swap_tag, frag (&xX)[MT], frag (&wX)[5], frag (&xY)[MT], frag (&wY)[5], const int32_t step_i) {
         const uint32_t nx_slot = rd_slot + STAGE == RING ? 0u : rd_slot + STAGE;
         // ---- even phase: second half of stage s+2 (its slot held stage s-1, whose last reads completed before the previous barrier)
         MM_STAMP(0);
@@ -867,12 +949,20 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
         if constexpr (!SPLIT) { if (--pr_run == 0) end_run(); }
         MM_STAMP(1);
         // stage s+1 is read in the odd phase: everything but the newest stage (s+2, both halves) must have landed
-        if constexpr (!SPLIT) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NDMA) : "memory");
+        if constexpr (STG) {
+            // wave 7, step 1: its parameter pieces of step 0 may stay in flight too
+            if (stg7 && step_i == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NDMA + NPAR) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NDMA) : "memory");
+        } else if constexpr (!SPLIT) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NDMA) : "memory");
         MM_STAMP(2);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         MM_BARRIER();
         MM_STAMP(3);
         // ---- odd phase: first half of stage s+3, into the slot of stage s (its last reads completed before the barrier above)
+        if constexpr (STG) {
+            // every wave is past the previous tile's epilogue (its parameter reads were drained in front of the barrier above)
+            if (stg7 && step_i == 0) dma_params();
+        }
         if constexpr (!SPLIT) dma_h1();
 #ifndef MM_ABL_NOREADS
         read_frags(xX, wX, nx_slot, 0u);
@@ -905,10 +995,10 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
         if constexpr (QKV) {
             int32_t tm_, tn_;
             decode_tile(it * G + slotx, tm_, tn_);
-            if (tn_ * BN >= p.n_rows) { for (int32_t i = 0; i < P_mine; ++i) step(std::true_type{}, xa, wa, xb, wb); }
-            else { for (int32_t i = 0; i < P_mine; ++i) step(std::false_type{}, xa, wa, xb, wb); }
+            if (tn_ * BN >= p.n_rows) { for (int32_t i = 0; i < P_mine; ++i) step(std::true_type{}, xa, wa, xb, wb, i); }
+            else { for (int32_t i = 0; i < P_mine; ++i) step(std::false_type{}, xa, wa, xb, wb, i); }
         } else {
-            for (int32_t i = 0; i < P_mine; ++i) step(std::integral_constant<bool, SWAP>{}, xa, wa, xb, wb);
+            for (int32_t i = 0; i < P_mine; ++i) step(std::integral_constant<bool, SWAP>{}, xa, wa, xb, wb, i);
         }
         epilogue();
         MM_STAMP(6);
@@ -1026,7 +1116,7 @@ __global__ __launch_bounds__(256) void gsw_mm_reduce_kernel(const MMArgs p, cons
 template <typename T, int EPI, bool SPLIT, int MT, bool LNF = false>
 int mm_launch_k(const MMArgs& a, uint32_t grid, hipStream_t st) {
     static bool attr_done = false;          // benign race: setting the attribute twice is harmless
-    constexpr size_t ldsb = 3u * (size_t)(64 * MT + 160) * 128u;       // the three-stage ring
+    constexpr size_t ldsb = 3u * (size_t)(64 * MT + 160) * 128u + (!SPLIT && (EPI == 2 || (EPI == 0 && !LNF)) ? 4096u : 0u);   // the three-stage ring (+ the staged epilogue parameters)
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)gsw_mm_kernel<T, EPI, SPLIT, MT, LNF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
@@ -1164,6 +1254,8 @@ int gsw_mm_launch(MMArgs& a, int dtype, void* stream) {
     if (bm_env == 128 || bm_env == 256) BM = bm_env;
     hipStream_t st = (hipStream_t)stream;
     a.splits = 1; a.ws = nullptr;
+    // the dense-row / GEGLU epilogues fetch the bias by 16-byte LDS-DMA pieces (STG in the kernel)
+    if ((a.mode == MM_MODE_DENSE || a.mode == MM_MODE_GEGLU) && ((uintptr_t)a.bias & 15u)) return GSW_ERR_BAD_ARG;
     int64_t cs_cap = 0;
     float* cs_req = gsw_mm_take_colstats(&cs_cap);
     a.colstats = nullptr;

@@ -51,7 +51,7 @@ def test_gemm_detects_transposes(P):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("M,K,I", [(512, 320, 1280), (1000, 640, 2560), (256, 1280, 5120), (9000, 320, 1280)])
+@pytest.mark.parametrize("M,K,I", [(512, 320, 1280), (1000, 640, 2560), (256, 1280, 5120), (9000, 320, 1280), (300, 128, 160), (520, 192, 320), (33000, 192, 1280)])
 def test_gemm_geglu_vs_torch(P, dtype, M, K, I):
     g = torch.Generator().manual_seed(M + I)
     x = torch.randn(M, K, generator=g).to(dtype).cuda()

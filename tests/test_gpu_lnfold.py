@@ -52,7 +52,8 @@ def test_row_records_and_stat(G, tile_rows, M, C):
 
 
 @pytest.mark.parametrize("mode", ["plain", "geglu", "trans"])
-@pytest.mark.parametrize("M,C,N", [(2048, 320, 640), (1024, 640, 1920), (512, 1280, 1280)])
+# (40960 rows: several tiles per workgroup -- the staged epilogue parameters of consecutive tiles share one LDS slot; K = 128: two steps per tile, staged inside the epilogue)
+@pytest.mark.parametrize("M,C,N", [(2048, 320, 640), (1024, 640, 1920), (512, 1280, 1280), (40960, 320, 1920), (1024, 128, 320)])
 def test_folded_gemm_vs_layernorm_then_gemm_vs_fp32(G, tile_rows, mode, M, C, N):
     if mode == "geglu":
         N = (N // 160) * 160
