@@ -24,6 +24,9 @@
 //     holds 8 consecutive outputs -> 16-byte stores.  EPI 0 dense rows (+ residual), EPI 1 PF rows (+ per-image row bias + residual),
 //     tokens -> PF scatter, sub-pixel scatter; EPI 2 GEGLU (weight rows packed [8 value | 8 gate] per 16-row block, value * gelu(gate));
 //     EPI 3 transposed output ([B, N, S]: the attention kernel's V^T operand; MFMA operands swapped).
+//   * The epilogue must not LOAD its parameters in the 8-wave variant: a vector load issued there queues behind the next tile's prefetched stages
+//     (vmcnt retires in order) and the arithmetic starts a full HBM latency late.  The dense-row and GEGLU kernels stage bias / LayerNorm-fold
+//     vectors / row statistics in the 4 KiB of LDS behind the ring by LDS-DMA pieces issued in the tile's first step (STG, dma_params).
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <hip/hip_bf16.h>
@@ -1326,6 +1329,7 @@ int gsw_gemm_strided(const void* x_dev, int64_t ldx, const void* w_dev, int64_t 
         || M * ldx >= ((int64_t)1 << 40) || (int64_t)N * ldw >= ((int64_t)1 << 31) || ldx >= ((int64_t)1 << 31) || ldy >= ((int64_t)1 << 31) || ldr >= ((int64_t)1 << 31))
         return GSW_ERR_UNSUPPORTED;
     if (mode == GSW_GEMM_GEGLU && resid_dev) return GSW_ERR_UNSUPPORTED;
+    if ((mode == GSW_GEMM_PLAIN || mode == GSW_GEMM_GEGLU) && ((uintptr_t)bias_dev & 15u)) return GSW_ERR_BAD_ARG;       // fetched by 16-byte LDS-DMA pieces
     if (mode == GSW_GEMM_TRANS && (resid_dev || S <= 0 || (S & 7) || M % S)) return GSW_ERR_UNSUPPORTED;
     if (mode == GSW_GEMM_TOK2PF && (S <= 0 || Wimg <= 0 || S % Wimg || M % S)) return GSW_ERR_BAD_ARG;
     const int64_t ncols = mode == GSW_GEMM_GEGLU ? N / 2 : N;

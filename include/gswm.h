@@ -187,8 +187,8 @@ int gsw_linear(const void* x_dev, const void* w_dev, const void* bias_dev, const
 /* X2 / G1 -- every dense linear layer of the eps model (diffusers BasicTransformerBlock / Transformer2DModel / TimestepEmbedding /
  * ResnetBlock2D.time_emb_proj, which the reference reaches through `pipe(...)` at extract.py:66-69) on the hand-written matmul engine
  * (csrc/gswm_mm.hip: persistent 256 x 160 tiles, 8 waves in lockstep, three-stage LDS-DMA ring of 64-wide K slices):
- *   x: [M, K] row-major, w: [N, K] (nn.Linear layout), bias: [N] or NULL; K % 64 == 0, N % 8 == 0 (N % 160 == 0 for GEGLU; a partial last
- *   160-column tile costs a full one); GSW_F16 / GSW_BF16.
+ *   x: [M, K] row-major, w: [N, K] (nn.Linear layout), bias: [N] or NULL (PLAIN / GEGLU: 16-byte aligned -- the epilogue fetches it by LDS-DMA;
+ *   GSW_ERR_BAD_ARG otherwise); K % 64 == 0, N % 8 == 0 (N % 160 == 0 for GEGLU; a partial last 160-column tile costs a full one); GSW_F16 / GSW_BF16.
  *   mode GSW_GEMM_PLAIN : y[M, N] = x w^T + bias (+ resid[M, N])
  *        GSW_GEMM_GEGLU : rows of w / bias interleaved per 16-ROW BLOCK as [8 value | 8 gate]: with I = N / 2 outputs, packed row
  *                         16 j + r holds value row 8 j + r for r < 8 and gate row I + 8 j + (r - 8) for r >= 8 of diffusers' [2 I, K]

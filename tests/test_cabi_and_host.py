@@ -187,6 +187,7 @@ def test_argument_validation_of_eps_model_and_image_entry_points():
     assert lib.gsw_gemm_strided(p, 64, p, 64, None, None, 160, p, 100, 4, 64, 160, 0, 0, 0, 1, None) == UNS      # ldy % 8
     assert lib.gsw_gemm_strided(p, 64, p, 64, None, None, 160, p, 96, 4, 64, 160, 0, 0, 0, 1, None) == BAD       # ldy < N
     assert lib.gsw_gemm(None, p, None, None, p, 4, 64, 160, 0, 0, 0, 1, None) == BAD
+    assert lib.gsw_gemm(p, p, ctypes.c_void_p(72), None, p, 4, 64, 160, 0, 0, 0, 1, None) == BAD                 # bias: 16-byte aligned (LDS-DMA pieces)
     assert lib.gsw_gemm_qkv(p, p, None, p, p, 256, 320, 600, 960, 128, 1, None) == UNS                           # a column tile must be of one kind
     assert lib.gsw_gemm_qkv(p, p, None, p, None, 256, 320, 640, 960, 128, 1, None) == BAD                        # no transposed output
     assert lib.gsw_gemm_qkv(p, p, None, p, p, 256, 320, 640, 960, 100, 1, None) == UNS                           # S % 8
