@@ -338,16 +338,29 @@ __global__ __launch_bounds__(512) void gsw_gn_pf_apply_kernel(const uint16_t* __
     const int32_t cv = C >> 3, tid = threadIdx.x;
     const int32_t cvec = tid % cv, prow = tid / cv;
     const int32_t HpWp = Hp * Wp, H = Hp - 2, W = Wp - 2, cpg = C / G;
-    if (tid < G) {
+    // Fold the statistics of every group: L lanes per group add every L-th record (independent loads in flight -- one thread per group walking up to 64
+    // slab records one after the other was most of this kernel's 18 us on a single image), then lane order: a fixed order, reproducible.
+    __shared__ float s_fs[16][GN_MAX_GROUPS], s_fq[16][GN_MAX_GROUPS];
+    int32_t L = 1;
+    while (L < 16 && 2 * L * G <= (int32_t)blockDim.x) L <<= 1;
+    if (tid < L * G) {
+        const int32_t g = tid % G, j = tid / G;
         float sm = 0.f, sq = 0.f;
-        for (int32_t k = 0; k < nslab_stats; ++k) {
-            const float* o = partial + (((int64_t)b * nslab_stats + k) * G + tid) * 2;
-            sm += o[0]; sq += o[1];
+        if (nslab_stats > 0) {
+            for (int32_t k = j; k < nslab_stats; k += L) {
+                const float2 o = *reinterpret_cast<const float2*>(partial + (((int64_t)b * nslab_stats + k) * G + g) * 2);
+                sm += o.x; sq += o.y;
+            }
+        } else {                                 // statistics as per-column-PAIR sums [B][C / 2][2] (gsw_gn_colstats_finish_kernel): this group's pairs
+            const float2* o = reinterpret_cast<const float2*>(partial) + (int64_t)b * (C >> 1) + g * (cpg >> 1);
+            for (int32_t k = j; k < (cpg >> 1); k += L) { sm += o[k].x; sq += o[k].y; }
         }
-        if (nslab_stats == 0) {                  // statistics as per-column-PAIR sums [B][C / 2][2] (gsw_gn_colstats_finish_kernel): fold this group's pairs in order
-            const float2* o = reinterpret_cast<const float2*>(partial) + (int64_t)b * (C >> 1) + tid * (cpg >> 1);
-            for (int32_t k = 0; k < (cpg >> 1); ++k) { sm += o[k].x; sq += o[k].y; }
-        }
+        s_fs[j][g] = sm; s_fq[j][g] = sq;
+    }
+    __syncthreads();
+    if (tid < G) {
+        float sm = s_fs[0][tid], sq = s_fq[0][tid];
+        for (int32_t j = 1; j < L; ++j) { sm += s_fs[j][tid]; sq += s_fq[j][tid]; }
         const float n = (float)(H * W * cpg);
         const float mean = sm / n;
         const float var = fmaxf(sq / n - mean * mean, 0.f);
