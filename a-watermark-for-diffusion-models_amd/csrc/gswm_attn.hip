@@ -383,10 +383,10 @@ int gsw_attention(const void* q_dev, const void* k_dev, const void* vt_dev, void
     if ((Sk & 7) || ldq < inner || ldk < inner || ldo < inner || ((ldq | ldk | ldo) & 7)) return GSW_ERR_UNSUPPORTED;
     static const int qb_env = getenv("GSW_ATTN_QB") ? atoi(getenv("GSW_ATTN_QB")) : 2;      // A/B switch for profiling
     const bool ragged = (Sq & 127) || (Sk & 63);
-    // 256-query workgroups once there are plenty of them: a grid of 128-query workgroups that still fits one per CU (one image: 5 heads x 32 query tiles at
-    // 64 x 64) keeps twice as many CUs busy (one image's self-attention 56 -> ~30 us)
+    // 256-query workgroups once there are plenty of them (7-12 % faster from ~1000 workgroups up); below ~400 of them the 128-query form keeps more CUs
+    // busy (one image at 64 x 64: 62 vs 91 us; profiles/r03y_attention_query_tile_sweep.txt)
     const int64_t wg256 = (int64_t)(Sq / 256) * B * H;
-    const int QB = ((Sq & 255) == 0 && Sq >= 512 && qb_env == 2 && head_dim < 80 && !ragged && wg256 > 128) ? 2 : 1;
+    const int QB = ((Sq & 255) == 0 && Sq >= 512 && qb_env >= 2 && head_dim < 80 && !ragged && (wg256 > 400 || qb_env == 3)) ? 2 : 1;      // (GSW_ATTN_QB: 1 / 3 force a form)
     const int64_t total = (int64_t)((Sq + 128 * QB - 1) / (128 * QB)) * B * H;
     if (total > 0x7FFFFFFF) return GSW_ERR_UNSUPPORTED;
     AttnArgs a;

@@ -29,7 +29,7 @@ def _mk(M, K, N, dtype, seed, resid=False):
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("M,K,N", [(256, 64, 160), (256, 128, 320), (8, 320, 320), (513, 192, 160), (1000, 320, 320), (4096, 320, 960), (777, 640, 640), (2048, 1280, 320),
-                                   (300, 1280, 1280), (16384, 320, 320), (70000, 320, 320), (12800, 640, 1920), (128, 1024, 1280), (64, 1280, 20160)])
+                                   (300, 1280, 1280), (16384, 320, 320), (70000, 320, 320), (12800, 640, 1920), (128, 1024, 1280), (64, 1280, 20160), (70000, 128, 320)])
 def test_gemm_plain_vs_torch_fp32(P, dtype, M, K, N):
     x, w, b, r = _mk(M, K, N, dtype, M + K + N, resid=True)
     ref = x.float() @ w.float().T + b.float()
@@ -51,7 +51,7 @@ def test_gemm_detects_transposes(P):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("M,K,I", [(512, 320, 1280), (1000, 640, 2560), (256, 1280, 5120), (9000, 320, 1280), (300, 128, 160), (520, 192, 320), (33000, 192, 1280)])
+@pytest.mark.parametrize("M,K,I", [(512, 320, 1280), (1000, 640, 2560), (256, 1280, 5120), (9000, 320, 1280), (300, 128, 160), (520, 192, 320), (33000, 192, 1280), (40000, 128, 320)])
 def test_gemm_geglu_vs_torch(P, dtype, M, K, I):
     g = torch.Generator().manual_seed(M + I)
     x = torch.randn(M, K, generator=g).to(dtype).cuda()
