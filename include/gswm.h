@@ -33,7 +33,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define GSW_VERSION 300 /* 0.3.0: gsw_conv_pf / gsw_conv3x3_res_pf take ld_rowbias; gsw_mm_set_workspace (split-K).  0.2.0: GEGLU weights packed per 16-row block (see gsw_gemm) */
+#define GSW_VERSION 301 /* 0.3.1: gsw_gemm / gsw_gemm_strided (PLAIN, GEGLU) want a 16-byte aligned bias.  0.3.0: gsw_conv_pf / gsw_conv3x3_res_pf take ld_rowbias; gsw_mm_set_workspace (split-K).  0.2.0: GEGLU weights packed per 16-row block (see gsw_gemm) */
 
 #define GSW_MSG_INLINE_MAX 256 /* message bytes carried inside the kernel arguments (2048 bit) */
 
