@@ -226,7 +226,7 @@ def run_codec(args, rank, world, local_rank, steps, warmup):
     # this very configuration; otherwise null
     traffic = traffic_src = None
     try:
-        pmc_file = os.path.join("profiles", "r02_codec_pmc.json")
+        pmc_file = os.path.join("profiles", "r03_codec_pmc.json")
         pmc = json.load(open(os.path.join(ROOT, pmc_file)))
         c = pmc["config"]
         if c["batch_per_gpu"] == B and c["lattice"] == list(shape) and c["message_bits"] == M and fast:
