@@ -111,6 +111,8 @@ def test_gemm_rejects_bad_operands(P):
         P.gemm(torch.randn(64, 100).half().cuda(), torch.randn(320, 100).half().cuda(), None)    # K % 64
     with pytest.raises(Exception):
         P.gemm(x, torch.randn(100, 320).half().cuda(), None)                                     # N % 160
+    with pytest.raises(ValueError):
+        P.gemm(x, w, torch.zeros(328).half().cuda()[4:324])                                      # bias 8 bytes off a 16-byte boundary (LDS-DMA pieces)
 
 
 # ---- N that is not a multiple of the 160-column tile (VAE: 128 / 256 / 512 channels), strided operands, row softmax, single-head attention
