@@ -533,6 +533,7 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
         decode_tile(PART ? slotx % ntiles : c_it * G + slotx, tile_m, tile_n);
         const int32_t m0 = tile_m * BM, n0 = tile_n * BN;
         const uint32_t q = lane >> 4, li = lane & 15u;
+        MM_STAMP(13);
         const bool vtile = QKV && n0 >= p.n_rows;                 // (wave-uniform) this tile belongs to the transposed part
         const bool transposed = SWAP || vtile;
         if constexpr (PART) {
@@ -766,6 +767,7 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
             // in even 16-lane rows and the sums of squares in odd ones, four row_shr steps fold the 16 rows of a lane row -- a fixed order, so the result
             // is reproducible -- and lanes 15 / 31 / 47 / 63 each write one 16-byte record (4 column pairs of one plane) for this wave's block of 16 MT rows.
             const bool cstat = p.colstats != nullptr;
+            MM_STAMP(14);
 #pragma unroll
             for (int in = 0; in < 5; ++in) {
                 float bq[4];
@@ -819,6 +821,7 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
                         *reinterpret_cast<mm_f4*>(dst) = mm_f4{rec[0], rec[1], rec[2], rec[3]};
                     }
                 }
+                MM_STAMP(8 + in);
             }
         } else if (EPI == 2) {
             // GEGLU: accumulator columns of an n-tile are [8 value | 8 gate] of outputs 8 in .. 8 in + 7 (within the group's 40 outputs): lanes < 32

@@ -13,11 +13,11 @@ __global__ void fill(_Float16* p, size_t n, unsigned seed) {
 int main(int argc, char** argv) {
     const long M = argc > 1 ? atol(argv[1]) : 32768; const int K = argc > 2 ? atoi(argv[2]) : 1280, N = argc > 3 ? atoi(argv[3]) : 2560;
     const int mode = argc > 4 ? atoi(argv[4]) : 0;          // GSW_GEMM_PLAIN 0 / GEGLU 1 / TRANS 2
-    _Float16 *x, *w, *y; hipMalloc(&x, M * K * 2); hipMalloc(&w, (size_t)N * K * 2); hipMalloc(&y, M * N * 2);
+    _Float16 *x, *w, *y; hipMalloc(&x, M * K * 2); hipMalloc(&w, (size_t)N * K * 2); hipMalloc(&y, (size_t)(M * 1.08) * N * 2 + (1 << 20));
     fill<<<1024, 256>>>(x, M * K, 1); fill<<<1024, 256>>>(w, (size_t)N * K, 2);
     unsigned long long* tb; hipMalloc(&tb, 4096); hipMemset(tb, 0, 4096);
     hipMemcpyToSymbol(HIP_SYMBOL(g_mm_trace_buf), &tb, sizeof(tb));
-    for (int r = 0; r < 3; ++r) { int rc = gsw_gemm(x, w, nullptr, nullptr, y, M, K, N, mode, mode == 2 ? 4096 : 0, 0, GSW_F16, nullptr); if (rc) { printf("rc %d\n", rc); return 1; } }
+    for (int r = 0; r < 3; ++r) { int rc = gsw_gemm(x, w, nullptr, nullptr, y, M, K, N, mode, mode >= 2 ? 4096 : 0, mode == 3 ? 64 : 0, GSW_F16, nullptr); if (rc) { printf("rc %d\n", rc); return 1; } }
     hipDeviceSynchronize();
     std::vector<unsigned long long> h(12 * 16);
     hipMemcpy(h.data(), tb, h.size() * 8, hipMemcpyDeviceToHost);
@@ -32,8 +32,8 @@ int main(int argc, char** argv) {
         printf("wave %d: %6.0f | %6.0f | %6.0f | %6.0f | %6.0f | %6.0f  = %6.0f per step ; epilogue %7.0f per tile\n", wv, t[0] / steps, t[1] / steps, t[2] / steps, t[3] / steps,
                t[4] / steps, t[5] / steps, tot, t[6] / (my_tiles * 3.0));
         const double nt = my_tiles * 3.0;
-        printf("        epilogue parts per tile: entry %5.0f | put0 %5.0f | barrier %5.0f | store0 %5.0f | bar+put1+bar %5.0f | store1 %5.0f | exit %5.0f\n", t[8] / nt, t[9] / nt, t[10] / nt,
-               t[11] / nt, t[12] / nt, t[13] / nt, (t[6] - 0.0) / nt);
+        printf("        epilogue per tile: tile decode %5.0f | row set-up %5.0f | column blocks 0 .. 4: %5.0f | %5.0f | %5.0f | %5.0f | %5.0f ; the rest %5.0f\n",
+               t[13] / nt, t[14] / nt, t[8] / nt, t[9] / nt, t[10] / nt, t[11] / nt, t[12] / nt, (t[6] - 0.0) / nt);
     }
     for (int wv : {8, 11}) {                                  // SPLIT only: the producer waves' step = issue | wait for the previous stage to land | barrier
         const unsigned long long* t = &h[wv * 16];
