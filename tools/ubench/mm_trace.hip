@@ -12,12 +12,14 @@ __global__ void fill(_Float16* p, size_t n, unsigned seed) {
 }
 int main(int argc, char** argv) {
     const long M = argc > 1 ? atol(argv[1]) : 32768; const int K = argc > 2 ? atoi(argv[2]) : 1280, N = argc > 3 ? atoi(argv[3]) : 2560;
-    const int mode = argc > 4 ? atoi(argv[4]) : 0;          // GSW_GEMM_PLAIN 0 / GEGLU 1 / TRANS 2
+    const int mode = argc > 4 ? atoi(argv[4]) : 0;          // GSW_GEMM_PLAIN 0 / GEGLU 1 / TRANS 2 / TOK2PF 3
+    const int use_bias = argc > 5 ? atoi(argv[5]) : 0;
     _Float16 *x, *w, *y; hipMalloc(&x, M * K * 2); hipMalloc(&w, (size_t)N * K * 2); hipMalloc(&y, (size_t)(M * 1.08) * N * 2 + (1 << 20));
     fill<<<1024, 256>>>(x, M * K, 1); fill<<<1024, 256>>>(w, (size_t)N * K, 2);
+    _Float16* bias = nullptr; if (use_bias) { hipMalloc(&bias, (size_t)N * 2); fill<<<64, 256>>>(bias, N, 3); }
     unsigned long long* tb; hipMalloc(&tb, 4096); hipMemset(tb, 0, 4096);
     hipMemcpyToSymbol(HIP_SYMBOL(g_mm_trace_buf), &tb, sizeof(tb));
-    for (int r = 0; r < 3; ++r) { int rc = gsw_gemm(x, w, nullptr, nullptr, y, M, K, N, mode, mode >= 2 ? 4096 : 0, mode == 3 ? 64 : 0, GSW_F16, nullptr); if (rc) { printf("rc %d\n", rc); return 1; } }
+    for (int r = 0; r < 3; ++r) { int rc = gsw_gemm(x, w, bias, nullptr, y, M, K, N, mode, mode >= 2 ? 4096 : 0, mode == 3 ? 64 : 0, GSW_F16, nullptr); if (rc) { printf("rc %d\n", rc); return 1; } }
     hipDeviceSynchronize();
     std::vector<unsigned long long> h(12 * 16);
     hipMemcpy(h.data(), tb, h.size() * 8, hipMemcpyDeviceToHost);
