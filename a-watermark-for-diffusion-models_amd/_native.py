@@ -79,12 +79,22 @@ _PROTOTYPES = {
                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "gsw_softmax_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_float, C.c_int, C.c_void_p]),
     "gsw_mm_config": (C.c_int, [C.c_int, C.c_int]),
+    "gsw_mm_get_config": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "gsw_mm_set_workspace": (C.c_int, [C.c_void_p, C.c_int64, C.c_int]),
     "gsw_mm_next_colstats": (C.c_int, [C.c_void_p, C.c_int64]),
     "gsw_mm_last_colstats": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "gsw_groupnorm_pf_cs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int,
                                       C.c_int, C.c_void_p]),
+    "gsw_groupnorm_pf_fused": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                         C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "gsw_gather_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_void_p]),
+    "gsw_nchw_to_pf": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "gsw_conv3x3_pf_nchw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "gsw_gemm_small_config": (C.c_int, [C.c_int64, C.c_int, C.c_int, C.c_int]),
+    "gsw_gemm_small": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int,
+                                 C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int), C.c_int,
+                                 C.c_int, C.c_void_p]),
     "gsw_linear": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
                              C.c_void_p]),
 }

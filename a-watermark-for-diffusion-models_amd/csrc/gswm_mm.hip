@@ -38,6 +38,7 @@
 
 #include "../../include/gswm.h"
 #include "gswm_mm.h"
+#include "gswm_mmtypes.h"
 
 // Process-wide tuning knobs of the engine (tests and A/B runs force a tiling; production leaves both on "auto").  Initialised from the environment
 // (GSW_MM_BM = 128 | 256, GSW_MM_SPLIT = bit mask over epilogue kinds) and settable through the C ABI (gsw_mm_config).
@@ -45,64 +46,6 @@ static std::atomic<int> g_mm_tile_rows{getenv("GSW_MM_BM") ? atoi(getenv("GSW_MM
 static std::atomic<int> g_mm_split_mask{getenv("GSW_MM_SPLIT") ? atoi(getenv("GSW_MM_SPLIT")) : 10 /* convolutions (EPI 1) and the transposed projection (EPI 3) */};
 
 namespace {
-
-typedef _Float16 mm_h8 __attribute__((ext_vector_type(8)));
-typedef __bf16 mm_b8 __attribute__((ext_vector_type(8)));
-typedef float mm_f4 __attribute__((ext_vector_type(4)));
-
-template <typename T> struct MM;
-template <> struct MM<_Float16> {
-    typedef mm_h8 frag;
-    static __device__ __forceinline__ mm_f4 mma(frag a, frag b, mm_f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
-    static __device__ __forceinline__ uint16_t cvt(float f) { return __half_as_ushort(__float2half_rn(f)); }
-    static __device__ __forceinline__ float up(uint16_t h) { return __half2float(__ushort_as_half(h)); }
-    static __device__ __forceinline__ uint32_t cvt2(float lo, float hi) {      // v_cvt_pk_f16_f32 (round to nearest even)
-        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-        typedef float f2 __attribute__((ext_vector_type(2)));
-        return __builtin_bit_cast(uint32_t, __builtin_convertvector(f2{lo, hi}, h2));
-    }
-    static __device__ __forceinline__ float up_lo(uint32_t p) { typedef _Float16 h2 __attribute__((ext_vector_type(2))); return (float)__builtin_bit_cast(h2, p)[0]; }
-    static __device__ __forceinline__ float up_hi(uint32_t p) { typedef _Float16 h2 __attribute__((ext_vector_type(2))); return (float)__builtin_bit_cast(h2, p)[1]; }
-    static __device__ __forceinline__ uint32_t mul2(uint32_t a, uint32_t b) {  // v_pk_mul_f16: the correctly rounded fp16 product of fp16 operands, two at a time
-        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-        return __builtin_bit_cast(uint32_t, __builtin_bit_cast(h2, a) * __builtin_bit_cast(h2, b));
-    }
-    static __device__ __forceinline__ uint32_t add2(uint32_t a, uint32_t b) {  // v_pk_add_f16: the correctly rounded sum of two fp16 values = cvt(up(a) + up(b)), two at a time
-        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-        return __builtin_bit_cast(uint32_t, __builtin_bit_cast(h2, a) + __builtin_bit_cast(h2, b));
-    }
-    // (sum, sum of squares) of a packed pair into fp32 accumulators: two v_dot2_f32_f16 (exact products, fp32 accumulation)
-    static __device__ __forceinline__ void stat2(uint32_t w, float& sm, float& sq) {
-        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-        const h2 v = __builtin_bit_cast(h2, w);
-        sm = __builtin_amdgcn_fdot2(v, h2{(_Float16)1.0f, (_Float16)1.0f}, sm, false);
-        sq = __builtin_amdgcn_fdot2(v, v, sq, false);
-    }
-};
-template <> struct MM<__bf16> {
-    typedef mm_b8 frag;
-    static __device__ __forceinline__ mm_f4 mma(frag a, frag b, mm_f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
-    static __device__ __forceinline__ uint16_t cvt(float f) {
-        union { __hip_bfloat16 h; uint16_t u; } c; c.h = __float2bfloat16(f); return c.u;
-    }
-    static __device__ __forceinline__ float up(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
-    static __device__ __forceinline__ uint32_t cvt2(float lo, float hi) {      // v_cvt_pk_bf16_f32 (round to nearest even)
-        typedef __bf16 b2 __attribute__((ext_vector_type(2)));
-        typedef float f2 __attribute__((ext_vector_type(2)));
-        return __builtin_bit_cast(uint32_t, __builtin_convertvector(f2{lo, hi}, b2));
-    }
-    static __device__ __forceinline__ float up_lo(uint32_t p) { return __uint_as_float(p << 16); }
-    static __device__ __forceinline__ float up_hi(uint32_t p) { return __uint_as_float(p & 0xFFFF0000u); }
-    static __device__ __forceinline__ uint32_t mul2(uint32_t a, uint32_t b) {  // bf16 x bf16 is exact in fp32: one rounding, like a bf16 multiply
-        return cvt2(up_lo(a) * up_lo(b), up_hi(a) * up_hi(b));
-    }
-    static __device__ __forceinline__ uint32_t add2(uint32_t a, uint32_t b) { return cvt2(up_lo(a) + up_lo(b), up_hi(a) + up_hi(b)); }
-    static __device__ __forceinline__ void stat2(uint32_t w, float& sm, float& sq) {
-        const float lo = up_lo(w), hi = up_hi(w);
-        sm += lo + hi;
-        sq = fmaf(lo, lo, fmaf(hi, hi, sq));
-    }
-};
 
 // MM_TRACE (tools/ubench/mm_trace.hip only): cycles between consecutive stamps, summed per interval kind in scalar registers (no memory
 // traffic inside the loop); workgroup 0's waves write their sums when the kernel ends
@@ -149,24 +92,7 @@ __device__ __forceinline__ void mm_lds_read_rows(uint32_t a, mm_f2 (&r)[MT]) {
 }
 
 // EPI: epilogue class the kernel is compiled for -- 0 dense rows (bias, optional residual), 1 generic (PF border / row bias / token scatter /
-// sub-pixel scatter), 2 GEGLU, 3 transposed output (MFMA operands swapped)
-// Abramowitz & Stegun 7.1.26 for the GEGLU epilogue: erfc(x) = (a1 t + ... + a5 t^5) exp(-x^2), t = 1 / (1 + p x), |error| <= 1.5e-7 (three orders below the
-// fp16 / bf16 rounding of the gelu it feeds), branch-free.  The library erff (two polynomial branches, both executed in a wave) made the epilogue of the
-// L0 feed-forward projection (K = 320: five K slices per tile) VALU-bound.
-// gelu(g) = g Phi(g) for the GEGLU epilogue, from h = erfc(|g| / sqrt 2) / 2 (the same 7.1.26 polynomial with the 1/2 and the 1/sqrt 2 folded into
-// its constants): gelu = max(g, 0) - |g| h -- no sign transfer, no 1 + erf, 13 instructions with the v_rcp and the v_exp.
-__device__ __forceinline__ float mm_gelu(float g) {
-    const float ag = fabsf(g);
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752f, ag, 1.0f));
-    float pl = fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
-    pl = fmaf(pl, t, 0.5f * 1.421413741f);
-    pl = fmaf(pl, t, 0.5f * -0.284496736f);
-    pl = fmaf(pl, t, 0.5f * 0.254829592f);
-    const float y = 0.84932180028801904f * g;                          // sqrt(log2(e) / 2) g: exp(-g^2 / 2) = exp2(-y^2)
-    const float e = __builtin_amdgcn_exp2f(-y * y);
-    return fmaf(-ag, pl * t * e, fmaxf(g, 0.0f));
-}
-
+// sub-pixel scatter), 2 GEGLU, 3 transposed output (MFMA operands swapped); mm_gelu: gswm_mmtypes.h
 // x + (the DPP-selected x of another lane; 0 where the selection has no source or the row is masked out)
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float mm_dpp_add(float x) {
@@ -1050,9 +976,34 @@ __global__ __launch_bounds__(256) void gsw_mm_reduce_kernel(const MMArgs p, cons
         if (m >= p.M || n >= p.N || (geglu && q >= 2u)) continue;
         mm_f4 a = mm_f4{0.f, 0.f, 0.f, 0.f}, g = mm_f4{0.f, 0.f, 0.f, 0.f};
         const float* src = p.ws + (size_t)u * 4;
-        for (int s = 0; s < p.splits; ++s) {
+        // the slabs of a tile are added in split order (a fixed order: deterministic), but LOADED eight at a time: one load per dependent add made this
+        // kernel latency-bound on its split count (16 splits = 16 L2 round trips in a row)
+        int s = 0;
+        for (; s + 8 <= p.splits; s += 8) {
+            mm_f4 t[8], tg[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = *reinterpret_cast<const mm_f4*>(src + (size_t)(s + j) * split_stride);
+            if (geglu) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) tg[j] = *reinterpret_cast<const mm_f4*>(src + (size_t)(s + j) * split_stride + 32 * 4);       // the gate columns: lane + 32
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a += t[j];
+            if (geglu) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) g += tg[j];
+            }
+        }
+        for (; s + 2 <= p.splits; s += 2) {
+            const mm_f4 t0 = *reinterpret_cast<const mm_f4*>(src + (size_t)s * split_stride), t1 = *reinterpret_cast<const mm_f4*>(src + (size_t)(s + 1) * split_stride);
+            mm_f4 g0 = mm_f4{0.f, 0.f, 0.f, 0.f}, g1 = g0;
+            if (geglu) { g0 = *reinterpret_cast<const mm_f4*>(src + (size_t)s * split_stride + 32 * 4); g1 = *reinterpret_cast<const mm_f4*>(src + (size_t)(s + 1) * split_stride + 32 * 4); }
+            a += t0; a += t1;
+            if (geglu) { g += g0; g += g1; }
+        }
+        for (; s < p.splits; ++s) {
             a += *reinterpret_cast<const mm_f4*>(src + (size_t)s * split_stride);
-            if (geglu) g += *reinterpret_cast<const mm_f4*>(src + (size_t)s * split_stride + 32 * 4);       // the gate columns: lane + 32
+            if (geglu) g += *reinterpret_cast<const mm_f4*>(src + (size_t)s * split_stride + 32 * 4);
         }
         float b4[4] = {0.f, 0.f, 0.f, 0.f};
         if (bias) { for (int j = 0; j < 4; ++j) b4[j] = MM<T>::up(bias[n + j]); }
@@ -1237,6 +1188,12 @@ int gsw_mm_config(int tile_rows, int split_mask) {
     if (split_mask < -1 || split_mask > 15) return GSW_ERR_BAD_ARG;
     if (tile_rows != -1) g_mm_tile_rows.store(tile_rows, std::memory_order_relaxed);
     if (split_mask != -1) g_mm_split_mask.store(split_mask, std::memory_order_relaxed);
+    return GSW_OK;
+}
+
+int gsw_mm_get_config(int* tile_rows, int* split_mask) {
+    if (tile_rows) *tile_rows = g_mm_tile_rows.load(std::memory_order_relaxed);
+    if (split_mask) *split_mask = g_mm_split_mask.load(std::memory_order_relaxed);
     return GSW_OK;
 }
 

@@ -107,3 +107,129 @@ def reduce_accuracy(matched_bits: torch.Tensor, total_bits: int) -> float:
         dist.all_reduce(m)
         dist.all_reduce(t)
     return float(m.item()) / float(t.item())
+
+
+# =====================================================================================================================
+# Preflight of the multi-GPU control plane (`bench.py --gpus N --preflight`, `python -m gswm_amd.extract --gpus N --preflight`): every rank
+# checks, in this order and each under a hard time limit, (1) the launcher environment, (2) that its GPU exists, (3) the rendezvous / RCCL
+# init, (4) a device-tensor broadcast, (5) all_gather_into_tensor, (6) an all-reduce -- exactly the collectives the product path uses
+# (broadcast_params, gather_bits, reduce_accuracy).  A stage that fails or hangs ends the rank with exit code 3 and ONE line naming the
+# failure class; the launcher (launch.spawn_ranks) then stops the sibling ranks.  Nothing here replaces the process: a hang is ended by
+# os._exit from a watchdog thread of the rank itself.
+# =====================================================================================================================
+PREFLIGHT_EXIT = 3
+_PREFLIGHT_HINTS = {
+    "launcher": "RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT missing or inconsistent: start the ranks with `--gpus N` (self-launch) or torch.distributed.run",
+    "devices": "this rank's GPU is not visible: check HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES and that the node has --gpus devices",
+    "rendezvous": "init_process_group did not complete: MASTER_ADDR must be 127.0.0.1 on one node; a stale process may hold MASTER_PORT; for RCCL across "
+                  "processes this driver needs HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC; without it hipIpcGetMemHandle fails with 'invalid argument')",
+    "broadcast": "the first device collective failed: RCCL could not move data between the GPUs (xGMI / IPC); see NCCL_DEBUG=INFO",
+    "all_gather": "all_gather_into_tensor failed or returned wrong ranks",
+    "all_reduce": "all_reduce failed or returned a wrong sum",
+}
+
+
+class PreflightError(RuntimeError):
+    def __init__(self, stage: str, detail: str):
+        super().__init__(f"{stage}: {detail} -- {_PREFLIGHT_HINTS.get(stage, '')}")
+        self.stage = stage
+
+
+def preflight(backend: str = "nccl", timeout_s: float = 120.0, init: bool = True) -> Dict:
+    """Run the six stages on this rank (see above) -> {"rank", "world", "backend", "ranks_seen", "stage_ms"}; raises PreflightError.  With
+    `timeout_s` > 0 a stage that hangs ends the process with PREFLIGHT_EXIT.  init=False: the process group already exists."""
+    import os
+    import sys
+    import threading
+    import time
+    from datetime import timedelta
+
+    stage_box = {"name": "launcher", "t0": time.monotonic()}
+    rank_txt = os.environ.get("RANK", "?")
+    done = threading.Event()
+
+    def watchdog():
+        while not done.wait(0.25):
+            if timeout_s > 0 and time.monotonic() - stage_box["t0"] > timeout_s:
+                print(f"[gswm preflight] rank {rank_txt}: {stage_box['name']}: no progress for {timeout_s:.0f} s -- "
+                      f"{_PREFLIGHT_HINTS.get(stage_box['name'], '')}", file=sys.stderr, flush=True)
+                os._exit(PREFLIGHT_EXIT)
+
+    threading.Thread(target=watchdog, daemon=True).start()
+    stage_ms: Dict[str, float] = {}
+
+    def enter(name):
+        now = time.monotonic()
+        stage_ms[stage_box["name"]] = (now - stage_box["t0"]) * 1e3
+        stage_box["name"], stage_box["t0"] = name, now
+
+    try:
+        try:
+            world, rank, local = (int(os.environ[k]) for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"))
+            if not (0 <= rank < world) or not os.environ.get("MASTER_ADDR") or not os.environ.get("MASTER_PORT"):
+                raise KeyError("MASTER_ADDR / MASTER_PORT")
+        except (KeyError, ValueError) as exc:
+            raise PreflightError("launcher", f"bad environment ({exc})") from None
+        enter("devices")
+        if backend == "nccl":
+            n = torch.cuda.device_count()
+            if local >= n:
+                raise PreflightError("devices", f"LOCAL_RANK {local} but {n} visible device(s)")
+            torch.cuda.set_device(local)
+        enter("rendezvous")
+        if init and not dist.is_initialized():
+            try:
+                kw = {"device_id": torch.device("cuda", local)} if backend == "nccl" else {}
+                dist.init_process_group(backend, timeout=timedelta(seconds=max(30.0, timeout_s)), **kw)
+            except Exception as exc:  # noqa: BLE001
+                raise PreflightError("rendezvous", f"{type(exc).__name__}: {exc}") from None
+        dev = _comm_device()
+        enter("broadcast")
+        try:
+            t = torch.arange(64, dtype=torch.int64, device=dev) * 3 + 1 if rank == 0 else torch.zeros(64, dtype=torch.int64, device=dev)
+            dist.broadcast(t, src=0)
+            ok = bool((t.cpu() == torch.arange(64, dtype=torch.int64) * 3 + 1).all())
+        except Exception as exc:  # noqa: BLE001
+            raise PreflightError("broadcast", f"{type(exc).__name__}: {exc}") from None
+        if not ok:
+            raise PreflightError("broadcast", "payload arrived corrupted")
+        enter("all_gather")
+        try:
+            out = torch.empty(world, dtype=torch.int64, device=dev)
+            dist.all_gather_into_tensor(out, torch.tensor([rank], dtype=torch.int64, device=dev))
+            seen = [int(v) for v in out.cpu().tolist()]
+        except Exception as exc:  # noqa: BLE001
+            raise PreflightError("all_gather", f"{type(exc).__name__}: {exc}") from None
+        if seen != list(range(world)):
+            raise PreflightError("all_gather", f"ranks seen {seen}, expected {list(range(world))}")
+        enter("all_reduce")
+        try:
+            s = torch.tensor([rank + 1], dtype=torch.int64, device=dev)
+            dist.all_reduce(s)
+            total = int(s.cpu().item())
+        except Exception as exc:  # noqa: BLE001
+            raise PreflightError("all_reduce", f"{type(exc).__name__}: {exc}") from None
+        if total != world * (world + 1) // 2:
+            raise PreflightError("all_reduce", f"sum {total}, expected {world * (world + 1) // 2}")
+        enter("done")
+    finally:
+        done.set()
+    return {"rank": rank, "world": world, "backend": backend, "ranks_seen": seen, "stage_ms": {k: round(v, 2) for k, v in stage_ms.items()}}
+
+
+def preflight_main(backend: str, timeout_s: float = 120.0) -> int:
+    """What `--preflight` runs on every rank: the report as ONE JSON line from rank 0 (exit 0), or one line naming the failure class (exit 3)."""
+    import json
+    import os
+    import sys
+    try:
+        rep = preflight(backend, timeout_s)
+    except PreflightError as exc:
+        print(f"[gswm preflight] rank {os.environ.get('RANK', '?')}: {exc}", file=sys.stderr, flush=True)
+        return PREFLIGHT_EXIT
+    if rep["rank"] == 0:
+        print(json.dumps({"preflight": True, "n_gpus": rep["world"], "backend": backend, "ranks_seen": rep["ranks_seen"], "stage_ms": rep["stage_ms"],
+                          "collectives": ["broadcast", "all_gather_into_tensor", "all_reduce"]}), flush=True)
+    if dist.is_initialized():
+        dist.destroy_process_group()
+    return 0

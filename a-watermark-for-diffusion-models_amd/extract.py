@@ -101,6 +101,12 @@ def _synthetic_allowed(args=None) -> bool:
     return bool(ALLOW_SYNTHETIC_WEIGHTS or os.environ.get("GSW_ALLOW_SYNTHETIC_WEIGHTS", "0") == "1" or (args is not None and getattr(args, "allow_synthetic_weights", False)))
 
 
+def _no_checkpoint(model_id) -> bool:
+    """True when `model_id` resolves to no local checkpoint (neither a directory nor a cached hub snapshot): synthetic weights or failure"""
+    from .checkpoint import resolve_model_dir
+    return resolve_model_dir(str(model_id)) is None
+
+
 def _read_json(path):
     import json
     with open(path) as f:
@@ -111,6 +117,8 @@ def _unet_from_config(cfg: dict):
     """unet/config.json (diffusers UNet2DConditionModel) -> the own module.  `attention_head_dim` is the number of heads in the SD 1.x /
     2.x configs (an int or one entry per block); head width = channels / heads."""
     from . import unet as U
+    from .checkpoint import validate_unet_config
+    validate_unet_config(cfg)
     boc = tuple(cfg.get("block_out_channels", (320, 640, 1280, 1280)))
     ahd = cfg.get("attention_head_dim", 8)
     heads = tuple(ahd) if isinstance(ahd, (list, tuple)) else (int(ahd),) * len(boc)
@@ -131,19 +139,24 @@ def _vae_from_config(cfg: dict):
 
 
 class Models:
-    """UNet + VAE + scheduler constants + the context of the empty prompt of one `model_id` (a local directory in diffusers layout: unet/,
-    vae/, scheduler/, optionally text_encoder/ + tokenizer/).  The modules are built from the directory's config.json files, so SD 1.x
-    and 2.x checkpoints both load."""
+    """UNet + VAE + scheduler constants + the context of the empty prompt of one `model_id`: a local directory in diffusers layout (unet/,
+    vae/, scheduler/, text_encoder/ + tokenizer/) or a hub id such as the reference's default `stabilityai/stable-diffusion-2-1-base`
+    (extract.py:183), which is looked up in the local Hugging Face cache exactly where diffusers' from_pretrained (extract.py:56-60) would have
+    left it (checkpoint.resolve_model_dir; nothing is ever downloaded).  The modules are built from the directory's config.json files, so SD 1.x
+    and 2.x checkpoints both load; safetensors, sharded safetensors and .bin weight files are read."""
 
     def __init__(self, model_id, device="cuda", dtype=torch.float16, allow_synthetic=False):
-        from . import unet as U, vae as V
-        self.device, self.dtype, self.model_id = torch.device(device), dtype, str(model_id)
-        self.synthetic = not os.path.isdir(self.model_id)
+        from . import unet as U, vae as V, checkpoint
+        self.device, self.dtype, self.model_name = torch.device(device), dtype, str(model_id)
+        resolved = checkpoint.resolve_model_dir(self.model_name)
+        self.synthetic = resolved is None
+        self.model_id = self.model_name if resolved is None else resolved        # from here on: the directory the files are read from
         self.scheduler = {}
         if self.synthetic:
             if not allow_synthetic:
                 raise FileNotFoundError(
-                    f"'{model_id}' is not a local directory in diffusers layout and there is no network to fetch it from. Pass a checkpoint directory as "
+                    f"'{model_id}' is neither a local directory in diffusers layout nor a snapshot in the local Hugging Face cache (searched: "
+                    f"{checkpoint.describe_search(self.model_name)}), and there is no network to fetch it from. Pass a checkpoint directory as "
                     "--model_id; for pipeline tests / benchmarks with seeded SYNTHETIC weights (bit accuracies are then meaningless) opt in with "
                     "--allow_synthetic_weights, GSW_ALLOW_SYNTHETIC_WEIGHTS=1 or extract.ALLOW_SYNTHETIC_WEIGHTS = True.")
             print(f"[gswm] '{model_id}' is not a local diffusers directory: SYNTHETIC weights (results are not meaningful)", file=sys.stderr)
@@ -159,10 +172,11 @@ class Models:
             scfg = os.path.join(self.model_id, "scheduler", "scheduler_config.json")
             if os.path.exists(scfg):
                 self.scheduler = _read_json(scfg)
+                checkpoint.validate_scheduler_config(self.scheduler)
         self.unet.to(self.device, dtype).eval()
         self.vae.to(self.device, dtype).eval()
         from .graph import graphed
-        self.eps = graphed(self.unet)           # the eps model of the loops: HIP-graph replay of the forward for small batches (graph.py), eager above
+        self.eps = graphed(self.unet, clone_output=False)           # the eps model of the loops: HIP-graph replay of the forward for small batches (graph.py), eager above
         self.prediction_type = self.scheduler.get("prediction_type", "epsilon")
         self.ctx_dim = self.unet.mid_block.attentions[0].transformer_blocks[0].attn2.to_k.in_features
         self.ctx_empty = self._empty_prompt_context()
@@ -294,7 +308,7 @@ def exactract_latents(args, *, device="cuda") -> torch.Tensor:
 
 def get_result_for_one_image(args):
     """extract.py:112-117 (same stdout text)."""
-    if not os.path.isdir(str(args.model_id)):
+    if _no_checkpoint(args.model_id):
         load_models(args.model_id, allow_synthetic=_synthetic_allowed(args))
         print(f"{SYNTHETIC_MARKER}: '{args.model_id}' is not a local checkpoint, the bit accuracy below is not meaningful", file=sys.stderr)
     reversed_latents = exactract_latents_batch([args.single_image_path], args)
@@ -491,7 +505,7 @@ def process_directory(args, *, batch_size=None):
     rank, _ = gdist.rank_world()
     script = _plan(args)
     jobs = [j for kind, j in script if kind == "job"]
-    synthetic = not os.path.isdir(str(args.model_id))
+    synthetic = _no_checkpoint(args.model_id)
     with _strictness(args, synthetic):
         if any(j.files for j in jobs):
             load_models(args.model_id, allow_synthetic=_synthetic_allowed(args))          # fail before touching any result file
@@ -515,7 +529,7 @@ def process_single_directory(dir_path, args, *, batch_size=None):
     batch_size = int(batch_size or getattr(args, "batch_size", 0) or 16)
     job = _DirJob(dir_path)
     if job.files:
-        synthetic = not os.path.isdir(str(args.model_id))
+        synthetic = _no_checkpoint(args.model_id)
         with _strictness(args, synthetic):
             load_models(args.model_id, allow_synthetic=_synthetic_allowed(args))
             _recover_many([(job, f) for f in job.files], args, batch_size)
@@ -545,6 +559,8 @@ def build_parser():
     parser.add_argument("--batch_size", type=int, default=16, help="(not a reference flag) images per device batch of the directory harness")
     parser.add_argument("--gpus", type=int, default=1, help="(not a reference flag) shard the images of a directory run over this many GPUs of the node: "
                                                            "one process per GPU, started here unless a launcher (torch.distributed.run) already did")
+    parser.add_argument("--preflight", action="store_true", help="(not a reference flag) only check the multi-GPU control plane: per rank device check, RCCL init, one "
+                                                                 "broadcast + all_gather_into_tensor + all_reduce under a hard time limit; exit 0 / 3")
     parser.add_argument("--strict_kernels", type=int, choices=[0, 1], default=None,
                         help="(not a reference flag) 1: raise when a GPU half-precision call would leave the hand-written kernels instead of warning "
                              "(default: 1 with a real checkpoint, 0 with synthetic weights)")
@@ -576,6 +592,12 @@ def main(argv=None):
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         env = {"PYTHONPATH": os.pathsep.join([root] + [p for p in os.environ.get("PYTHONPATH", "").split(os.pathsep) if p])}
         raise SystemExit(launch.spawn_ranks([sys.executable, "-m", "gswm_amd.extract"] + argv, int(args.gpus), env_extra=env))
+    if args.preflight:
+        from . import dist as gdist
+        if "WORLD_SIZE" not in os.environ:
+            os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29532"))
+        backend = os.environ.get("GSW_DIST_BACKEND", "nccl" if torch.cuda.is_available() else "gloo")
+        raise SystemExit(gdist.preflight_main(backend, float(os.environ.get("GSW_PREFLIGHT_TIMEOUT_S", "120"))))
     args.key = bytes.fromhex(args.key_hex)
     if args.nonce_hex != "":
         args.nonce = bytes.fromhex(args.nonce_hex)
@@ -590,7 +612,7 @@ def main(argv=None):
         elif args.single_image_path != "":
             from . import dist as gdist
             if gdist.rank_world()[0] == 0:            # one image: nothing to shard
-                with _strictness(args, not os.path.isdir(str(args.model_id))):
+                with _strictness(args, _no_checkpoint(args.model_id)):
                     get_result_for_one_image(args)
         else:
             print("Please set the argument 'images_directory_path' or 'single_image_path'")

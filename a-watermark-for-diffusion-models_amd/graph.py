@@ -13,9 +13,13 @@ What the graph bakes in, and how it stays valid:
   * the padded context copy and the cross-attention K / V^T of every layer (computed ONCE per context, outside the graph, cached on the
     context tensor by unet.Attention) -- when the caller passes a different context, ctx_s is overwritten and those are recomputed IN PLACE
     (unet._padded_ctx / Attention refresh into their existing buffers), so the addresses the graph reads never change;
-  * weights and their packed copies -- replacing or editing parameters (load_state_dict, .to()) invalidates every graph (checked through the
-    parameters' version counters and storage pointers whenever the context changes, i.e. once per loop; `reset()` forces it).
-Capture failing for any reason falls back to eager IN THIS PROCESS (never a re-exec) and is reported once.
+  * weights and their packed copies -- replacing or editing parameters (load_state_dict, .to(), a LoRA merge) invalidates every graph: the
+    parameters' version counters and storage pointers are checked whenever the context changes AND every CHECK_EVERY replays of an entry (a
+    harness that keeps one context for its whole life would otherwise replay stale weights for ever); `reset()` forces it;
+  * the launch sequence itself -- the module-level switches of unet.py / pf.py and the engine's tiling knobs (gsw_mm_config) are part of an
+    entry's key, so an A/B toggle after a capture captures anew instead of silently replaying the old sequence.
+Capture failing for any reason falls back to eager IN THIS PROCESS (never a re-exec) and is reported once.  Entries are kept in an LRU of
+MAX_ENTRIES (each pins a private activation pool and a 20 MiB split-K scratch).
 
 A graph replay runs exactly the launches of the eager forward with the same arguments: outputs are bit-identical (tests/test_gpu_graph.py).
 """
@@ -23,6 +27,7 @@ from __future__ import annotations
 
 import os
 import warnings
+from collections import OrderedDict
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -35,6 +40,19 @@ def _env_mode() -> str:
 # "auto": graphs for forwards of at most AUTO_MAX_ROWS rows (above that a forward is tens of milliseconds of GPU work and the launch path is
 # hidden behind it; the graph would only pin a second copy of the activation memory)
 AUTO_MAX_ROWS = 32
+CHECK_EVERY = 32        # replays of an entry between two checks of the parameters' versions (~0.3 ms per check: ~700 parameters)
+MAX_ENTRIES = 8         # captured (shape, dtype, context shape, switches) entries kept; the least recently used one is dropped beyond that
+
+
+def _switches():
+    """Everything outside the arguments that decides WHICH launches a forward makes: captured graphs are keyed by it."""
+    from . import pf, unet as U, _native as N
+    import ctypes as C
+    tr, sm = C.c_int(0), C.c_int(0)
+    N.lib().gsw_mm_get_config(C.byref(tr), C.byref(sm))
+    return (U.FUSED_KERNELS, U.USE_PF, U.UPSAMPLE_SUBPIXEL, U.CACHE_CONTEXT_KV, U.FUSED_QK, U.FUSED_QKV, U.OWN_ATTENTION, U.OWN_GEMM, U.TEMB_TABLE,
+            U.CONV_OUT_DIRECT_MAX_PIXELS, pf.FUSE_GN_STATS, pf.GN_FUSED_MAX_WGS, pf.GN_FUSED_MAX_PIXELS, pf.FOLD_LN, pf.FOLD_LN_MIN_ROWS, pf.SPLITK_MAX,
+            pf.SPLITK_BYTES, tr.value, sm.value)
 
 
 class _Entry:
@@ -57,17 +75,20 @@ class GraphedEpsModel:
     """Callable `eps_model(x, t, ctx)` for ddim.py that replays a captured forward of `model` when that pays, else calls it eagerly.
 
     mode: "auto" (default; env GSW_GRAPH overrides) -> graphs up to AUTO_MAX_ROWS rows; "always"; "never".
-    The returned tensor is the graph's static output buffer: it is valid until the next call with the same shape (the loops consume it in the
-    scheduler-step kernel right away)."""
+    clone_output (default True): the result is a copy of the graph's static output buffer (4 x H x W values per row: one small launch), so two
+    results of the same shape can be held side by side; False hands out the static buffer itself, valid until the next call with the same
+    shape -- what the in-repo loops need, which consume eps in the scheduler-step kernel right away."""
 
-    def __init__(self, model, mode: Optional[str] = None, max_rows: int = AUTO_MAX_ROWS):
+    def __init__(self, model, mode: Optional[str] = None, max_rows: int = AUTO_MAX_ROWS, clone_output: bool = True):
         self.model = model
         m = (mode or _env_mode()).lower()
         self.mode = {"1": "always", "0": "never", "on": "always", "off": "never"}.get(m, m)
         if self.mode not in ("auto", "always", "never"):
             raise ValueError(f"GSW_GRAPH / mode must be auto | always | never (got {m!r})")
         self.max_rows = max_rows
-        self._entries: Dict[Tuple, _Entry] = {}
+        self.clone_output = clone_output
+        self.capture_fallbacks: Dict[str, int] = {}        # unet.FALLBACKS counted while capturing: a library kernel baked into a graph is invisible at replay
+        self._entries: "OrderedDict[Tuple, _Entry]" = OrderedDict()
         self._weights_key = None
         self._failed: Dict[Tuple, str] = {}
         self.stats = {"captures": 0, "replays": 0, "eager": 0, "context_refreshes": 0}
@@ -100,12 +121,15 @@ class GraphedEpsModel:
         from . import pf
         # the split-K scratch of the matmul engine is baked into the graph too: one per graph, so replays never share scratch with eager launches
         e.ws = torch.empty(pf.SPLITK_BYTES, dtype=torch.uint8, device=x.device)
+        from . import unet as U
+        fb_before = dict(U.FALLBACKS)
         try:
-            # warm-up on a side stream: builds the packed weights, the padded context + cross-attention K / V^T (cached on ctx_s, OUTSIDE the
-            # graph's pool), kernel attributes and workspaces, so that the captured forward contains the per-step launches only
+            # warm-up on a side stream: builds the packed weights, the time-embedding table, the padded context + cross-attention K / V^T (cached on
+            # ctx_s, OUTSIDE the graph's pool), kernel attributes, so that the captured forward contains the per-step launches only.  It already runs
+            # with the entry's split-K scratch (no per-stream scratch is left behind)
             side = torch.cuda.Stream(device=x.device)
             side.wait_stream(torch.cuda.current_stream(x.device))
-            with torch.cuda.stream(side), torch.no_grad():
+            with torch.cuda.stream(side), torch.no_grad(), pf.splitk_workspace(e.ws):
                 self.model(e.x_s, e.t_s, e.ctx_s)
                 self.model(e.x_s, e.t_s, e.ctx_s)
             torch.cuda.current_stream(x.device).wait_stream(side)
@@ -113,6 +137,9 @@ class GraphedEpsModel:
             with torch.no_grad(), pf.splitk_workspace(e.ws), torch.cuda.graph(g):
                 e.out = self.model(e.x_s, e.t_s, e.ctx_s)
             e.graph = g
+            for k_, v_ in U.FALLBACKS.items():             # launches off the hand-written path that the capture baked in (counted per warm-up + capture)
+                if v_ != fb_before.get(k_, 0):
+                    self.capture_fallbacks[k_] = self.capture_fallbacks.get(k_, 0) + 1
         except Exception as exc:      # noqa: BLE001 -- any capture failure means "run eagerly", in this process
             self._failed[key] = f"{type(exc).__name__}: {exc}"
             warnings.warn(f"gswm graph: capture of the eps model for {key} failed ({self._failed[key]}); running it eagerly", RuntimeWarning, stacklevel=3)
@@ -127,14 +154,14 @@ class GraphedEpsModel:
             return self.model(x, t, ctx)
         if not torch.is_tensor(t):
             t = torch.as_tensor(t, device=x.device)
-        key = (tuple(x.shape), x.dtype, str(x.device), tuple(t.shape), t.dtype, tuple(ctx.shape), ctx.dtype)
+        key = (tuple(x.shape), x.dtype, str(x.device), tuple(t.shape), t.dtype, tuple(ctx.shape), ctx.dtype, _switches())
         if key in self._failed:
             self.stats["eager"] += 1
             return self.model(x, t, ctx)
         e = self._entries.get(key)
         cid = _ctx_identity(ctx)
-        if e is None or not _same_ctx(cid, e.ctx_id):
-            # (checked when a graph is captured and whenever the context changes, i.e. once per loop, not per step: ~700 parameters)
+        if e is None or not _same_ctx(cid, e.ctx_id) or e.replays % CHECK_EVERY == 0:
+            # (checked when a graph is captured, whenever the context changes, and every CHECK_EVERY replays: ~700 parameters, ~0.3 ms)
             wk = self._params_key()
             if wk != self._weights_key:         # parameters replaced / edited: every captured address or packed copy may be stale
                 self._entries.clear()
@@ -146,6 +173,8 @@ class GraphedEpsModel:
                 self.stats["eager"] += 1
                 return self.model(x, t, ctx)
             self._entries[key] = e
+            while len(self._entries) > MAX_ENTRIES:
+                self._entries.popitem(last=False)
         elif not _same_ctx(cid, e.ctx_id):
             # a different context: overwrite the static copy and bring the padded copy + every layer's K / V^T up to date IN PLACE (eagerly, on
             # this stream, ordered in front of the replay).  Holding a reference to the caller's tensor keeps the identity test sound.
@@ -158,9 +187,10 @@ class GraphedEpsModel:
         e.graph.replay()
         e.replays += 1
         self.stats["replays"] += 1
-        return e.out
+        self._entries.move_to_end(key)
+        return e.out.clone() if self.clone_output else e.out
 
 
-def graphed(model, mode: Optional[str] = None):
+def graphed(model, mode: Optional[str] = None, clone_output: bool = True):
     """Wrap an eps model once (idempotent)."""
-    return model if isinstance(model, GraphedEpsModel) else GraphedEpsModel(model, mode)
+    return model if isinstance(model, GraphedEpsModel) else GraphedEpsModel(model, mode, clone_output=clone_output)

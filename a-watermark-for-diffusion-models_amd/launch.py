@@ -47,7 +47,10 @@ def spawn_ranks(cmd: List[str], nprocs: int, *, timeout: Optional[float] = None,
     timeout -- are terminated and its exit code is returned; `timeout` seconds (None = no limit) bound the whole job (exit code 124)."""
     port = _free_port()
     base = {k: v for k, v in os.environ.items() if k not in LAUNCH_ENV}
-    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL across processes needs it on this driver
+    # dmabuf IPC: this image's host driver supports no legacy IPC handles -- without the setting RCCL / device-tensor sharing across processes fails with
+    # `hipIpcGetMemHandle: invalid argument` (the build environment exports it for the same reason; setdefault: an explicit value of the caller wins).
+    # `--preflight` (dist.preflight) is the check that it worked: RCCL init + a device broadcast + all_gather_into_tensor + all_reduce per rank.
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if env_extra:
         base.update(env_extra)
     procs: List[subprocess.Popen] = []

@@ -130,9 +130,10 @@ class ColStats:
         self.buf, self.rows, self.npar, self.blocks = buf, rows, npar, blocks      # blocks: per parity buffer (the buffer's stride)
 
 
-def _colstats_arm(M: int, Nn: int, device, npar: int = 1):
-    """Arm the one-shot request for a launch with M output pixels (per parity launch) and Nn columns -> (buffer, block capacity) or None."""
-    if not FUSE_GN_STATS:
+def _colstats_arm(M: int, Nn: int, device, npar: int = 1, geom=None):
+    """Arm the one-shot request for a launch with M output pixels (per parity launch) and Nn columns -> (buffer, block capacity) or None.
+    geom = (B, H, W) of the output: small batches take the one-launch GroupNorm, which reads the tensor itself (no records needed)."""
+    if not FUSE_GN_STATS or (geom is not None and _gn_fused_ok(geom[0], geom[1], geom[2], Nn, 32)):
         return None
     cap_blocks = (M + 127) // 128 * 4                 # 32-row blocks of 128-row tiles (64-row blocks of 256-row tiles need fewer)
     buf = torch.empty(npar * cap_blocks * Nn, dtype=torch.float32, device=device)      # [npar][blocks][2 planes][Nn / 2]
@@ -257,7 +258,7 @@ def conv_pf(x: PF, w_packed: torch.Tensor, bias: Optional[torch.Tensor], *, ksiz
     with torch.cuda.device(x.buf.device):
         _ensure_workspace(x.buf.device)
         e0 = tm.start() if tm is not None else None
-        armed = _colstats_arm(x.B * Ho * Wo, Nn, x.buf.device) if Nn >= 128 else None
+        armed = _colstats_arm(x.B * Ho * Wo, Nn, x.buf.device, geom=(x.B, Ho, Wo)) if Nn >= 128 else None
         with _colstats_scope(armed):
             N.check(N.lib().gsw_conv_pf(xp, w_packed.data_ptr(), bias.data_ptr() if bias is not None else None,
                                         rowbias.data_ptr() if rowbias is not None else None, ldrb,
@@ -352,11 +353,48 @@ def _gn_workspace(device, B, groups, C=0):
     return _GN_WS[k]
 
 
+# One-launch GroupNorm for small batches (gsw_groupnorm_pf_fused: a workgroup per (image, group) keeps the group in registers): used while the grid stays
+# a few hundred workgroups -- beyond that the two coalesced passes (or the producer's column records) win
+GN_FUSED_MAX_WGS = int(__import__("os").environ.get("GSW_GN_FUSED_MAX_WGS", "512"))
+GN_FUSED_MAX_PIXELS = int(__import__("os").environ.get("GSW_GN_FUSED_MAX_PIXELS", "1024"))      # measured on one image: 32 x 32 and below 5.5-10 us against ~13.5 for the
+                                                                                                 # two launches; 64 x 64 22 us (4-byte accesses 640 bytes apart)
+
+
+def _gn_fused_ok(B: int, H: int, W: int, C: int, groups: int) -> bool:
+    if B * groups > GN_FUSED_MAX_WGS or H * W > GN_FUSED_MAX_PIXELS or C % groups or (C // groups) % 2 or C % 8:
+        return False
+    npair = C // groups // 2
+    if npair * W > 1024 or B * (H + 2) * (W + 2) * C >= 1 << 31:
+        return False
+    rl = min(1024 // (npair * W), H)
+    while H % rl:
+        rl -= 1
+    return (H + rl - 1) // rl <= 64
+
+
+def _groupnorm_fused(x: PF, x2: Optional[PF], gamma, beta, groups, eps, act, tokens):
+    dev = x.buf.device
+    C = x.C + (x2.C if x2 is not None else 0)
+    if tokens:
+        res = torch.empty((x.B, x.H * x.W, C), dtype=x.buf.dtype, device=dev)
+        optr = res.data_ptr()
+    else:
+        res = PF.empty(x.B, x.H, x.W, C, x.buf.dtype, dev)
+        optr = res.rows.data_ptr()
+    with torch.cuda.device(dev):
+        N.check(N.lib().gsw_groupnorm_pf_fused(x.rows.data_ptr(), x2.rows.data_ptr() if x2 is not None else None, x.C if x2 is not None else 0,
+                                               gamma.data_ptr(), beta.data_ptr(), optr, x.B, x.H, x.W, C, groups, eps, 1 if act else 0,
+                                               1 if tokens else 0, _dt(x.buf.dtype), _stream_ptr()))
+    return res
+
+
 def groupnorm_pf(x: PF, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float, *, act: bool = True, tokens: bool = False):
     """act(GroupNorm(x)) on a PF tensor -> PF (zero border) or dense tokens [B, H*W, C] (tokens=True)."""
     dev = x.buf.device
     _same(gamma, x.buf, "gamma", x.C)
     _same(beta, x.buf, "beta", x.C)
+    if _gn_fused_ok(x.B, x.H, x.W, x.C, groups):
+        return _groupnorm_fused(x, None, gamma, beta, groups, eps, act, tokens)
     ws = _gn_workspace(dev, x.B, groups, x.C)
     if tokens:
         out = torch.empty((x.B, x.H * x.W, x.C), dtype=x.buf.dtype, device=dev)
@@ -464,7 +502,7 @@ def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
         _ensure_workspace(x.device)
         e0 = tm.start() if tm is not None else None
         # stats_for (tok2pf): the PF tensor whose payload this launch writes -- it gets the launch's column records (or None)
-        armed = _colstats_arm(M, Nn, x.device) if (stats_for is not None and mode == "tok2pf") else None
+        armed = _colstats_arm(M, Nn, x.device, geom=(M // tokens, tokens // width, width)) if (stats_for is not None and mode == "tok2pf") else None
         rs_buf = None
         if rowstats and mode == "plain" and FOLD_LN:
             # row records for the LayerNorm that consumes this output (gsw_mm_next_rowstats): [M][2 * ceil(N / 160)][2] floats
@@ -601,6 +639,10 @@ def groupnorm_pf2(x: PF, x2: Optional[PF], gamma: torch.Tensor, beta: torch.Tens
     _same(x2.buf, x.buf, "x2")
     _same(gamma, x.buf, "gamma", C)
     _same(beta, x.buf, "beta", C)
+    if (x2.B, x2.H, x2.W) != (x.B, x.H, x.W):
+        raise ValueError("groupnorm_pf2: the two sources differ in geometry")
+    if x.C % 8 == 0 and _gn_fused_ok(x.B, x.H, x.W, C, groups):
+        return _groupnorm_fused(x, x2, gamma, beta, groups, eps, act, False)
     ws = _gn_workspace(dev, x.B, groups, C)
     y = PF.empty(x.B, x.H, x.W, C, x.buf.dtype, dev)
     if FUSE_GN_STATS and _stats_usable(x) and _stats_usable(x2) and C <= 4096 and (C // groups) % 2 == 0 and x.C % 2 == 0:
@@ -636,7 +678,7 @@ def conv3x3_res_pf(x: PF, w_cat: torch.Tensor, bias: Optional[torch.Tensor], *, 
     with torch.cuda.device(x.buf.device):
         _ensure_workspace(x.buf.device)
         e0 = tm.start() if tm is not None else None
-        armed = _colstats_arm(x.B * x.H * x.W, Nn, x.buf.device)
+        armed = _colstats_arm(x.B * x.H * x.W, Nn, x.buf.device, geom=(x.B, x.H, x.W))
         with _colstats_scope(armed):
             N.check(N.lib().gsw_conv3x3_res_pf(x.rows.data_ptr(), w_cat.data_ptr(), bias.data_ptr() if bias is not None else None,
                                                rowbias.data_ptr() if rowbias is not None else None, ldrb,
@@ -727,7 +769,7 @@ def conv_up2x_pf(x: PF, w4: torch.Tensor, bias: Optional[torch.Tensor]) -> PF:
     with torch.cuda.device(x.buf.device):
         _ensure_workspace(x.buf.device)
         e0 = tm.start() if tm is not None else None
-        armed = _colstats_arm(x.B * x.H * x.W, Nn, x.buf.device, npar=4)
+        armed = _colstats_arm(x.B * x.H * x.W, Nn, x.buf.device, npar=4, geom=(x.B, 2 * x.H, 2 * x.W))
         with _colstats_scope(armed):
             N.check(N.lib().gsw_conv_up2x_pf(x.rows.data_ptr(), w4.data_ptr(), bias.data_ptr() if bias is not None else None, y.rows.data_ptr(),
                                              x.B, x.H, x.W, x.C, Nn, _dt(x.buf.dtype), _stream_ptr()))

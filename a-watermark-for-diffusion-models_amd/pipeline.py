@@ -22,7 +22,7 @@ class GaussianShadingPipeline:
                  ctx_uncond: Optional[torch.Tensor] = None, prediction_type: str = "epsilon"):
         if hasattr(eps_model, "prepare_context"):          # a unet.UNet2DCondition: small batches replay a captured HIP graph of the forward (graph.py)
             from .graph import graphed
-            eps_model = graphed(eps_model)
+            eps_model = graphed(eps_model, clone_output=False)      # the loops of ddim.py consume eps in the scheduler-step kernel right away
         self.eps_model = eps_model
         self.key, self.nonce, self.message = key, nonce, message
         self.shape = (4, height // 8, width // 8)

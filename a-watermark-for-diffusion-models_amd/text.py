@@ -210,17 +210,12 @@ class ClipTextEncoder(nn.Module):
 
     @classmethod
     def from_dir(cls, enc_dir: str) -> "ClipTextEncoder":
-        from safetensors.torch import load_file
+        from .checkpoint import load_component_state_dict
         with open(os.path.join(enc_dir, "config.json")) as f:
             cfg = json.load(f)
         model = cls(cfg)
-        for name in ("model.safetensors", "model.fp16.safetensors"):
-            path = os.path.join(enc_dir, name)
-            if os.path.exists(path):
-                break
-        else:
-            raise FileNotFoundError(f"{enc_dir}: no model.safetensors / model.fp16.safetensors")
-        sd = {k: v for k, v in load_file(path).items() if not k.endswith("position_ids") and not k.startswith("text_projection")}
+        raw = load_component_state_dict(enc_dir, "text_encoder")       # model.safetensors / .fp16 / sharded / pytorch_model.bin
+        sd = {k: v for k, v in raw.items() if not k.endswith("position_ids") and not k.startswith("text_projection")}
         sd = {(k if k.startswith("text_model.") else "text_model." + k): v for k, v in sd.items()}       # newer transformers drop the prefix
         missing, unexpected = model.load_state_dict(sd, strict=False)
         if missing or unexpected:

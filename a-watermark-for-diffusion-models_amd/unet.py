@@ -154,10 +154,10 @@ class TimestepEmbedding(nn.Module):
 class TembRows:
     """silu(time embedding) [B, temb] and, per resnet, its time_emb_proj output as a column slice [B, cout] of ONE GEMM over the concatenated
     projection weights (22 resnets -> one launch instead of 22; the convolution epilogue reads the slice through its row stride)."""
-    __slots__ = ("act", "rows")
+    __slots__ = ("act", "rows", "table")
 
-    def __init__(self, act, rows):
-        self.act, self.rows = act, rows
+    def __init__(self, act, rows, table=None):
+        self.act, self.rows, self.table = act, rows, table      # table: the [B, sum of channels] matrix the row slices view
 
 
 class ResnetBlock2D(nn.Module):
@@ -584,12 +584,16 @@ class UNet2DCondition(nn.Module):
 
     def forward(self, x: torch.Tensor, t: torch.Tensor, ctx: torch.Tensor) -> torch.Tensor:
         """x [B,4,h,w], t [B] (or scalar tensor) timesteps, ctx [B,77,1024] -> model output [B,4,h,w]."""
+        if self._pf_ok(x):
+            rows = _temb_rows_from_table(self, t, x) if TEMB_TABLE else None
+            if rows is not None:
+                return self._forward_pf(x, rows, ctx)
         if t.dim() == 0:
             t = t.expand(x.shape[0])
         temb = self.time_embedding(timestep_embedding(t, self.c0).to(x.dtype))
         temb = F.silu(temb)                      # every resnet applies SiLU to the same embedding: do it once
         if self._pf_ok(x):
-            return self._forward_pf(x, temb, ctx)
+            return self._forward_pf(x, _temb_rows(self, temb), ctx)
         if USE_PF and FUSED_KERNELS and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16):
             _note_fallback(f"UNet forward on {tuple(x.shape)} {x.dtype}: off the padded-flat path (fp16 / bf16, conv channels % 64, lattice % {1 << (len(self.down_blocks) - 1)}): plain torch modules")
         h = self.conv_in(x)
@@ -653,16 +657,73 @@ def _temb_rows(self, temb: torch.Tensor):
         n = r.time_emb_proj.out_features
         rows[id(r)] = rb[:, off:off + n]
         off += n
-    return TembRows(temb, rows)
+    return TembRows(temb, rows, rb)
 
 
-def _unet_forward_pf(self, x: torch.Tensor, temb: torch.Tensor, ctx: torch.Tensor) -> torch.Tensor:
-    from .pf import PF, conv_pf
-    temb = _temb_rows(self, temb)
+TEMB_TABLE = True     # integer timesteps: the whole time-embedding chain (sinusoid -> linear -> SiLU -> linear -> SiLU -> every resnet's time_emb_proj) is a
+                      # function of t alone -- tabulated once over the training timesteps, a forward gathers its rows (one launch instead of ~20, and the
+                      # 50 MB of projection weights are not streamed per forward)
+NUM_TRAIN_TIMESTEPS = 1000
+
+
+def _temb_rows_from_table(self, t: torch.Tensor, x: torch.Tensor):
+    """TembRows gathered from the per-model table [num_train_timesteps, sum of the resnets' channels], or None when t is not an integer tensor / the
+    projections do not run on the engine.  Timesteps outside [0, num_train_timesteps) are clamped (the reference's schedulers never produce them)."""
+    if t.dtype not in (torch.int64, torch.int32) or not t.is_cuda or t.numel() not in (1, x.shape[0]):
+        return None
+    resnets = getattr(self, "_gsw_resnets", None)
+    if resnets is None:
+        resnets = self._gsw_resnets = [m for m in self.modules() if isinstance(m, ResnetBlock2D)]
+    if not resnets or any(r.time_emb_proj.out_features % 8 for r in resnets):
+        return None
+    te = self.time_embedding
+    if te.linear_1.weight.dtype != x.dtype or te.linear_1.weight.device != x.device:
+        return None
+    from .pf import cached
+    from . import _native as N
+    from .codec import _stream_ptr
+    params = (te.linear_1.weight, te.linear_1.bias, te.linear_2.weight, te.linear_2.bias) + tuple(p for r in resnets for p in (r.time_emb_proj.weight, r.time_emb_proj.bias))
+
+    def build():
+        with torch.no_grad():
+            tt = torch.arange(NUM_TRAIN_TIMESTEPS, device=x.device)
+            temb = F.silu(te(timestep_embedding(tt, self.c0).to(x.dtype)))
+            rows = _temb_rows(self, temb)
+            if not isinstance(rows, TembRows):
+                return None
+            return rows.table.contiguous()
+
+    table = cached(self, "_gsw_temb_table", params, build)
+    if table is None:
+        return None
+    B, n_tot = x.shape[0], table.shape[1]
+    idx = t if t.dtype == torch.int64 else t.to(torch.int64)
+    out = torch.empty((B, n_tot), dtype=table.dtype, device=table.device)
+    with torch.cuda.device(x.device):
+        N.check(N.lib().gsw_gather_rows(table.data_ptr(), n_tot * table.element_size(), table.shape[0], idx.data_ptr(), 0 if idx.numel() == 1 else 1,
+                                        out.data_ptr(), n_tot * table.element_size(), B, n_tot * table.element_size(), _stream_ptr()))
+    rows, off = {}, 0
+    for r in resnets:
+        n = r.time_emb_proj.out_features
+        rows[id(r)] = out[:, off:off + n]
+        off += n
+    return TembRows(None, rows, out)
+
+
+CONV_OUT_DIRECT_MAX_PIXELS = 65536      # conv_out (320 -> 4) as the one-wave-per-16-pixels kernel writing NCHW directly (gsw_conv3x3_pf_nchw); above that the
+                                        # LDS-tiled 64-column kernel moves fewer bytes through L2
+
+
+def _unet_forward_pf(self, x: torch.Tensor, temb, ctx: torch.Tensor) -> torch.Tensor:
+    from .pf import PF, conv_pf, cached, pack_conv_weight
+    from . import _native as N
+    from .codec import _dt, _stream_ptr
     w_in, w_out, b_out = _edge_conv_weights(self)
     B, cin, H, W = x.shape
-    xin = PF.zeros(B, H, W, 64, x.dtype, x.device)
-    xin.interior[..., :cin].copy_(x.permute(0, 2, 3, 1))
+    xin = PF.empty(B, H, W, 64, x.dtype, x.device)
+    xc = x.contiguous()
+    with torch.cuda.device(x.device):
+        N.check(N.lib().gsw_nchw_to_pf(xc.data_ptr(), xin.rows.data_ptr(), B, cin, H, W, 64, _dt(x.dtype), _stream_ptr()))
     h = conv_pf(xin, w_in, self.conv_in.bias)
     skips = [h]
     for blk in self.down_blocks:
@@ -670,8 +731,17 @@ def _unet_forward_pf(self, x: torch.Tensor, temb: torch.Tensor, ctx: torch.Tenso
     h = self.mid_block.forward_pf(h, temb, ctx)
     for blk in self.up_blocks:
         h = blk.forward_pf(h, temb, ctx, skips)
-    y = conv_pf(_gn_pf(h, self.conv_norm_out, act=True), w_out, b_out)
-    return y.interior[..., : self.conv_out.out_channels].permute(0, 3, 1, 2).contiguous()
+    hn = _gn_pf(h, self.conv_norm_out, act=True)
+    nout = self.conv_out.out_channels
+    if B * H * W <= CONV_OUT_DIRECT_MAX_PIXELS and nout <= 16 and hn.C % 32 == 0 and self.conv_out.bias is not None:
+        wo = cached(self.conv_out, "_gsw_packed_direct", (self.conv_out.weight,), lambda: pack_conv_weight(self.conv_out.weight.detach()))
+        y = torch.empty((B, nout, H, W), dtype=x.dtype, device=x.device)
+        with torch.cuda.device(x.device):
+            N.check(N.lib().gsw_conv3x3_pf_nchw(hn.rows.data_ptr(), wo.data_ptr(), self.conv_out.bias.data_ptr(), y.data_ptr(), B, H, W, hn.C, nout,
+                                                _dt(x.dtype), _stream_ptr()))
+        return y
+    y = conv_pf(hn, w_out, b_out)
+    return y.interior[..., :nout].permute(0, 3, 1, 2).contiguous()
 
 
 def _unet_prepare_context(self, ctx: torch.Tensor) -> None:
@@ -717,16 +787,10 @@ def synthetic_init_(model: nn.Module, seed: int = 0, out_scale: float = 1.0) -> 
 
 
 def load_diffusers_state_dict(model: nn.Module, weight_dir: str) -> nn.Module:
-    """Load `<weight_dir>/unet/diffusion_pytorch_model.safetensors` (diffusers layout; names match this module 1:1)."""
-    import os
-    from safetensors.torch import load_file
-    path = weight_dir
-    for cand in ("unet/diffusion_pytorch_model.safetensors", "unet/diffusion_pytorch_model.fp16.safetensors", "diffusion_pytorch_model.safetensors",
-                 "diffusion_pytorch_model.fp16.safetensors"):
-        if os.path.exists(os.path.join(weight_dir, cand)):
-            path = os.path.join(weight_dir, cand)
-            break
-    sd = load_file(path)
+    """Load the UNet weights of a diffusers-layout directory (`<weight_dir>/unet/diffusion_pytorch_model.*`: safetensors, sharded safetensors or .bin,
+    checkpoint.load_component_state_dict); parameter names match this module 1:1, strictly both ways."""
+    from .checkpoint import load_component_state_dict
+    sd = dict(load_component_state_dict(weight_dir, "unet"))
     own = dict(model.named_parameters())
     for k, v in list(sd.items()):               # SD 1.x: proj_in / proj_out stored as 1x1 convolutions
         if k in own and v.dim() == 4 and own[k].dim() == 2 and v.shape[2:] == (1, 1):

@@ -381,14 +381,8 @@ def synthetic_init_(model: nn.Module, seed: int = 0) -> nn.Module:
 
 
 def load_diffusers_state_dict(model: nn.Module, weight_dir: str) -> nn.Module:
-    from safetensors.torch import load_file
-    path = weight_dir
-    for cand in ("vae/diffusion_pytorch_model.safetensors", "vae/diffusion_pytorch_model.fp16.safetensors", "diffusion_pytorch_model.safetensors",
-                 "diffusion_pytorch_model.fp16.safetensors"):
-        if os.path.exists(os.path.join(weight_dir, cand)):
-            path = os.path.join(weight_dir, cand)
-            break
-    sd = load_file(path)
+    from .checkpoint import load_component_state_dict
+    sd = load_component_state_dict(weight_dir, "vae")          # safetensors, sharded safetensors or .bin
     # older diffusers checkpoints name the mid-block attention projections query/key/value/proj_attn
     ren = {"query": "to_q", "key": "to_k", "value": "to_v", "proj_attn": "to_out.0"}
     fixed = {}

@@ -237,6 +237,7 @@ int gsw_gemm_strided(const void* x_dev, int64_t ldx, const void* w_dev, int64_t 
  *   split_mask : bit e set = epilogue kind e (0 dense rows, 1 PF / convolution, 2 GEGLU, 3 transposed) runs the 12-wave variant whose
  *                waves 8-11 own the LDS-DMA; -1 = keep (default 10: convolutions and the transposed projection) */
 int gsw_mm_config(int tile_rows, int split_mask);
+int gsw_mm_get_config(int* tile_rows, int* split_mask); /* the current values (either pointer may be NULL): what a captured launch sequence depends on */
 
 /* Split-K workspace of the CALLING THREAD (caller-owned device memory on the device of the streams it launches on; 16-byte aligned).
  * Small-batch launches of the eps model -- one image's 8 x 8 level is a single 64-row tile against 180-360 K stages (the reference's own use:
@@ -253,6 +254,43 @@ int gsw_mm_set_workspace(void* ws_dev, int64_t bytes, int max_splits);
 /* X1 / G1 tail -- diffusers AutoencoderKL mid-block attention (one head as wide as the block, 512): softmax over the rows of the score matrix
  * between the two engine products.  In place: x[r, 0:cols] <- softmax(scale * x[r, 0:cols]); rows `ld` elements apart; cols % 8 == 0. */
 int gsw_softmax_rows(void* x_dev, int64_t rows, int cols, int64_t ld, float scale, int dtype, void* stream);
+
+/* ---- The small-batch regime of the eps model (csrc/gswm_small.hip).  The reference inverts ONE latent per call (extract.py:112-117: 50 UNet
+ * evaluations of one 4x64x64 latent), BASELINE configs[1] is batch 8: a forward is then a chain of ~500 dependent launches of 5-20 us, each paying
+ * the ~4.7 us floor of a kernel boundary plus its own fill and drain, so what counts is FEWER and SHORTER launches.
+ *
+ * gsw_groupnorm_pf_fused: gsw_groupnorm_pf2 in ONE launch (no workspace): one workgroup per (image, group) holds the group's values in registers
+ *   between the statistics and the normalisation (exact two-pass variance).  Groups an even number of channels wide; returns GSW_ERR_UNSUPPORTED
+ *   when a group does not fit one workgroup's registers (more than 64 pixels per pixel lane: use gsw_groupnorm_pf2 then) -- meant for B * groups
+ *   up to a few hundred workgroups.
+ * gsw_gather_rows: out[b] = table[clamp(index[b * index_stride], 0, nrows - 1)] (index_stride 0: one index for all rows): the time-embedding chain
+ *   of diffusers' UNet2DConditionModel (sinusoid -> linear -> SiLU -> linear -> SiLU -> every resnet's time_emb_proj) depends on the timestep only,
+ *   so it is tabulated once over the num_train_timesteps integer timesteps and a forward gathers its rows.  16-byte aligned rows.
+ * gsw_nchw_to_pf: latent [B, Cin, H, W] -> PF rows [B, H+2, W+2, Cp]: zero border, channels >= Cin zero (conv_in reads one 64-wide K block).
+ * gsw_conv3x3_pf_nchw: 3x3 stride-1 convolution of a PF tensor with Nout <= 16 output channels, written as NCHW [B, Nout, H, W] (+ bias): the
+ *   UNet's conv_out (320 -> 4; diffusers UNet2DConditionModel.conv_out behind extract.py:66-69).  w: [Nout][9 * C] tap-major, channel-minor; C % 32 == 0. */
+int gsw_groupnorm_pf_fused(const void* x_dev, const void* x2_dev, int Ca, const void* gamma_dev, const void* beta_dev, void* out_dev, int B, int H, int W,
+                           int C, int groups, float eps, int act, int out_tokens, int dtype, void* stream);
+int gsw_gather_rows(const void* table_dev, int64_t ld_bytes, int64_t nrows, const int64_t* index_dev, int index_stride, void* out_dev, int64_t out_ld_bytes,
+                    int B, int64_t row_bytes, void* stream);
+int gsw_nchw_to_pf(const void* x_dev, void* y_dev, int B, int Cin, int H, int W, int Cp, int dtype, void* stream);
+int gsw_conv3x3_pf_nchw(const void* x_dev, const void* w_dev, const void* bias_dev, void* y_dev, int B, int H, int W, int C, int Nout, int dtype, void* stream);
+
+/* Dense linears of the transformer blocks at SMALL M (one or two images: 64 ... 16384 token rows), where the engine's 128 x 160 tiles leave most CUs
+ * without one: a four-wave workgroup owns a 64 x 64 / 32 x 64 / 16 x 64 / 16 x 32 output tile (config 0 .. 3; -1 = gsw_gemm_small_config's choice),
+ * splits K four ways INSIDE the workgroup (fragments straight from global memory, partial tiles added in wave order through LDS: deterministic, no
+ * second launch) and runs the epilogue of `mode` (GSW_GEMM_PLAIN / GEGLU / TRANS / TOK2PF, operands as for gsw_gemm_strided) with the engine's
+ * rounding points.  K % 32 == 0, K >= 128, M % 16 == 0, N % 16 == 0 (GEGLU: N % 32 == 0), M <= 16384; 32-bit element offsets.
+ *   ln_records_dev : LayerNorm fold (see gsw_gemm_ln) straight from the RAW row records [M][ln_slots][2] the producer of x left -- no finishing launch;
+ *                    then w_dev = W diag(gamma), ln_u_dev / ln_v_dev fp32 [N] (16-byte aligned), bias_dev must be NULL; NULL = plain bias epilogue
+ *   rowstats_dev   : GSW_GEMM_PLAIN only, optional: per output row and column tile the (sum, sum of squares) of the stored values,
+ *                    [M][*rowstats_slots][2] floats, *rowstats_slots = ceil(N / tile columns) (0 when none were written);
+ *                    capacity >= M * ceil(N / 32) * 2 covers every configuration.
+ * gsw_gemm_small_config: the configuration the kernel would pick for a shape, or -1 when the shape is not this kernel's. */
+int gsw_gemm_small_config(int64_t M, int K, int N, int mode);
+int gsw_gemm_small(const void* x_dev, int64_t ldx, const void* w_dev, int64_t ldw, const void* bias_dev, const void* resid_dev, int64_t ldr, void* y_dev, int64_t ldy,
+                   int64_t M, int K, int N, int mode, int S, int Wimg, const float* ln_records_dev, int ln_slots, float ln_eps, const float* ln_u_dev,
+                   const float* ln_v_dev, float* rowstats_dev, int64_t rowstats_capacity, int* rowstats_slots, int config, int dtype, void* stream);
 
 /* diffusers Upsample2D (nearest 2x + 3x3 convolution) from the low-resolution PF input, by sub-pixel decomposition: w4 =
  * [4 output parities (dy*2+dx)][N][4 taps (a*2+b)][C], the 3x3 weights pre-summed over the taps that read the same source pixel

@@ -14,7 +14,10 @@ def G():
     import types
     import gswm_amd
     from gswm_amd import pf, _native
-    return types.SimpleNamespace(pf=pf, lib=_native.lib())
+    old = pf.GN_FUSED_MAX_WGS
+    pf.GN_FUSED_MAX_WGS = 0          # this module is about the column records: small batches would otherwise take the one-launch GroupNorm (tests/test_gpu_small.py)
+    yield types.SimpleNamespace(pf=pf, lib=_native.lib())
+    pf.GN_FUSED_MAX_WGS = old
 
 
 @pytest.fixture(params=[0, 128, 256], ids=["auto", "BM128", "BM256"])

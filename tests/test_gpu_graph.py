@@ -121,3 +121,57 @@ def test_pipeline_wraps_the_unet_and_full_size_forward_matches(G, keys):
         got2 = pipe.eps_model(x * 0.5, td, c)
         assert torch.equal(got2, m(x * 0.5, td, c))
     assert pipe.eps_model.stats["captures"] == 1 and G.unet.FALLBACKS == {}
+
+
+def test_graph_notices_weight_edits_under_an_unchanged_context(G):
+    """a harness that keeps ONE context for its whole life: the parameters are re-checked every CHECK_EVERY replays, not only on a context change"""
+    m = _small_unet(G)
+    gm = G.graph.GraphedEpsModel(m, mode="always")
+    x, c = _inputs(1)
+    td = torch.full((), 41, dtype=torch.int64, device="cuda")
+    with torch.no_grad():
+        y0 = gm(x, td, c)
+        m.conv_out.bias.add_(0.5)
+        ys = [gm(x, td, c) for _ in range(G.graph.CHECK_EVERY + 1)]
+        want = m(x, td, c)
+    assert gm.stats["captures"] == 2
+    assert torch.equal(ys[-1], want) and not torch.equal(ys[-1], y0)
+
+
+def test_graph_entries_are_keyed_by_the_module_switches(G):
+    """an A/B toggle after a capture captures anew (and the old entry serves again when the switch comes back) instead of replaying the old sequence"""
+    from gswm_amd import pf
+    m = _small_unet(G)
+    gm = G.graph.GraphedEpsModel(m, mode="always")
+    x, c = _inputs(2)
+    td = torch.full((), 41, dtype=torch.int64, device="cuda")
+    with torch.no_grad():
+        y_a = gm(x, td, c)
+        old = pf.GN_FUSED_MAX_WGS
+        pf.GN_FUSED_MAX_WGS = 0
+        try:
+            y_b = gm(x, td, c)
+            assert gm.stats["captures"] == 2
+            assert torch.equal(y_b, m(x, td, c))
+        finally:
+            pf.GN_FUSED_MAX_WGS = old
+        y_a2 = gm(x, td, c)
+    assert gm.stats["captures"] == 2 and torch.equal(y_a, y_a2)
+
+
+def test_graph_results_are_not_aliased_and_entries_are_bounded(G):
+    m = _small_unet(G)
+    gm = G.graph.GraphedEpsModel(m, mode="always")
+    x, c = _inputs(1)
+    t1, t2 = (torch.full((), t, dtype=torch.int64, device="cuda") for t in (41, 901))
+    with torch.no_grad():
+        e1 = gm(x, t1, c)
+        e2 = gm(x, t2, c)
+        assert e1.data_ptr() != e2.data_ptr() and not torch.equal(e1, e2)
+        assert torch.equal(e1, m(x, t1, c)) and torch.equal(e2, m(x, t2, c))
+        raw = G.graph.GraphedEpsModel(m, mode="always", clone_output=False)
+        assert raw(x, t1, c).data_ptr() == raw(x, t2, c).data_ptr()          # the static buffer itself: the in-repo loops' form
+        for hw in (8, 16, 24, 32, 40, 48, 56, 64, 72, 80):
+            xs, _ = _inputs(1, hw=hw)
+            gm(xs, t1, c)
+    assert len(gm._entries) <= G.graph.MAX_ENTRIES

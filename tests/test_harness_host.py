@@ -259,3 +259,150 @@ def test_comfy_node_interface_matches_the_reference_workflow_names():
     assert n.RETURN_TYPES == ("LATENT", "IMAGE") and n.FUNCTION == "create_gs_latents" and n.CATEGORY == "GSWatermark-lthero/latent/noise"
     k = C.GSKSamplerAdvanced
     assert k.RETURN_TYPES == ("LATENT",) and k.FUNCTION == "sample" and k.CATEGORY == "GSWatermark-lthero/sampling"
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# real-checkpoint readiness: hub ids through the local Hugging Face cache, weight file formats, SD 1.5's layout, config validation
+# ---------------------------------------------------------------------------------------------------------------------
+def _hub_cache_with(tmp_path, monkeypatch, repo_id, build):
+    """<cache>/models--org--name/{refs/main, snapshots/<rev>/...} as huggingface_hub lays it out; `build(snapshot_dir)` fills the snapshot"""
+    import os
+    cache = tmp_path / "hf_home" / "hub"
+    rev = "0123456789abcdef0123456789abcdef01234567"
+    snap = cache / ("models--" + repo_id.replace("/", "--")) / "snapshots" / rev
+    os.makedirs(snap.parent.parent / "refs")
+    (snap.parent.parent / "refs" / "main").write_text(rev)
+    out = build(str(snap))
+    for var in ("HF_HUB_CACHE", "HUGGINGFACE_HUB_CACHE", "DIFFUSERS_CACHE", "XDG_CACHE_HOME"):
+        monkeypatch.delenv(var, raising=False)
+    monkeypatch.setenv("HF_HOME", str(tmp_path / "hf_home"))
+    return str(snap), out
+
+
+def test_hub_id_resolves_through_the_local_hf_cache(tmp_path, monkeypatch):
+    """the reference's default --model_id (extract.py:183) on a machine that has run the reference: found under $HF_HOME/hub, nothing downloaded"""
+    from gswm_amd import checkpoint as C
+    monkeypatch.setattr(E, "_MODEL_CACHE", {})
+    snap, (unet, vae, enc) = _hub_cache_with(tmp_path, monkeypatch, "stabilityai/stable-diffusion-2-1-base", lambda d: write_tiny_checkpoint(d))
+    assert C.resolve_model_dir("stabilityai/stable-diffusion-2-1-base") == snap
+    assert C.resolve_model_dir("stabilityai/another-model") is None and C.resolve_model_dir("not a repo id") is None
+    assert not E._no_checkpoint("stabilityai/stable-diffusion-2-1-base") and E._no_checkpoint("runwayml/stable-diffusion-v1-5")
+    m = E.Models("stabilityai/stable-diffusion-2-1-base", device="cpu", dtype=torch.float32)
+    assert not m.synthetic and m.model_id == snap and m.model_name == "stabilityai/stable-diffusion-2-1-base"
+    sd = unet.state_dict()
+    assert all(torch.equal(v, sd[k]) for k, v in m.unet.state_dict().items())
+    # HF_HUB_CACHE wins over HF_HOME, and a missing id says where it looked
+    monkeypatch.setenv("HF_HUB_CACHE", str(tmp_path / "elsewhere"))
+    assert C.resolve_model_dir("stabilityai/stable-diffusion-2-1-base") == snap           # still found through HF_HOME (every root is searched)
+    assert C.hub_cache_dirs()[0] == str(tmp_path / "elsewhere")
+    with pytest.raises(FileNotFoundError, match="models--runwayml--stable-diffusion-v1-5"):
+        E.Models("runwayml/stable-diffusion-v1-5", device="cpu", dtype=torch.float32)
+
+
+@pytest.mark.parametrize("fmt", ["bin", "bin_fp16", "sharded_safetensors", "sharded_bin"])
+def test_weight_file_formats(tmp_path, fmt):
+    """.bin (torch.save) and sharded checkpoints (index.json + shards) load to the same modules as the single safetensors file"""
+    import json, os
+    from safetensors.torch import load_file, save_file
+    root = str(tmp_path / "ckpt")
+    unet, vae, enc = write_tiny_checkpoint(root)
+    for sub, stem in (("unet", "diffusion_pytorch_model"), ("vae", "diffusion_pytorch_model"), ("text_encoder", "model")):
+        src = os.path.join(root, sub, stem + ".safetensors")
+        sd = load_file(src)
+        os.remove(src)
+        if fmt == "bin":
+            torch.save(sd, os.path.join(root, sub, ("pytorch_model" if sub == "text_encoder" else stem) + ".bin"))
+        elif fmt == "bin_fp16":
+            torch.save(sd, os.path.join(root, sub, stem + ".fp16.bin"))
+        else:
+            ext = ".safetensors" if fmt == "sharded_safetensors" else ".bin"
+            keys = sorted(sd)
+            parts = [keys[: len(keys) // 3], keys[len(keys) // 3: 2 * len(keys) // 3], keys[2 * len(keys) // 3:]]
+            wm = {}
+            for i, ks in enumerate(parts):
+                name = f"{stem}-{i + 1:05d}-of-00003{ext}"
+                part = {k: sd[k].contiguous() for k in ks}
+                save_file(part, os.path.join(root, sub, name)) if ext == ".safetensors" else torch.save(part, os.path.join(root, sub, name))
+                wm.update({k: name for k in ks})
+            with open(os.path.join(root, sub, stem + ext + ".index.json"), "w") as f:
+                json.dump({"metadata": {}, "weight_map": wm}, f)
+    m = E.Models(root, device="cpu", dtype=torch.float32)
+    for mine, ref in ((m.unet, unet), (m.vae, vae)):
+        sd = ref.state_dict()
+        assert all(torch.equal(v, sd[k]) for k, v in mine.state_dict().items())
+    from gswm_amd import text as T
+    assert torch.allclose(m.ctx_empty, enc(T.ClipTokenizer.from_dir(root + "/tokenizer")([""])), atol=1e-6)
+    # a shard named by the index but missing on disk is an error, not a partial load
+    if fmt.startswith("sharded"):
+        victim = [f for f in os.listdir(os.path.join(root, "unet")) if "-00002-" in f][0]
+        os.remove(os.path.join(root, "unet", victim))
+        with pytest.raises(FileNotFoundError, match="00002"):
+            E.Models(root, device="cpu", dtype=torch.float32)
+
+
+def _sd_shaped_config(kind):
+    """unet/config.json of stabilityai/stable-diffusion-2-1-base resp. runwayml/stable-diffusion-v1-5 as published (widths divided by 5 for the CPU)"""
+    base = {"_class_name": "UNet2DConditionModel", "_diffusers_version": "0.10.0", "act_fn": "silu", "center_input_sample": False, "downsample_padding": 1,
+            "flip_sin_to_cos": True, "freq_shift": 0, "in_channels": 4, "out_channels": 4, "layers_per_block": 2, "mid_block_scale_factor": 1, "norm_eps": 1e-05,
+            "norm_num_groups": 32, "block_out_channels": [64, 128, 256, 256], "down_block_types": ["CrossAttnDownBlock2D"] * 3 + ["DownBlock2D"],
+            "up_block_types": ["UpBlock2D"] + ["CrossAttnUpBlock2D"] * 3}
+    if kind == "sd21":
+        base.update({"attention_head_dim": [1, 2, 4, 4], "cross_attention_dim": 1024, "dual_cross_attention": False, "only_cross_attention": False,
+                     "sample_size": 64, "use_linear_projection": True, "upcast_attention": True, "num_class_embeds": None, "class_embed_type": None,
+                     "mid_block_type": "UNetMidBlock2DCrossAttn", "resnet_time_scale_shift": "default"})
+    else:
+        base.update({"attention_head_dim": 8, "cross_attention_dim": 768, "sample_size": 64})
+    return base
+
+
+@pytest.mark.parametrize("kind", ["sd21", "sd15"])
+def test_sd_shaped_unet_configs_load_in_diffusers_key_layout(tmp_path, kind):
+    """the published config.json shapes of SD 2.1-base (linear proj_in / proj_out, per-block head counts, upcast_attention) and SD 1.5 (8 heads
+    everywhere, proj_in / proj_out stored as 1x1 convolutions [C, C, 1, 1]) round-trip through the loader and compute the same forward"""
+    import json, os
+    from safetensors.torch import save_file
+    cfg = _sd_shaped_config(kind)
+    ref = U.synthetic_init_(E._unet_from_config(cfg), 11)
+    heads = [b.attentions[0].transformer_blocks[0].attn1.heads for b in ref.down_blocks if b.attentions is not None]
+    assert heads == ([1, 2, 4] if kind == "sd21" else [8, 8, 8])
+    sd = {k: v.contiguous() for k, v in ref.state_dict().items()}
+    if kind == "sd15":
+        for k in list(sd):
+            if k.endswith(("proj_in.weight", "proj_out.weight")):
+                sd[k] = sd[k][:, :, None, None].contiguous()          # diffusers < use_linear_projection: Conv2d(C, C, 1)
+    root = str(tmp_path / kind)
+    os.makedirs(os.path.join(root, "unet"))
+    save_file(sd, os.path.join(root, "unet", "diffusion_pytorch_model.safetensors"))
+    with open(os.path.join(root, "unet", "config.json"), "w") as f:
+        json.dump(cfg, f)
+    mine = E._unet_from_config(E._read_json(os.path.join(root, "unet", "config.json")))
+    U.load_diffusers_state_dict(mine, root)
+    rs = ref.state_dict()
+    assert all(torch.equal(v, rs[k]) for k, v in mine.state_dict().items())
+    x, t, c = torch.randn(1, 4, 16, 16), torch.tensor([7]), torch.randn(1, 77, cfg["cross_attention_dim"])
+    with torch.no_grad():
+        assert torch.equal(mine(x, t, c), ref(x, t, c))
+    # a tensor too many, or one missing, is refused (strict both ways)
+    sd["extra.weight"] = torch.zeros(1)
+    save_file(sd, os.path.join(root, "unet", "diffusion_pytorch_model.safetensors"))
+    with pytest.raises(RuntimeError, match="unexpected"):
+        U.load_diffusers_state_dict(E._unet_from_config(cfg), root)
+
+
+def test_config_entries_outside_the_implemented_space_are_refused_by_name():
+    from gswm_amd import checkpoint as C
+    ok = _sd_shaped_config("sd21")
+    C.validate_unet_config(ok)
+    for k, v in (("class_embed_type", "timestep"), ("addition_embed_type", "text_time"), ("dual_cross_attention", True), ("transformer_layers_per_block", 2),
+                 ("resnet_time_scale_shift", "scale_shift"), ("mid_block_type", "UNetMidBlock2DSimpleCrossAttn"), ("only_cross_attention", True),
+                 ("time_embedding_type", "fourier"), ("norm_eps", 1e-6), ("encoder_hid_dim", 1024), ("conv_out_kernel", 1)):
+        with pytest.raises(ValueError, match=k):
+            C.validate_unet_config(dict(ok, **{k: v}))
+    with pytest.raises(ValueError, match="down block type"):
+        C.validate_unet_config(dict(ok, down_block_types=["SimpleCrossAttnDownBlock2D"] * 3 + ["DownBlock2D"]))
+    with pytest.raises(ValueError, match="mirror"):
+        C.validate_unet_config(dict(ok, up_block_types=["CrossAttnUpBlock2D"] * 4))
+    C.validate_scheduler_config({"prediction_type": "v_prediction", "timestep_spacing": "leading", "clip_sample": False})
+    for k, v in (("prediction_type", "sample"), ("timestep_spacing", "trailing"), ("clip_sample", True), ("rescale_betas_zero_snr", True), ("beta_schedule", "linear")):
+        with pytest.raises(ValueError, match=k if k != "clip_sample" else "clip_sample"):
+            C.validate_scheduler_config({k: v})
