@@ -134,6 +134,7 @@ def test_unet_forward_with_and_without_the_small_batch_kernels(G):
     U = G.unet
     m = U.synthetic_init_(U.UNet2DCondition(), 0).cuda().half().eval()
     g = torch.Generator().manual_seed(3)
+    U.FALLBACKS.clear()
     for B in (1, 2):
         x = torch.randn(B, 4, 64, 64, generator=g).half().cuda()
         c = torch.randn(B, 77, 1024, generator=g).half().cuda()
