@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GSWM_LIB", os.path.join(_HERE, "libgswm.so"))     # GSWM_LIB: an alternative build of the same ABI (kernel A/Bs)
 
 GSW_F32, GSW_F16, GSW_BF16, GSW_F64 = 0, 1, 2, 3
-GSW_OK, GSW_ERR_BAD_ARG, GSW_ERR_UNSUPPORTED, GSW_ERR_RAGGED, GSW_ERR_HIP = 0, 1, 2, 3, 4
+GSW_OK, GSW_ERR_BAD_ARG, GSW_ERR_UNSUPPORTED, GSW_ERR_RAGGED, GSW_ERR_HIP, GSW_WARN_NO_RECORDS = 0, 1, 2, 3, 4, 5
 GSW_EMBED_EXACT_F64, GSW_EMBED_FAST_F32 = 0, 1
 GSW_FLAG_SATURATED, GSW_FLAG_NAN = 1, 2
 GSW_MSG_INLINE_MAX = 256
@@ -20,6 +20,15 @@ GSW_IMG_U8_HWC, GSW_IMG_F16_CHW, GSW_IMG_F32_CHW = 0, 1, 2
 GSW_PW_BRIGHTNESS, GSW_PW_CONTRAST, GSW_PW_INVERT, GSW_PW_GRAY, GSW_PW_HFLIP, GSW_PW_VFLIP, GSW_PW_NOISE = range(7)
 
 _u8p = C.POINTER(C.c_uint8)
+
+
+class GswMmExtras(C.Structure):
+    """include/gswm.h: everything an engine launch needs besides its operands (records requested, split-K scratch), and what it did"""
+    _fields_ = [("colstats_dev", C.c_void_p), ("colstats_capacity", C.c_int64), ("rowstats_dev", C.c_void_p), ("rowstats_capacity", C.c_int64),
+                ("workspace_dev", C.c_void_p), ("workspace_bytes", C.c_int64), ("max_splits", C.c_int),
+                ("colstats_rows_per_block", C.c_int), ("colstats_blocks", C.c_int), ("rowstats_slots", C.c_int), ("splits", C.c_int)]
+
+
 _PROTOTYPES = {
     "gsw_version": (C.c_int, []),
     "gsw_strerror": (C.c_char_p, [C.c_int]),
@@ -95,6 +104,15 @@ _PROTOTYPES = {
     "gsw_gemm_small": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int,
                                  C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int), C.c_int,
                                  C.c_int, C.c_void_p]),
+    "gsw_gemm_ex": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int,
+                              C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "gsw_gemm_ln_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                 C.c_void_p, C.c_void_p]),
+    "gsw_conv_pf_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                 C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "gsw_conv3x3_res_pf_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "gsw_conv_up2x_pf_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "gsw_linear": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
                              C.c_void_p]),
 }

@@ -525,7 +525,7 @@ __global__ __launch_bounds__(256) void gsw_add_layernorm_kernel(const uint16_t* 
 extern __attribute__((visibility("hidden"))) thread_local int g_last_hip_error;   // gswm_kernels.hip; read by gsw_last_hip_error()
 #define g_conv_hip_error g_last_hip_error
 #define GSW_CONV_HIP(call) do { hipError_t _e = (call); if (_e != hipSuccess) { g_conv_hip_error = (int)_e; return GSW_ERR_HIP; } } while (0)
-static int launch_engine(const ConvArgs& a, int64_t M, int N, int dtype, void* stream);
+static int launch_engine(const ConvArgs& a, int64_t M, int N, int dtype, void* stream, GswMmExtras* ex);
 static bool use_engine(const ConvArgs& a, int N);
 
 // Convolutions on the matmul engine (csrc/gswm_mm.hip): every tap is a row offset into the padded-flat activation, so the 3x3 (or
@@ -554,7 +554,7 @@ static void zero_border(void* y, int B, int Hp, int Wp, int N, hipStream_t st) {
     hipLaunchKernelGGL(gsw_pf_zero_border_kernel, dim3(grid), dim3(256), 0, st, (uint16_t*)y, B, Hp, Wp, N / 8);
 }
 
-static int launch_engine(const ConvArgs& a, int64_t M, int N, int dtype, void* stream) {
+static int launch_engine(const ConvArgs& a, int64_t M, int N, int dtype, void* stream, GswMmExtras* ex) {
     MMArgs m;
     const int tw = a.ntaps == 9 ? 3 : a.ntaps == 4 ? 2 : 1;
     m.seg[0] = MMSeg{a.x, a.ldx, a.C / 64, a.ntaps, tw, a.in_Wp, a.tap_off[0], 0};
@@ -577,7 +577,7 @@ static int launch_engine(const ConvArgs& a, int64_t M, int N, int dtype, void* s
     m.mode = a.up ? MM_MODE_UP2X : MM_MODE_PF;
     m.Hp = a.Hp; m.Wp = a.Wp; m.in_Hp = a.in_Hp; m.in_Wp = a.in_Wp; m.stride = a.stride; m.S = 1; m.Wimg = 1; m.up = a.up;
     if (!a.up && !whole) zero_border(a.y, B, a.Hp, a.Wp, N, (hipStream_t)stream);
-    return gsw_mm_launch(m, dtype, stream);
+    return gsw_mm_launch(m, dtype, stream, ex);
 }
 
 static bool use_engine(const ConvArgs& a, int N) {
@@ -587,10 +587,15 @@ static bool use_engine(const ConvArgs& a, int N) {
     return (a.ntaps == 9 || a.ntaps == 4 || a.ntaps == 1) && N % 8 == 0 && N >= 128 && a.C % 64 == 0 && a.C1 % 64 == 0 && a.C2 % 64 == 0;
 }
 
-static int launch_conv_gemm(ConvArgs& a, int64_t M, int N, int dtype, void* stream);
+static int launch_conv_gemm(ConvArgs& a, int64_t M, int N, int dtype, void* stream, GswMmExtras* ex);
 
 int gsw_conv_pf(const void* x_dev, const void* w_dev, const void* bias_dev, const void* rowbias_dev, int ld_rowbias, const void* resid_dev, void* y_dev,
                 int B, int H, int W, int C, int N, int ksize, int stride, int ldx, int dtype, void* stream) {
+    return gsw_conv_pf_ex(x_dev, w_dev, bias_dev, rowbias_dev, ld_rowbias, resid_dev, y_dev, B, H, W, C, N, ksize, stride, ldx, dtype, nullptr, stream);
+}
+
+int gsw_conv_pf_ex(const void* x_dev, const void* w_dev, const void* bias_dev, const void* rowbias_dev, int ld_rowbias, const void* resid_dev, void* y_dev,
+                   int B, int H, int W, int C, int N, int ksize, int stride, int ldx, int dtype, GswMmExtras* ex, void* stream) {
     // H, W: OUTPUT spatial size; input spatial size is (H*stride, W*stride)
     if (!x_dev || !w_dev || !y_dev || B <= 0 || H <= 0 || W <= 0 || C <= 0 || N <= 0) return GSW_ERR_BAD_ARG;
     if ((ksize != 1 && ksize != 3) || (stride != 1 && stride != 2) || (ksize == 1 && stride != 1)) return GSW_ERR_BAD_ARG;
@@ -616,12 +621,15 @@ int gsw_conv_pf(const void* x_dev, const void* w_dev, const void* bias_dev, cons
     a.dense = 0; a.geglu = 0; a.ldy = N;
     a.x1 = nullptr; a.x2 = nullptr; a.C1 = 0; a.C2 = 0; a.up = 0;
     if (N % CV_BN && !use_engine(a, N)) return GSW_ERR_UNSUPPORTED;      // the round-1 kernels tile N by 64; the engine takes any N % 8 from 128 up
-    return launch_conv_gemm(a, M, N, dtype, stream);
+    return launch_conv_gemm(a, M, N, dtype, stream, ex);
 }
 
-static int launch_conv_gemm(ConvArgs& a, int64_t M, int N, int dtype, void* stream) {
+static int launch_conv_gemm(ConvArgs& a, int64_t M, int N, int dtype, void* stream, GswMmExtras* ex) {
     hipStream_t st = (hipStream_t)stream;
-    if (use_engine(a, N)) return launch_engine(a, M, N, dtype, stream);
+    if (use_engine(a, N)) return launch_engine(a, M, N, dtype, stream, ex);
+    // off the engine: no records, no split-K (a legacy one-shot request is consumed so that it cannot reach a later launch)
+    if (ex) { ex->colstats_rows_per_block = 0; ex->colstats_blocks = 0; ex->rowstats_slots = 0; ex->splits = 1; }
+    else { GswMmExtras drop; gsw_mm_legacy_extras(&drop); gsw_mm_legacy_done(&drop); }
     if (N % CV_BN || a.C1 || a.C2 || a.up) return GSW_ERR_UNSUPPORTED;
     const uint32_t grid = (uint32_t)(((M + CV_BM - 1) / CV_BM) * (N / CV_BN));
     if (dtype == GSW_F16) hipLaunchKernelGGL((gsw_conv_gemm_kernel<_Float16>), dim3(grid), dim3(CV_THREADS), 0, st, a);
@@ -770,6 +778,11 @@ int gsw_linear(const void* x_dev, const void* w_dev, const void* bias_dev, const
 
 int gsw_conv3x3_res_pf(const void* x_dev, const void* w_dev, const void* bias_dev, const void* rowbias_dev, int ld_rowbias, const void* resid_dev, void* y_dev,
                        int B, int H, int W, int C, int N, const void* x1_dev, int C1, const void* x2_dev, int C2, int dtype, void* stream) {
+    return gsw_conv3x3_res_pf_ex(x_dev, w_dev, bias_dev, rowbias_dev, ld_rowbias, resid_dev, y_dev, B, H, W, C, N, x1_dev, C1, x2_dev, C2, dtype, nullptr, stream);
+}
+
+int gsw_conv3x3_res_pf_ex(const void* x_dev, const void* w_dev, const void* bias_dev, const void* rowbias_dev, int ld_rowbias, const void* resid_dev, void* y_dev,
+                          int B, int H, int W, int C, int N, const void* x1_dev, int C1, const void* x2_dev, int C2, int dtype, GswMmExtras* ex, void* stream) {
     // 3x3 stride-1 convolution of x plus 1x1 convolutions of x1 (C1 channels) and x2 (C2 channels) in ONE GEMM:
     // w_dev = [N][9*C + C1 + C2].  The resnet's conv2 + conv_shortcut(cat(x1, x2)) + residual in a single kernel.
     if (!x_dev || !w_dev || !y_dev || B <= 0 || H <= 0 || W <= 0 || C <= 0 || N <= 0) return GSW_ERR_BAD_ARG;
@@ -789,10 +802,15 @@ int gsw_conv3x3_res_pf(const void* x_dev, const void* w_dev, const void* bias_de
         for (int kw = 0; kw < 3; ++kw) a.tap_off[kh * 3 + kw] = (kh - 1) * a.Wp + (kw - 1);
     a.dense = 0; a.geglu = 0; a.ldy = N;
     a.x1 = x1_dev; a.x2 = x2_dev; a.C1 = x1_dev ? C1 : 0; a.C2 = x2_dev ? C2 : 0; a.up = 0;
-    return launch_engine(a, M, N, dtype, stream);
+    return launch_engine(a, M, N, dtype, stream, ex);
 }
 
 int gsw_conv_up2x_pf(const void* x_dev, const void* w4_dev, const void* bias_dev, void* y_dev, int B, int H, int W, int C, int N, int dtype, void* stream) {
+    return gsw_conv_up2x_pf_ex(x_dev, w4_dev, bias_dev, y_dev, B, H, W, C, N, dtype, nullptr, stream);
+}
+
+int gsw_conv_up2x_pf_ex(const void* x_dev, const void* w4_dev, const void* bias_dev, void* y_dev, int B, int H, int W, int C, int N, int dtype, GswMmExtras* ex_user,
+                        void* stream) {
     // nearest-neighbour 2x upsampling followed by a 3x3 convolution (diffusers Upsample2D), computed from the LOW-resolution input:
     // output pixel (2i+dy, 2j+dx) only ever sees the 2x2 low-resolution neighbourhood (i+dy-1 .. i+dy, j+dx-1 .. j+dx), with the 3x3
     // weights summed over the taps that land on the same source pixel.  Four launches of the matmul engine (ntaps = 4, K = 4C), 2.25x
@@ -813,18 +831,28 @@ int gsw_conv_up2x_pf(const void* x_dev, const void* w4_dev, const void* bias_dev
     a.stride = 1; a.dense = 0; a.up = 1;
     zero_border(y_dev, B, 2 * H + 2, 2 * W + 2, N, (hipStream_t)stream);
     const size_t esz = 2;
-    // a pending column-statistics request covers the whole output: each parity launch fills its quarter of the buffer ([4][blocks][N][2])
-    int64_t cs_cap = 0;
-    float* cs_base = gsw_mm_take_colstats(&cs_cap);
+    // a column-statistics request covers the whole output: each parity launch fills its quarter of the buffer ([4][blocks][N][2]); the four launches
+    // report the same geometry (the last one's is handed back), or none of them writes records
+    GswMmExtras legacy, *ex = ex_user;
+    if (!ex) { gsw_mm_legacy_extras(&legacy); ex = &legacy; }
+    float* const cs_base = ex->colstats_capacity > 0 ? ex->colstats_dev : nullptr;
+    const int64_t cs_cap = cs_base ? ex->colstats_capacity : 0;
+    GswMmExtras sub = *ex;
+    struct Done { GswMmExtras* user; GswMmExtras* ex; GswMmExtras* sub; bool legacy; ~Done() {
+        ex->colstats_rows_per_block = sub->colstats_rows_per_block; ex->colstats_blocks = sub->colstats_blocks; ex->rowstats_slots = 0; ex->splits = sub->splits;
+        if (legacy) gsw_mm_legacy_done(ex); } } done{ex_user, ex, &sub, ex_user == nullptr};
+    sub.colstats_rows_per_block = 0; sub.colstats_blocks = 0; sub.splits = 1;
     for (int par = 0; par < 4; ++par) {
-        if (cs_base) gsw_mm_give_colstats(cs_base + (size_t)par * (size_t)(cs_cap / 4), cs_cap / 4);
+        sub.colstats_dev = cs_base ? cs_base + (size_t)par * (size_t)(cs_cap / 4) : nullptr;
+        sub.colstats_capacity = cs_base ? cs_cap / 4 : 0;
+        sub.rowstats_dev = nullptr; sub.rowstats_capacity = 0;
         const int dy = par >> 1, dx = par & 1;
         for (int i = 0; i < 9; ++i) a.tap_off[i] = 0;
         for (int ta = 0; ta < 2; ++ta)
             for (int tb = 0; tb < 2; ++tb) a.tap_off[ta * 2 + tb] = (ta + dy - 1) * a.Wp + (tb + dx - 1);
         a.w = (const uint8_t*)w4_dev + (size_t)par * N * 4 * C * esz;
         a.up = 1 + par;
-        { const int rc = launch_engine(a, M, N, dtype, stream); if (rc != GSW_OK) return rc; }
+        { const int rc = launch_engine(a, M, N, dtype, stream, &sub); if (rc != GSW_OK) return rc; }
     }
     return GSW_OK;
 }

@@ -1252,6 +1252,7 @@ const char* gsw_strerror(int s) {
         case GSW_ERR_UNSUPPORTED: return "unsupported lattice / message geometry";
         case GSW_ERR_RAGGED: return "padded lattice bit count is not a multiple of message_length (reference raises IndexError)";
         case GSW_ERR_HIP: return "HIP runtime error";
+        case GSW_WARN_NO_RECORDS: return "the launch wrote no statistics records for the armed request (split-K / whole-tensor / off-engine launch)";
         default: return "unknown status";
     }
 }

@@ -52,10 +52,12 @@ struct MMArgs {
     float* ws;            // filled by gsw_mm_launch: split-K workspace, [splits][ntiles][8 waves][5 * MT accumulators][64 lanes] float4
 };
 
-int gsw_mm_launch(MMArgs& a, int dtype, void* stream);
-
-// one-shot column-statistics request of the calling thread (gsw_mm_next_colstats): take it (clears it) / hand a (sub-)buffer to the next launch
-float* gsw_mm_take_colstats(int64_t* capacity_floats);
-void gsw_mm_give_colstats(float* dev, int64_t capacity_floats);
+// ex: the launch's extras (records requested, split-K scratch; results written back).  nullptr = the DEPRECATED thread-local one-shot state
+// (gsw_mm_next_colstats / gsw_mm_next_rowstats / gsw_mm_set_workspace), which gsw_mm_legacy_extras turns into a struct of the same kind.
+struct GswMmExtras;
+int gsw_mm_launch(MMArgs& a, int dtype, void* stream, GswMmExtras* ex);
+// the calling thread's one-shot requests and workspace as extras (the requests are consumed); gsw_mm_legacy_done stores what the launch reported
+void gsw_mm_legacy_extras(GswMmExtras* ex);
+void gsw_mm_legacy_done(const GswMmExtras* ex);
 
 #endif

@@ -1137,50 +1137,62 @@ int gsw_mm_set_workspace(void* ws_dev, int64_t bytes, int max_splits) {
     return GSW_OK;
 }
 
-// Column statistics (MMArgs::colstats): a one-shot request of the calling thread, consumed (and cleared) by its next engine launch
+// DEPRECATED one-shot side channels (ABI < 0.4.0): column / row record requests of the calling thread, consumed (and cleared) by its next engine launch.
+// They are shims over GswMmExtras now: a legacy entry point (ex == NULL) builds its extras from this state and stores the results back here.
 static thread_local float* t_cs_next = nullptr;
 static thread_local int64_t t_cs_cap = 0;
 static thread_local int t_cs_rows = 0, t_cs_blocks = 0;      // what the last launch produced: rows per block (0 = nothing), blocks
-
-float* gsw_mm_take_colstats(int64_t* capacity_floats) {
-    float* q = t_cs_next;
-    if (capacity_floats) *capacity_floats = t_cs_cap;
-    t_cs_next = nullptr; t_cs_cap = 0;
-    return q;
-}
-void gsw_mm_give_colstats(float* dev, int64_t capacity_floats) { t_cs_next = dev; t_cs_cap = dev ? capacity_floats : 0; }
-
-// Row statistics (MMArgs::rowstats): the same one-shot protocol for the dense-row launches whose output a LayerNorm consumes
+static thread_local bool t_cs_armed = false;                 // a request was armed since the last gsw_mm_last_colstats
 static thread_local float* t_rs_next = nullptr;
 static thread_local int64_t t_rs_cap = 0;
 static thread_local int t_rs_slots = 0;
+static thread_local bool t_rs_armed = false;
+
+void gsw_mm_legacy_extras(GswMmExtras* ex) {
+    ex->colstats_dev = t_cs_next; ex->colstats_capacity = t_cs_cap;
+    ex->rowstats_dev = t_rs_next; ex->rowstats_capacity = t_rs_cap;
+    ex->workspace_dev = t_mm_ws; ex->workspace_bytes = t_mm_ws_bytes; ex->max_splits = t_mm_max_splits;
+    ex->colstats_rows_per_block = 0; ex->colstats_blocks = 0; ex->rowstats_slots = 0; ex->splits = 1;
+    t_cs_next = nullptr; t_cs_cap = 0; t_cs_rows = 0; t_cs_blocks = 0;
+    t_rs_next = nullptr; t_rs_cap = 0; t_rs_slots = 0;
+}
+
+void gsw_mm_legacy_done(const GswMmExtras* ex) {
+    t_cs_rows = ex->colstats_rows_per_block; t_cs_blocks = ex->colstats_blocks;
+    t_rs_slots = ex->rowstats_slots;
+}
 
 int gsw_mm_next_rowstats(float* stats_dev, int64_t capacity_floats) {
     if (capacity_floats < 0 || (capacity_floats > 0 && !stats_dev) || ((uintptr_t)stats_dev & 7)) return GSW_ERR_BAD_ARG;
     t_rs_next = capacity_floats > 0 ? stats_dev : nullptr;
     t_rs_cap = t_rs_next ? capacity_floats : 0;
     t_rs_slots = 0;
+    t_rs_armed = t_rs_next != nullptr;
     return GSW_OK;
 }
 
 int gsw_mm_last_rowstats(int* slots) {
     if (slots) *slots = t_rs_slots;
-    t_rs_next = nullptr; t_rs_cap = 0;
-    return GSW_OK;
+    const bool dropped = t_rs_armed && t_rs_slots == 0;
+    t_rs_next = nullptr; t_rs_cap = 0; t_rs_armed = false;
+    return dropped ? GSW_WARN_NO_RECORDS : GSW_OK;
 }
 
 int gsw_mm_next_colstats(float* stats_dev, int64_t capacity_floats) {
     if (capacity_floats < 0 || (capacity_floats > 0 && !stats_dev) || ((uintptr_t)stats_dev & 15)) return GSW_ERR_BAD_ARG;
-    gsw_mm_give_colstats(capacity_floats > 0 ? stats_dev : nullptr, capacity_floats);
+    t_cs_next = capacity_floats > 0 ? stats_dev : nullptr;
+    t_cs_cap = t_cs_next ? capacity_floats : 0;
     t_cs_rows = 0; t_cs_blocks = 0;
+    t_cs_armed = t_cs_next != nullptr;
     return GSW_OK;
 }
 
 int gsw_mm_last_colstats(int* rows_per_block, int* blocks) {
     if (rows_per_block) *rows_per_block = t_cs_rows;
     if (blocks) *blocks = t_cs_blocks;
-    gsw_mm_give_colstats(nullptr, 0);          // a request the launch never saw (a kernel off the engine) must not reach a later launch
-    return GSW_OK;
+    const bool dropped = t_cs_armed && t_cs_rows == 0;
+    t_cs_next = nullptr; t_cs_cap = 0; t_cs_armed = false;   // a request the launch never saw (a kernel off the engine) must not reach a later launch
+    return dropped ? GSW_WARN_NO_RECORDS : GSW_OK;
 }
 
 int gsw_mm_config(int tile_rows, int split_mask) {
@@ -1198,8 +1210,18 @@ int gsw_mm_get_config(int* tile_rows, int* split_mask) {
 }
 
 // Launch the engine for a prepared MMArgs (segments, weights, epilogue); fills the tiling fields.
-int gsw_mm_launch(MMArgs& a, int dtype, void* stream) {
+int gsw_mm_launch(MMArgs& a, int dtype, void* stream, GswMmExtras* ex) {
+    GswMmExtras legacy;
+    const bool is_legacy = ex == nullptr;
+    if (is_legacy) { gsw_mm_legacy_extras(&legacy); ex = &legacy; }
+    else { ex->colstats_rows_per_block = 0; ex->colstats_blocks = 0; ex->rowstats_slots = 0; ex->splits = 1; }
+    struct Done { GswMmExtras* e; bool legacy; ~Done() { if (legacy) gsw_mm_legacy_done(e); } } done{ex, is_legacy};
     if (dtype != GSW_F16 && dtype != GSW_BF16) return GSW_ERR_BAD_ARG;
+    if (ex->colstats_capacity < 0 || ex->rowstats_capacity < 0 || ex->workspace_bytes < 0 || ex->max_splits < 0 || ex->max_splits > 64
+        || ((uintptr_t)ex->colstats_dev & 15) || ((uintptr_t)ex->rowstats_dev & 7) || ((uintptr_t)ex->workspace_dev & 15)) return GSW_ERR_BAD_ARG;
+    void* const ws_dev = ex->workspace_bytes > 0 ? ex->workspace_dev : nullptr;
+    const int64_t ws_bytes = ws_dev ? ex->workspace_bytes : 0;
+    const int max_splits = ex->max_splits;
     // N: any multiple of 8 (the last 160-column tile may be partial: weight rows are clamped, stores masked); GEGLU pairs columns inside a tile
     if (a.N % 8 || (a.mode == MM_MODE_GEGLU && a.N % 160) || a.M <= 0 || a.P <= 0) return GSW_ERR_UNSUPPORTED;
     if (a.mode == MM_MODE_QKV && (a.n_rows <= 0 || a.n_rows % 160 || a.n_rows >= a.N || !a.y2)) return GSW_ERR_UNSUPPORTED;
@@ -1219,24 +1241,22 @@ int gsw_mm_launch(MMArgs& a, int dtype, void* stream) {
     a.splits = 1; a.ws = nullptr;
     // the dense-row / GEGLU epilogues fetch the bias by 16-byte LDS-DMA pieces (STG in the kernel)
     if ((a.mode == MM_MODE_DENSE || a.mode == MM_MODE_GEGLU) && ((uintptr_t)a.bias & 15u)) return GSW_ERR_BAD_ARG;
-    int64_t cs_cap = 0;
-    float* cs_req = gsw_mm_take_colstats(&cs_cap);
+    float* const cs_req = ex->colstats_capacity > 0 ? ex->colstats_dev : nullptr;
+    const int64_t cs_cap = cs_req ? ex->colstats_capacity : 0;
+    float* const rs_req = ex->rowstats_capacity > 0 ? ex->rowstats_dev : nullptr;
+    const int64_t rs_cap = rs_req ? ex->rowstats_capacity : 0;
     a.colstats = nullptr;
-    t_cs_rows = 0; t_cs_blocks = 0;
-    float* rs_req = t_rs_next;
-    const int64_t rs_cap = t_rs_cap;
-    t_rs_next = nullptr; t_rs_cap = 0; t_rs_slots = 0;
     a.rowstats = nullptr;
     if (a.ln_stat && (a.mode != MM_MODE_DENSE && a.mode != MM_MODE_GEGLU && a.mode != MM_MODE_TRANS)) return GSW_ERR_UNSUPPORTED;
     if (a.ln_stat && a.rowbias) return GSW_ERR_UNSUPPORTED;
     // Split-K for launches that cannot fill the chip with output tiles (the deep levels at small batch: 8 x 8 pixels of one image are ONE row tile
     // against 180-360 K stages): `splits` workgroups share a tile's stages, fp32 partials go through the caller's workspace, a second small kernel
     // adds them in a fixed order and runs the epilogue.  Needs a workspace (gsw_mm_set_workspace); without one the launch runs unsplit.
-    if (t_mm_ws && t_mm_max_splits != 1 && !a.ln_stat) {
+    if (ws_dev && max_splits != 1 && !a.ln_stat) {
         const int bm_s = 128;
         const int64_t nt = (((int64_t)a.M + bm_s - 1) / bm_s) * tiles_n;
         int splits = 1;
-        if (t_mm_max_splits > 1) splits = std::min<int64_t>(std::min<int64_t>(t_mm_max_splits, a.P), 256 / std::max<int64_t>(nt, 1));
+        if (max_splits > 1) splits = std::min<int64_t>(std::min<int64_t>(max_splits, a.P), 256 / std::max<int64_t>(nt, 1));
         else if (nt <= 128 && a.P >= 8) {
             // cost model fitted to tools/splitk_sweep.py (profiles/r03d_splitk_sweep.txt), microseconds: a workgroup pays ~3 to get going and ~0.55 per
             // stage; a split launch adds the reduce kernel (~4.5 for the second launch and its latency) and the slab traffic (80 KiB per slab at ~3 MB/us).
@@ -1249,10 +1269,11 @@ int gsw_mm_launch(MMArgs& a, int dtype, void* stream) {
             }
         }
         const int64_t need = (int64_t)splits * nt * 8 * 5 * (bm_s / 64) * 64 * 16;
-        if (splits >= 2 && need <= t_mm_ws_bytes) {
+        if (splits >= 2 && need <= ws_bytes) {
             a.tiles_n = (int32_t)tiles_n;
             a.ntiles = (int32_t)nt;
-            a.splits = splits; a.ws = (float*)t_mm_ws;
+            a.splits = splits; a.ws = (float*)ws_dev;
+            ex->splits = splits;
             const uint32_t grid = (uint32_t)((nt * splits + 7) / 8 * 8);
             const int e = dtype == GSW_F16 ? mm_launch_splitk<_Float16>(a, grid, bm_s / 64, st) : mm_launch_splitk<__bf16>(a, grid, bm_s / 64, st);
             if (e != 0) { g_last_hip_error = e; return GSW_ERR_HIP; }
@@ -1267,13 +1288,13 @@ int gsw_mm_launch(MMArgs& a, int dtype, void* stream) {
     // row statistics: plain dense-row launches (EPI 0), unsplit
     if (rs_req && a.mode == MM_MODE_DENSE && !a.rowbias && !a.ln_stat && (int64_t)a.M * 2 * tiles_n * 2 <= rs_cap) {
         a.rowstats = rs_req;
-        t_rs_slots = (int)(2 * tiles_n);
+        ex->rowstats_slots = (int)(2 * tiles_n);
     }
     // column statistics: EPI 1 launches whose M dimension enumerates real pixels / tokens (interior enumeration or the token scatter), unsplit
     if (cs_req && (a.mode == MM_MODE_TOK2PF || ((a.mode == MM_MODE_PF || a.mode == MM_MODE_UP2X) && (a.flags & MM_FLAG_COMPACT)))
         && tiles_m * 4 * (int64_t)a.N <= cs_cap) {
         a.colstats = cs_req;
-        t_cs_rows = BM / 4; t_cs_blocks = (int)(tiles_m * 4);
+        ex->colstats_rows_per_block = BM / 4; ex->colstats_blocks = (int)(tiles_m * 4);
     }
     const int epi = a.mode == MM_MODE_QKV ? 5 : a.mode == MM_MODE_TRANS ? 3 : a.mode == MM_MODE_GEGLU ? 2 : (a.mode == MM_MODE_DENSE && !a.rowbias) ? 0 : 1;
     const int e = dtype == GSW_F16 ? mm_launch_e<_Float16>(a, epi, grid, BM / 64, st) : mm_launch_e<__bf16>(a, epi, grid, BM / 64, st);
@@ -1283,6 +1304,11 @@ int gsw_mm_launch(MMArgs& a, int dtype, void* stream) {
 
 int gsw_gemm_strided(const void* x_dev, int64_t ldx, const void* w_dev, int64_t ldw, const void* bias_dev, const void* resid_dev, int64_t ldr,
                      void* y_dev, int64_t ldy, int64_t M, int K, int N, int mode, int S, int Wimg, int dtype, void* stream) {
+    return gsw_gemm_ex(x_dev, ldx, w_dev, ldw, bias_dev, resid_dev, ldr, y_dev, ldy, M, K, N, mode, S, Wimg, dtype, nullptr, stream);
+}
+
+int gsw_gemm_ex(const void* x_dev, int64_t ldx, const void* w_dev, int64_t ldw, const void* bias_dev, const void* resid_dev, int64_t ldr, void* y_dev, int64_t ldy,
+                int64_t M, int K, int N, int mode, int S, int Wimg, int dtype, GswMmExtras* ex, void* stream) {
     if (!x_dev || !w_dev || !y_dev || M <= 0 || K <= 0 || N <= 0) return GSW_ERR_BAD_ARG;
     if (mode != GSW_GEMM_PLAIN && mode != GSW_GEMM_GEGLU && mode != GSW_GEMM_TRANS && mode != GSW_GEMM_TOK2PF) return GSW_ERR_BAD_ARG;
     if (K % 64 || N % 8 || (mode == GSW_GEMM_GEGLU && N % 160) || M > 0x7FFFFF00 || ldx < K || ldw < K || (ldx & 7) || (ldw & 7) || (ldy & 7) || (ldr & 7)
@@ -1307,7 +1333,7 @@ int gsw_gemm_strided(const void* x_dev, int64_t ldx, const void* w_dev, int64_t 
     if (mode == GSW_GEMM_GEGLU) a.mode = MM_MODE_GEGLU;
     else if (mode == GSW_GEMM_TRANS) a.mode = MM_MODE_TRANS;
     else if (mode == GSW_GEMM_TOK2PF) { a.mode = MM_MODE_TOK2PF; a.Wp = Wimg + 2; a.Hp = S / Wimg + 2; }
-    return gsw_mm_launch(a, dtype, stream);
+    return gsw_mm_launch(a, dtype, stream, ex);
 }
 
 int gsw_gemm_qkv(const void* x_dev, const void* w_dev, const void* bias_dev, void* rows_dev, void* trans_dev, int64_t M, int K, int N_rows, int N,
@@ -1326,7 +1352,7 @@ int gsw_gemm_qkv(const void* x_dev, const void* w_dev, const void* bias_dev, voi
     a.ldy = N_rows; a.ldr = N_rows; a.ldrb = N;
     a.Hp = 1; a.Wp = 1; a.in_Hp = 1; a.in_Wp = 1; a.stride = 1; a.S = S; a.Wimg = 1; a.up = 0; a.flags = MM_FLAG_NONE;
     a.mode = MM_MODE_QKV;
-    return gsw_mm_launch(a, dtype, stream);
+    return gsw_mm_launch(a, dtype, stream, nullptr);
 }
 
 // Row records [M][slots][2] (sum, sum of squares per 80-column half tile) -> (rstd, -rstd * mean) per row, the form the LayerNorm-folded epilogues read
@@ -1352,6 +1378,11 @@ int gsw_ln_rowstats_finish(const float* records_dev, int slots, int64_t M, int C
 
 int gsw_gemm_ln(const void* x_dev, const float* ln_stat_dev, const void* w_dev, const float* u_dev, const float* v_dev, void* y_dev, int64_t M, int K, int N,
                 int mode, int S, int dtype, void* stream) {
+    return gsw_gemm_ln_ex(x_dev, ln_stat_dev, w_dev, u_dev, v_dev, y_dev, M, K, N, mode, S, dtype, nullptr, stream);
+}
+
+int gsw_gemm_ln_ex(const void* x_dev, const float* ln_stat_dev, const void* w_dev, const float* u_dev, const float* v_dev, void* y_dev, int64_t M, int K, int N,
+                   int mode, int S, int dtype, GswMmExtras* ex, void* stream) {
     // y = LayerNorm(x) W^T + b without materialising LayerNorm(x): w_dev = W diag(gamma) [N][K], u = (row sums of w_dev), v = W beta + b (fp32 [N]),
     // ln_stat_dev float2 [M] = (rstd, -rstd * mean) of the rows of x (gsw_ln_rowstats_finish).  mode: GSW_GEMM_PLAIN / GEGLU (packed rows) / TRANS.
     if (!x_dev || !ln_stat_dev || !w_dev || !u_dev || !v_dev || !y_dev || M <= 0 || K <= 0 || N <= 0) return GSW_ERR_BAD_ARG;
@@ -1370,7 +1401,7 @@ int gsw_gemm_ln(const void* x_dev, const float* ln_stat_dev, const void* w_dev, 
     a.ldy = ncols; a.ldr = ncols; a.ldrb = N;
     a.Hp = 1; a.Wp = 1; a.in_Hp = 1; a.in_Wp = 1; a.stride = 1; a.S = S > 0 ? S : 1; a.Wimg = 1; a.up = 0; a.flags = MM_FLAG_NONE;
     a.mode = mode == GSW_GEMM_GEGLU ? MM_MODE_GEGLU : mode == GSW_GEMM_TRANS ? MM_MODE_TRANS : MM_MODE_DENSE;
-    return gsw_mm_launch(a, dtype, stream);
+    return gsw_mm_launch(a, dtype, stream, ex);
 }
 
 int gsw_gemm(const void* x_dev, const void* w_dev, const void* bias_dev, const void* resid_dev, void* y_dev, int64_t M, int K, int N,

@@ -93,9 +93,12 @@ def ddim_sample(eps_model: EpsModel, z_T: torch.Tensor, ctx_text: torch.Tensor, 
     use_cfg = guidance_scale != 1.0 and ctx_uncond is not None
     ctx2 = torch.cat([ctx_uncond, ctx_text], dim=0) if use_cfg else None
     B = x.shape[0]
+    # an eps model that knows the two halves of the guidance batch are the same latents (unet.UNet2DCondition: cfg_dup) computes what does not depend on
+    # the context once; any other callable gets the reference's doubled batch (`torch.cat([latents] * 2)`, modified_stable_diffusion_gs.pyc)
+    dup = bool(getattr(eps_model, "supports_cfg_dup", False))
     for (t, a, b), t_dev in zip(steps, tt):
         if use_cfg:
-            out = eps_model(torch.cat([x, x], dim=0), t_dev, ctx2)
+            out = eps_model(x, t_dev, ctx2, cfg_dup=True) if dup else eps_model(torch.cat([x, x], dim=0), t_dev, ctx2)
             codec.ddim_step_cfg(x, out[:B], out[B:], a, b, guidance_scale, out=x)
         else:
             codec.ddim_step(x, eps_model(x, t_dev, ctx_text), a, b, out=x)

@@ -51,7 +51,7 @@ def _switches():
     tr, sm = C.c_int(0), C.c_int(0)
     N.lib().gsw_mm_get_config(C.byref(tr), C.byref(sm))
     return (U.FUSED_KERNELS, U.USE_PF, U.UPSAMPLE_SUBPIXEL, U.CACHE_CONTEXT_KV, U.FUSED_QK, U.FUSED_QKV, U.OWN_ATTENTION, U.OWN_GEMM, U.TEMB_TABLE,
-            U.CONV_OUT_DIRECT_MAX_PIXELS, pf.FUSE_GN_STATS, pf.GN_FUSED_MAX_WGS, pf.GN_FUSED_MAX_PIXELS, pf.FOLD_LN, pf.FOLD_LN_MIN_ROWS, pf.SPLITK_MAX,
+            U.CONV_OUT_DIRECT_MAX_PIXELS, U.CFG_SHARED_PREFIX, pf.FUSE_GN_STATS, pf.GN_FUSED_MAX_WGS, pf.GN_FUSED_MAX_PIXELS, pf.FOLD_LN, pf.FOLD_LN_MIN_ROWS, pf.SPLITK_MAX,
             pf.SPLITK_BYTES, tr.value, sm.value)
 
 
@@ -112,7 +112,7 @@ class GraphedEpsModel:
         self._entries.clear()
         self._failed.clear()
 
-    def _capture(self, key, x, t, ctx) -> Optional[_Entry]:
+    def _capture(self, key, x, t, ctx, kw) -> Optional[_Entry]:
         e = _Entry()
         e.x_s = torch.empty_like(x, memory_format=torch.contiguous_format).copy_(x)
         e.t_s = torch.empty_like(t).copy_(t)
@@ -130,12 +130,12 @@ class GraphedEpsModel:
             side = torch.cuda.Stream(device=x.device)
             side.wait_stream(torch.cuda.current_stream(x.device))
             with torch.cuda.stream(side), torch.no_grad(), pf.splitk_workspace(e.ws):
-                self.model(e.x_s, e.t_s, e.ctx_s)
-                self.model(e.x_s, e.t_s, e.ctx_s)
+                self.model(e.x_s, e.t_s, e.ctx_s, **kw)
+                self.model(e.x_s, e.t_s, e.ctx_s, **kw)
             torch.cuda.current_stream(x.device).wait_stream(side)
             g = torch.cuda.CUDAGraph()
             with torch.no_grad(), pf.splitk_workspace(e.ws), torch.cuda.graph(g):
-                e.out = self.model(e.x_s, e.t_s, e.ctx_s)
+                e.out = self.model(e.x_s, e.t_s, e.ctx_s, **kw)
             e.graph = g
             for k_, v_ in U.FALLBACKS.items():             # launches off the hand-written path that the capture baked in (counted per warm-up + capture)
                 if v_ != fb_before.get(k_, 0):
@@ -148,16 +148,19 @@ class GraphedEpsModel:
         return e
 
     @torch.no_grad()
-    def __call__(self, x: torch.Tensor, t: torch.Tensor, ctx: torch.Tensor) -> torch.Tensor:
-        if not self._wants_graph(x):
+    def __call__(self, x: torch.Tensor, t: torch.Tensor, ctx: torch.Tensor, cfg_dup: bool = False) -> torch.Tensor:
+        """cfg_dup: passed on to the model (unet.UNet2DCondition.forward: ctx holds 2B contexts for the B latents of x); the row count that decides
+        between graph and eager is the context's."""
+        kw = {"cfg_dup": True} if cfg_dup else {}
+        if not self._wants_graph(ctx if cfg_dup else x):
             self.stats["eager"] += 1
-            return self.model(x, t, ctx)
+            return self.model(x, t, ctx, **kw)
         if not torch.is_tensor(t):
             t = torch.as_tensor(t, device=x.device)
-        key = (tuple(x.shape), x.dtype, str(x.device), tuple(t.shape), t.dtype, tuple(ctx.shape), ctx.dtype, _switches())
+        key = (tuple(x.shape), x.dtype, str(x.device), tuple(t.shape), t.dtype, tuple(ctx.shape), ctx.dtype, bool(cfg_dup), _switches())
         if key in self._failed:
             self.stats["eager"] += 1
-            return self.model(x, t, ctx)
+            return self.model(x, t, ctx, **kw)
         e = self._entries.get(key)
         cid = _ctx_identity(ctx)
         if e is None or not _same_ctx(cid, e.ctx_id) or e.replays % CHECK_EVERY == 0:
@@ -168,10 +171,10 @@ class GraphedEpsModel:
                 self._weights_key = wk
                 e = None
         if e is None:
-            e = self._capture(key, x, t, ctx)
+            e = self._capture(key, x, t, ctx, kw)
             if e is None:
                 self.stats["eager"] += 1
-                return self.model(x, t, ctx)
+                return self.model(x, t, ctx, **kw)
             self._entries[key] = e
             while len(self._entries) > MAX_ENTRIES:
                 self._entries.popitem(last=False)

@@ -9,6 +9,8 @@ from typing import Optional
 
 import torch
 
+import ctypes as _C
+
 from . import _native as N
 from .codec import _dt, _stream_ptr
 
@@ -97,6 +99,31 @@ def _ensure_workspace(device) -> None:
     _WS_TLS.last = key
 
 
+def _workspace(device) -> torch.Tensor:
+    """the split-K scratch of the calling thread's (device, current stream) -- or the one a splitk_workspace block pins"""
+    ov = _WS_OVERRIDE
+    if ov is not None:
+        return ov
+    dev = torch.device(device)
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _WS.get(key)
+    if ws is None:
+        ws = _WS[key] = torch.empty(SPLITK_BYTES, dtype=torch.uint8, device=dev)
+    return ws
+
+
+def _extras(device, colstats: Optional[torch.Tensor] = None, rowstats: Optional[torch.Tensor] = None) -> "N.GswMmExtras":
+    """GswMmExtras of one launch (include/gswm.h): explicit arguments instead of the deprecated thread-local one-shot calls"""
+    ws = _workspace(device)
+    ex = N.GswMmExtras()
+    if colstats is not None:
+        ex.colstats_dev, ex.colstats_capacity = colstats.data_ptr(), colstats.numel()
+    if rowstats is not None:
+        ex.rowstats_dev, ex.rowstats_capacity = rowstats.data_ptr(), rowstats.numel()
+    ex.workspace_dev, ex.workspace_bytes, ex.max_splits = ws.data_ptr(), ws.numel(), int(SPLITK_MAX)
+    return ex
+
+
 class splitk_workspace:
     """with splitk_workspace(buf): every engine launch of the block uses `buf` (a uint8 device tensor) as its split-K scratch -- graph.py pins one
     per captured graph, so replays never share scratch with eager launches or other graphs."""
@@ -131,39 +158,20 @@ class ColStats:
 
 
 def _colstats_arm(M: int, Nn: int, device, npar: int = 1, geom=None):
-    """Arm the one-shot request for a launch with M output pixels (per parity launch) and Nn columns -> (buffer, block capacity) or None.
+    """The column-record buffer for a launch with M output pixels (per parity launch) and Nn columns -> (buffer, block capacity) or None.
     geom = (B, H, W) of the output: small batches take the one-launch GroupNorm, which reads the tensor itself (no records needed)."""
     if not FUSE_GN_STATS or (geom is not None and _gn_fused_ok(geom[0], geom[1], geom[2], Nn, 32)):
         return None
     cap_blocks = (M + 127) // 128 * 4                 # 32-row blocks of 128-row tiles (64-row blocks of 256-row tiles need fewer)
     buf = torch.empty(npar * cap_blocks * Nn, dtype=torch.float32, device=device)      # [npar][blocks][2 planes][Nn / 2]
-    N.check(N.lib().gsw_mm_next_colstats(buf.data_ptr(), buf.numel()))
     return buf, cap_blocks
 
 
-def _colstats_collect(armed, npar: int = 1) -> Optional[ColStats]:
-    """What the launch produced (None when it could not: split-K, whole-tensor enumeration, a kernel off the engine); clears the request."""
-    if armed is None:
+def _colstats_collect(armed, ex, npar: int = 1) -> Optional[ColStats]:
+    """What the launch reported in its extras (None when it wrote no records: split-K, whole-tensor enumeration, a kernel off the engine)."""
+    if armed is None or ex.colstats_rows_per_block <= 0:
         return None
-    import ctypes as C
-    rows, blocks = C.c_int(0), C.c_int(0)
-    N.check(N.lib().gsw_mm_last_colstats(C.byref(rows), C.byref(blocks)))
-    return ColStats(armed[0], rows.value, npar, armed[1]) if rows.value > 0 else None
-
-
-class _colstats_scope:
-    """A launch that raises (bad arguments on either side of the ABI) must not leave its one-shot request armed for a later launch."""
-
-    def __init__(self, armed):
-        self.armed = armed
-
-    def __enter__(self):
-        return self
-
-    def __exit__(self, et, ev, tb):
-        if et is not None and self.armed is not None:
-            N.lib().gsw_mm_last_colstats(None, None)
-        return False
+    return ColStats(armed[0], int(ex.colstats_rows_per_block), npar, armed[1])
 
 
 def _stats_usable(x: "PF") -> bool:
@@ -256,15 +264,14 @@ def conv_pf(x: PF, w_packed: torch.Tensor, bias: Optional[torch.Tensor], *, ksiz
         xp += (x.W + 2 + 1) * x.C * x.buf.element_size()
     tm = CONV_TIMER
     with torch.cuda.device(x.buf.device):
-        _ensure_workspace(x.buf.device)
         e0 = tm.start() if tm is not None else None
         armed = _colstats_arm(x.B * Ho * Wo, Nn, x.buf.device, geom=(x.B, Ho, Wo)) if Nn >= 128 else None
-        with _colstats_scope(armed):
-            N.check(N.lib().gsw_conv_pf(xp, w_packed.data_ptr(), bias.data_ptr() if bias is not None else None,
-                                        rowbias.data_ptr() if rowbias is not None else None, ldrb,
-                                        resid.rows.data_ptr() if resid is not None else None, y.rows.data_ptr(),
-                                        x.B, Ho, Wo, C, Nn, ksize, stride, x.C, _dt(x.buf.dtype), _stream_ptr()))
-        y.stats = _colstats_collect(armed)
+        ex = _extras(x.buf.device, colstats=None if armed is None else armed[0])
+        N.check(N.lib().gsw_conv_pf_ex(xp, w_packed.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                       rowbias.data_ptr() if rowbias is not None else None, ldrb,
+                                       resid.rows.data_ptr() if resid is not None else None, y.rows.data_ptr(),
+                                       x.B, Ho, Wo, C, Nn, ksize, stride, x.C, _dt(x.buf.dtype), _C.byref(ex), _stream_ptr()))
+        y.stats = _colstats_collect(armed, ex)
         if tm is not None:
             name = _conv_kernel_name(Wo, Nn, ksize, stride)
             tm.stop(e0, (name, x.B, Ho, Wo, ksize * ksize * C, Nn, stride) if tm.by_shape else name, 2.0 * x.B * Ho * Wo * Nn * ksize * ksize * C)
@@ -305,10 +312,10 @@ def gemm_strided(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, bias: Opti
     _same(bias, x, "bias", Nn)
     tm = CONV_TIMER
     with torch.cuda.device(x.device):
-        _ensure_workspace(x.device)
         e0 = tm.start() if tm is not None else None
-        N.check(N.lib().gsw_gemm_strided(x.data_ptr(), ldx, w.data_ptr(), ldw, bias.data_ptr() if bias is not None else None, None, ldy,
-                                         out.data_ptr(), ldy, M, K, Nn, 0, 0, 0, _dt(x.dtype), _stream_ptr()))
+        ex = _extras(x.device)
+        N.check(N.lib().gsw_gemm_ex(x.data_ptr(), ldx, w.data_ptr(), ldw, bias.data_ptr() if bias is not None else None, None, ldy,
+                                    out.data_ptr(), ldy, M, K, Nn, 0, 0, 0, _dt(x.dtype), _C.byref(ex), _stream_ptr()))
         if tm is not None:
             tm.stop(e0, ("gsw_mm_kernel", M, K, Nn, "plain") if tm.by_shape else "gsw_mm_kernel", 2.0 * M * K * Nn)
     return out
@@ -499,27 +506,22 @@ def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
         _same(resid, x, "resid", rows * Nn)
     tm = CONV_TIMER
     with torch.cuda.device(x.device):
-        _ensure_workspace(x.device)
         e0 = tm.start() if tm is not None else None
         # stats_for (tok2pf): the PF tensor whose payload this launch writes -- it gets the launch's column records (or None)
         armed = _colstats_arm(M, Nn, x.device, geom=(M // tokens, tokens // width, width)) if (stats_for is not None and mode == "tok2pf") else None
         rs_buf = None
         if rowstats and mode == "plain" and FOLD_LN:
-            # row records for the LayerNorm that consumes this output (gsw_mm_next_rowstats): [M][2 * ceil(N / 160)][2] floats
+            # row records for the LayerNorm that consumes this output (GswMmExtras.rowstats_dev): [M][2 * ceil(N / 160)][2] floats
             rs_buf = torch.empty(M * 2 * ((Nn + 159) // 160) * 2, dtype=torch.float32, device=x.device)
-            N.check(N.lib().gsw_mm_next_rowstats(rs_buf.data_ptr(), rs_buf.numel()))
-        with _colstats_scope(armed), _rowstats_scope(rs_buf):
-            N.check(N.lib().gsw_gemm(x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None,
-                                     resid.data_ptr() if resid is not None else None, y.data_ptr(), M, K, Nn, m, tokens, width,
-                                     _dt(x.dtype), _stream_ptr()))
+        ex = _extras(x.device, colstats=None if armed is None else armed[0], rowstats=rs_buf)
+        ncols = Nn // 2 if mode == "geglu" else Nn
+        N.check(N.lib().gsw_gemm_ex(x.data_ptr(), K, w.data_ptr(), K, bias.data_ptr() if bias is not None else None,
+                                    resid.data_ptr() if resid is not None else None, Nn, y.data_ptr(), ncols, M, K, Nn, m, tokens, width,
+                                    _dt(x.dtype), _C.byref(ex), _stream_ptr()))
         if stats_for is not None:
-            stats_for.stats = _colstats_collect(armed)
-        if rs_buf is not None:
-            import ctypes as C
-            slots = C.c_int(0)
-            N.check(N.lib().gsw_mm_last_rowstats(C.byref(slots)))
-            if slots.value > 0:
-                y._gsw_rowstats = (rs_buf, slots.value)          # rides on the output tensor; in-place edits of y must drop it
+            stats_for.stats = _colstats_collect(armed, ex)
+        if rs_buf is not None and ex.rowstats_slots > 0:
+            y._gsw_rowstats = (rs_buf, int(ex.rowstats_slots))          # rides on the output tensor; in-place edits of y must drop it
         if tm is not None:
             tm.stop(e0, ("gsw_mm_kernel", M, K, Nn, mode) if tm.by_shape else "gsw_mm_kernel", 2.0 * M * K * Nn)
     return y
@@ -528,19 +530,6 @@ def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
 # ---- LayerNorm folded into the consuming GEMM (gsw_gemm_ln): LN(x) W^T + b = rstd (x W'^T) + nrm u + v, W' = W diag(gamma), u = W' 1, v = W beta + b
 FOLD_LN = True
 FOLD_LN_MIN_ROWS = int(__import__("os").environ.get("GSW_FOLD_LN_MIN_ROWS", "1024"))       # below that the consumers would rather take the split-K form, which the folded epilogue does not have
-
-
-class _rowstats_scope:
-    def __init__(self, buf):
-        self.buf = buf
-
-    def __enter__(self):
-        return self
-
-    def __exit__(self, et, ev, tb):
-        if et is not None and self.buf is not None:
-            N.lib().gsw_mm_last_rowstats(None)
-        return False
 
 
 def ln_stat(x: torch.Tensor, eps: float) -> Optional[torch.Tensor]:
@@ -596,10 +585,10 @@ def gemm_ln(x: torch.Tensor, stat: torch.Tensor, wp: torch.Tensor, u: torch.Tens
         raise ValueError(mode)
     tm = CONV_TIMER
     with torch.cuda.device(x.device):
-        _ensure_workspace(x.device)
         e0 = tm.start() if tm is not None else None
-        N.check(N.lib().gsw_gemm_ln(x.data_ptr(), stat.data_ptr(), wp.data_ptr(), u.data_ptr(), v.data_ptr(), y.data_ptr(), M, K, Nn,
-                                    GEMM_MODES[mode], tokens, _dt(x.dtype), _stream_ptr()))
+        ex = _extras(x.device)
+        N.check(N.lib().gsw_gemm_ln_ex(x.data_ptr(), stat.data_ptr(), wp.data_ptr(), u.data_ptr(), v.data_ptr(), y.data_ptr(), M, K, Nn,
+                                       GEMM_MODES[mode], tokens, _dt(x.dtype), _C.byref(ex), _stream_ptr()))
         if tm is not None:
             tm.stop(e0, ("gsw_mm_kernel", M, K, Nn, mode + "+ln") if tm.by_shape else "gsw_mm_kernel", 2.0 * M * K * Nn)
     return y
@@ -676,18 +665,17 @@ def conv3x3_res_pf(x: PF, w_cat: torch.Tensor, bias: Optional[torch.Tensor], *, 
     y = PF.empty(x.B, x.H, x.W, Nn, x.buf.dtype, x.buf.device)
     tm = CONV_TIMER
     with torch.cuda.device(x.buf.device):
-        _ensure_workspace(x.buf.device)
         e0 = tm.start() if tm is not None else None
         armed = _colstats_arm(x.B * x.H * x.W, Nn, x.buf.device, geom=(x.B, x.H, x.W))
-        with _colstats_scope(armed):
-            N.check(N.lib().gsw_conv3x3_res_pf(x.rows.data_ptr(), w_cat.data_ptr(), bias.data_ptr() if bias is not None else None,
-                                               rowbias.data_ptr() if rowbias is not None else None, ldrb,
-                                               resid.rows.data_ptr() if resid is not None else None, y.rows.data_ptr(),
-                                               x.B, x.H, x.W, x.C, Nn,
-                                               x1.rows.data_ptr() if x1 is not None else None, x1.C if x1 is not None else 0,
-                                               x2.rows.data_ptr() if x2 is not None else None, x2.C if x2 is not None else 0,
-                                               _dt(x.buf.dtype), _stream_ptr()))
-        y.stats = _colstats_collect(armed)
+        ex = _extras(x.buf.device, colstats=None if armed is None else armed[0])
+        N.check(N.lib().gsw_conv3x3_res_pf_ex(x.rows.data_ptr(), w_cat.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                              rowbias.data_ptr() if rowbias is not None else None, ldrb,
+                                              resid.rows.data_ptr() if resid is not None else None, y.rows.data_ptr(),
+                                              x.B, x.H, x.W, x.C, Nn,
+                                              x1.rows.data_ptr() if x1 is not None else None, x1.C if x1 is not None else 0,
+                                              x2.rows.data_ptr() if x2 is not None else None, x2.C if x2 is not None else 0,
+                                              _dt(x.buf.dtype), _C.byref(ex), _stream_ptr()))
+        y.stats = _colstats_collect(armed, ex)
         if tm is not None:
             k = 9 * x.C + (x1.C if x1 is not None else 0) + (x2.C if x2 is not None else 0)
             name = _conv_kernel_name(x.W, Nn, 3, 1)
@@ -705,8 +693,18 @@ def attention_ok(x: torch.Tensor, heads: int, head_dim: int, n_q: int, n_k: int)
 attention_hd64_ok = attention_ok
 
 
+def dup_pf(x: "PF") -> "PF":
+    """[x | x] along the batch: the B images of a PF tensor as a PF tensor of 2B images (borders and payload copied, fresh guard rows; the column
+    records of x describe each half)."""
+    y = PF.empty(2 * x.B, x.H, x.W, x.C, x.buf.dtype, x.buf.device)
+    r = y.rows
+    r[: x.M].copy_(x.rows)
+    r[x.M:].copy_(x.rows)
+    return y
+
+
 def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, scale: Optional[float] = None,
-              valid_keys: Optional[int] = None) -> torch.Tensor:
+              valid_keys: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """softmax(q k^T * scale) v on the hand-written flash-attention kernel (csrc/gswm_attn.hip), head_dim 40 / 64 / 80 / 160, any
     number of queries, keys a multiple of 8 (sequences off the 128-query / 64-key tiles run the kernel's ragged variant).
     q [B, Sq, heads*d], k [B, Sk, heads*d], vt [B, heads*d, Sk] (V transposed) -> [B, Sq, heads*d]; keys >= valid_keys are
@@ -728,7 +726,10 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, sc
     for t_, nm in ((k, "k"), (vt, "vt")):
         if t_.dtype != q.dtype or t_.device != q.device:
             raise ValueError(f"attention: {nm} is {t_.dtype} on {t_.device}, q is {q.dtype} on {q.device}")
-    out = torch.empty((B, Sq, inner), dtype=q.dtype, device=q.device)
+    if out is None:
+        out = torch.empty((B, Sq, inner), dtype=q.dtype, device=q.device)
+    elif tuple(out.shape) != (B, Sq, inner) or out.dtype != q.dtype or out.device != q.device or not out.is_contiguous():
+        raise ValueError("attention: out must be a contiguous [B, Sq, heads * d] tensor like q")
     with torch.cuda.device(q.device):
         N.check(N.lib().gsw_attention(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), B, heads, d, Sq, Sk,
                                       Sk if valid_keys is None else int(valid_keys), ldq, ldk, inner,
@@ -767,13 +768,12 @@ def conv_up2x_pf(x: PF, w4: torch.Tensor, bias: Optional[torch.Tensor]) -> PF:
     y = PF.empty(x.B, 2 * x.H, 2 * x.W, Nn, x.buf.dtype, x.buf.device)          # gsw_conv_up2x_pf zeroes the border rows itself
     tm = CONV_TIMER
     with torch.cuda.device(x.buf.device):
-        _ensure_workspace(x.buf.device)
         e0 = tm.start() if tm is not None else None
         armed = _colstats_arm(x.B * x.H * x.W, Nn, x.buf.device, npar=4, geom=(x.B, 2 * x.H, 2 * x.W))
-        with _colstats_scope(armed):
-            N.check(N.lib().gsw_conv_up2x_pf(x.rows.data_ptr(), w4.data_ptr(), bias.data_ptr() if bias is not None else None, y.rows.data_ptr(),
-                                             x.B, x.H, x.W, x.C, Nn, _dt(x.buf.dtype), _stream_ptr()))
-        y.stats = _colstats_collect(armed, npar=4)
+        ex = _extras(x.buf.device, colstats=None if armed is None else armed[0])
+        N.check(N.lib().gsw_conv_up2x_pf_ex(x.rows.data_ptr(), w4.data_ptr(), bias.data_ptr() if bias is not None else None, y.rows.data_ptr(),
+                                            x.B, x.H, x.W, x.C, Nn, _dt(x.buf.dtype), _C.byref(ex), _stream_ptr()))
+        y.stats = _colstats_collect(armed, ex, npar=4)
         if tm is not None:      # EXECUTED FLOPs (16 C MACs per output: four 2x2 convolutions); the 3x3-on-upsampled form it replaces is 2.25x that
             name = "gsw_mm_kernel(up2x)"
             tm.stop(e0, (name, x.B, 2 * x.H, 2 * x.W, 4 * x.C, Nn, 1) if tm.by_shape else name,

@@ -267,6 +267,24 @@ class Attention(nn.Module):
             o = attention(gemm_ln(x, stat, *fq), k_ctx, vt_ctx, self.heads, valid_keys=valid)
         return _lin(o, self.to_out[0], resid, rowstats=True)
 
+    def cross_dup(self, x, ctx, *, stat=None, norm: Optional[nn.LayerNorm] = None):
+        """Classifier-free guidance with shared latents: x [B, S, C] holds the queries' input ONCE, ctx [2B, 77, D] = (uncond | text) contexts.  The
+        query projection runs on B rows; the 77-key attention once per context half, both writing one [2B, S, C] tensor; -> attention output (before
+        the output projection).  stat / norm: LayerNorm folded into the projection (x is the raw residual stream), else x is already normalised."""
+        from .pf import attention, cached, fold_ln_weights, gemm_ln
+        B = x.shape[0]
+        src, valid = _padded_ctx(ctx)
+        k_ctx, vt_ctx = self.context_kv(src)
+        if stat is not None:
+            fq = cached(self, "_gsw_ln_q", (self.to_q.weight, norm.weight, norm.bias), lambda: fold_ln_weights(self.to_q.weight.detach(), None, norm.weight, norm.bias))
+            q = gemm_ln(x, stat, *fq)
+        else:
+            q = _lin(x, self.to_q)
+        o = torch.empty((2 * B, x.shape[1], self.to_q.out_features), dtype=x.dtype, device=x.device)
+        attention(q, k_ctx[:B], vt_ctx[:B], self.heads, valid_keys=valid, out=o[:B])
+        attention(q, k_ctx[B:], vt_ctx[B:], self.heads, valid_keys=valid, out=o[B:])
+        return o
+
     def ln_foldable(self, x, ctx=None) -> bool:
         from .pf import attention_ok
         n = x.shape[1]
@@ -370,7 +388,19 @@ class BasicTransformerBlock(nn.Module):
         self.norm3 = nn.LayerNorm(dim)
         self.ff = FeedForward(dim)
 
-    def forward(self, x, ctx):
+    def dup_ok(self, x, ctx) -> bool:
+        """forward(x, ctx, dup=True) is available: the fused path with the own attention kernel and cached context K / V"""
+        from .pf import attention_ok
+        a = self.attn2
+        return (FUSED_KERNELS and OWN_ATTENTION and CACHE_CONTEXT_KV and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and x.is_contiguous()
+                and x.shape[-1] % 8 == 0 and x.shape[-1] <= 1536 and ctx.shape[0] == 2 * x.shape[0]
+                and attention_ok(x, a.heads, a.to_q.out_features // a.heads, x.shape[1], (ctx.shape[1] + 63) // 64 * 64))
+
+    def forward(self, x, ctx, dup: bool = False):
+        """dup (classifier-free guidance, see UNet2DCondition.forward): x [B, S, C], ctx [2B, ...] -> [2B, S, C]; self-attention and the cross-attention
+        queries are computed once on the B rows the two halves share."""
+        if dup and not self.dup_ok(x, ctx):
+            x, dup = torch.cat([x, x], dim=0), False
         if FUSED_KERNELS and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and x.is_contiguous() and x.shape[-1] % 8 == 0 \
                 and x.shape[-1] <= 1536:
             from .codec import add_layernorm
@@ -385,12 +415,21 @@ class BasicTransformerBlock(nn.Module):
             else:
                 _, n = add_layernorm(x, None, self.norm1.weight, self.norm1.bias, self.norm1.eps)
                 x = self.attn1(n, resid=x)
-            st = ln_stat(x, self.norm2.eps) if self.attn2.ln_foldable(x, ctx) else None
-            if st is not None:
-                x = self.attn2.forward_ln(x, st, self.norm2, ctx, resid=x)
+            if dup:
+                st = ln_stat(x, self.norm2.eps) if self.attn2.ln_foldable(x, ctx[: x.shape[0]]) else None
+                if st is not None:
+                    o = self.attn2.cross_dup(x, ctx, stat=st, norm=self.norm2)
+                else:
+                    _, n = add_layernorm(x, None, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+                    o = self.attn2.cross_dup(n, ctx)
+                x = _lin(o, self.attn2.to_out[0], torch.cat([x, x], dim=0), rowstats=True)      # from here on: 2B rows
             else:
-                _, n = add_layernorm(x, None, self.norm2.weight, self.norm2.bias, self.norm2.eps)
-                x = self.attn2(n, ctx, resid=x)
+                st = ln_stat(x, self.norm2.eps) if self.attn2.ln_foldable(x, ctx) else None
+                if st is not None:
+                    x = self.attn2.forward_ln(x, st, self.norm2, ctx, resid=x)
+                else:
+                    _, n = add_layernorm(x, None, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+                    x = self.attn2(n, ctx, resid=x)
             st = ln_stat(x, self.norm3.eps) if (inner4 % 80 == 0 and _own_gemm_ok(x, x.shape[-1], 2 * inner4)) else None
             if st is not None:
                 return self.ff.forward_ln(x, st, self.norm3, resid=x)
@@ -418,10 +457,14 @@ class Transformer2DModel(nn.Module):
         y = self.proj_out(y).reshape(b, h, w, c).permute(0, 3, 1, 2)
         return x + y
 
-    def forward_pf(self, x, ctx):
+    def forward_pf(self, x, ctx, dup: bool = False):
+        """dup: x holds B images, ctx 2B contexts -> a PF tensor of 2B images (see UNet2DCondition.forward)"""
         y = _lin(_gn_pf(x, self.norm, act=False, tokens=True), self.proj_in, rowstats=True)      # GroupNorm writes dense tokens directly
-        for blk in self.transformer_blocks:
-            y = blk(y, ctx)
+        for i, blk in enumerate(self.transformer_blocks):
+            y = blk(y, ctx, dup=dup and i == 0)
+        if dup:
+            from .pf import dup_pf
+            x = dup_pf(x)
         if _own_gemm_ok(y, self.proj_out.in_features, self.proj_out.out_features):
             from .pf import gemm        # proj_out + residual written straight into the PF tensor's interior rows (x has no other reader)
             w, b = _wb(self.proj_out, y)
@@ -485,12 +528,16 @@ class DownBlock(nn.Module):
             skips.append(x)
         return x
 
-    def forward_pf(self, x, temb, ctx, skips):
+    def forward_pf(self, x, temb, ctx, skips, dup_temb=None):
+        """dup_temb (first down block under classifier-free guidance with shared latents): x holds B images, ctx 2B contexts; the first resnet and the
+        first transformer up to its cross-attention run on B images, everything after on 2B with the doubled time-embedding rows `dup_temb`"""
         from .pf import PF
         for i, r in enumerate(self.resnets):
             x = r.forward_pf(x, temb)
             if self.attentions is not None:
-                x = self.attentions[i].forward_pf(x, ctx)
+                x = self.attentions[i].forward_pf(x, ctx, dup=dup_temb is not None and i == 0)
+                if dup_temb is not None and i == 0:
+                    temb = dup_temb
             skips.append(x)
         if self.downsamplers is not None:
             x = self.downsamplers[0].forward_pf(x)
@@ -582,18 +629,29 @@ class UNet2DCondition(nn.Module):
         self.conv_norm_out = nn.GroupNorm(32, c0, eps=1e-5)
         self.conv_out = nn.Conv2d(c0, out_channels, 3, padding=1)
 
-    def forward(self, x: torch.Tensor, t: torch.Tensor, ctx: torch.Tensor) -> torch.Tensor:
-        """x [B,4,h,w], t [B] (or scalar tensor) timesteps, ctx [B,77,1024] -> model output [B,4,h,w]."""
+    supports_cfg_dup = True
+
+    def forward(self, x: torch.Tensor, t: torch.Tensor, ctx: torch.Tensor, cfg_dup: bool = False) -> torch.Tensor:
+        """x [B,4,h,w], t [B] (or scalar tensor) timesteps, ctx [B,77,1024] -> model output [B,4,h,w].
+        cfg_dup (classifier-free guidance, the reference's `torch.cat([latents] * 2)` of modified_stable_diffusion_gs.pyc): ctx holds 2B contexts
+        (uncond | text) for the SAME B latents -> output [2B,4,h,w].  Until the first cross-attention the two halves of the batch are the same
+        numbers -- conv_in, the first resnet, the first transformer's GroupNorm / proj_in / self-attention / query projection -- so they are computed
+        once on B rows (CFG_SHARED_PREFIX; per-row results are what the doubled batch would compute)."""
+        if cfg_dup:
+            if ctx.shape[0] != 2 * x.shape[0] or t.numel() not in (1, x.shape[0]):
+                raise ValueError("cfg_dup: ctx must hold 2B contexts for the B latents, t one timestep or B")
+            if not (CFG_SHARED_PREFIX and self._pf_ok(x) and self._cfg_dup_ok(x, ctx)):
+                return self.forward(torch.cat([x, x], dim=0), t if t.numel() == 1 else torch.cat([t, t]), ctx)
         if self._pf_ok(x):
             rows = _temb_rows_from_table(self, t, x) if TEMB_TABLE else None
             if rows is not None:
-                return self._forward_pf(x, rows, ctx)
+                return self._forward_pf(x, rows, ctx, cfg_dup)
         if t.dim() == 0:
             t = t.expand(x.shape[0])
         temb = self.time_embedding(timestep_embedding(t, self.c0).to(x.dtype))
         temb = F.silu(temb)                      # every resnet applies SiLU to the same embedding: do it once
         if self._pf_ok(x):
-            return self._forward_pf(x, _temb_rows(self, temb), ctx)
+            return self._forward_pf(x, _temb_rows(self, temb), ctx, cfg_dup)
         if USE_PF and FUSED_KERNELS and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16):
             _note_fallback(f"UNet forward on {tuple(x.shape)} {x.dtype}: off the padded-flat path (fp16 / bf16, conv channels % 64, lattice % {1 << (len(self.down_blocks) - 1)}): plain torch modules")
         h = self.conv_in(x)
@@ -714,8 +772,36 @@ CONV_OUT_DIRECT_MAX_PIXELS = 65536      # conv_out (320 -> 4) as the one-wave-pe
                                         # LDS-tiled 64-column kernel moves fewer bytes through L2
 
 
-def _unet_forward_pf(self, x: torch.Tensor, temb, ctx: torch.Tensor) -> torch.Tensor:
-    from .pf import PF, conv_pf, cached, pack_conv_weight
+CFG_SHARED_PREFIX = __import__("os").environ.get("GSW_CFG_SHARED_PREFIX", "1") != "0"      # classifier-free guidance: the part of a forward that does not see the context runs once for both halves of the batch
+
+
+def _unet_cfg_dup_ok(self, x: torch.Tensor, ctx: torch.Tensor) -> bool:
+    b0 = self.down_blocks[0]
+    if b0.attentions is None or not isinstance(b0.attentions[0].transformer_blocks[0], BasicTransformerBlock):
+        return False
+    tokens = torch.empty((x.shape[0], x.shape[2] * x.shape[3], b0.attentions[0].proj_in.out_features), dtype=x.dtype, device="meta")
+    blk = b0.attentions[0].transformer_blocks[0]
+    a = blk.attn2
+    from .pf import ATTN_HEAD_DIMS
+    return (FUSED_KERNELS and OWN_ATTENTION and CACHE_CONTEXT_KV and OWN_GEMM and tokens.shape[-1] % 8 == 0 and tokens.shape[-1] <= 1536
+            and (a.to_q.out_features // a.heads) in ATTN_HEAD_DIMS and _own_gemm_ok(x, a.to_q.in_features, a.to_q.out_features))
+
+
+def _dup_temb(temb):
+    """time-embedding rows of B images -> of the 2B images of the doubled batch"""
+    if isinstance(temb, TembRows):
+        tab = torch.cat([temb.table, temb.table], dim=0)
+        rows, off = {}, 0
+        for k, v in temb.rows.items():           # (insertion order = column order)
+            n = v.shape[1]
+            rows[k] = tab[:, off:off + n]
+            off += n
+        return TembRows(None if temb.act is None else torch.cat([temb.act, temb.act], dim=0), rows, tab)
+    return torch.cat([temb, temb], dim=0)
+
+
+def _unet_forward_pf(self, x: torch.Tensor, temb, ctx: torch.Tensor, cfg_dup: bool = False) -> torch.Tensor:
+    from .pf import PF, conv_pf, cached, pack_conv_weight, dup_pf
     from . import _native as N
     from .codec import _dt, _stream_ptr
     w_in, w_out, b_out = _edge_conv_weights(self)
@@ -726,7 +812,15 @@ def _unet_forward_pf(self, x: torch.Tensor, temb, ctx: torch.Tensor) -> torch.Te
         N.check(N.lib().gsw_nchw_to_pf(xc.data_ptr(), xin.rows.data_ptr(), B, cin, H, W, 64, _dt(x.dtype), _stream_ptr()))
     h = conv_pf(xin, w_in, self.conv_in.bias)
     skips = [h]
-    for blk in self.down_blocks:
+    if cfg_dup:
+        temb2 = _dup_temb(temb)
+        h = self.down_blocks[0].forward_pf(h, temb, ctx, skips, dup_temb=temb2)
+        skips[0] = dup_pf(skips[0])              # the conv_in skip is consumed by the last up-block resnet, on 2B images
+        temb, B = temb2, 2 * B
+        rest = self.down_blocks[1:]
+    else:
+        rest = self.down_blocks
+    for blk in rest:
         h = blk.forward_pf(h, temb, ctx, skips)
     h = self.mid_block.forward_pf(h, temb, ctx)
     for blk in self.up_blocks:
@@ -758,6 +852,7 @@ def _unet_prepare_context(self, ctx: torch.Tensor) -> None:
                 a.context_kv(src)
 
 
+UNet2DCondition._cfg_dup_ok = _unet_cfg_dup_ok
 UNet2DCondition.prepare_context = _unet_prepare_context
 UNet2DCondition._pf_ok = _unet_pf_ok
 UNet2DCondition._forward_pf = _unet_forward_pf
@@ -799,6 +894,29 @@ def load_diffusers_state_dict(model: nn.Module, weight_dir: str) -> nn.Module:
     if missing or unexpected:
         raise RuntimeError(f"state dict mismatch: missing {missing[:5]}..., unexpected {unexpected[:5]}...")
     return model
+
+
+def count_cfg_shared_prefix_flops(model: nn.Module, h: int = 64, w: int = 64) -> int:
+    """FLOPs per image of the part of a forward that does not see the context (conv_in, the first resnet, the first transformer's proj_in, self-attention
+    and cross-attention query projection): what a cfg_dup forward executes once for two rows of the guidance batch."""
+    from torch.utils.flop_counter import FlopCounterMode
+    import copy
+    m = copy.deepcopy(model).to("meta")
+    dt = next(m.parameters()).dtype
+    b0 = m.down_blocks[0]
+    if b0.attentions is None:
+        return 0
+    tr = b0.attentions[0]
+    blk = tr.transformer_blocks[0]
+    x = torch.empty(1, m.conv_in.in_channels, h, w, device="meta", dtype=dt)
+    temb = torch.empty(1, m.time_embedding.linear_2.out_features, device="meta", dtype=dt)
+    with FlopCounterMode(display=False) as fc:
+        hh = m.conv_in(x)
+        hh = b0.resnets[0](hh, temb)
+        y = tr.proj_in(tr.norm(hh).permute(0, 2, 3, 1).reshape(1, h * w, -1))
+        y = y + blk.attn1(blk.norm1(y))
+        blk.attn2.to_q(blk.norm2(y))
+    return int(fc.get_total_flops())
 
 
 def count_flops_per_image(model: nn.Module, h: int = 64, w: int = 64, ctx_len: int = 77, ctx_dim: Optional[int] = None) -> int:

@@ -21,23 +21,31 @@ class TimedModel:
         import torch
         self.model, self.flops_per_row, self.torch = model, flops_per_row, torch
         self.events, self.flops, self.enabled = [], 0.0, False
+        self.prefix_flops_per_row = 0.0          # FLOPs of the context-free prefix of a forward (unet.count_cfg_shared_prefix_flops), set by run_e2e
 
-    def __call__(self, x, t, ctx):
+    @property
+    def supports_cfg_dup(self):
+        return bool(getattr(self.model, "supports_cfg_dup", False))
+
+    def __call__(self, x, t, ctx, **kw):
         if not self.enabled:
-            return self.model(x, t, ctx)
+            return self.model(x, t, ctx, **kw)
         s, e = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
         s.record()
-        y = self.model(x, t, ctx)
+        y = self.model(x, t, ctx, **kw)
         e.record()
-        self.events.append((s, e, x.shape[0]))
+        # rows of the guidance batch: the shared prefix of a cfg_dup forward runs once for two rows -- its FLOPs are counted once (prefix_flops_per_row)
+        self.events.append((s, e, ctx.shape[0] if kw.get("cfg_dup") else x.shape[0], x.shape[0] if kw.get("cfg_dup") else 0))
         return y
 
     def summary(self):
-        tot_ms = sum(s.elapsed_time(e) for s, e, _ in self.events)
-        rows = sum(r for _, _, r in self.events)
+        tot_ms = sum(s.elapsed_time(e) for s, e, _, _ in self.events)
+        rows = sum(r for _, _, r, _ in self.events)
+        shared = sum(d for _, _, _, d in self.events)
+        flops = rows * self.flops_per_row - shared * self.prefix_flops_per_row      # EXECUTED FLOPs
         return {"calls": len(self.events), "avg_ms": tot_ms / max(1, len(self.events)), "total_ms": tot_ms,
-                "tflops": rows * self.flops_per_row / (tot_ms * 1e-3) / 1e12 if tot_ms else 0.0,
-                "flops_per_call_avg": rows * self.flops_per_row / max(1, len(self.events))}
+                "tflops": flops / (tot_ms * 1e-3) / 1e12 if tot_ms else 0.0, "flops_per_call_avg": flops / max(1, len(self.events)),
+                "rows": rows, "rows_whose_context_free_prefix_was_shared": shared, "prefix_flops_per_row": self.prefix_flops_per_row}
 
 
 def cpu_baseline_e2e(unet_cfg, ddim_steps, M, h=64, w=64, with_vae=False):
@@ -129,6 +137,7 @@ def run_e2e(args, rank, world, local_rank):
     from gswm_amd.graph import graphed
     eps = graphed(model, clone_output=False)                                    # forwards of <= 32 rows replay a captured HIP graph (GSW_GRAPH=never: eager A/B)
     tm = TimedModel(eps, flops_row)
+    tm.prefix_flops_per_row = float(U.count_cfg_shared_prefix_flops(model, h, w)) if U.CFG_SHARED_PREFIX else 0.0
     g = torch.Generator(device="cpu").manual_seed(1)
     ctx_uncond = (torch.randn(1, 77, ctx_dim, generator=g) * 1.0).to(dev, dtype)        # stands for CLIP("")
     ctx_text = (torch.randn(B, 77, ctx_dim, generator=g) * 1.0).to(dev, dtype)          # stands for CLIP(prompt)

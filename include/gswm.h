@@ -33,7 +33,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define GSW_VERSION 301 /* 0.3.1: gsw_gemm / gsw_gemm_strided (PLAIN, GEGLU) want a 16-byte aligned bias.  0.3.0: gsw_conv_pf / gsw_conv3x3_res_pf take ld_rowbias; gsw_mm_set_workspace (split-K).  0.2.0: GEGLU weights packed per 16-row block (see gsw_gemm) */
+#define GSW_VERSION 400 /* 0.4.0: explicit-argument launches (GswMmExtras, gsw_*_ex); the one-shot side channels (gsw_mm_next_colstats / gsw_mm_next_rowstats / gsw_mm_set_workspace) are deprecated shims over them; gsw_mm_last_colstats / gsw_mm_last_rowstats return GSW_WARN_NO_RECORDS for a dropped request; small-batch kernels (gsw_groupnorm_pf_fused, gsw_gather_rows, gsw_nchw_to_pf, gsw_conv3x3_pf_nchw, gsw_gemm_small).  0.3.1: 0.3.1: gsw_gemm / gsw_gemm_strided (PLAIN, GEGLU) want a 16-byte aligned bias.  0.3.0: gsw_conv_pf / gsw_conv3x3_res_pf take ld_rowbias; gsw_mm_set_workspace (split-K).  0.2.0: GEGLU weights packed per 16-row block (see gsw_gemm) */
 
 #define GSW_MSG_INLINE_MAX 256 /* message bytes carried inside the kernel arguments (2048 bit) */
 
@@ -50,7 +50,9 @@ typedef enum gsw_status {
     GSW_ERR_UNSUPPORTED = 2, /* lattice too large for the LDS-resident vote             */
     GSW_ERR_RAGGED = 3,      /* 8*ceil(n_elems/8) is not a multiple of msg_bits: the reference raises
                                 IndexError at extract.py:98                                             */
-    GSW_ERR_HIP = 4          /* a HIP runtime call failed; gsw_last_hip_error() has the hipError_t      */
+    GSW_ERR_HIP = 4,         /* a HIP runtime call failed; gsw_last_hip_error() has the hipError_t      */
+    GSW_WARN_NO_RECORDS = 5  /* gsw_mm_last_colstats / gsw_mm_last_rowstats: a request WAS armed but the launch that consumed it wrote no records
+                                (it split K, enumerated whole tensors, or ran off the engine) -- the caller must take the statistics pass instead */
 } gsw_status;
 
 /* embed flags */
@@ -154,14 +156,48 @@ int gsw_groupnorm_pf(const void* x_dev, const void* gamma_dev, const void* beta_
 int gsw_groupnorm_pf2(const void* x_dev, const void* x2_dev, int Ca, const void* gamma_dev, const void* beta_dev, void* out_dev, float* workspace_dev,
                       int B, int H, int W, int C, int groups, float eps, int act, int out_tokens, int dtype, void* stream);
 
-/* GroupNorm statistics without a pass over the tensor.  gsw_mm_next_colstats arms a ONE-SHOT request of the calling thread: the next convolution /
+/* ---- Explicit-argument launches of the matmul engine (ABI 0.4.0).  Everything a launch needs besides its operands travels in ONE caller-owned struct:
+ * no thread-local "arm, then launch" state, nothing shared between two streams of one thread, and what the launch actually did comes back in the
+ * same struct.  The one-shot calls further down (gsw_mm_next_colstats, gsw_mm_next_rowstats, gsw_mm_set_workspace) are kept as DEPRECATED shims
+ * over this: new callers pass a GswMmExtras (or NULL for "no records, no split-K").
+ *   colstats_dev / colstats_capacity : in  -- request the column records of gsw_mm_next_colstats (NULL: none)
+ *   rowstats_dev / rowstats_capacity : in  -- request the row records of gsw_mm_next_rowstats (NULL: none)
+ *   workspace_dev / workspace_bytes / max_splits : in -- split-K scratch and policy, as gsw_mm_set_workspace (NULL: the launch runs unsplit)
+ *   colstats_rows_per_block, colstats_blocks : out -- 0 / 0 when the launch wrote no column records (it split K, enumerated whole tensors, ...)
+ *   rowstats_slots : out -- records per row written (0: none)
+ *   splits         : out -- K splits of the launch (1: unsplit) */
+typedef struct GswMmExtras {
+    float* colstats_dev;
+    int64_t colstats_capacity;
+    float* rowstats_dev;
+    int64_t rowstats_capacity;
+    void* workspace_dev;
+    int64_t workspace_bytes;
+    int max_splits;
+    int colstats_rows_per_block, colstats_blocks, rowstats_slots, splits;
+} GswMmExtras;
+
+/* gsw_gemm_strided / gsw_gemm_ln / gsw_conv_pf / gsw_conv3x3_res_pf / gsw_conv_up2x_pf with explicit extras (ex may be NULL). */
+int gsw_gemm_ex(const void* x_dev, int64_t ldx, const void* w_dev, int64_t ldw, const void* bias_dev, const void* resid_dev, int64_t ldr, void* y_dev, int64_t ldy,
+                int64_t M, int K, int N, int mode, int S, int Wimg, int dtype, GswMmExtras* ex, void* stream);
+int gsw_gemm_ln_ex(const void* x_dev, const float* ln_stat_dev, const void* w_dev, const float* u_dev, const float* v_dev, void* y_dev, int64_t M, int K, int N,
+                   int mode, int S, int dtype, GswMmExtras* ex, void* stream);
+int gsw_conv_pf_ex(const void* x_dev, const void* w_dev, const void* bias_dev, const void* rowbias_dev, int ld_rowbias, const void* resid_dev, void* y_dev,
+                   int B, int H, int W, int C, int N, int ksize, int stride, int ldx, int dtype, GswMmExtras* ex, void* stream);
+int gsw_conv3x3_res_pf_ex(const void* x_dev, const void* w_dev, const void* bias_dev, const void* rowbias_dev, int ld_rowbias, const void* resid_dev, void* y_dev,
+                          int B, int H, int W, int C, int N, const void* x1_dev, int C1, const void* x2_dev, int C2, int dtype, GswMmExtras* ex, void* stream);
+int gsw_conv_up2x_pf_ex(const void* x_dev, const void* w4_dev, const void* bias_dev, void* y_dev, int B, int H, int W, int C, int N, int dtype, GswMmExtras* ex,
+                        void* stream);
+
+/* (DEPRECATED one-shot form; see GswMmExtras.)  GroupNorm statistics without a pass over the tensor.  gsw_mm_next_colstats arms a ONE-SHOT request of the calling thread: the next convolution /
  * token-scatter launch of the matmul engine (gsw_conv_pf, gsw_conv3x3_res_pf, gsw_conv_up2x_pf, gsw_gemm with GSW_GEMM_TOK2PF) also writes, per
  * block of 32 or 64 consecutive output pixels and per PAIR of output columns (2c, 2c + 1), the sum and the sum of squares of the values it stores:
  *   stats_dev [npar][blocks][2 planes: sums | sums of squares][N / 2] floats, npar = 1 (4 for gsw_conv_up2x_pf: one quarter of the buffer per parity
  *   launch, records over the low-resolution pixels); capacity_floats >= npar * ceil(M / 128) * 4 * N covers either tile height (M = output pixels
  *   of ONE launch).
  * gsw_mm_last_colstats reports what the launch produced -- rows per block (0: nothing, e.g. a split-K or whole-tensor launch, or a kernel off the
- * engine) and blocks written -- and clears a request no launch consumed.  gsw_groupnorm_pf_cs is gsw_groupnorm_pf2 with the statistics folded from
+ * engine) and blocks written -- and clears a request no launch consumed; it returns GSW_WARN_NO_RECORDS (not GSW_OK) when a request had been armed
+ * and came back empty.  gsw_groupnorm_pf_cs is gsw_groupnorm_pf2 with the statistics folded from
  * such records (cs*_blocks = blocks per parity buffer, i.e. the buffer's stride): pixels per image must be a multiple of the block rows and the
  * groups an even number of channels wide; workspace_dev >= max(B * 64 * groups * 2, B * C) floats. */
 int gsw_mm_next_colstats(float* stats_dev, int64_t capacity_floats);
@@ -216,7 +252,8 @@ int gsw_gemm_qkv(const void* x_dev, const void* w_dev, const void* bias_dev, voi
  * is never written or read.
  *   gsw_mm_next_rowstats : one-shot request (like gsw_mm_next_colstats): the next plain gsw_gemm (+ residual) also writes, per output row and 80-column
  *                          half tile, the (sum, sum of squares) of what it stores: stats_dev [M][slots][2] floats, capacity >= M * 2 ceil(N / 160) * 2.
- *   gsw_mm_last_rowstats : slots written per row (0: the launch produced none, e.g. split-K); clears an unconsumed request.
+ *   gsw_mm_last_rowstats : slots written per row (0: the launch produced none, e.g. split-K; the call then returns GSW_WARN_NO_RECORDS); clears an
+ *                          unconsumed request.  (DEPRECATED one-shot form of GswMmExtras.rowstats_*.)
  *   gsw_ln_rowstats_finish: records -> stat_dev float2 [M] = (rstd, -rstd * mean) over the C columns.
  *   gsw_gemm_ln          : the consuming GEMM; w_dev = W' (GEGLU: packed like gsw_gemm), u_dev / v_dev fp32 [N] in the same row order, 16-byte aligned;
  *                          mode GSW_GEMM_PLAIN / GSW_GEMM_GEGLU / GSW_GEMM_TRANS; M % 8 == 0. */
@@ -239,7 +276,7 @@ int gsw_gemm_strided(const void* x_dev, int64_t ldx, const void* w_dev, int64_t 
 int gsw_mm_config(int tile_rows, int split_mask);
 int gsw_mm_get_config(int* tile_rows, int* split_mask); /* the current values (either pointer may be NULL): what a captured launch sequence depends on */
 
-/* Split-K workspace of the CALLING THREAD (caller-owned device memory on the device of the streams it launches on; 16-byte aligned).
+/* (DEPRECATED thread-local form of GswMmExtras.workspace_*.)  Split-K workspace of the CALLING THREAD (caller-owned device memory on the device of the streams it launches on; 16-byte aligned).
  * Small-batch launches of the eps model -- one image's 8 x 8 level is a single 64-row tile against 180-360 K stages (the reference's own use:
  * extract.py:112-117 inverts ONE latent per call) -- cannot fill 256 CUs with output tiles.  When a workspace is set, a launch whose 128-row
  * tiling has <= 128 tiles lets up to 16 workgroups share a tile's K stages whenever a small cost model (fitted to tools/splitk_sweep.py) predicts

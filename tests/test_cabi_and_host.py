@@ -30,13 +30,13 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"libgswm.so does not export {s}"
     assert sorted(N.exported_symbols()) == syms            # the ctypes prototypes cover the whole header
-    assert lib.gsw_version() == 301
+    assert lib.gsw_version() == 400
     assert lib.gsw_strerror(0) == b"ok" and b"IndexError" in lib.gsw_strerror(N.GSW_ERR_RAGGED)
 
 
 def test_constants_match_header():
     txt = open(os.path.join(ROOT, "include", "gswm.h")).read()
-    for name in ("GSW_F32", "GSW_F16", "GSW_BF16", "GSW_F64", "GSW_OK", "GSW_ERR_BAD_ARG", "GSW_ERR_UNSUPPORTED", "GSW_ERR_RAGGED", "GSW_ERR_HIP"):
+    for name in ("GSW_F32", "GSW_F16", "GSW_BF16", "GSW_F64", "GSW_OK", "GSW_ERR_BAD_ARG", "GSW_ERR_UNSUPPORTED", "GSW_ERR_RAGGED", "GSW_ERR_HIP", "GSW_WARN_NO_RECORDS"):
         m = re.search(rf"\b{name}\s*=\s*(\d+)", txt)
         assert m and int(m.group(1)) == getattr(N, name), name
     for name in ("GSW_EMBED_FAST_F32", "GSW_FLAG_SATURATED", "GSW_FLAG_NAN", "GSW_MSG_INLINE_MAX"):
@@ -198,7 +198,9 @@ def test_argument_validation_of_eps_model_and_image_entry_points():
     assert lib.gsw_mm_next_colstats(None, 16) == BAD and lib.gsw_mm_next_colstats(ctypes.c_void_p(68), 16) == BAD
     rows, blocks = ctypes.c_int(-1), ctypes.c_int(-1)
     assert lib.gsw_mm_next_colstats(p, 1 << 10) == N.GSW_OK
-    assert lib.gsw_mm_last_colstats(ctypes.byref(rows), ctypes.byref(blocks)) == N.GSW_OK and rows.value == 0 and blocks.value == 0   # nothing launched; request cleared
+    # an armed request that comes back empty is reported (nothing launched here); the request is cleared, a second call has nothing to complain about
+    assert lib.gsw_mm_last_colstats(ctypes.byref(rows), ctypes.byref(blocks)) == N.GSW_WARN_NO_RECORDS and rows.value == 0 and blocks.value == 0
+    assert lib.gsw_mm_last_colstats(ctypes.byref(rows), ctypes.byref(blocks)) == N.GSW_OK
     assert lib.gsw_groupnorm_pf_cs(p, None, 0, p, 64, 1, 4, None, 0, 0, 0, p, p, p, p, 1, 8, 8, 330, 33, 1e-5, 1, 0, 1, None) == UNS  # C % 8
     assert lib.gsw_groupnorm_pf_cs(p, None, 0, p, 64, 1, 4, None, 0, 0, 0, p, p, p, p, 1, 8, 8, 96, 32, 1e-5, 1, 0, 1, None) == UNS   # odd group width (column pairs)
     assert lib.gsw_groupnorm_pf_cs(p, None, 0, p, 48, 1, 4, None, 0, 0, 0, p, p, p, p, 1, 8, 8, 320, 32, 1e-5, 1, 0, 1, None) == UNS  # 64 pixels per image, 48-row blocks
@@ -212,7 +214,21 @@ def test_argument_validation_of_eps_model_and_image_entry_points():
     assert lib.gsw_ln_rowstats_finish(None, 4, 256, 320, 1e-5, p, None) == BAD and lib.gsw_ln_rowstats_finish(p, 0, 256, 320, 1e-5, p, None) == BAD
     slots = ctypes.c_int(-1)
     assert lib.gsw_mm_next_rowstats(None, 16) == BAD and lib.gsw_mm_next_rowstats(p, 1 << 10) == N.GSW_OK
-    assert lib.gsw_mm_last_rowstats(ctypes.byref(slots)) == N.GSW_OK and slots.value == 0
+    assert lib.gsw_mm_last_rowstats(ctypes.byref(slots)) == N.GSW_WARN_NO_RECORDS and slots.value == 0
+    assert lib.gsw_mm_last_rowstats(ctypes.byref(slots)) == N.GSW_OK
+    # explicit-argument launches (GswMmExtras): validated like their one-shot predecessors, nothing armed, nothing left behind
+    ex = N.GswMmExtras()
+    ex.colstats_dev, ex.colstats_capacity = 68, 16
+    assert lib.gsw_gemm_ex(p, 64, p, 64, None, None, 160, p, 160, 4, 64, 160, 0, 0, 0, 1, ctypes.byref(ex), None) == BAD         # colstats alignment
+    ex = N.GswMmExtras()
+    ex.workspace_dev, ex.workspace_bytes, ex.max_splits = p.value, 1024, 65
+    assert lib.gsw_gemm_ex(p, 64, p, 64, None, None, 160, p, 160, 4, 64, 160, 0, 0, 0, 1, ctypes.byref(ex), None) == BAD         # max_splits
+    ex = N.GswMmExtras()
+    assert lib.gsw_gemm_ex(p, 64, p, 64, None, None, 160, p, 96, 4, 64, 160, 0, 0, 0, 1, ctypes.byref(ex), None) == BAD          # ldy < N, as gsw_gemm_strided
+    assert lib.gsw_gemm_ln_ex(p, None, p, p, p, p, 256, 320, 640, 0, 0, 1, ctypes.byref(ex), None) == BAD
+    assert lib.gsw_conv_pf_ex(None, p, None, None, 0, None, p, 1, 8, 8, 64, 128, 3, 1, 64, 1, ctypes.byref(ex), None) == BAD
+    assert lib.gsw_conv3x3_res_pf_ex(p, p, None, None, 0, None, p, 1, 8, 8, 64, 64, None, 0, None, 0, 1, ctypes.byref(ex), None) == UNS   # N < 128
+    assert lib.gsw_conv_up2x_pf_ex(p, p, None, p, 1, 8, 8, 60, 128, 1, ctypes.byref(ex), None) == UNS                          # C % 64
     assert lib.gsw_softmax_rows(p, 4, 100, 104, 1.0, 1, None) == UNS                                             # cols % 8
     assert lib.gsw_softmax_rows(p, 4, 128, 64, 1.0, 1, None) == BAD                                              # ld < cols
     assert lib.gsw_softmax_rows(p, 0, 128, 128, 1.0, 1, None) == N.GSW_OK

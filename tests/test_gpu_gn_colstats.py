@@ -136,7 +136,7 @@ def test_a_request_no_launch_consumed_does_not_leak(G):
     assert G.lib.gsw_mm_next_colstats(buf.data_ptr(), buf.numel()) == 0
     import ctypes as C
     rows, blocks = C.c_int(-1), C.c_int(-1)
-    assert G.lib.gsw_mm_last_colstats(C.byref(rows), C.byref(blocks)) == 0 and rows.value == 0
+    assert G.lib.gsw_mm_last_colstats(C.byref(rows), C.byref(blocks)) == 5 and rows.value == 0          # GSW_WARN_NO_RECORDS: armed, nothing written
     x = torch.randn(2, 64, 16, 16, device="cuda").half()
     w = torch.randn(128, 64, 3, 3, device="cuda").half() * 0.05
     prev = G.pf.FUSE_GN_STATS
@@ -148,3 +148,36 @@ def test_a_request_no_launch_consumed_does_not_leak(G):
     torch.cuda.synchronize()
     assert y.stats is None and float(buf.abs().sum()) == 0.0
     assert G.lib.gsw_mm_next_colstats(buf.data_ptr() + 4, 16) != 0          # alignment
+
+
+def test_explicit_extras_report_what_the_launch_did(G):
+    """GswMmExtras (ABI 0.4.0): the records requested and the split-K scratch travel with the launch, and the launch says whether it wrote records --
+    a split-K launch drops the request VISIBLY (rows per block 0, splits > 1), the one-shot form returns GSW_WARN_NO_RECORDS for the same case"""
+    import ctypes as C
+    from gswm_amd import _native as N
+    from gswm_amd.codec import _dt
+    B, Cc, Nn, H, W = 1, 1280, 1280, 8, 8
+    x = G.pf.PF.from_nchw(torch.randn(B, Cc, H, W, device="cuda").half())
+    w = G.pf.pack_conv_weight((torch.randn(Nn, Cc, 3, 3, device="cuda") * 0.01).half())
+    y = G.pf.PF.empty(B, H, W, Nn, torch.float16, "cuda")
+    rec = torch.zeros(4 * 4 * Nn, dtype=torch.float32, device="cuda")
+    ws = torch.empty(G.pf.SPLITK_BYTES, dtype=torch.uint8, device="cuda")
+    ex = N.GswMmExtras()
+    ex.colstats_dev, ex.colstats_capacity = rec.data_ptr(), rec.numel()
+    ex.workspace_dev, ex.workspace_bytes, ex.max_splits = ws.data_ptr(), ws.numel(), 0
+    assert G.lib.gsw_conv_pf_ex(x.rows.data_ptr(), w.data_ptr(), None, None, 0, None, y.rows.data_ptr(), B, H, W, Cc, Nn, 3, 1, Cc, _dt(torch.float16), C.byref(ex), None) == 0
+    assert ex.splits > 1 and ex.colstats_rows_per_block == 0 and ex.colstats_blocks == 0          # one image's 8 x 8 level: split-K, no records
+    y_split = y.to_nchw().clone()
+    ex2 = N.GswMmExtras()                                                                          # no workspace: unsplit
+    ex2.colstats_dev, ex2.colstats_capacity = rec.data_ptr(), rec.numel()
+    assert G.lib.gsw_conv_pf_ex(x.rows.data_ptr(), w.data_ptr(), None, None, 0, None, y.rows.data_ptr(), B, H, W, Cc, Nn, 3, 1, Cc, _dt(torch.float16), C.byref(ex2), None) == 0
+    assert ex2.splits == 1
+    assert (y.to_nchw().float() - y_split.float()).abs().max().item() <= 2e-3 * y_split.float().abs().max().item()
+    # the deprecated one-shot form of the first launch: the dropped request is an explicit status now
+    assert G.lib.gsw_mm_set_workspace(ws.data_ptr(), ws.numel(), 0) == 0
+    assert G.lib.gsw_mm_next_colstats(rec.data_ptr(), rec.numel()) == 0
+    assert G.lib.gsw_conv_pf(x.rows.data_ptr(), w.data_ptr(), None, None, 0, None, y.rows.data_ptr(), B, H, W, Cc, Nn, 3, 1, Cc, _dt(torch.float16), None) == 0
+    rows, blocks = C.c_int(-1), C.c_int(-1)
+    assert G.lib.gsw_mm_last_colstats(C.byref(rows), C.byref(blocks)) == N.GSW_WARN_NO_RECORDS and rows.value == 0
+    assert G.lib.gsw_mm_set_workspace(None, 0, 0) == 0
+    torch.cuda.synchronize()

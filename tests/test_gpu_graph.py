@@ -175,3 +175,52 @@ def test_graph_results_are_not_aliased_and_entries_are_bounded(G):
             xs, _ = _inputs(1, hw=hw)
             gm(xs, t1, c)
     assert len(gm._entries) <= G.graph.MAX_ENTRIES
+
+
+@pytest.mark.parametrize("rows", [1, 3])
+def test_cfg_dup_forward_equals_the_doubled_batch(G, rows):
+    """classifier-free guidance with shared latents: forward(x [B], ctx [2B], cfg_dup=True) == forward(cat[x, x], ctx) -- the context-free prefix (conv_in,
+    first resnet, first transformer up to its cross-attention queries) is computed once; eager and through the graph; per-image timesteps too"""
+    m = _small_unet(G)
+    G.unet.FALLBACKS.clear()
+    x, _ = _inputs(rows)
+    _, c2 = _inputs(2 * rows, seed=11)
+    td = torch.full((), 301, dtype=torch.int64, device="cuda")
+    with torch.no_grad():
+        want = m(torch.cat([x, x]), td, c2)
+        got = m(x, td, c2, cfg_dup=True)
+        assert got.shape == want.shape
+        scale = want.float().abs().max().item()
+        assert (got.float() - want.float()).abs().max().item() <= 2e-3 * scale          # (tilings / split-K choices differ with the row count: fp32 summation order)
+        gm = G.graph.GraphedEpsModel(m, mode="always")
+        assert gm.supports_cfg_dup
+        for t in (301, 7):
+            tdd = torch.full((), t, dtype=torch.int64, device="cuda")
+            assert torch.equal(gm(x, tdd, c2, cfg_dup=True), m(x, tdd, c2, cfg_dup=True))
+        assert gm.stats["captures"] == 1 and gm.stats["replays"] == 2
+        tt = torch.arange(rows, device="cuda") * 37 + 5
+        want_t = m(torch.cat([x, x]), torch.cat([tt, tt]), c2)
+        got_t = m(x, tt, c2, cfg_dup=True)
+        assert (got_t.float() - want_t.float()).abs().max().item() <= 2e-3 * scale
+        # switched off: the doubled batch itself
+        G.unet.CFG_SHARED_PREFIX = False
+        try:
+            assert torch.equal(m(x, td, c2, cfg_dup=True), want)
+        finally:
+            G.unet.CFG_SHARED_PREFIX = True
+        with pytest.raises(ValueError):
+            m(x, td, c2[:rows], cfg_dup=True)
+    assert G.unet.FALLBACKS == {}, G.unet.FALLBACKS
+
+
+def test_sampling_loop_with_shared_prefix_equals_the_doubled_batch(G):
+    """ddim_sample: the model that knows about the shared latents against a plain callable that gets the reference's doubled batch"""
+    m = _small_unet(G, seed=4)
+    g = torch.Generator().manual_seed(9)
+    z = torch.randn(2, 4, 32, 32, generator=g).cuda().half()
+    cu = torch.randn(1, 77, 128, generator=g).cuda().half().expand(2, -1, -1).contiguous()
+    ct = torch.randn(2, 77, 128, generator=g).cuda().half()
+    sched = G.ddim.DDIMSchedule(num_inference_steps=6)
+    a = G.ddim.ddim_sample(m, z, ct, sched, ctx_uncond=cu, guidance_scale=7.5)
+    b = G.ddim.ddim_sample(lambda x, t, c: m(x, t, c), z, ct, sched, ctx_uncond=cu, guidance_scale=7.5)
+    assert (a.float() - b.float()).abs().max().item() <= 1e-2 * b.float().abs().max().item()
