@@ -25,6 +25,7 @@ struct MMArgs {
     int32_t ldw;
     int32_t M, N;         // M: rows of the output row space (all padded-flat rows, or the interior pixels with MM_FLAG_COMPACT)
     int32_t tiles_n, ntiles;      // filled by gsw_mm_launch
+    int32_t panel;                // filled by gsw_mm_launch: column tiles per panel of the tile order (8; all of them when their weight tiles fit an XCD's L2)
     const void* bias;     // [N] or null
     const void* rowbias;  // [images][ldrb] or null (MM_MODE_PF): per-image row bias, rows ldrb elements apart (a column slice of a wider matrix)
     const void* resid;    // [rows][ldr] or null, addressed like the output

@@ -175,15 +175,17 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
     const int32_t k_lo = PART ? (int32_t)(((int64_t)part_split * p.P) / p.splits) : 0;
     const int32_t P_mine = PART ? (int32_t)(((int64_t)(part_split + 1u) * p.P) / p.splits) - k_lo : p.P;
     const T* Wbase = reinterpret_cast<const T*>(p.w);
-    // logical tile -> (tile_m, tile_n): N is walked in PANELS of 8 tiles (M fastest across panels' rows), so the 32 tiles an XCD works on
-    // at a time are a 4 x 8 block: 4 activation tiles + 8 weight tiles in its L2 instead of 1 + 32 for a wide projection
+    // logical tile -> (tile_m, tile_n): N is walked in PANELS of p.panel (8) tiles (M fastest across panels' rows), so the 32 tiles an XCD works on
+    // at a time are a 4 x 8 block: 4 activation tiles + 8 weight tiles in its L2 instead of 1 + 32 for a wide projection.  Every panel streams the
+    // activation matrix once more, so when ALL weight tiles of the launch fit an XCD's L2 (short K: the 64 x 64 level's GEGLU projection, 16 tiles of
+    // 100 KB) the panel is the whole N and the activations are read once
     auto decode_tile = [&](uint32_t L, int32_t& tm, int32_t& tn) {
-        const uint32_t tiles_m = ntiles / (uint32_t)p.tiles_n;
-        const uint32_t full = tiles_m * 8u;
+        const uint32_t tiles_m = ntiles / (uint32_t)p.tiles_n, pw = (uint32_t)p.panel;
+        const uint32_t full = tiles_m * pw;
         const uint32_t pn = L / full, rem = L - pn * full;
-        const uint32_t width = min(8u, (uint32_t)p.tiles_n - pn * 8u);
+        const uint32_t width = min(pw, (uint32_t)p.tiles_n - pn * pw);
         tm = (int32_t)(rem / width);
-        tn = (int32_t)(pn * 8u + rem - (rem / width) * width);
+        tn = (int32_t)(pn * pw + rem - (rem / width) * width);
     };
 
     // ---------------------------------------------------------------- producer: per-lane source pointers advanced by uniform steps.
@@ -967,9 +969,9 @@ __global__ __launch_bounds__(256) void gsw_mm_reduce_kernel(const MMArgs p, cons
         const uint32_t in = accidx / (uint32_t)MT, im = accidx - in * (uint32_t)MT;
         const uint32_t wm = wave & 3u, grp = wave >> 2, q = lane >> 4, li = lane & 15u;
         // logical tile -> (tile_m, tile_n): the panel order of the engine
-        const uint32_t full = tiles_m * 8u, pn = L / full, rem = L - pn * full;
-        const uint32_t width = min(8u, (uint32_t)p.tiles_n - pn * 8u);
-        const int32_t tile_m = (int32_t)(rem / width), tile_n = (int32_t)(pn * 8u + rem - (rem / width) * width);
+        const uint32_t pw = (uint32_t)p.panel, full = tiles_m * pw, pn = L / full, rem = L - pn * full;
+        const uint32_t width = min(pw, (uint32_t)p.tiles_n - pn * pw);
+        const int32_t tile_m = (int32_t)(rem / width), tile_n = (int32_t)(pn * pw + rem - (rem / width) * width);
         const int32_t m = tile_m * BM + (int32_t)(wm * (uint32_t)(16 * MT) + im * 16u + li);
         const int32_t n = tile_n * 160 + (int32_t)(grp * 80u + in * 16u + q * 4u);
         const bool geglu = p.mode == MM_MODE_GEGLU;
@@ -1227,6 +1229,13 @@ int gsw_mm_launch(MMArgs& a, int dtype, void* stream, GswMmExtras* ex) {
     if (a.mode == MM_MODE_QKV && (a.n_rows <= 0 || a.n_rows % 160 || a.n_rows >= a.N || !a.y2)) return GSW_ERR_UNSUPPORTED;
     constexpr int BN = 160;
     const int64_t tiles_n = (a.N + BN - 1) / BN;
+    // panel of the tile order: 8 column tiles, or all of them when their weight tiles (tiles_n x 160 rows x K) stay under ~2 MiB of an XCD's 4 MiB L2
+    {
+        static const int panel_env = getenv("GSW_MM_PANEL") ? atoi(getenv("GSW_MM_PANEL")) : 0;       // A/B switch: 8 = the fixed panel of ABI < 0.4.0
+        a.panel = 8;
+        if (tiles_n > 8 && tiles_n <= 32 && tiles_n * BN * (int64_t)a.P * 64 * 2 <= (2 << 20)) a.panel = (int32_t)tiles_n;
+        if (panel_env > 0) a.panel = panel_env;
+    }
     // 256-row tiles unless they would leave CUs without one: then 128-row tiles (GSW_MM_BM=128 / 256 forces one for A/B runs)
     const int bm_env = g_mm_tile_rows.load(std::memory_order_relaxed);
     // (pricing a 128-row tile at 0.55 of a 256-row one and minimising rounds of 256 workgroups -- e.g. 384 tiles -> 768 half tiles -- measured slower:
