@@ -215,6 +215,10 @@ __global__ __launch_bounds__(256, (DU > 10 ? 1 : 2)) void gsw_attn_fwd_kernel(At
             }
         }
         if ((t + 1) * 64 > p.Sk_valid) {            // padded keys of the last tile(s) (cross-attention, 77 context tokens): score -inf
+            // This must stay a BRANCH (wave-uniform: one s_cbranch per tile).  Left to itself hipcc if-converts the block into 60 v_cmp + 120 v_cndmask +
+            // ~80 integer adds that EVERY tile of the steady state executes: 28 % of the loop's VALU instructions, on a kernel whose time is its VALU +
+            // MFMA issue time (tools/isa_loop_mix.py, profiles/r04g_attention_loop_isa_mix.txt).  An asm statement cannot be speculated.
+            asm volatile("; masked tile" ::: "memory");
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll

@@ -1095,7 +1095,10 @@ int mm_launch_t(const MMArgs& a, uint32_t grid, int mt, hipStream_t st) {
     }
     // bit e of the split mask set = epilogue kind e runs the 12-wave variant whose waves 8-11 own the LDS-DMA (gsw_mm_config / GSW_MM_SPLIT: A/B switch)
     const bool split = (g_mm_split_mask.load(std::memory_order_relaxed) >> EPI) & 1;
-    if (mt == 4) return split ? mm_launch_k<T, EPI, true, 4>(a, grid, st) : mm_launch_k<T, EPI, false, 4>(a, grid, st);
+    // (dense rows, 256-row tile: the 12-wave form does not fit its 168 registers -- 32-40 bytes of scratch per lane -- so that combination is not
+    // instantiated and always runs the 8-wave form; the mask bit still selects the 12-wave 128-row variant)
+    if constexpr (EPI == 0) { if (mt == 4) return mm_launch_k<T, EPI, false, 4>(a, grid, st); }
+    else { if (mt == 4) return split ? mm_launch_k<T, EPI, true, 4>(a, grid, st) : mm_launch_k<T, EPI, false, 4>(a, grid, st); }
     return split ? mm_launch_k<T, EPI, true, 2>(a, grid, st) : mm_launch_k<T, EPI, false, 2>(a, grid, st);
     }
 }

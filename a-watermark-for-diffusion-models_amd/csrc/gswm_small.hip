@@ -240,13 +240,13 @@ int gsw_groupnorm_pf_fused(const void* x_dev, const void* x2_dev, int Ca, const 
     while (H % RL) --RL;                                              // a divisor of H: every row lane owns the same number of rows
     const int threads = std::min(1024, (npair * W * RL + 63) / 64 * 64);
     const int units = (H + RL - 1) / RL;
-    if (units > 64) return GSW_ERR_UNSUPPORTED;                       // the group does not fit the registers of one workgroup: use gsw_groupnorm_pf2
+    if (units > 32) return GSW_ERR_UNSUPPORTED;                       // the group does not fit the registers of one workgroup (128 per thread at 1024 threads): use gsw_groupnorm_pf2
     hipStream_t st = (hipStream_t)stream;
     const int bf = dtype == GSW_BF16;
 #define GSW_GNF_LAUNCH(MU)                                                                                                                        \
     hipLaunchKernelGGL(gsw_gn_fused_kernel<MU>, dim3(groups, B), dim3(threads), 0, st, (const uint16_t*)x_dev, (const uint16_t*)x2_dev, Ca, (const uint16_t*)gamma_dev, \
                        (const uint16_t*)beta_dev, (uint16_t*)out_dev, C, groups, H, W, npair, RL, eps, act, out_tokens, bf)
-    if (units <= 8) GSW_GNF_LAUNCH(8); else if (units <= 16) GSW_GNF_LAUNCH(16); else if (units <= 32) GSW_GNF_LAUNCH(32); else GSW_GNF_LAUNCH(64);
+    if (units <= 8) GSW_GNF_LAUNCH(8); else if (units <= 16) GSW_GNF_LAUNCH(16); else GSW_GNF_LAUNCH(32);
 #undef GSW_GNF_LAUNCH
     GSW_SM_CHECK_LAUNCH();
     return GSW_OK;

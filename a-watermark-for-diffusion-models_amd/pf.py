@@ -376,7 +376,7 @@ def _gn_fused_ok(B: int, H: int, W: int, C: int, groups: int) -> bool:
     rl = min(1024 // (npair * W), H)
     while H % rl:
         rl -= 1
-    return (H + rl - 1) // rl <= 64
+    return (H + rl - 1) // rl <= 32
 
 
 def _groupnorm_fused(x: PF, x2: Optional[PF], gamma, beta, groups, eps, act, tokens):

@@ -271,7 +271,7 @@ int gsw_gemm_strided(const void* x_dev, int64_t ldx, const void* w_dev, int64_t 
 /* Process-wide tuning knobs of the matmul engine, for parity tests and A/B measurements only (production leaves both on "auto"; this is the
  * one piece of global state behind the ABI, also settable through the environment as GSW_MM_BM / GSW_MM_SPLIT before the first launch):
  *   tile_rows  : 0 = automatic (256-row output tiles unless they would leave CUs without one, then 128), 128 or 256 = forced; -1 = keep
- *   split_mask : bit e set = epilogue kind e (0 dense rows, 1 PF / convolution, 2 GEGLU, 3 transposed) runs the 12-wave variant whose
+ *   split_mask : bit e set = epilogue kind e (0 dense rows -- 128-row tiles only: the 256-row dense-row tile has no 12-wave form --, 1 PF / convolution, 2 GEGLU, 3 transposed) runs the 12-wave variant whose
  *                waves 8-11 own the LDS-DMA; -1 = keep (default 10: convolutions and the transposed projection) */
 int gsw_mm_config(int tile_rows, int split_mask);
 int gsw_mm_get_config(int* tile_rows, int* split_mask); /* the current values (either pointer may be NULL): what a captured launch sequence depends on */
@@ -298,7 +298,7 @@ int gsw_softmax_rows(void* x_dev, int64_t rows, int cols, int64_t ld, float scal
  *
  * gsw_groupnorm_pf_fused: gsw_groupnorm_pf2 in ONE launch (no workspace): one workgroup per (image, group) holds the group's values in registers
  *   between the statistics and the normalisation (exact two-pass variance).  Groups an even number of channels wide; returns GSW_ERR_UNSUPPORTED
- *   when a group does not fit one workgroup's registers (more than 64 pixels per pixel lane: use gsw_groupnorm_pf2 then) -- meant for B * groups
+ *   when a group does not fit one workgroup's registers (more than 32 image rows per row lane, or an image row of the group wider than 1024 threads: use gsw_groupnorm_pf2 then) -- meant for B * groups
  *   up to a few hundred workgroups.
  * gsw_gather_rows: out[b] = table[clamp(index[b * index_stride], 0, nrows - 1)] (index_stride 0: one index for all rows): the time-embedding chain
  *   of diffusers' UNet2DConditionModel (sinusoid -> linear -> SiLU -> linear -> SiLU -> every resnet's time_emb_proj) depends on the timestep only,

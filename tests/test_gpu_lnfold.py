@@ -88,6 +88,32 @@ def test_folded_gemm_vs_layernorm_then_gemm_vs_fp32(G, tile_rows, mode, M, C, N)
     assert e_new <= 1.5 * e_old + 5e-4, (e_new, e_old)          # the folded form skips the fp16 rounding of LayerNorm(x): it is not less accurate
 
 
+@pytest.mark.parametrize("sigmas", [50.0, 100.0])
+@pytest.mark.parametrize("M,C", [(1024, 320), (1024, 1280)])
+def test_row_statistics_with_a_large_common_offset(G, sigmas, M, C):
+    """The row records are one-pass (sum, sum of squares) in fp32: var = E[x^2] - mean^2 cancels when |mean| >> std.  Rows whose mean is 50 / 100 standard
+    deviations away from zero (far beyond what a residual stream holds) still give rstd to 1e-3 / 4e-3 relative -- the fp16 output rounding is 5e-4 --
+    and the folded GEMM stays within the fp16 bound of the fp32 reference; the validity range (|mean| / std up to ~100) is stated in DESIGN.md."""
+    g = torch.Generator().manual_seed(int(sigmas) + C)
+    a = torch.randn(M, 320, generator=g).half().cuda()
+    w = (torch.randn(C, 320, generator=g) * 320 ** -0.5 * 0.05).half().cuda()          # output std ~0.05
+    b = torch.full((C,), 0.05 * sigmas).half().cuda()                                   # + a common offset of `sigmas` standard deviations
+    x = G.pf.gemm(a, w, b, rowstats=True)
+    st = G.pf.ln_stat(x, 1e-5)
+    assert st is not None
+    xf = x.double()
+    mean, var = xf.mean(1), xf.var(1, unbiased=False)
+    assert float((mean.abs() / var.sqrt()).min()) > 0.8 * sigmas
+    rstd = (var + 1e-5).rsqrt()
+    rel = ((st[:, 0].double() - rstd).abs() / rstd).max().item()
+    assert rel <= (1e-3 if sigmas <= 50 else 4e-3), rel
+    gamma, beta = torch.ones(C).half().cuda(), torch.zeros(C).half().cuda()
+    w2 = (torch.randn(640, C, generator=g) * C ** -0.5).half().cuda()
+    y = G.pf.gemm_ln(x, st, *G.pf.fold_ln_weights(w2, None, gamma, beta))
+    ref = F.layer_norm(x.float(), (C,), None, None, 1e-5) @ w2.float().T
+    assert (y.float() - ref).abs().max().item() <= 6e-3 * ref.abs().max().item()
+
+
 def test_transformer_block_folded_vs_unfolded_vs_fp32(G):
     U = G.unet
     torch.manual_seed(0)
