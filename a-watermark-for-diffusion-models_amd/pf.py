@@ -451,6 +451,8 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], *, re
 
 
 GEMM_MODES = {"plain": 0, "geglu": 1, "trans": 2, "tok2pf": 3}
+SMALL_GEMM_MAX_ROWS = int(__import__("os").environ.get("GSW_SMALL_GEMM_MAX_ROWS", "128"))      # dense linears of at most that many rows run on gsw_gemm_small (0: never)
+SMALL_GEMM_MAX_K = 2560
 
 
 def _same(t: Optional[torch.Tensor], like: torch.Tensor, name: str, numel: Optional[int] = None):
@@ -505,12 +507,31 @@ def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
         _same(y, x, "out", rows * Nn)
         _same(resid, x, "resid", rows * Nn)
     tm = CONV_TIMER
+    if (SMALL_GEMM_MAX_ROWS and M <= SMALL_GEMM_MAX_ROWS and mode in ("plain", "trans", "tok2pf") and K <= SMALL_GEMM_MAX_K and M % 16 == 0 and Nn % 16 == 0
+            and K % 32 == 0 and K >= 128 and (mode != "trans" or tokens % 4 == 0)):
+        # one or two images' 8 x 8 level (64 / 128 token rows): the small-M kernel (K split four ways inside the workgroup, one launch) beats the engine's
+        # split-K pair there (7.5 vs 11.2 us, profiles/r04c_small_m_gemm_vs_engine.txt); above that the engine wins
+        rs_buf = torch.empty(M * ((Nn + 31) // 32) * 2, dtype=torch.float32, device=x.device) if (rowstats and mode == "plain" and FOLD_LN and M >= FOLD_LN_MIN_ROWS and M % 8 == 0) else None
+        slots = _C.c_int(0)
+        with torch.cuda.device(x.device):
+            e0 = tm.start() if tm is not None else None
+            N.check(N.lib().gsw_gemm_small(x.data_ptr(), K, w.data_ptr(), K, bias.data_ptr() if bias is not None else None,
+                                           resid.data_ptr() if resid is not None else None, Nn, y.data_ptr(), Nn, M, K, Nn, m, tokens, width, None, 0, 0.0, None, None,
+                                           rs_buf.data_ptr() if rs_buf is not None else None, rs_buf.numel() if rs_buf is not None else 0, _C.byref(slots), -1,
+                                           _dt(x.dtype), _stream_ptr()))
+            if tm is not None:
+                tm.stop(e0, ("gsw_mm_small_kernel", M, K, Nn, mode) if tm.by_shape else "gsw_mm_small_kernel", 2.0 * M * K * Nn)
+        if stats_for is not None:
+            stats_for.stats = None
+        if rs_buf is not None and slots.value > 0:
+            y._gsw_rowstats = (rs_buf, int(slots.value))
+        return y
     with torch.cuda.device(x.device):
         e0 = tm.start() if tm is not None else None
         # stats_for (tok2pf): the PF tensor whose payload this launch writes -- it gets the launch's column records (or None)
         armed = _colstats_arm(M, Nn, x.device, geom=(M // tokens, tokens // width, width)) if (stats_for is not None and mode == "tok2pf") else None
         rs_buf = None
-        if rowstats and mode == "plain" and FOLD_LN:
+        if rowstats and mode == "plain" and FOLD_LN and M >= FOLD_LN_MIN_ROWS and M % 8 == 0:      # (below that ln_stat never folds: no records needed)
             # row records for the LayerNorm that consumes this output (GswMmExtras.rowstats_dev): [M][2 * ceil(N / 160)][2] floats
             rs_buf = torch.empty(M * 2 * ((Nn + 159) // 160) * 2, dtype=torch.float32, device=x.device)
         ex = _extras(x.device, colstats=None if armed is None else armed[0], rowstats=rs_buf)

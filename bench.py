@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--message-length", type=int, default=256)
     ap.add_argument("--exact", action="store_true", help="Cephes fp64 inverse CDF instead of the fp32 fast path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-images", type=int, default=12, help="images of the 1-core CPU-baseline sample (0.7-2.2 s each); the all-cores leg adds ~12 s")
+    ap.add_argument("--cpu-images", type=int, default=12, help="images of the 1-core CPU-baseline sample (0.7-2.2 s each); the all-cores leg adds a 12 s window + pool start-up")
     ap.add_argument("--ddim-steps", type=int, default=50)
     ap.add_argument("--image-stages", choices=["none", "vae", "vae+jpeg"], default="vae",
                     help="e2e: also run (and time) VAE decode -> uint8 image -> [JPEG QF] -> ToTensor/normalise -> VAE encode per image "
@@ -64,8 +64,9 @@ def parse():
 
 
 def _cpu_worker(job):
-    """One worker of the all-cores leg: n images of the reference-shaped scalar port (embed + recover), each worker its own NumPy seed."""
-    n_images, message_length, seed = job
+    """One worker of a CPU-baseline leg: images of the reference-shaped scalar port (embed + recover), each worker its own NumPy seed; either a fixed
+    number of images or as many as fit before `deadline` (time.time(); at least one)."""
+    n_images, message_length, seed, deadline = job
     import types
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -73,18 +74,44 @@ def _cpu_worker(job):
     opt = types.SimpleNamespace(key_hex=README_KEY, nonce_hex=README_NONCE)
     a = types.SimpleNamespace(key=bytes.fromhex(README_KEY), nonce=bytes.fromhex(README_NONCE), l=1, message_length=message_length)
     np.random.seed(seed)
-    ok = True
-    for _ in range(n_images):
+    ok, done = True, 0
+    while done < n_images if deadline is None else (done == 0 or time.time() < deadline):
         z = O.gs_watermark_init_noise_scalar(opt, "lthero")
         bits = O.recover_exactracted_message_scalar(z.astype(np.float16), a)
         ok &= O.calculate_bit_accuracy((b"lthero" + b"\0" * 26).hex(), bits)[1] == 1.0
-    return n_images, bool(ok)
+        done += 1
+    return done, bool(ok), time.time()
 
 
-def cpu_baseline(n_images: int, message_length: int, all_cores: bool = True):
-    """Reference-shaped scalar port (oracle) on this host: embed + recover per image on ONE core and -- SURVEY.md 8d(ii) -- on ALL host cores
-    (multiprocessing, one process per core, os.cpu_count() stated), plus the vectorised NumPy restatement as a best-CPU line.  Called BEFORE
-    anything touches the GPU: the pool's children are fresh interpreters ("spawn") of a process that has no HIP state."""
+def _usable_cpus() -> int:
+    """CPUs this process may actually use: the scheduler affinity, cut down to the cgroup's CPU quota when there is one (a container on a 256-thread
+    host is often entitled to a fraction of it: 256 busy processes then only thrash)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                       # cgroup v2: "<quota> <period>" or "max <period>"
+            q, per = f.read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(per))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, -(-q // per)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+def cpu_baseline(n_images: int, message_length: int, all_cores: bool = True, window_s: float = 12.0):
+    """Reference-shaped scalar port (oracle) on this host: embed + recover per image on ONE core and -- SURVEY.md 8d(ii) -- on ALL usable host cores
+    (multiprocessing, one process per core, os.cpu_count() and the usable count stated), plus the vectorised NumPy restatement as a best-CPU line.
+    Bounded: the all-cores leg is a fixed WINDOW of `window_s` seconds (every worker counts the images it finishes in it), so the default bench stays
+    within minutes on any host.  Called BEFORE anything touches the GPU: the pool's children are fresh interpreters ("spawn") of a process without HIP state."""
     import types
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -92,7 +119,7 @@ def cpu_baseline(n_images: int, message_length: int, all_cores: bool = True):
     opt = types.SimpleNamespace(key_hex=README_KEY, nonce_hex=README_NONCE)
     a = types.SimpleNamespace(key=bytes.fromhex(README_KEY), nonce=bytes.fromhex(README_NONCE), l=1, message_length=message_length)
     t0 = time.perf_counter()
-    _, ok = _cpu_worker((n_images, message_length, 0))
+    _, ok, _ = _cpu_worker((n_images, message_length, 0, None))
     dt = time.perf_counter() - t0
     # best-CPU line: the vectorised numpy restatement
     t1 = time.perf_counter()
@@ -109,27 +136,23 @@ def cpu_baseline(n_images: int, message_length: int, all_cores: bool = True):
            "one_core": one, "vectorised_numpy_images_per_s": nv / dv, "host_cpus": os.cpu_count()}
     if all_cores:
         import multiprocessing as mp
-        ncpu = os.cpu_count() or 1
-        try:
-            ncpu = min(ncpu, len(os.sched_getaffinity(0)))
-        except (AttributeError, OSError):
-            pass
-        per = max(2, min(8, int(round(12.0 / max(dt / n_images, 1e-3)))))        # ~12 s of work per worker
+        ncpu = _usable_cpus()
         t2 = time.perf_counter()
         with mp.get_context("spawn").Pool(ncpu) as pool:
-            pool.map(_cpu_worker, [(1, message_length, 1000 + i) for i in range(ncpu)])          # start-up + imports + first call, untimed
+            pool.map(_cpu_worker, [(1, message_length, 1000 + i, None) for i in range(ncpu)], chunksize=1)       # start-up + imports + first call, untimed
             t3 = time.perf_counter()
-            res = pool.map(_cpu_worker, [(per, message_length, 2000 + i) for i in range(ncpu)])
-            da = time.perf_counter() - t3
+            w0 = time.time()
+            res = pool.map(_cpu_worker, [(0, message_length, 2000 + i, w0 + window_s) for i in range(ncpu)], chunksize=1)
         n_all = sum(r[0] for r in res)
         ok_all = all(r[1] for r in res)
+        da = max(r[2] for r in res) - w0                                  # the window runs until the last worker has finished the image it was on
         allc = {"value": n_all / da, "unit": "images/s", "cores": ncpu,
-                "sample": f"{ncpu} processes x {per} images (multiprocessing, one per core; os.cpu_count() = {os.cpu_count()}), {da:.1f} s "
+                "sample": f"{ncpu} processes (multiprocessing, one per usable core; os.cpu_count() = {os.cpu_count()}), {n_all} images in a {da:.1f} s window "
                           f"(+ {t3 - t2:.1f} s pool start-up, untimed); lossless={ok_all}"}
-        # the headline CPU figure is the stronger baseline: every host core busy
+        # the headline CPU figure is the stronger baseline: every usable host core busy
         out.update({"value": allc["value"], "cores": ncpu, "all_cores": allc,
-                    "sample": f"{ncpu} cores x {per} images, 4x64x64, embed+recover, scalar scipy.stats.norm.ppf/cdf per element (reference-shaped port of "
-                              f"gs_insert.py:49-66 + extract.py:72-101), {da:.1f} s; 1 core: {one['value']:.2f} images/s; lossless={bool(ok and ok_all)}"})
+                    "sample": f"{ncpu} cores, {n_all} images in {da:.1f} s, 4x64x64, embed+recover, scalar scipy.stats.norm.ppf/cdf per element (reference-shaped port of "
+                              f"gs_insert.py:49-66 + extract.py:72-101); 1 core: {one['value']:.2f} images/s; lossless={bool(ok and ok_all)}"})
     return out
 
 
@@ -269,7 +292,7 @@ def run_codec(args, rank, world, local_rank, steps, warmup, cpu_codec=None):
     # this very configuration; otherwise null
     traffic = traffic_src = None
     try:
-        pmc_file = os.path.join("profiles", "r03_codec_pmc.json")
+        pmc_file = os.path.join("profiles", "r04_codec_pmc.json")
         pmc = json.load(open(os.path.join(ROOT, pmc_file)))
         c = pmc["config"]
         if c["batch_per_gpu"] == B and c["lattice"] == list(shape) and c["message_bits"] == M and fast:

@@ -130,7 +130,8 @@ def test_conv3x3_pf_nchw_vs_torch_fp32(G, dtype, B, C, N, H, W):
 
 def test_unet_forward_with_and_without_the_small_batch_kernels(G):
     """One- and two-row forwards through the time-embedding table / fused GroupNorm / direct conv_out against the same forward with those switched off
-    (the chain of GEMMs, the two-launch GroupNorm, the 64-column conv_out): the same function up to roundings of intermediate tensors."""
+    (the chain of GEMMs, the two-launch GroupNorm, the 64-column conv_out, the engine for the 8 x 8 level's dense linears): the same function up to roundings
+    of intermediate tensors."""
     U = G.unet
     m = U.synthetic_init_(U.UNet2DCondition(), 0).cuda().half().eval()
     g = torch.Generator().manual_seed(3)
@@ -142,13 +143,13 @@ def test_unet_forward_with_and_without_the_small_batch_kernels(G):
         G.pf.GN_FUSED_MAX_PIXELS = 1024                # the dispatch's own rule
         with torch.no_grad():
             y_new = m(x, t, c)
-            old = (U.TEMB_TABLE, G.pf.GN_FUSED_MAX_WGS, U.CONV_OUT_DIRECT_MAX_PIXELS)
-            U.TEMB_TABLE, G.pf.GN_FUSED_MAX_WGS, U.CONV_OUT_DIRECT_MAX_PIXELS = False, 0, 0
+            old = (U.TEMB_TABLE, G.pf.GN_FUSED_MAX_WGS, U.CONV_OUT_DIRECT_MAX_PIXELS, G.pf.SMALL_GEMM_MAX_ROWS)
+            U.TEMB_TABLE, G.pf.GN_FUSED_MAX_WGS, U.CONV_OUT_DIRECT_MAX_PIXELS, G.pf.SMALL_GEMM_MAX_ROWS = False, 0, 0, 0
             try:
                 y_old = m(x, t, c)
                 y_float_t = m(x, t.float(), c)              # a float timestep takes the chain as well
             finally:
-                U.TEMB_TABLE, G.pf.GN_FUSED_MAX_WGS, U.CONV_OUT_DIRECT_MAX_PIXELS = old
+                U.TEMB_TABLE, G.pf.GN_FUSED_MAX_WGS, U.CONV_OUT_DIRECT_MAX_PIXELS, G.pf.SMALL_GEMM_MAX_ROWS = old
         scale = y_old.float().abs().max().item()
         assert (y_new.float() - y_old.float()).abs().max().item() <= 1e-2 * scale
         assert torch.equal(y_old, y_float_t)
