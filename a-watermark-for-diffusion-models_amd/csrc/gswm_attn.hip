@@ -92,7 +92,10 @@ constexpr uint32_t VP = 136;                               // V^T LDS row pitch 
 // 576 tokens at the SD 1.5 third level).  Query lanes past Sq read row 0 and store nothing; key rows / V^T columns past Sk are fetched
 // from a clamped (valid, finite) address and masked through Sk_valid like padded context keys.
 template <typename T, int QB, int DU, bool PAIR, bool RAGGED>
-__global__ __launch_bounds__(256, (DU > 10 ? 1 : 2)) void gsw_attn_fwd_kernel(AttnArgs p) {
+#ifndef ATTN_MINWAVES
+#define ATTN_MINWAVES 2          // (tools/attn_ablate.sh builds side libraries with 3 / 4: occupancy experiments)
+#endif
+__global__ __launch_bounds__(256, (DU > 10 ? 1 : (QB == 1 ? ATTN_MINWAVES : 2))) void gsw_attn_fwd_kernel(AttnArgs p) {
     using v8 = typename AT<T>::v8;
     using v4 = typename AT<T>::v4;
     constexpr int D = DU * 8, KC = (DU + 1) / 2, DB = (D + 31) / 32;
@@ -209,16 +212,21 @@ __global__ __launch_bounds__(256, (DU > 10 ? 1 : 2)) void gsw_attn_fwd_kernel(At
         for (int kc = 0; kc < KC; ++kc) {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
+#ifdef ATTN_ABL_NOLDSR
+                const v8 a = qreg[0][kc];                                                    // (ablation: no K fragment read)
+#else
                 const v8 a = *reinterpret_cast<const v8*>(Kl + (uint32_t)(kb * 32 + (int)c32) * KP + (uint32_t)kc * 32u + h * 16u);
+#endif
+#ifndef ATTN_ABL_NOQK
 #pragma unroll
                 for (int qb = 0; qb < QB; ++qb) s[qb][kb] = AT<T>::mfma(a, qreg[qb][kc], s[qb][kb]);
+#else
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) s[qb][kb][kc] += (float)a[0] + (float)qreg[qb][kc][1];      // (ablation: keeps the LDS read and the registers alive)
+#endif
             }
         }
         if ((t + 1) * 64 > p.Sk_valid) {            // padded keys of the last tile(s) (cross-attention, 77 context tokens): score -inf
-            // This must stay a BRANCH (wave-uniform: one s_cbranch per tile).  Left to itself hipcc if-converts the block into 60 v_cmp + 120 v_cndmask +
-            // ~80 integer adds that EVERY tile of the steady state executes: 28 % of the loop's VALU instructions, on a kernel whose time is its VALU +
-            // MFMA issue time (tools/isa_loop_mix.py, profiles/r04g_attention_loop_isa_mix.txt).  An asm statement cannot be speculated.
-            asm volatile("; masked tile" ::: "memory");
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -233,6 +241,15 @@ __global__ __launch_bounds__(256, (DU > 10 ? 1 : 2)) void gsw_attn_fwd_kernel(At
 
         // ---- online softmax (base-2 domain); a query lives in lanes c32 and c32 + 32
         v8 pb[QB][2][2];
+#ifdef ATTN_ABL_NOSOFTMAX
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) pb[qb][kb][i >> 3][i & 7] = (T)s[qb][kb][i];
+        l_i[0] += cs;
+#else
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
             float mx = s[qb][0][0];
@@ -249,19 +266,28 @@ __global__ __launch_bounds__(256, (DU > 10 ? 1 : 2)) void gsw_attn_fwd_kernel(At
             for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
+#ifdef ATTN_ABL_NOEXP
+                    const float e = fmaf(s[qb][kb][i], cs, -m_new);                 // (ablation: one full-rate op instead of v_exp_f32)
+#else
                     const float e = __builtin_amdgcn_exp2f(fmaf(s[qb][kb][i], cs, -m_new));
+#endif
                     rs += e;
                     pb[qb][kb][i >> 3][i & 7] = (T)e;
                 }
             }
             l_i[qb] = fmaf(l_i[qb], alpha, rs);
+#ifdef ATTN_ABL_NORESCALE
+            if (false) {
+#else
             if (__any(alpha != 1.0f)) {                 // once the running maxima have settled the whole wave skips the rescale
+#endif
 #pragma unroll
                 for (int db = 0; db < DB; ++db)
 #pragma unroll
                     for (int i = 0; i < 16; ++i) o[qb][db][i] *= alpha;
             }
         }
+#endif
 
         // ---- O^T += V^T P^T
 #pragma unroll
@@ -271,11 +297,21 @@ __global__ __launch_bounds__(256, (DU > 10 ? 1 : 2)) void gsw_attn_fwd_kernel(At
 #pragma unroll
                 for (int db = 0; db < DB; ++db) {
                     const uint8_t* vp = Vl + (uint32_t)(db * 32 + (int)c32) * VP + (uint32_t)(kb * 32 + tt * 16 + (int)h * 4) * 2u;
+#ifdef ATTN_ABL_NOLDSR
+                    const v4 lo = __builtin_shufflevector(qreg[0][0], qreg[0][0], 0, 1, 2, 3), hi = __builtin_shufflevector(qreg[0][0], qreg[0][0], 4, 5, 6, 7);
+                    (void)vp;
+#else
                     const v4 lo = *reinterpret_cast<const v4*>(vp);
                     const v4 hi = *reinterpret_cast<const v4*>(vp + 16);
+#endif
                     const v8 a = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#ifndef ATTN_ABL_NOPV
 #pragma unroll
                     for (int qb = 0; qb < QB; ++qb) o[qb][db] = AT<T>::mfma(a, pb[qb][kb][tt], o[qb][db]);
+#else
+#pragma unroll
+                    for (int qb = 0; qb < QB; ++qb) o[qb][db][kb * 2 + tt] += (float)a[0] + (float)pb[qb][kb][tt][1];
+#endif
                 }
             }
         }
@@ -288,6 +324,10 @@ __global__ __launch_bounds__(256, (DU > 10 ? 1 : 2)) void gsw_attn_fwd_kernel(At
         GSW_ATTN_LSTORE(1u)
         __syncthreads();
         for (int32_t t = 0; t < nt; t += 2) {
+#ifdef ATTN_ABL_NOSTAGE
+            tile((uint32_t)(t & 1), t);                  // (ablation: no global loads, no LDS writes, no barrier inside the loop)
+            if (t + 1 < nt) tile((uint32_t)((t + 1) & 1), t + 1);
+#else
             // tiles t and t+1 are visible; t+2 and t+3 are fetched, written into the two idle stages, and published by ONE barrier
             GSW_ATTN_GLOAD((t + 2 < nt ? t + 2 : nt - 1) << 6)
             __builtin_amdgcn_sched_barrier(0);
@@ -300,6 +340,7 @@ __global__ __launch_bounds__(256, (DU > 10 ? 1 : 2)) void gsw_attn_fwd_kernel(At
                 GSW_ATTN_LSTORE((uint32_t)((t + 3) & 3))
             }
             __syncthreads();
+#endif
         }
     } else {
         GSW_ATTN_GLOAD(0)
