@@ -11,7 +11,10 @@ pytestmark = pytest.mark.gpu
 def P():
     import gswm_amd
     from gswm_amd import pf
-    return pf
+    old = pf.SMALL_GEMM_MAX_ROWS
+    pf.SMALL_GEMM_MAX_ROWS = 0          # this module tests the matmul ENGINE (at <= 128 rows pf.gemm would otherwise take gsw_gemm_small: tests/test_gpu_small.py)
+    yield pf
+    pf.SMALL_GEMM_MAX_ROWS = old
 
 
 def _tol(dtype):

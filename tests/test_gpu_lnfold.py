@@ -14,7 +14,10 @@ def G():
     import types
     import gswm_amd
     from gswm_amd import pf, unet, codec, _native
-    return types.SimpleNamespace(pf=pf, unet=unet, codec=codec, lib=_native.lib())
+    old = pf.SMALL_GEMM_MAX_ROWS
+    pf.SMALL_GEMM_MAX_ROWS = 0          # this module tests the matmul ENGINE (at <= 128 rows pf.gemm would otherwise take gsw_gemm_small: tests/test_gpu_small.py)
+    yield types.SimpleNamespace(pf=pf, unet=unet, codec=codec, lib=_native.lib())
+    pf.SMALL_GEMM_MAX_ROWS = old
 
 
 @pytest.fixture(params=[0, 128, 256], ids=["auto", "BM128", "BM256"])

@@ -16,7 +16,10 @@ def G():
     import types
     import gswm_amd
     from gswm_amd import pf, unet, vae, _native
-    return types.SimpleNamespace(pf=pf, unet=unet, vae=vae, lib=_native.lib())
+    old = pf.SMALL_GEMM_MAX_ROWS
+    pf.SMALL_GEMM_MAX_ROWS = 0          # this module tests the matmul ENGINE (at <= 128 rows pf.gemm would otherwise take gsw_gemm_small: tests/test_gpu_small.py)
+    yield types.SimpleNamespace(pf=pf, unet=unet, vae=vae, lib=_native.lib())
+    pf.SMALL_GEMM_MAX_ROWS = old
 
 
 @pytest.fixture(params=[256, 128], ids=["BM256", "BM128"])

@@ -12,7 +12,10 @@ def G():
     import types
     import gswm_amd
     from gswm_amd import pf, unet, _native
-    return types.SimpleNamespace(pf=pf, unet=unet, lib=_native.lib())
+    old = pf.SMALL_GEMM_MAX_ROWS
+    pf.SMALL_GEMM_MAX_ROWS = 0          # the bit-for-bit comparisons of this module are engine against engine (at <= 128 rows pf.gemm would take gsw_gemm_small)
+    yield types.SimpleNamespace(pf=pf, unet=unet, lib=_native.lib())
+    pf.SMALL_GEMM_MAX_ROWS = old
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
