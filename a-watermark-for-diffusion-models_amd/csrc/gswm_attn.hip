@@ -24,6 +24,10 @@
 // At head_dim 64 every 16 MFMAs come with ~170 VALU instructions (32 v_exp_f32, max / sum / convert / rescale) per wave.
 // Tried and dropped: row sums of P on the matrix pipe (one more MFMA per 16-key slice with an all-ones A operand instead of 32 v_add_f32 per tile and
 // query block -- the pipe idles half the time): 813 vs 831 TFLOP/s at 4096 keys.
+// What sets the time (round 4, profiles/r04h_power_cap_probe.txt): on random operands the kernel runs at 1.99 GHz / 1.36 kW of the board's 1.4 kW, on all-zero operands
+// at 2.39 GHz and finishes 28 % sooner -- the power management, not an issue port.  A/B macros kept for that measurement (tools/attn_ablate.sh): ATTN_ABL_PK (packed
+// v_pk_fma_f32 / v_pk_add_f32 softmax arithmetic), ATTN_ABL_DOT (row sums by v_dot2c_f32_f16 on the converted pairs) -- together 16-18 % fewer VALU instructions per
+// tile, same time to the percent -- and ATTN_ABL_PRIO (s_setprio around the MFMA blocks: 3-4 % slower).
 // Tried and dropped: software pipelining over 32-key blocks (S^T of block u+1 issued before the softmax of block u, 3 LDS stages,
 // one barrier per tile): 790 vs 831 TFLOP/s -- the per-block max / exchange / rescale overhead doubles and hipcc does not interleave
 // the two streams any better than the wave scheduler already does across the 2-4 resident waves.
@@ -40,9 +44,11 @@ namespace {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // value of the lane 32 positions away, combined: v_permlane32_swap_b32 exchanges the upper half of one register with the lower half of
 // another in the VALU (no LDS round trip like ds_bpermute, which sits on the critical path between the S^T MFMAs and the exponentials)
@@ -213,6 +219,9 @@ __global__ __launch_bounds__(256, (DU > 10 ? 1 : (QB == 1 ? ATTN_MINWAVES : 2)))
         for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
             for (int i = 0; i < 16; ++i) { s[qb][0][i] = 0.f; s[qb][1][i] = 0.f; }
+#ifdef ATTN_ABL_PRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc) {
 #pragma unroll
@@ -231,6 +240,9 @@ __global__ __launch_bounds__(256, (DU > 10 ? 1 : (QB == 1 ? ATTN_MINWAVES : 2)))
 #endif
             }
         }
+#ifdef ATTN_ABL_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         if ((t + 1) * 64 > p.Sk_valid) {            // padded keys of the last tile(s) (cross-attention, 77 context tokens): score -inf
             asm volatile("; masked tile");             // (a wave-uniform branch the steady state jumps over; the comment marks the block for tools/isa_loop_mix.py)
 #pragma unroll
@@ -268,6 +280,33 @@ __global__ __launch_bounds__(256, (DU > 10 ? 1 : (QB == 1 ? ATTN_MINWAVES : 2)))
             const float alpha = __builtin_amdgcn_exp2f(m_i[qb] - m_new);      // raw v_exp_f32: arguments are <= 0, underflow to 0 is the intent
             m_i[qb] = m_new;
             float rs = 0.f;
+#ifdef ATTN_ABL_PK
+            // two scores per VALU instruction where the ISA has a packed fp32 form: v_pk_fma_f32 for s * scale - m, v_pk_add_f32 for the row sum (even / odd partial sums)
+            f32x2 rs2 = f32x2{0.f, 0.f};
+            const f32x2 cs2 = f32x2{cs, cs}, nm2 = f32x2{-m_new, -m_new};
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                for (int i = 0; i < 16; i += 2) {
+                    const f32x2 a2 = __builtin_elementwise_fma(f32x2{s[qb][kb][i], s[qb][kb][i + 1]}, cs2, nm2);
+                    const f32x2 e2 = f32x2{__builtin_amdgcn_exp2f(a2[0]), __builtin_amdgcn_exp2f(a2[1])};
+#ifdef ATTN_ABL_DOT
+                    if constexpr (sizeof(T) == 2 && !__is_same(T, __bf16)) {
+                        // row sum from the ROUNDED probabilities (the ones the second product multiplies V with): one v_dot2_f32_f16 per converted pair
+                        const f16x2 pr = f16x2{(_Float16)e2[0], (_Float16)e2[1]};
+                        rs = __builtin_amdgcn_fdot2(pr, f16x2{(_Float16)1.0f, (_Float16)1.0f}, rs, false);
+                        pb[qb][kb][i >> 3][i & 7] = (T)pr[0];
+                        pb[qb][kb][i >> 3][(i & 7) + 1] = (T)pr[1];
+                        continue;
+                    }
+#endif
+                    rs2 += e2;
+                    pb[qb][kb][i >> 3][i & 7] = (T)e2[0];
+                    pb[qb][kb][i >> 3][(i & 7) + 1] = (T)e2[1];
+                }
+            }
+            rs += rs2[0] + rs2[1];
+#else
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
@@ -281,6 +320,7 @@ __global__ __launch_bounds__(256, (DU > 10 ? 1 : (QB == 1 ? ATTN_MINWAVES : 2)))
                     pb[qb][kb][i >> 3][i & 7] = (T)e;
                 }
             }
+#endif
             l_i[qb] = fmaf(l_i[qb], alpha, rs);
 #ifdef ATTN_ABL_NORESCALE
             if (false) {
@@ -296,6 +336,9 @@ __global__ __launch_bounds__(256, (DU > 10 ? 1 : (QB == 1 ? ATTN_MINWAVES : 2)))
 #endif
 
         // ---- O^T += V^T P^T
+#ifdef ATTN_ABL_PRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
@@ -321,7 +364,9 @@ __global__ __launch_bounds__(256, (DU > 10 ? 1 : (QB == 1 ? ATTN_MINWAVES : 2)))
                 }
             }
         }
-
+#ifdef ATTN_ABL_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
     };
     if constexpr (PIPE) {
         // ---- the three parts of a tile as separate pieces: S^T of a staged tile, the online softmax of a finished S^T, O^T += V^T P^T

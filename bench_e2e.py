@@ -185,6 +185,9 @@ def run_e2e(args, rank, world, local_rank):
     matched = torch.zeros((), dtype=torch.int64, device=dev)
     flagged = torch.zeros((), dtype=torch.int64, device=dev)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]      # step boundaries (recorded, never waited on inside the region)
+    from bench_board import BoardSampler
+    board = BoardSampler(local_rank)               # shader clock + board power of this rank's device while the region runs (a 20 Hz sysfs reader thread)
+    board.__enter__()
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(args.steps):
@@ -197,6 +200,7 @@ def run_e2e(args, rank, world, local_rank):
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    board.__exit__()
     fallbacks = dict(U.FALLBACKS)
     if vae is not None:
         fallbacks.update({"vae: " + k: v for k, v in V.FALLBACKS.items()})
@@ -253,6 +257,9 @@ def run_e2e(args, rank, world, local_rank):
         }
         cs = conv_timer.summary()
         out["fallbacks_off_the_hand_written_path"] = fallbacks
+        # what the board did during the timed region: under the 1400 W limit the MFMA-heavy kernels of this path run at 1.7-2.0 GHz on random operands
+        # (profiles/r04h_power_cap_probe.txt), so the fractions below -- against the 2.4 GHz peak -- come with the clock they were measured at
+        out["board"] = board.summary()
         if cs:
             # The dominant kernel is the matmul engine, gsw_mm_kernel<T, EPI, SPLIT, MT>: ONE kernel template that runs every convolution and every
             # dense linear of UNet and VAE.  `roofline` is the whole family (every instantiation): achieved = the FLOPs the kernel EXECUTES for the
@@ -290,6 +297,9 @@ def run_e2e(args, rank, world, local_rank):
                                 "measured_in": measured_in}
         if "roofline" not in out:
             out["roofline"] = out["roofline_unet"]
+        if out["board"] and out["board"].get("sclk_fraction_of_nominal"):
+            for key in ("roofline", "roofline_unet"):
+                out[key] = dict(out[key], frac_of_peak_at_sustained_clock=out[key]["frac"] / out["board"]["sclk_fraction_of_nominal"])
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_e2e(unet_cfg, S, M, h, w, with_vae=vae is not None)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
