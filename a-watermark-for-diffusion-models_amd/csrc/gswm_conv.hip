@@ -568,9 +568,15 @@ static int launch_engine(const ConvArgs& a, int64_t M, int N, int dtype, void* s
     // Small tensors (one or two images: the launch is latency-bound, not throughput-bound) enumerate ALL padded rows instead and let the epilogue
     // write the zeros of the border rows itself: one kernel less per convolution (62 per forward; a launch costs ~6 us of a 6.6 ms one-image forward).
     // Border rows read their taps from neighbouring / guard rows whose contents are arbitrary -- their accumulators are discarded.
+    // In between (8-64 images at the deep levels) the choice follows the engine's own plan: the interior enumeration has fewer row tiles, which can be what lets the
+    // launch split K over the whole chip (16 images at 16 x 16: 5184 padded rows are 168 tiles of 256, 4096 interior rows 128 -> 2 x 128 workgroups), for one
+    // border kernel (~5 us) more.
     const int B = (int)(M / ((int64_t)a.Hp * a.Wp));
-    const bool whole = !a.up && a.stride == 1 && M <= 8192;
-    m.M = whole ? (int32_t)M : B * (a.Hp - 2) * (a.Wp - 2); m.N = N;
+    const int64_t M_int = (int64_t)B * (a.Hp - 2) * (a.Wp - 2);
+    bool whole = !a.up && a.stride == 1 && M <= 8192;
+    if (whole && M > 1024 && !(ex && ex->max_splits > 1))
+        whole = gsw_mm_predict_us(M, N, m.P, ex) <= gsw_mm_predict_us(M_int, N, m.P, ex) + 5.0;
+    m.M = whole ? (int32_t)M : (int32_t)M_int; m.N = N;
     m.flags = whole ? MM_FLAG_NONE : MM_FLAG_COMPACT;
     m.bias = a.bias; m.rowbias = a.rowbias; m.resid = a.resid; m.y = a.y; m.colstats = nullptr; m.y2 = nullptr; m.n_rows = 0; m.ln_stat = nullptr; m.ln_u = nullptr; m.ln_v = nullptr;
     m.ldy = N; m.ldr = N; m.ldrb = a.ldrb;

@@ -57,6 +57,9 @@ struct MMArgs {
 // (gsw_mm_next_colstats / gsw_mm_next_rowstats / gsw_mm_set_workspace), which gsw_mm_legacy_extras turns into a struct of the same kind.
 struct GswMmExtras;
 int gsw_mm_launch(MMArgs& a, int dtype, void* stream, GswMmExtras* ex);
+// microseconds the engine's plan (tiling, split-K) predicts for M x N outputs over P stages with these extras (nullptr: the thread-local state): the convolution
+// front end chooses its row enumeration with it
+double gsw_mm_predict_us(int64_t M, int N, int P, const GswMmExtras* ex);
 // the calling thread's one-shot requests and workspace as extras (the requests are consumed); gsw_mm_legacy_done stores what the launch reported
 void gsw_mm_legacy_extras(GswMmExtras* ex);
 void gsw_mm_legacy_done(const GswMmExtras* ex);

@@ -1104,10 +1104,10 @@ int mm_launch_t(const MMArgs& a, uint32_t grid, int mt, hipStream_t st) {
 }
 template <typename T>
 int mm_launch_splitk(const MMArgs& a, uint32_t grid, int mt, hipStream_t st) {
-    // always 128-row tiles: the launches that split have few rows, and the 256-row variant of this kernel does not fit the 168 registers of the
-    // 12-wave form (80 accumulators + both fragment sets + the slab addressing)
-    if (mt != 2) return (int)hipErrorInvalidValue;
-    const int e = mm_launch_k<T, 4, true, 2>(a, grid, st);
+    // 128- or 256-row tiles (gsw_mm_launch decides).  The 256-row variant keeps six slab addresses in scratch ACROSS the loop (12 registers over the 168 of the
+    // 12-wave form: stored before the first stage, reloaded in the epilogue, nothing inside the loop -- a workgroup of a split launch runs one tile)
+    if (mt != 2 && mt != 4) return (int)hipErrorInvalidValue;
+    const int e = mt == 4 ? mm_launch_k<T, 4, true, 4>(a, grid, st) : mm_launch_k<T, 4, true, 2>(a, grid, st);
     if (e != 0) return e;
     const int64_t units = (int64_t)a.ntiles * 8 * 5 * mt * 64;
     hipLaunchKernelGGL((gsw_mm_reduce_kernel<T>), dim3((uint32_t)std::min<int64_t>((units + 255) / 256, 2048)), dim3(256), 0, st, a, mt);
@@ -1214,6 +1214,60 @@ int gsw_mm_get_config(int* tile_rows, int* split_mask) {
     return GSW_OK;
 }
 
+// Tiling and split-K plan of a launch, with the time the cost model predicts for it (microseconds; fitted to tools/splitk_sweep.py, profiles/r03d_splitk_sweep.txt:
+// a workgroup pays ~3 to get going and ~0.55 per stage of a 128-row tile (bound by its LDS-DMA) or ~0.70 per stage of a 256-row tile (bound by the matrix pipe);
+// a split launch adds the reduce kernel, ~4.5 for the second launch and its latency, and the slab traffic, 80 KiB per 128-row slab at ~3 MB/us).
+//   unsplit: 256-row tiles unless they would leave CUs without one, then 128-row tiles -- but not when the 256-row tiling still has 128 or more tiles: the deep
+//   levels at 4096 rows re-read a 30-60 MB weight matrix once per row tile through L2, and half as many row tiles on half the CUs beat twice as many on all of them
+//   (profiles/r03_splitk_sweep_256.txt: 155 vs 210 us, 141 vs 180, 295 vs 394); long K only: a short-K weight matrix stays in L2 and all CUs win.
+//   (Pricing a 128-row tile at 0.55 of a 256-row one and minimising rounds of 256 workgroups measured slower: the half tile re-fetches the weight tile twice as often.)
+//   split: only for a predicted gain of 20 % or more over the unsplit launch (the medium dense shapes lose: their reduce costs more than their short K loop); the tile
+//   of a split launch is 128 rows, or 256 when there are rows for it -- a 256-row tile costs ~1.25 stage times of a 128-row one and does twice the work (16 images at
+//   16 x 16 or 64 at 8 x 8 are 128 tiles of 256 rows: half the chip unsplit, 2 x 128 workgroups split).  Forced splits (max_splits > 1: tests) use 128 rows unless
+//   gsw_mm_config forces the 256-row tile.
+struct MMPlan { int bm; int splits; double t_us; };
+static MMPlan mm_plan(int64_t M, int64_t tiles_n, int32_t P, bool can_split, int max_splits) {
+    const int bm_env = g_mm_tile_rows.load(std::memory_order_relaxed);          // GSW_MM_BM / gsw_mm_config: 128 / 256 forces a tiling (A/B runs, tests)
+    const int64_t nt256 = ((M + 255) / 256) * tiles_n;
+    int BM = nt256 < (P >= 64 ? 128 : 256) && M > 128 ? 128 : 256;
+    if (bm_env == 128 || bm_env == 256) BM = bm_env;
+    const int64_t nt_un = ((M + BM - 1) / BM) * tiles_n;
+    MMPlan pl{BM, 1, 3.0 + (BM == 256 ? 0.70 : 0.55) * (double)P * (double)((nt_un + 255) / 256)};
+    if (!can_split) return pl;
+    if (max_splits > 1) {
+        const int bm_s = bm_env == 256 && M > 128 ? 256 : 128;
+        const int64_t nt_f = ((M + bm_s - 1) / bm_s) * tiles_n;
+        const int sp = (int)std::min<int64_t>(std::min<int64_t>(max_splits, P), 256 / std::max<int64_t>(nt_f, 1));
+        if (sp >= 2) { pl.bm = bm_s; pl.splits = sp; }
+        return pl;
+    }
+    if (P < 8) return pl;
+    double best = 0.8 * pl.t_us;
+    for (int bm_c = 128; bm_c <= 256; bm_c += 128) {
+        if (bm_c == 256 && (M <= 128 || bm_env == 128)) continue;
+        if (bm_c == 128 && bm_env == 256) continue;
+        const int64_t nt_c = ((M + bm_c - 1) / bm_c) * tiles_n;
+        if (nt_c > 128) continue;
+        const double c_stage = bm_c == 256 ? 0.70 : 0.55, slab = bm_c == 256 ? 0.054 : 0.027;
+        for (int s_ = 2; s_ <= 16 && s_ * nt_c <= 256 && 2 * s_ <= P; ++s_) {
+            const double t = 3.0 + c_stage * (double)((P + s_ - 1) / s_) + 4.5 + slab * (double)(s_ * nt_c);
+            if (t < best) { best = t; pl.bm = bm_c; pl.splits = s_; pl.t_us = t; }
+        }
+    }
+    return pl;
+}
+
+// What the plan of a launch of M x N outputs over P stages predicts (microseconds): the convolution front end chooses between its two row enumerations with it.
+// ex: the launch's extras, or nullptr for the calling thread's deprecated one-shot state.
+double gsw_mm_predict_us(int64_t M, int N, int P, const GswMmExtras* ex) {
+    const bool have_ws = ex ? (ex->workspace_bytes > 0 && ex->workspace_dev) : (t_mm_ws != nullptr && t_mm_ws_bytes > 0);
+    const int max_splits = ex ? ex->max_splits : t_mm_max_splits;
+    const MMPlan pl = mm_plan(M, ((int64_t)N + 159) / 160, P, have_ws && max_splits != 1, max_splits);
+    const int64_t need = (int64_t)pl.splits * (((M + pl.bm - 1) / pl.bm) * (((int64_t)N + 159) / 160)) * 8 * 5 * (pl.bm / 64) * 64 * 16;
+    if (pl.splits >= 2 && need > (ex ? ex->workspace_bytes : t_mm_ws_bytes)) return mm_plan(M, ((int64_t)N + 159) / 160, P, false, 1).t_us;
+    return pl.t_us;
+}
+
 // Launch the engine for a prepared MMArgs (segments, weights, epilogue); fills the tiling fields.
 int gsw_mm_launch(MMArgs& a, int dtype, void* stream, GswMmExtras* ex) {
     GswMmExtras legacy;
@@ -1239,16 +1293,8 @@ int gsw_mm_launch(MMArgs& a, int dtype, void* stream, GswMmExtras* ex) {
         if (tiles_n > 8 && tiles_n <= 32 && tiles_n * BN * (int64_t)a.P * 64 * 2 <= (2 << 20)) a.panel = (int32_t)tiles_n;
         if (panel_env > 0) a.panel = panel_env;
     }
-    // 256-row tiles unless they would leave CUs without one: then 128-row tiles (GSW_MM_BM=128 / 256 forces one for A/B runs)
-    const int bm_env = g_mm_tile_rows.load(std::memory_order_relaxed);
-    // (pricing a 128-row tile at 0.55 of a 256-row one and minimising rounds of 256 workgroups -- e.g. 384 tiles -> 768 half tiles -- measured slower:
-    // the half tile re-fetches the weight tile twice as often)
-    // ... but not when the 256-row tiling still has 128 or more tiles: the deep levels at 4096 rows (8 x 8 at batch 64, 16 x 16 at batch 16) re-read a
-    // 30-60 MB weight matrix once per row tile through L2, and half as many row tiles on half the CUs beat twice as many on all of them
-    // (profiles/r03_splitk_sweep_256.txt: 155 vs 210 us, 141 vs 180, 295 vs 394)
-    const int64_t nt256_ = (((int64_t)a.M + 255) / 256) * tiles_n;
-    int BM = nt256_ < (a.P >= 64 ? 128 : 256) && a.M > 128 ? 128 : 256;       // (long K only: a short-K weight matrix stays in L2 and all CUs win)
-    if (bm_env == 128 || bm_env == 256) BM = bm_env;
+    const MMPlan plan = mm_plan(a.M, tiles_n, a.P, ws_dev && max_splits != 1 && !a.ln_stat, max_splits);       // tiling and split-K policy: see mm_plan
+    const int BM = plan.splits >= 2 ? mm_plan(a.M, tiles_n, a.P, false, 1).bm : plan.bm;      // the tile of the UNSPLIT launch (also taken when a split plan does not fit the workspace)
     hipStream_t st = (hipStream_t)stream;
     a.splits = 1; a.ws = nullptr;
     // the dense-row / GEGLU epilogues fetch the bias by 16-byte LDS-DMA pieces (STG in the kernel)
@@ -1264,24 +1310,11 @@ int gsw_mm_launch(MMArgs& a, int dtype, void* stream, GswMmExtras* ex) {
     // Split-K for launches that cannot fill the chip with output tiles (the deep levels at small batch: 8 x 8 pixels of one image are ONE row tile
     // against 180-360 K stages): `splits` workgroups share a tile's stages, fp32 partials go through the caller's workspace, a second small kernel
     // adds them in a fixed order and runs the epilogue.  Needs a workspace (gsw_mm_set_workspace); without one the launch runs unsplit.
-    if (ws_dev && max_splits != 1 && !a.ln_stat) {
-        const int bm_s = 128;
+    if (plan.splits >= 2) {
+        const int bm_s = plan.bm, splits = plan.splits;
         const int64_t nt = (((int64_t)a.M + bm_s - 1) / bm_s) * tiles_n;
-        int splits = 1;
-        if (max_splits > 1) splits = std::min<int64_t>(std::min<int64_t>(max_splits, a.P), 256 / std::max<int64_t>(nt, 1));
-        else if (nt <= 128 && a.P >= 8) {
-            // cost model fitted to tools/splitk_sweep.py (profiles/r03d_splitk_sweep.txt), microseconds: a workgroup pays ~3 to get going and ~0.55 per
-            // stage; a split launch adds the reduce kernel (~4.5 for the second launch and its latency) and the slab traffic (80 KiB per slab at ~3 MB/us).
-            // Split only for a predicted gain of 20 % or more (the medium dense shapes lose: their reduce costs more than their short K loop).
-            const double t_un = 3.0 + 0.55 * (double)a.P;
-            double best = 0.8 * t_un;
-            for (int s_ = 2; s_ <= 16 && s_ * nt <= 256 && 2 * s_ <= a.P; ++s_) {
-                const double t = 3.0 + 0.55 * (double)((a.P + s_ - 1) / s_) + 4.5 + 0.027 * (double)(s_ * nt);
-                if (t < best) { best = t; splits = s_; }
-            }
-        }
         const int64_t need = (int64_t)splits * nt * 8 * 5 * (bm_s / 64) * 64 * 16;
-        if (splits >= 2 && need <= ws_bytes) {
+        if (need <= ws_bytes) {
             a.tiles_n = (int32_t)tiles_n;
             a.ntiles = (int32_t)nt;
             a.splits = splits; a.ws = (float*)ws_dev;

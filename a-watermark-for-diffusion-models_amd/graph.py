@@ -19,7 +19,7 @@ What the graph bakes in, and how it stays valid:
   * the launch sequence itself -- the module-level switches of unet.py / pf.py and the engine's tiling knobs (gsw_mm_config) are part of an
     entry's key, so an A/B toggle after a capture captures anew instead of silently replaying the old sequence.
 Capture failing for any reason falls back to eager IN THIS PROCESS (never a re-exec) and is reported once.  Entries are kept in an LRU of
-MAX_ENTRIES (each pins a private activation pool and a 20 MiB split-K scratch).
+MAX_ENTRIES (each pins a private activation pool and a 40 MiB split-K scratch).
 
 A graph replay runs exactly the launches of the eager forward with the same arguments: outputs are bit-identical (tests/test_gpu_graph.py).
 """

@@ -77,7 +77,8 @@ class PF:
 
 # ---- split-K workspace of the matmul engine (gsw_mm_set_workspace): one scratch buffer per (device, stream), handed to the library whenever the
 # calling thread's (device, stream) changes.  Launches on one stream share it (a launch and its reduce kernel are stream-ordered).
-SPLITK_BYTES = 20 << 20        # 256 slabs of 80 KiB: every launch that splits fits
+SPLITK_BYTES = 40 << 20        # 256 slabs of 160 KiB (256-row tiles; 80 KiB for 128-row tiles): every launch that splits fits
+LAUNCH_LOG = None              # a list: every engine launch appends its GswMmExtras (tests: which launches split, and how)
 SPLITK_MAX = 0                 # 0 automatic, 1 never split, k > 1: force k-way splits wherever K allows (parity tests)
 _WS = {}
 _WS_TLS = __import__("threading").local()
@@ -121,6 +122,8 @@ def _extras(device, colstats: Optional[torch.Tensor] = None, rowstats: Optional[
     if rowstats is not None:
         ex.rowstats_dev, ex.rowstats_capacity = rowstats.data_ptr(), rowstats.numel()
     ex.workspace_dev, ex.workspace_bytes, ex.max_splits = ws.data_ptr(), ws.numel(), int(SPLITK_MAX)
+    if LAUNCH_LOG is not None:
+        LAUNCH_LOG.append(ex)          # the launch fills in what it did (ex.splits, record geometry): tests read it afterwards
     return ex
 
 

@@ -280,9 +280,9 @@ int gsw_mm_get_config(int* tile_rows, int* split_mask); /* the current values (e
  * Small-batch launches of the eps model -- one image's 8 x 8 level is a single 64-row tile against 180-360 K stages (the reference's own use:
  * extract.py:112-117 inverts ONE latent per call) -- cannot fill 256 CUs with output tiles.  When a workspace is set, a launch whose 128-row
  * tiling has <= 128 tiles lets up to 16 workgroups share a tile's K stages whenever a small cost model (fitted to tools/splitk_sweep.py) predicts
- * a gain of 20 % or more: each workgroup dumps its fp32 accumulators into a slab ([splits][tiles][8 waves][10 accumulators][64 lanes] float4), and
+ * a gain of 20 % or more: each workgroup dumps its fp32 accumulators into a slab ([splits][tiles][8 waves][5 * (tile rows / 64) accumulators][64 lanes] float4), and
  * a second kernel adds the slabs in split order (deterministic) and runs the epilogue of the launch's mode.  bytes = 0 removes the workspace
- * (launches run unsplit).  20 MiB covers every launch (256 slabs of 80 KiB).
+ * (launches run unsplit).  40 MiB covers every launch (256 slabs of 160 KiB: 256-row tiles; 128-row tiles need half).
  * The workspace is scratch between a launch and its reduce kernel, both on the launch's stream: launches on ONE stream may share it, launches
  * on different streams need different workspaces (set one per stream before launching there).
  *   max_splits : 0 = automatic, 1 = never split, k > 1 = split every launch min(k, stages, 256 / tiles) ways (parity tests) */

@@ -202,3 +202,103 @@ def test_small_batch_unet_forward_split_vs_unsplit_vs_fp32(G):
     scale = ref.abs().max().item()
     assert (y0.float() - ref).abs().max().item() <= 1e-2 * scale and (y1.float() - ref).abs().max().item() <= 1e-2 * scale
     assert U.FALLBACKS == {}, U.FALLBACKS
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# 256-row tiles in split launches (round 4): forced through gsw_mm_config, and the automatic policy on the shapes it was added for
+# ---------------------------------------------------------------------------------------------------------------------
+@contextlib.contextmanager
+def tile_rows(G, rows):
+    import ctypes as C
+    tr, sm = C.c_int(0), C.c_int(0)
+    assert G.lib.gsw_mm_get_config(C.byref(tr), C.byref(sm)) == 0
+    assert G.lib.gsw_mm_config(rows, sm.value) == 0
+    try:
+        yield
+    finally:
+        assert G.lib.gsw_mm_config(tr.value, sm.value) == 0
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("k", [2, 5])
+def test_256_row_split_tiles_every_mode(G, dtype, k):
+    g = torch.Generator().manual_seed(7 * k)
+    rnd = lambda *s: torch.randn(*s, generator=g)
+    tol = TOL[dtype]
+    with tile_rows(G, 256):
+        # dense rows (+ residual), ragged M and N
+        M, K, N = 1000, 5120, 1288
+        x, w, b, r = rnd(M, K).to(dtype).cuda(), (rnd(N, K) * K ** -0.5).to(dtype).cuda(), rnd(N).to(dtype).cuda(), rnd(M, N).to(dtype).cuda()
+        ref = x.float() @ w.float().T + b.float() + r.float()
+        G.pf.LAUNCH_LOG = log = []
+        try:
+            with splits(G, k):
+                y, y2 = G.pf.gemm(x, w, b, resid=r), G.pf.gemm(x, w, b, resid=r)
+        finally:
+            G.pf.LAUNCH_LOG = None
+        assert [e.splits for e in log] == [k, k]
+        assert torch.equal(y, y2) and _rel(y, ref) <= 2 * tol
+        with splits(G, 1):
+            y1 = G.pf.gemm(x, w, b, resid=r)
+        assert _rel(y, y1) <= 2 * tol
+        # GEGLU
+        M, K, I = 512, 1280, 640
+        x, w, b = rnd(M, K).to(dtype).cuda(), (rnd(2 * I, K) * K ** -0.5).to(dtype).cuda(), rnd(2 * I).to(dtype).cuda()
+        wp, bp = G.pf.pack_geglu_weight(w, b)
+        proj = x.float() @ w.float().T + b.float()
+        with splits(G, k):
+            yg = G.pf.gemm(x, wp, bp, mode="geglu")
+        assert _rel(yg, proj[:, :I] * F.gelu(proj[:, I:])) <= 2 * tol
+        # transposed value projection
+        Bn, S, K2, N2 = 3, 256, 1280, 1280
+        xs, w2, b2 = rnd(Bn, S, K2).to(dtype).cuda(), (rnd(N2, K2) * K2 ** -0.5).to(dtype).cuda(), rnd(N2).to(dtype).cuda()
+        with splits(G, k):
+            yT = G.pf.gemm(xs, w2, b2, mode="trans", tokens=S)
+        assert _rel(yT, (xs.float() @ w2.float().T + b2.float()).transpose(1, 2)) <= tol
+        # convolution with row bias and residual; the resnet's three-segment launch; the sub-pixel upsampler
+        B, C, Nn, H, W = 3, 1280, 1280, 16, 16
+        xc, wc, bc = rnd(B, C, H, W).to(dtype).cuda(), (rnd(Nn, C, 3, 3) * (9 * C) ** -0.5).to(dtype).cuda(), rnd(Nn).to(dtype).cuda()
+        rb, res = rnd(B, Nn).to(dtype).cuda(), rnd(B, Nn, H, W).to(dtype).cuda()
+        refc = F.conv2d(xc.float(), wc.float(), bc.float(), padding=1) + rb.float()[:, :, None, None] + res.float()
+        P = G.pf.PF.from_nchw
+        with splits(G, k):
+            yc = G.pf.conv_pf(P(xc), G.pf.pack_conv_weight(wc), bc, rowbias=rb, resid=P(res))
+        assert _rel(yc.to_nchw(), refc) <= 2 * tol
+        gr = yc.grid
+        assert gr[:, 0].abs().max() == 0 and gr[:, -1].abs().max() == 0 and gr[:, :, 0].abs().max() == 0 and gr[:, :, -1].abs().max() == 0
+        x1, x2, w1 = rnd(B, 1280, H, W).to(dtype).cuda(), rnd(B, 640, H, W).to(dtype).cuda(), (rnd(Nn, 1920) * 1920 ** -0.5).to(dtype).cuda()
+        ref3 = F.conv2d(xc.float(), wc.float(), bc.float(), padding=1) + F.conv2d(torch.cat([x1, x2], 1).float(), w1.float()[:, :, None, None])
+        with splits(G, k):
+            y3 = G.pf.conv3x3_res_pf(P(xc), torch.cat([G.pf.pack_conv_weight(wc), w1], dim=1).contiguous(), bc, x1=P(x1), x2=P(x2))
+        assert _rel(y3.to_nchw(), ref3) <= 2 * tol
+        refu = F.conv2d(F.interpolate(xc.float(), scale_factor=2.0, mode="nearest"), wc.float(), bc.float(), padding=1)
+        with splits(G, k):
+            yu = G.pf.conv_up2x_pf(P(xc), G.pf.pack_upsample_weight(wc), bc)
+        assert _rel(yu.to_nchw(), refu) <= 3 * tol
+
+
+def test_automatic_policy_takes_256_row_tiles_where_half_the_cus_would_idle(G):
+    """16 images at 16 x 16 (the third level at batch 8 with guidance) and 64 at 8 x 8 (the deepest level of the inversion half at batch 64): 4096 output rows x
+    1280 columns = 128 tiles of 256 rows.  Unsplit that is half the chip; with 128-row tiles it cannot split at all (256 tiles); the policy takes 2 x 128 workgroups."""
+    dtype = torch.float16
+    g = torch.Generator().manual_seed(11)
+    for (B, H) in ((16, 16), (64, 8)):
+        x = torch.randn(B, 1280, H, H, generator=g).to(dtype).cuda()
+        w = (torch.randn(1280, 1280, 3, 3, generator=g) * (9 * 1280) ** -0.5).to(dtype).cuda()
+        b = torch.randn(1280, generator=g).to(dtype).cuda()
+        ref = F.conv2d(x.float(), w.float(), b.float(), padding=1)
+        G.pf.LAUNCH_LOG = log = []
+        try:
+            y = G.pf.conv_pf(G.pf.PF.from_nchw(x), G.pf.pack_conv_weight(w), b)
+        finally:
+            G.pf.LAUNCH_LOG = None
+        assert [e.splits for e in log] == [2], [e.splits for e in log]
+        assert _rel(y.to_nchw(), ref) <= 2e-3
+    # ... and leaves launches alone that fill the chip: 128 images at 8 x 8 (256 tiles of 256 rows)
+    x = torch.randn(128, 1280, 8, 8, generator=g).to(dtype).cuda()
+    G.pf.LAUNCH_LOG = log = []
+    try:
+        G.pf.conv_pf(G.pf.PF.from_nchw(x), G.pf.pack_conv_weight(w), b)
+    finally:
+        G.pf.LAUNCH_LOG = None
+    assert [e.splits for e in log] == [1]
