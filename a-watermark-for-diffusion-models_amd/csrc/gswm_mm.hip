@@ -1214,25 +1214,35 @@ int gsw_mm_get_config(int* tile_rows, int* split_mask) {
     return GSW_OK;
 }
 
-// Tiling and split-K plan of a launch, with the time the cost model predicts for it (microseconds; fitted to tools/splitk_sweep.py, profiles/r03d_splitk_sweep.txt:
-// a workgroup pays ~3 to get going and ~0.55 per stage of a 128-row tile (bound by its LDS-DMA) or ~0.70 per stage of a 256-row tile (bound by the matrix pipe);
-// a split launch adds the reduce kernel, ~4.5 for the second launch and its latency, and the slab traffic, 80 KiB per 128-row slab at ~3 MB/us).
-//   unsplit: 256-row tiles unless they would leave CUs without one, then 128-row tiles -- but not when the 256-row tiling still has 128 or more tiles: the deep
-//   levels at 4096 rows re-read a 30-60 MB weight matrix once per row tile through L2, and half as many row tiles on half the CUs beat twice as many on all of them
-//   (profiles/r03_splitk_sweep_256.txt: 155 vs 210 us, 141 vs 180, 295 vs 394); long K only: a short-K weight matrix stays in L2 and all CUs win.
-//   (Pricing a 128-row tile at 0.55 of a 256-row one and minimising rounds of 256 workgroups measured slower: the half tile re-fetches the weight tile twice as often.)
-//   split: only for a predicted gain of 20 % or more over the unsplit launch (the medium dense shapes lose: their reduce costs more than their short K loop); the tile
-//   of a split launch is 128 rows, or 256 when there are rows for it -- a 256-row tile costs ~1.25 stage times of a 128-row one and does twice the work (16 images at
-//   16 x 16 or 64 at 8 x 8 are 128 tiles of 256 rows: half the chip unsplit, 2 x 128 workgroups split).  Forced splits (max_splits > 1: tests) use 128 rows unless
-//   gsw_mm_config forces the 256-row tile.
+// Tiling and split-K plan of a launch, with the time the cost model predicts for it (microseconds).  The model is fitted to tools/splitk_tile_sweep.py
+// (profiles/r04i_splitk_tile_sweep.txt: 35 shapes x tile rows x split counts, HBM-cold weights, graph-captured; rms error 6 %, mean regret of its choices 1 %):
+//   a stage of a 128-row tile costs 0.56 us while at most half the CUs work and 0.67 with all of them; a stage of a 256-row tile 0.79-0.81 and 1.13 (the chip is
+//   power- and L2-bound when every CU multiplies: section 4.8 of DESIGN.md); an unsplit launch pays 2.5 us on top, a split one 12.5 (its reduce kernel) and 0.014 per
+//   80 KiB of slab.
+// Unsplit tile: for long K (>= 40 stages) and at most one round of 256-row tiles the model decides -- 128-row tiles when 256-row ones would leave half the chip idle
+// (4096 x 1280 outputs: 127 vs 162 us at K = 11520; 52 vs 69 at K = 5120; the round-3 rule kept 256 rows there from a sweep whose weights were L2-hot).  Short K keeps
+// the measured rule of round 3 (128-row tiles whenever 256-row ones do not fill the chip: a short-K weight matrix stays in L2 and all CUs win), more than one round
+// keeps 256-row tiles (a half tile re-fetches the weight tile twice as often).
+// Split: at most 128 tiles, at least 8 stages, up to 16 ways and 256 workgroups, 128- or 256-row tiles, taken for a predicted gain of 5 % or more.  Forced splits
+// (max_splits > 1: tests) use 128 rows unless gsw_mm_config forces the 256-row tile.
 struct MMPlan { int bm; int splits; double t_us; };
+static inline double mm_stage_us(int bm, double W) {
+    const double over = W > 128.0 ? (W - 128.0) / 128.0 : 0.0;
+    return bm == 128 ? 0.56 + 0.11 * over : 0.79 + 0.02 * std::min(1.0, W / 128.0) + 0.32 * over;
+}
 static MMPlan mm_plan(int64_t M, int64_t tiles_n, int32_t P, bool can_split, int max_splits) {
     const int bm_env = g_mm_tile_rows.load(std::memory_order_relaxed);          // GSW_MM_BM / gsw_mm_config: 128 / 256 forces a tiling (A/B runs, tests)
-    const int64_t nt256 = ((M + 255) / 256) * tiles_n;
-    int BM = nt256 < (P >= 64 ? 128 : 256) && M > 128 ? 128 : 256;
+    const int64_t nt256 = ((M + 255) / 256) * tiles_n, nt128 = ((M + 127) / 128) * tiles_n;
+    auto t_unsplit = [&](int bm) {
+        const int64_t nt = bm == 256 ? nt256 : nt128, rounds = (nt + 255) / 256;
+        return 2.5 + mm_stage_us(bm, rounds == 1 ? (double)nt : 256.0) * (double)P * (double)rounds;
+    };
+    int BM;
     if (bm_env == 128 || bm_env == 256) BM = bm_env;
-    const int64_t nt_un = ((M + BM - 1) / BM) * tiles_n;
-    MMPlan pl{BM, 1, 3.0 + (BM == 256 ? 0.70 : 0.55) * (double)P * (double)((nt_un + 255) / 256)};
+    else if (M <= 128) BM = 256;
+    else if (P >= 40 && nt256 <= 256) BM = t_unsplit(128) < t_unsplit(256) ? 128 : 256;
+    else BM = nt256 < (P >= 64 ? 128 : 256) ? 128 : 256;
+    MMPlan pl{BM, 1, t_unsplit(BM)};
     if (!can_split) return pl;
     if (max_splits > 1) {
         const int bm_s = bm_env == 256 && M > 128 ? 256 : 128;
@@ -1242,15 +1252,14 @@ static MMPlan mm_plan(int64_t M, int64_t tiles_n, int32_t P, bool can_split, int
         return pl;
     }
     if (P < 8) return pl;
-    double best = 0.8 * pl.t_us;
+    double best = pl.t_us / 1.05;
     for (int bm_c = 128; bm_c <= 256; bm_c += 128) {
         if (bm_c == 256 && (M <= 128 || bm_env == 128)) continue;
         if (bm_c == 128 && bm_env == 256) continue;
-        const int64_t nt_c = ((M + bm_c - 1) / bm_c) * tiles_n;
+        const int64_t nt_c = bm_c == 256 ? nt256 : nt128;
         if (nt_c > 128) continue;
-        const double c_stage = bm_c == 256 ? 0.70 : 0.55, slab = bm_c == 256 ? 0.054 : 0.027;
         for (int s_ = 2; s_ <= 16 && s_ * nt_c <= 256 && 2 * s_ <= P; ++s_) {
-            const double t = 3.0 + c_stage * (double)((P + s_ - 1) / s_) + 4.5 + slab * (double)(s_ * nt_c);
+            const double t = 12.5 + mm_stage_us(bm_c, (double)(s_ * nt_c)) * (double)((P + s_ - 1) / s_) + 0.014 * (double)(s_ * nt_c * (bm_c / 128));
             if (t < best) { best = t; pl.bm = bm_c; pl.splits = s_; pl.t_us = t; }
         }
     }

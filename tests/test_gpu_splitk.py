@@ -279,12 +279,13 @@ def test_256_row_split_tiles_every_mode(G, dtype, k):
 
 def test_automatic_policy_takes_256_row_tiles_where_half_the_cus_would_idle(G):
     """16 images at 16 x 16 (the third level at batch 8 with guidance) and 64 at 8 x 8 (the deepest level of the inversion half at batch 64): 4096 output rows x
-    1280 columns = 128 tiles of 256 rows.  Unsplit that is half the chip; with 128-row tiles it cannot split at all (256 tiles); the policy takes 2 x 128 workgroups."""
+    1280 columns = 128 tiles of 256 rows = half the chip.  With 128-row tiles such a launch cannot split at all (256 tiles); from K = 17280 up the plan takes
+    2 x 128 workgroups of 256-row tiles (and the interior row enumeration that makes them 128), below it 256 unsplit 128-row tiles (csrc/gswm_mm.hip: mm_plan)."""
     dtype = torch.float16
     g = torch.Generator().manual_seed(11)
-    for (B, H) in ((16, 16), (64, 8)):
-        x = torch.randn(B, 1280, H, H, generator=g).to(dtype).cuda()
-        w = (torch.randn(1280, 1280, 3, 3, generator=g) * (9 * 1280) ** -0.5).to(dtype).cuda()
+    for (B, H, C, want) in ((16, 16, 1920, 2), (64, 8, 2560, 2), (16, 16, 1280, 1)):
+        x = torch.randn(B, C, H, H, generator=g).to(dtype).cuda()
+        w = (torch.randn(1280, C, 3, 3, generator=g) * (9 * C) ** -0.5).to(dtype).cuda()
         b = torch.randn(1280, generator=g).to(dtype).cuda()
         ref = F.conv2d(x.float(), w.float(), b.float(), padding=1)
         G.pf.LAUNCH_LOG = log = []
@@ -292,10 +293,13 @@ def test_automatic_policy_takes_256_row_tiles_where_half_the_cus_would_idle(G):
             y = G.pf.conv_pf(G.pf.PF.from_nchw(x), G.pf.pack_conv_weight(w), b)
         finally:
             G.pf.LAUNCH_LOG = None
-        assert [e.splits for e in log] == [2], [e.splits for e in log]
+        assert [e.splits for e in log] == [want], (B, H, C, [e.splits for e in log])
         assert _rel(y.to_nchw(), ref) <= 2e-3
+        gr = y.grid
+        assert gr[:, 0].abs().max() == 0 and gr[:, -1].abs().max() == 0 and gr[:, :, 0].abs().max() == 0 and gr[:, :, -1].abs().max() == 0
     # ... and leaves launches alone that fill the chip: 128 images at 8 x 8 (256 tiles of 256 rows)
     x = torch.randn(128, 1280, 8, 8, generator=g).to(dtype).cuda()
+    w = (torch.randn(1280, 1280, 3, 3, generator=g) * (9 * 1280) ** -0.5).to(dtype).cuda()
     G.pf.LAUNCH_LOG = log = []
     try:
         G.pf.conv_pf(G.pf.PF.from_nchw(x), G.pf.pack_conv_weight(w), b)
