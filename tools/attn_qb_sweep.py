@@ -1,29 +1,32 @@
-"""128- vs 256-query workgroups of the self-attention kernel over small batches (GSW_ATTN_QB=1 / 3 force a form).  python tools/attn_qb_sweep.py"""
-import os, sys, subprocess
-if len(sys.argv) > 1:
-    import torch
-    sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-    import gswm_amd  # noqa: F401
-    from gswm_amd import pf
-    out = []
-    for S, H in ((4096, 5), (1024, 10)):
-        for B in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 64):
-            q, k, v = (torch.randn(B, S, H * 64, device="cuda").half() for _ in range(3))
-            vt = v.transpose(1, 2).contiguous()
-            for _ in range(3): pf.attention_hd64(q, k, vt, H)
-            torch.cuda.synchronize(); s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            for _ in range(20): pf.attention_hd64(q, k, vt, H)
-            e.record(); torch.cuda.synchronize()
-            out.append(f"{S} {H} {B} {s.elapsed_time(e) / 20 * 1e3:.1f}")
-    print("\n".join(out))
-else:
-    res = {}
-    for qb in ("1", "3"):
-        r = subprocess.run([sys.executable, __file__, "run"], env=dict(os.environ, GSW_ATTN_QB=qb), capture_output=True, text=True)
-        for line in r.stdout.splitlines():
-            p = line.split()
-            if len(p) == 4 and p[0].isdigit(): res[(int(p[0]), int(p[1]), int(p[2]), qb)] = float(p[3])
-    print("S H B | 128-query WGs (us) | 256-query WGs (us) | 256-query grid")
-    for (S, H, B, qb) in sorted(k for k in res if k[3] == "1"):
-        print(f"{S:5d} {H:3d} {B:3d} | {res[(S, H, B, '1')]:9.1f} | {res.get((S, H, B, '3'), float('nan')):9.1f} | {S // 256 * B * H}")
+"""Self-attention launch time by batch rows and level under the current GSW_ATTN_QB setting (unset: the dispatch rule; 1: 128-query workgroups; 3: 256-query
+workgroups wherever the shape allows) -- run once per setting; calibrates the query-tile rule of gsw_attention (csrc/gswm_attn.hip).  Graph-captured, 8 launches per replay."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
+import gswm_amd  # noqa: E402,F401
+from gswm_amd import pf  # noqa: E402
+
+tag = os.environ.get("GSW_ATTN_QB", "rule")
+for rows in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64):
+    for S, H in ((4096, 5), (1024, 10), (256, 20)):
+        q, k, v = (torch.randn(rows, S, H * 64, device="cuda").half() for _ in range(3))
+        vt = v.transpose(1, 2).contiguous()
+        out = torch.empty_like(q)
+        pf.attention_hd64(q, k, vt, H, out=out)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(8):
+                pf.attention_hd64(q, k, vt, H, out=out)
+        g.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        print(f"{tag} rows={rows:3d} S={S:5d} H={H:2d} wg256={rows * H * S // 256:6d}: {e0.elapsed_time(e1) * 1e3 / 40:8.1f} us", flush=True)
