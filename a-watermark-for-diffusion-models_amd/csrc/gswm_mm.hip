@@ -867,6 +867,15 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
             __builtin_amdgcn_sched_group_barrier(0x008, NM - per * NV - NR, 0);
         }
     };
+#ifdef MM_ABL_NOMFMA
+    // (ablation builds, tools/mm_ablate.sh: one cheap VALU consumer per fragment instead of the 20 MFMAs, so that the LDS reads stay alive)
+    auto touch20 = [&](frag (&xf)[MT], frag (&wf)[5]) {
+#pragma unroll
+        for (int im = 0; im < MT; ++im) acc[0][im][0] += (float)xf[im][0];
+#pragma unroll
+        for (int in = 0; in < 5; ++in) acc[in][0][1] += (float)wf[in][0];
+    };
+#endif
     // X holds the fragments of (stage s, k-half 0) on entry; Y is filled with (s, k-half 1), then X with (s+1, k-half 0)
     auto step = [&](auto swap_tag, frag (&xX)[MT], frag (&wX)[5], frag (&xY)[MT], frag (&wY)[5], const int32_t step_i) {
         const uint32_t nx_slot = rd_slot + STAGE == RING ? 0u : rd_slot + STAGE;
@@ -878,6 +887,8 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
 #endif
 #ifndef MM_ABL_NOMFMA
         mfma20(swap_tag, xX, wX);
+#else
+        touch20(xX, wX);
 #endif
         pin_order();
         if constexpr (!SPLIT) { if (--pr_run == 0) end_run(); }
@@ -903,6 +914,8 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
 #endif
 #ifndef MM_ABL_NOMFMA
         mfma20(swap_tag, xY, wY);
+#else
+        touch20(xY, wY);
 #endif
         pin_order();
         MM_STAMP(4);

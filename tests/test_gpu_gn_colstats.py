@@ -67,11 +67,18 @@ def test_conv_records_and_groupnorm(G, tile_rows, B, C, N, H, W, ks, stride):
     b = torch.randn(N, generator=g).to(dt).cuda()
     rb = torch.randn(B, N, generator=g).to(dt).cuda()
     P = G.pf.PF.from_nchw
-    y = G.pf.conv_pf(P(x), G.pf.pack_conv_weight(w), b, ksize=ks, stride=stride, rowbias=rb)
+    G.pf.LAUNCH_LOG = log = []
+    try:
+        y = G.pf.conv_pf(P(x), G.pf.pack_conv_weight(w), b, ksize=ks, stride=stride, rowbias=rb)
+    finally:
+        G.pf.LAUNCH_LOG = None
     if y.B * (y.H + 2) * (y.W + 2) <= 8192 and stride == 1:
         assert y.stats is None           # small tensors enumerate all padded rows (no records): GroupNorm takes the separate pass
         return
-    _check_records(y.stats, y.to_nchw())
+    if any(e.splits > 1 for e in log):   # a launch the plan splits (84 images at 8 x 8: 84 tiles of 256 rows -> 3 x 84 workgroups) writes no records either:
+        assert y.stats is None           # its reduce kernel runs the epilogue; GroupNorm takes the separate pass, checked below like the record path
+    else:
+        _check_records(y.stats, y.to_nchw())
     gamma, beta = torch.randn(N, generator=g).to(dt).cuda(), torch.randn(N, generator=g).to(dt).cuda()
     a, bb = _gn_both(G, y, gamma, beta, 32, 1e-5, True)
     ref = _gn_ref(y.to_nchw(), gamma, beta, 32, 1e-5, True)

@@ -1,7 +1,8 @@
 """Clock and power while a kernel family runs for seconds: is a kernel's time set by a unit's throughput or by the board's power limit?
 A sampler thread reads the GPU's sysfs sensors (hwmon power1_average / power1_input, freq1_input = shader clock; falls back to `rocm-smi --json`) every 20 ms while
 the main thread replays one workload back to back; per workload: kernel time, mean / min shader clock, mean / max power.
-usage: python tools/power_probe.py [attn|conv|dense|all]      (GSWM_LIB selects an ablation build of the attention kernel, tools/attn_ablate.sh)"""
+usage: python tools/power_probe.py [attn|conv|dense|mm|all]      (mm: the convolution and dense lines on random operands only)
+      (GSWM_LIB selects an ablation build of the attention kernel, tools/attn_ablate.sh)"""
 import os
 import sys
 import time
@@ -53,17 +54,21 @@ if what in ("attn", "all"):
     run("attention S=4096 H=5 B=128 (random operands)", lambda: pf.attention_hd64(q, k, vt, H), flops=4.0 * B * H * S * S * 64)
     z = torch.zeros_like(q); zt = torch.zeros_like(vt)
     run("attention S=4096 H=5 B=128 (all-zero operands)", lambda: pf.attention_hd64(z, z, zt, H), flops=4.0 * B * H * S * S * 64)
-if what in ("conv", "all"):
+if what in ("conv", "all", "mm"):
     for (C, N, Hh, B) in ((320, 320, 64, 128), (1280, 1280, 16, 128)):
         x = pf.PF.from_nchw(torch.randn(B, C, Hh, Hh, device="cuda", dtype=dt))
         w = pf.pack_conv_weight((torch.randn(N, C, 3, 3, device="cuda") * (9 * C) ** -0.5).to(dt))
         b = torch.randn(N, device="cuda", dtype=dt)
         run(f"conv3x3 {Hh}x{Hh} C={C} N={N} B={B} (random operands)", lambda: pf.conv_pf(x, w, b), flops=2.0 * B * Hh * Hh * 9 * C * N)
+        if what == "mm":
+            continue
         xz = pf.PF.from_nchw(torch.zeros(B, C, Hh, Hh, device="cuda", dtype=dt)); wz = torch.zeros_like(w)
         run(f"conv3x3 {Hh}x{Hh} C={C} N={N} B={B} (all-zero operands)", lambda: pf.conv_pf(xz, wz, b), flops=2.0 * B * Hh * Hh * 9 * C * N)
-if what in ("dense", "all"):
+if what in ("dense", "all", "mm"):
     for (M, K, N) in ((524288, 320, 320), (32768, 5120, 1280)):
         x = torch.randn(M, K, device="cuda", dtype=dt); w = (torch.randn(N, K, device="cuda") * K ** -0.5).to(dt)
         run(f"dense M={M} K={K} N={N} (random operands)", lambda: pf.gemm(x, w, None), flops=2.0 * M * K * N)
+        if what == "mm":
+            continue
         xz = torch.zeros_like(x); wz = torch.zeros_like(w)
         run(f"dense M={M} K={K} N={N} (all-zero operands)", lambda: pf.gemm(xz, wz, None), flops=2.0 * M * K * N)
