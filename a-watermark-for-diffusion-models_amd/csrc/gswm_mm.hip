@@ -314,8 +314,18 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
             // Barrier k (k = 0 .. stages) is the consumers' "stage k is in LDS and the slot of stage k-1 is free": stage s+2 is issued after
             // barrier s-1... i.e. right after the barrier that retired the slot's previous tenant, and stage s+1 has landed before barrier s.
             int32_t pr_left = 0x7FFFFFFF;                                    // (PART) stages of this workgroup's K range still to issue
+#ifdef MM_ABL_A9
+            uint32_t abl_i = 0;                                  // (ablation: activation pieces on one stage in nine -- the DMA volume of a halo tile reused by the nine taps)
+            bool abl_a = true;
+#endif
             auto dma_stage = [&]() {
-#ifndef MM_ABL_NOA                                             // (ablation builds of tools/ubench/mm_trace.hip: results wrong by design)
+#ifdef MM_ABL_A9
+                abl_a = abl_i == 0; abl_i = abl_i == 8 ? 0 : abl_i + 1;
+                if (abl_a) {
+#pragma unroll
+                    for (int i = 0; i < NPA; ++i) dma_piece_a(i);
+                }
+#elif !defined(MM_ABL_NOA)                                      // (ablation builds of tools/ubench/mm_trace.hip: results wrong by design)
 #pragma unroll
                 for (int i = 0; i < NPA; ++i) dma_piece_a(i);
 #endif
@@ -374,7 +384,12 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
             for (uint32_t sidx = 0; sidx < total; ++sidx) {
                 dma_stage();                                                     // stage sidx + 2 (a cached dummy location once the work is issued)
                 MM_STAMP(0);
+#ifdef MM_ABL_A9
+                if (abl_a) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NDMA) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NPW) : "memory");
+#else
                 asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NWAIT) : "memory");     // stage sidx + 1 has landed
+#endif
                 MM_STAMP(1);
                 MM_BARRIER();
                 MM_STAMP(2);

@@ -14,10 +14,11 @@ def G():
     import types
     import gswm_amd
     from gswm_amd import pf, _native
-    old = pf.GN_FUSED_MAX_WGS
+    old, old_sk = pf.GN_FUSED_MAX_WGS, pf.SPLITK_MAX
     pf.GN_FUSED_MAX_WGS = 0          # this module is about the column records: small batches would otherwise take the one-launch GroupNorm (tests/test_gpu_small.py)
-    yield types.SimpleNamespace(pf=pf, lib=_native.lib())
-    pf.GN_FUSED_MAX_WGS = old
+    pf.SPLITK_MAX = 1                # ... and a launch the plan splits writes none (its reduce kernel runs the epilogue): pinned off here, covered by
+    yield types.SimpleNamespace(pf=pf, lib=_native.lib())          # test_a_split_producer_writes_no_records_and_groupnorm_takes_the_separate_pass below
+    pf.GN_FUSED_MAX_WGS, pf.SPLITK_MAX = old, old_sk
 
 
 @pytest.fixture(params=[0, 128, 256], ids=["auto", "BM128", "BM256"])
@@ -188,3 +189,26 @@ def test_explicit_extras_report_what_the_launch_did(G):
     assert G.lib.gsw_mm_last_colstats(C.byref(rows), C.byref(blocks)) == N.GSW_WARN_NO_RECORDS and rows.value == 0
     assert G.lib.gsw_mm_set_workspace(None, 0, 0) == 0
     torch.cuda.synchronize()
+
+
+def test_a_split_producer_writes_no_records_and_groupnorm_takes_the_separate_pass(G):
+    """84 images at 8 x 8, 1280 -> 640: 84 tiles of 256 rows -- the plan splits K three ways (csrc/gswm_mm.hip: mm_plan); the reduce kernel writes no records"""
+    dt = torch.float16
+    g = torch.Generator().manual_seed(5)
+    B, C, N, H, W = 84, 1280, 640, 8, 8
+    x = torch.randn(B, C, H, W, generator=g).to(dt).cuda()
+    w = (torch.randn(N, C, 3, 3, generator=g) * (9 * C) ** -0.5).to(dt).cuda()
+    b = torch.randn(N, generator=g).to(dt).cuda()
+    prev = G.pf.SPLITK_MAX
+    G.pf.SPLITK_MAX = 0
+    G.pf.LAUNCH_LOG = log = []
+    try:
+        y = G.pf.conv_pf(G.pf.PF.from_nchw(x), G.pf.pack_conv_weight(w), b)
+    finally:
+        G.pf.LAUNCH_LOG = None
+        G.pf.SPLITK_MAX = prev
+    assert any(e.splits > 1 for e in log) and y.stats is None
+    gamma, beta = torch.randn(N, generator=g).to(dt).cuda(), torch.randn(N, generator=g).to(dt).cuda()
+    a = G.pf.groupnorm_pf2(y, None, gamma, beta, 32, 1e-5, act=True)
+    ref = _gn_ref(y.to_nchw(), gamma, beta, 32, 1e-5, True)
+    assert (a.to_nchw().float() - ref).abs().max().item() <= 4e-3 * max(1.0, ref.abs().max().item())
