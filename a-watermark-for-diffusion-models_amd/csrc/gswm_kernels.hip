@@ -689,6 +689,9 @@ struct SrcDdim {  // z = round_T(a*x + b*e): the last inversion step fused into 
         return v >= t.y1f ? 1u : 0u;
     }
 };
+// input streams a source reads per element (the register budget of the extract kernels' load batches)
+template <typename S> struct SrcStreams { static constexpr int n = 1; };
+template <typename T> struct SrcStreams<SrcDdim<T>> { static constexpr int n = 2; };
 
 struct ExtractArgs {
     GswCipher ck;
@@ -797,7 +800,9 @@ __global__ __launch_bounds__(1024) void gsw_extract_wave_kernel(ExtractArgs p, S
 #pragma unroll
         for (int s = 0; s < NSETS; ++s) { acc[s][0] = acc[s][1] = 0; wide[s][0] = wide[s][1] = wide[s][2] = wide[s][3] = 0; }
         uint32_t tmax = 0, in_acc = 0;
-        constexpr int QB = 32 / NW;            // cipher bytes per lane per batch: 32 data VGPRs in flight
+        // cipher bytes per lane per batch: 32 data VGPRs in flight -- 16 for the fused last step on fp32 latents with four counter sets (two input streams of 8 words
+        // per byte + 24 counters: at the 128 registers of a 1024-thread workgroup that instantiation spilled 13)
+        constexpr int QB = (NSETS >= 4 && NW == 8 && SrcStreams<Src>::n == 2) ? 2 : 32 / NW;
         constexpr int PER_SET = QB / NSETS;
         for (uint32_t r0 = 0; r0 < rounds; r0 += QB) {
             uint32_t w[QB][NW];

@@ -482,13 +482,18 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
         if constexpr (PART) {
             // slab of virtual tile v: [wave][5 * MT accumulators][lane] float4 -- one coalesced 1 KiB store per accumulator; 16-row blocks past M are
             // neither stored nor read back
-            float* slab = p.ws + ((size_t)slotx * 8u + wave) * (size_t)(5 * MT * 64 * 4);
+            // (the slot index goes through an empty asm so that the address arithmetic stays HERE: hoisted above the loop it cost the 256-row variant, at the
+            // 168-register cap of the 12-wave form, six spilled address pairs; wave-uniform base + 32-bit lane offset)
+            uint32_t sx = slotx * 8u + wave;
+            asm volatile("" : "+s"(sx));
+            float* slab = p.ws + (size_t)sx * (size_t)(5 * MT * 64 * 4);
+            const uint32_t loff = lane * 4u;
 #pragma unroll
             for (int in = 0; in < 5; ++in)
 #pragma unroll
                 for (int im = 0; im < MT; ++im)
                     if (m0 + (int32_t)(wm * (16u * MT)) + im * 16 < p.M)
-                        *reinterpret_cast<mm_f4*>(slab + ((in * MT + im) * 64 + (int)lane) * 4) = acc[in][im];
+                        *reinterpret_cast<mm_f4*>(slab + (uint32_t)((in * MT + im) * 256) + loff) = acc[in][im];
             ++c_it;
             return;
         }
@@ -1132,8 +1137,7 @@ int mm_launch_t(const MMArgs& a, uint32_t grid, int mt, hipStream_t st) {
 }
 template <typename T>
 int mm_launch_splitk(const MMArgs& a, uint32_t grid, int mt, hipStream_t st) {
-    // 128- or 256-row tiles (gsw_mm_launch decides).  The 256-row variant keeps six slab addresses in scratch ACROSS the loop (12 registers over the 168 of the
-    // 12-wave form: stored before the first stage, reloaded in the epilogue, nothing inside the loop -- a workgroup of a split launch runs one tile)
+    // 128- or 256-row tiles (mm_plan decides); both variants fit the 168 registers of the 12-wave form (152 / 100) without scratch
     if (mt != 2 && mt != 4) return (int)hipErrorInvalidValue;
     const int e = mt == 4 ? mm_launch_k<T, 4, true, 4>(a, grid, st) : mm_launch_k<T, 4, true, 2>(a, grid, st);
     if (e != 0) return e;
