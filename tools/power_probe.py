@@ -41,7 +41,7 @@ def run(name, fn, seconds=3.0, flops=None):
 torch.cuda.init()
 print("sensors:", BoardSampler(0).sens, "| lib:", os.environ.get("GSWM_LIB", "(in-tree)"), flush=True)
 what = sys.argv[1] if len(sys.argv) > 1 else "all"
-dt = torch.float16
+dt = torch.bfloat16 if "bf16" in sys.argv else torch.float16          # (bf16: same kernels, 8-bit mantissas -- how much of the power is the multipliers' width?)
 time.sleep(1.0)
 with BoardSampler(0, 0.02) as sm0:
     time.sleep(0.3)
@@ -49,7 +49,7 @@ print("idle:", sm0.summary(), flush=True)
 if what in ("attn", "all"):
     B, S, H = 128, 4096, 5
     g = torch.Generator().manual_seed(0)
-    q, k, v = (torch.randn(B, S, H * 64, generator=g).cuda().half() for _ in range(3))
+    q, k, v = (torch.randn(B, S, H * 64, generator=g).cuda().to(dt) for _ in range(3))
     vt = v.transpose(1, 2).contiguous()
     run("attention S=4096 H=5 B=128 (random operands)", lambda: pf.attention_hd64(q, k, vt, H), flops=4.0 * B * H * S * S * 64)
     z = torch.zeros_like(q); zt = torch.zeros_like(vt)
