@@ -1255,7 +1255,7 @@ int gsw_mm_get_config(int* tile_rows, int* split_mask) {
 // (4096 x 1280 outputs: 127 vs 162 us at K = 11520; 52 vs 69 at K = 5120; the round-3 rule kept 256 rows there from a sweep whose weights were L2-hot).  Short K keeps
 // the measured rule of round 3 (128-row tiles whenever 256-row ones do not fill the chip: a short-K weight matrix stays in L2 and all CUs win), more than one round
 // keeps 256-row tiles (a half tile re-fetches the weight tile twice as often).
-// Split: at most 128 tiles, at least 8 stages, up to 16 ways and 256 workgroups, 128- or 256-row tiles, taken for a predicted gain of 5 % or more.  Forced splits
+// Split: at most 128 tiles, at least 8 stages, up to 32 ways (one image at 8 x 8: 8 tiles x 32 = the whole chip, 19.9 vs 21.1 us at 16 ways) and 256 workgroups, 128- or 256-row tiles, taken for a predicted gain of 5 % or more.  Forced splits
 // (max_splits > 1: tests) use 128 rows unless gsw_mm_config forces the 256-row tile.
 struct MMPlan { int bm; int splits; double t_us; };
 static inline double mm_stage_us(int bm, double W) {
@@ -1290,7 +1290,7 @@ static MMPlan mm_plan(int64_t M, int64_t tiles_n, int32_t P, bool can_split, int
         if (bm_c == 128 && bm_env == 256) continue;
         const int64_t nt_c = bm_c == 256 ? nt256 : nt128;
         if (nt_c > 128) continue;
-        for (int s_ = 2; s_ <= 16 && s_ * nt_c <= 256 && 2 * s_ <= P; ++s_) {
+        for (int s_ = 2; s_ <= 32 && s_ * nt_c <= 256 && 2 * s_ <= P; ++s_) {
             const double t = 12.5 + mm_stage_us(bm_c, (double)(s_ * nt_c)) * (double)((P + s_ - 1) / s_) + 0.014 * (double)(s_ * nt_c * (bm_c / 128));
             if (t < best) { best = t; pl.bm = bm_c; pl.splits = s_; pl.t_us = t; }
         }

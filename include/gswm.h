@@ -278,9 +278,9 @@ int gsw_mm_get_config(int* tile_rows, int* split_mask); /* the current values (e
 
 /* (DEPRECATED thread-local form of GswMmExtras.workspace_*.)  Split-K workspace of the CALLING THREAD (caller-owned device memory on the device of the streams it launches on; 16-byte aligned).
  * Small-batch launches of the eps model -- one image's 8 x 8 level is a single 64-row tile against 180-360 K stages (the reference's own use:
- * extract.py:112-117 inverts ONE latent per call) -- cannot fill 256 CUs with output tiles.  When a workspace is set, a launch whose 128-row
- * tiling has <= 128 tiles lets up to 16 workgroups share a tile's K stages whenever a small cost model (fitted to tools/splitk_sweep.py) predicts
- * a gain of 20 % or more: each workgroup dumps its fp32 accumulators into a slab ([splits][tiles][8 waves][5 * (tile rows / 64) accumulators][64 lanes] float4), and
+ * extract.py:112-117 inverts ONE latent per call) -- cannot fill 256 CUs with output tiles.  When a workspace is set, a launch whose 128- or 256-row
+ * tiling has <= 128 tiles lets up to 32 workgroups share a tile's K stages (at most 256 workgroups in all) whenever the engine's cost model (fitted to
+ * tools/splitk_tile_sweep.py) predicts a gain of 5 % or more: each workgroup dumps its fp32 accumulators into a slab ([splits][tiles][8 waves][5 * (tile rows / 64) accumulators][64 lanes] float4), and
  * a second kernel adds the slabs in split order (deterministic) and runs the epilogue of the launch's mode.  bytes = 0 removes the workspace
  * (launches run unsplit).  40 MiB covers every launch (256 slabs of 160 KiB: 256-row tiles; 128-row tiles need half).
  * The workspace is scratch between a launch and its reduce kernel, both on the launch's stream: launches on ONE stream may share it, launches

@@ -6,7 +6,8 @@ mkdir -p $O
 cd $R
 timeout 1200 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc=$?"
 timeout 600 python3 bench.py --tier e2e --batch 1 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_e2e_b1.json 2> $O/bench_e2e_b1.err; echo "b1 rc=$?"
-timeout 600 python3 bench.py --tier e2e --batch 8 --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_e2e_b8.json 2> $O/bench_e2e_b8.err; echo "b8 rc=$?"
+timeout 600 python3 bench.py --tier e2e --batch 8 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_e2e_b8.json 2> $O/bench_e2e_b8.err; echo "b8 rc=$?"
+timeout 900 python3 bench.py --tier e2e --batch 32 --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_e2e_b32.json 2> $O/bench_e2e_b32.err; echo "b32 rc=$?"
 timeout 900 python3 bench.py --tier e2e --batch 32 --steps 1 --warmup 1 --image-stages vae+jpeg --no-cpu-baseline > $O/bench_sd21_jpeg_b32.json 2> $O/bench_sd21_jpeg_b32.err; echo "jpeg rc=$?"
 timeout 900 python3 bench.py --tier e2e --batch 16 --steps 1 --warmup 1 --unet sd15 --height 768 --width 768 --no-cpu-baseline > $O/bench_sd15_768_b16.json 2> $O/bench_sd15_768_b16.err; echo "sd15 rc=$?"
 timeout 300 python3 bench.py --gpus 1 --preflight > $O/preflight_1gpu.json 2> $O/preflight_1gpu.err; echo "preflight rc=$?"
@@ -37,7 +38,7 @@ du -sh $O; ls $O | head -50
 python3 -c "
 import json
 d=json.load(open('$O/bench_default.json')); print('default', d['value'], d['ms_per_step'], d['lossless'], d['roofline']['achieved'], d['roofline'].get('dense_tflops'), d['roofline'].get('conv3x3_tflops'), d['cpu_baseline'], d['tiers']['codec']['value'], d['tiers']['codec']['cpu_baseline'])
-for f in ('bench_e2e_b1','bench_e2e_b8','bench_sd21_jpeg_b32','bench_sd15_768_b16'):
+for f in ('bench_e2e_b1','bench_e2e_b8','bench_e2e_b32','bench_sd21_jpeg_b32','bench_sd15_768_b16'):
     d=json.load(open('$O/'+f+'.json')); print(f, d['value'], d['ms_per_step'], d['lossless'], d['fallbacks_off_the_hand_written_path'])
 print(open('$O/preflight_1gpu.json').read())
 "
