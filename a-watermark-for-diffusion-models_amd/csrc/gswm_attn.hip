@@ -33,6 +33,7 @@
 // the two streams any better than the wave scheduler already does across the 2-4 resident waves.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
 #include <cstdlib>
 
@@ -85,6 +86,8 @@ struct AttnArgs {
     float scale_log2;   // softmax scale * log2(e)
     uint32_t nqt;       // query tiles per (batch, head)
     uint32_t total;     // nqt * B * H
+    uint32_t ksplit;    // KVS kernels: workgroups that share a query tile, each over its own range of key tiles (1 elsewhere)
+    float* part;        // KVS kernels: partial results [total][ksplit][4 waves][DB * 16 + 2][64 lanes] floats (unnormalised O^T accumulators, running maximum, partial row sum)
 };
 
 constexpr uint32_t VP = 136;                               // V^T LDS row pitch in bytes (64 keys + 8 B: conflict-free ds_read_b64)
@@ -101,7 +104,10 @@ constexpr uint32_t VP = 136;                               // V^T LDS row pitch 
 // RAGGED: Sq is not a multiple of the workgroup tile and / or Sk not a multiple of 64 (the mid block: 64 tokens at 512x512, 144 at 768x768;
 // 576 tokens at the SD 1.5 third level).  Query lanes past Sq read row 0 and store nothing; key rows / V^T columns past Sk are fetched
 // from a clamped (valid, finite) address and masked through Sk_valid like padded context keys.
-template <typename T, int QB, int DU, bool PAIR, bool RAGGED, bool PIPE = false>
+// KVS (QB = 1, whole tiles; one image's self-attention: 160 workgroups for 256 CUs, each walking 64 key tiles): `ksplit` workgroups share a query tile, each over its
+// own range of key tiles; they leave their unnormalised accumulators, running maximum and partial row sum in a workspace and gsw_attn_combine_kernel merges them
+// (the usual rescaling by 2^(m_s - m)).  One image at 64 x 64: 62 -> ~30 us per launch.
+template <typename T, int QB, int DU, bool PAIR, bool RAGGED, bool PIPE = false, bool KVS = false>
 #ifndef ATTN_MINWAVES
 #define ATTN_MINWAVES 2          // (tools/attn_ablate.sh builds side libraries with 3 / 4: occupancy experiments)
 #endif
@@ -114,6 +120,7 @@ __global__ __launch_bounds__(256, (DU > 10 ? 1 : (QB == 1 ? ATTN_MINWAVES : 2)))
     constexpr int NU = (64 * DU + 255) / 256;                     // 16-byte staging units per thread, tile and operand
     constexpr uint32_t NSTG = PIPE ? 3 : (PAIR ? 4 : 2);
     static_assert(!PIPE || (QB == 1 && !RAGGED && !PAIR), "the cross-tile pipeline: 32 queries per wave, whole tiles");
+    static_assert(!KVS || (QB == 1 && !RAGGED && !PAIR && !PIPE), "key-split form: 32 queries per wave, whole tiles, the plain two-stage loop");
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];          // NSTG * STAGE bytes
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u, h = lane >> 5, c32 = lane & 31u;
     constexpr uint32_t QW = 32u * QB, QWG = 4u * QW;          // queries per wave / per workgroup
@@ -121,7 +128,10 @@ __global__ __launch_bounds__(256, (DU > 10 ? 1 : (QB == 1 ? ATTN_MINWAVES : 2)))
     // XCD-aware placement: hardware sends workgroup b to XCD b % 8; give each XCD a contiguous range of logical ids, whose
     // consecutive members are the query tiles of one (batch, head)
     uint32_t logical = blockIdx.x;
-    if ((p.total & 7u) == 0) logical = (blockIdx.x & 7u) * (p.total >> 3) + (blockIdx.x >> 3);
+    const uint32_t total_wg = KVS ? p.total * p.ksplit : p.total;      // (KVS: the splits of a query tile are neighbours, so the K / V of a (batch, head) still meet in one L2)
+    if ((total_wg & 7u) == 0) logical = (blockIdx.x & 7u) * (total_wg >> 3) + (blockIdx.x >> 3);
+    uint32_t ks = 0;
+    if constexpr (KVS) { const uint32_t lq = logical / p.ksplit; ks = logical - lq * p.ksplit; logical = lq; }
     const uint32_t bh = logical / p.nqt, qt = logical - bh * p.nqt;
     const uint32_t b = bh / (uint32_t)p.H, hh = bh - b * (uint32_t)p.H;
 
@@ -560,19 +570,34 @@ __global__ __launch_bounds__(256, (DU > 10 ? 1 : (QB == 1 ? ATTN_MINWAVES : 2)))
 #endif
         }
     } else {
-        GSW_ATTN_GLOAD(0)
+        // (KVS: this workgroup's share of the key tiles)
+        const int32_t t_lo = KVS ? (int32_t)(((int64_t)ks * nt) / (int32_t)p.ksplit) : 0;
+        const int32_t t_hi = KVS ? (int32_t)(((int64_t)(ks + 1u) * nt) / (int32_t)p.ksplit) : nt;
+        GSW_ATTN_GLOAD(t_lo << 6)
         GSW_ATTN_LSTORE(0u)
         __syncthreads();
-        for (int32_t t = 0; t < nt; ++t) {
+        for (int32_t t = t_lo; t < t_hi; ++t) {
             // prefetch the next tile into registers -- unconditionally (the last iteration re-fetches its own tile into the idle stage):
             // a conditional load made the compiler merge the registers right after the branch, i.e. wait for HBM inside the MFMA phase
-            const int32_t tn = t + 1 < nt ? t + 1 : t;
+            const int32_t tn = t + 1 < t_hi ? t + 1 : t;
             GSW_ATTN_GLOAD(tn << 6)
             __builtin_amdgcn_sched_barrier(0);          // keep the prefetch at the top of the iteration (the scheduler sinks it otherwise)
-            tile((uint32_t)(t & 1), t);
-            GSW_ATTN_LSTORE((uint32_t)((t + 1) & 1))
+            tile((uint32_t)((t - t_lo) & 1), t);
+            GSW_ATTN_LSTORE((uint32_t)((t - t_lo + 1) & 1))
             __syncthreads();
         }
+    }
+
+    if constexpr (KVS) {
+        // ---- partial result of this key range: accumulators as they are (one coalesced 256-byte store per register), then m and the lane's partial row sum
+        float* base = p.part + (((size_t)logical * p.ksplit + ks) * 4u + wave) * (size_t)((DB * 16 + 2) * 64) + lane;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) base[(db * 16 + i) * 64] = o[0][db][i];
+        base[(DB * 16) * 64] = m_i[0];
+        base[(DB * 16 + 1) * 64] = l_i[0];
+        return;
     }
 
     // ---- normalise and store: lane holds O^T[d][query c32] for d = db*32 + (i/4)*8 + h*4 + (i%4)
@@ -604,6 +629,53 @@ __global__ __launch_bounds__(256, (DU > 10 ? 1 : (QB == 1 ? ATTN_MINWAVES : 2)))
 #undef GSW_ATTN_UNIT_DECL
 }
 
+// Second half of a key-split attention launch: one workgroup per query tile with the thread geometry of the first half; every lane merges its `ksplit` partial
+// accumulators (fixed order: deterministic), normalises and stores like the unsplit kernel.
+template <typename T, int DU>
+__global__ __launch_bounds__(256) void gsw_attn_combine_kernel(AttnArgs p) {
+    using v4 = typename AT<T>::v4;
+    constexpr int D = DU * 8, DB = (D + 31) / 32;
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u, h = lane >> 5, c32 = lane & 31u;
+    const uint32_t logical = blockIdx.x;
+    const uint32_t bh = logical / p.nqt, qt = logical - bh * p.nqt;
+    const uint32_t b = bh / (uint32_t)p.H, hh = bh - b * (uint32_t)p.H;
+    const uint32_t qi = qt * 128u + wave * 32u + c32;
+    constexpr size_t REC = (size_t)(DB * 16 + 2) * 64;
+    const float* base = p.part + ((size_t)logical * p.ksplit * 4u + wave) * REC + lane;
+    float m = -INFINITY;
+    for (uint32_t s = 0; s < p.ksplit; ++s) m = fmaxf(m, base[(size_t)s * 4u * REC + (DB * 16) * 64]);
+    f32x16 o[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[db][i] = 0.f;
+    float l = 0.f;
+    for (uint32_t s = 0; s < p.ksplit; ++s) {
+        const float* r = base + (size_t)s * 4u * REC;
+        const float sc = __builtin_amdgcn_exp2f(r[(DB * 16) * 64] - m);
+        l = fmaf(r[(DB * 16 + 1) * 64], sc, l);
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o[db][i] = fmaf(r[(db * 16 + i) * 64], sc, o[db][i]);
+    }
+    const float inv = 1.0f / xhalf_sum(l);
+    T* O = reinterpret_cast<T*>(p.o) + ((int64_t)b * p.Sq + qi) * p.ldo + hh * (uint32_t)D;
+#pragma unroll
+    for (int db = 0; db < DB; ++db) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int d0 = db * 32 + g * 8 + (int)h * 4;
+            if (db * 32 + g * 8 + 8 <= D || d0 < D) {          // rows >= head_dim are padding
+                v4 w;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w[j] = (T)(o[db][g * 4 + j] * inv);
+                *reinterpret_cast<v4*>(O + d0) = w;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 #ifndef ATTN_PIPE_MIN_TILES
@@ -611,9 +683,28 @@ __global__ __launch_bounds__(256, (DU > 10 ? 1 : (QB == 1 ? ATTN_MINWAVES : 2)))
                                         // 3.74 vs 3.63 ms in the QB = 1 form, 3.28 ms for QB = 2; profiles/r04g_attention_ablation_and_isa_mix.txt), kept as an A/B switch (GSW_ATTN_PIPE=1)
 #endif
 template <typename T, int QB, int DU>
-static int launch_attn_cfg(const AttnArgs& a, uint32_t grid, bool ragged, hipStream_t st) {
+static int launch_attn_cfg(const AttnArgs& a, uint32_t grid, bool ragged, float* ws, int64_t ws_bytes, hipStream_t st) {
     constexpr int KC = (DU + 1) / 2, DB = (DU * 8 + 31) / 32;
     constexpr uint32_t stage = 64 * (KC * 32 + 16) + DB * 32 * 136;
+    // Key-split form: few query tiles against many key tiles (one image's self-attention at 64 x 64: 62 -> 49 us).  As many splits as keep every workgroup
+    // resident at once (2 per CU); only from 32 key tiles up -- the second launch and the partial results cost ~12 us, and at 16 tiles (32 x 32: 17.6 -> 21.4 us)
+    // that is more than the split saves.  Needs the caller's workspace (gsw_attention_ws); GSW_ATTN_KVS=0 switches it off (A/B), k > 1 forces k ways from 8 tiles up.
+    if constexpr (QB == 1 && (DU == 8 || DU == 5)) {
+        static const int kvs_env = getenv("GSW_ATTN_KVS") ? atoi(getenv("GSW_ATTN_KVS")) : 1;
+        const int32_t nt = a.Sk >> 6;
+        if (!ragged && kvs_env && ws && a.Sk_valid == a.Sk && a.total <= 256u && nt >= (kvs_env > 1 ? 8 : 32)) {
+            uint32_t ksplit = (uint32_t)std::min<int64_t>(std::min<int64_t>(512 / a.total, nt / 4), 8);
+            if (kvs_env > 1) ksplit = (uint32_t)std::min<int>(kvs_env, nt);                                   // (tests: force a split count)
+            const int64_t need = (int64_t)a.total * ksplit * 4 * (DB * 16 + 2) * 64 * (int64_t)sizeof(float);
+            if (ksplit >= 2 && need <= ws_bytes) {
+                AttnArgs k = a;
+                k.ksplit = ksplit; k.part = ws;
+                hipLaunchKernelGGL((gsw_attn_fwd_kernel<T, 1, DU, false, false, false, true>), dim3(a.total * ksplit), dim3(256), 2 * stage, st, k);
+                hipLaunchKernelGGL((gsw_attn_combine_kernel<T, DU>), dim3(a.total), dim3(256), 0, st, k);
+                return GSW_OK;
+            }
+        }
+    }
     static const int pair_env = getenv("GSW_ATTN_PAIR") ? atoi(getenv("GSW_ATTN_PAIR")) : 1;      // A/B switch for profiling
     const bool pair = !ragged && pair_env && 4 * stage <= 80 * 1024 && (a.Sk >> 6) >= 16;      // long key sequences only: +2 % at 4096 keys, a loss at 256
     // the cross-tile pipeline (QB = 1 form only): GSW_ATTN_PIPE=0 / 1 forces it off / on where it applies
@@ -644,15 +735,21 @@ static int launch_attn_cfg(const AttnArgs& a, uint32_t grid, bool ragged, hipStr
 }
 
 template <typename T>
-static int launch_attn(const AttnArgs& a, int head_dim, int QB, uint32_t grid, bool ragged, hipStream_t st) {
-    if (head_dim == 64) return QB == 2 ? launch_attn_cfg<T, 2, 8>(a, grid, ragged, st) : launch_attn_cfg<T, 1, 8>(a, grid, ragged, st);
-    if (head_dim == 40) return QB == 2 ? launch_attn_cfg<T, 2, 5>(a, grid, ragged, st) : launch_attn_cfg<T, 1, 5>(a, grid, ragged, st);
-    if (head_dim == 80) return launch_attn_cfg<T, 1, 10>(a, grid, ragged, st);
-    return launch_attn_cfg<T, 1, 20>(a, grid, ragged, st);
+static int launch_attn(const AttnArgs& a, int head_dim, int QB, uint32_t grid, bool ragged, float* ws, int64_t wsb, hipStream_t st) {
+    if (head_dim == 64) return QB == 2 ? launch_attn_cfg<T, 2, 8>(a, grid, ragged, ws, wsb, st) : launch_attn_cfg<T, 1, 8>(a, grid, ragged, ws, wsb, st);
+    if (head_dim == 40) return QB == 2 ? launch_attn_cfg<T, 2, 5>(a, grid, ragged, ws, wsb, st) : launch_attn_cfg<T, 1, 5>(a, grid, ragged, ws, wsb, st);
+    if (head_dim == 80) return launch_attn_cfg<T, 1, 10>(a, grid, ragged, ws, wsb, st);
+    return launch_attn_cfg<T, 1, 20>(a, grid, ragged, ws, wsb, st);
 }
 
 int gsw_attention(const void* q_dev, const void* k_dev, const void* vt_dev, void* out_dev, int B, int H, int head_dim, int Sq, int Sk, int Sk_valid,
                   int ldq, int ldk, int ldo, float scale, int dtype, void* stream) {
+    return gsw_attention_ws(q_dev, k_dev, vt_dev, out_dev, B, H, head_dim, Sq, Sk, Sk_valid, ldq, ldk, ldo, scale, dtype, nullptr, 0, stream);
+}
+
+int gsw_attention_ws(const void* q_dev, const void* k_dev, const void* vt_dev, void* out_dev, int B, int H, int head_dim, int Sq, int Sk, int Sk_valid,
+                     int ldq, int ldk, int ldo, float scale, int dtype, void* workspace_dev, int64_t workspace_bytes, void* stream) {
+    if (workspace_bytes < 0 || (workspace_bytes > 0 && !workspace_dev) || ((uintptr_t)workspace_dev & 15)) return GSW_ERR_BAD_ARG;
     // q: [B, Sq, >= H*head_dim] (row stride ldq), k: [B, Sk, >= H*head_dim] (row stride ldk), vt: [B, H*head_dim, Sk] contiguous (V
     // transposed), out: [B, Sq, >= H*head_dim] (row stride ldo).  head_dim 40 / 64 / 80 / 160; any Sq; Sk % 8 == 0; row strides
     // multiples of 8 elements; keys in [Sk_valid, Sk) are padding and get zero weight.
@@ -675,8 +772,10 @@ int gsw_attention(const void* q_dev, const void* k_dev, const void* vt_dev, void
     a.scale_log2 = scale * 1.4426950408889634f;
     a.nqt = (uint32_t)((Sq + 128 * QB - 1) / (128 * QB));
     a.total = (uint32_t)total;
-    const int rc = dtype == GSW_F16 ? launch_attn<_Float16>(a, head_dim, QB, (uint32_t)total, ragged, (hipStream_t)stream)
-                                    : launch_attn<__bf16>(a, head_dim, QB, (uint32_t)total, ragged, (hipStream_t)stream);
+    a.ksplit = 1; a.part = nullptr;
+    float* const ws = workspace_bytes > 0 ? (float*)workspace_dev : nullptr;
+    const int rc = dtype == GSW_F16 ? launch_attn<_Float16>(a, head_dim, QB, (uint32_t)total, ragged, ws, workspace_bytes, (hipStream_t)stream)
+                                    : launch_attn<__bf16>(a, head_dim, QB, (uint32_t)total, ragged, ws, workspace_bytes, (hipStream_t)stream);
     if (rc != GSW_OK) return rc;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g_last_hip_error = (int)e; return GSW_ERR_HIP; }

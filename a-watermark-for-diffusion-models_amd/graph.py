@@ -52,7 +52,7 @@ def _switches():
     N.lib().gsw_mm_get_config(C.byref(tr), C.byref(sm))
     return (U.FUSED_KERNELS, U.USE_PF, U.UPSAMPLE_SUBPIXEL, U.CACHE_CONTEXT_KV, U.FUSED_QK, U.FUSED_QKV, U.OWN_ATTENTION, U.OWN_GEMM, U.TEMB_TABLE,
             U.CONV_OUT_DIRECT_MAX_PIXELS, U.CFG_SHARED_PREFIX, pf.FUSE_GN_STATS, pf.GN_FUSED_MAX_WGS, pf.GN_FUSED_MAX_PIXELS, pf.FOLD_LN, pf.FOLD_LN_MIN_ROWS, pf.SPLITK_MAX,
-            pf.SPLITK_BYTES, pf.SMALL_GEMM_MAX_ROWS, tr.value, sm.value)
+            pf.SPLITK_BYTES, pf.SMALL_GEMM_MAX_ROWS, pf.ATTN_KEY_SPLIT, tr.value, sm.value)
 
 
 class _Entry:

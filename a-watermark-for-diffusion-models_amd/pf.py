@@ -78,6 +78,7 @@ class PF:
 # ---- split-K workspace of the matmul engine (gsw_mm_set_workspace): one scratch buffer per (device, stream), handed to the library whenever the
 # calling thread's (device, stream) changes.  Launches on one stream share it (a launch and its reduce kernel are stream-ordered).
 SPLITK_BYTES = 40 << 20        # 256 slabs of 160 KiB (256-row tiles; 80 KiB for 128-row tiles): every launch that splits fits
+ATTN_KEY_SPLIT = True          # self-attention with few query tiles (one image) splits its keys over several workgroups (gsw_attention_ws)
 LAUNCH_LOG = None              # a list: every engine launch appends its GswMmExtras (tests: which launches split, and how)
 SPLITK_MAX = 0                 # 0 automatic, 1 never split, k > 1: force k-way splits wherever K allows (parity tests)
 _WS = {}
@@ -755,9 +756,13 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, sc
     elif tuple(out.shape) != (B, Sq, inner) or out.dtype != q.dtype or out.device != q.device or not out.is_contiguous():
         raise ValueError("attention: out must be a contiguous [B, Sq, heads * d] tensor like q")
     with torch.cuda.device(q.device):
-        N.check(N.lib().gsw_attention(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), B, heads, d, Sq, Sk,
-                                      Sk if valid_keys is None else int(valid_keys), ldq, ldk, inner,
-                                      float(scale if scale is not None else d ** -0.5), _dt(q.dtype), _stream_ptr()))
+        # the split-K scratch of this stream doubles as the key-split scratch (few query tiles against many key tiles: one image's self-attention); both are
+        # free between two launches of a stream
+        ws = _workspace(q.device) if ATTN_KEY_SPLIT else None
+        N.check(N.lib().gsw_attention_ws(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), B, heads, d, Sq, Sk,
+                                         Sk if valid_keys is None else int(valid_keys), ldq, ldk, inner,
+                                         float(scale if scale is not None else d ** -0.5), _dt(q.dtype), 0 if ws is None else ws.data_ptr(),
+                                         0 if ws is None else ws.numel(), _stream_ptr()))
     return out
 
 

@@ -347,6 +347,13 @@ int gsw_conv_up2x_pf(const void* x_dev, const void* w4_dev, const void* bias_dev
  * loads and masked keys).  gsw_attention_hd64 == gsw_attention(head_dim = 64). */
 int gsw_attention(const void* q_dev, const void* k_dev, const void* vt_dev, void* out_dev, int B, int H, int head_dim, int Sq, int Sk,
                   int Sk_valid, int ldq, int ldk, int ldo, float scale, int dtype, void* stream);
+/* The same with a caller-owned scratch buffer (16-byte aligned device memory, free again when the launch's stream has run it): few query tiles against many
+ * key tiles -- one image's self-attention at 64 x 64 is 160 workgroups for 256 CUs, each walking 64 key tiles -- are then run as up to 8 workgroups per query
+ * tile (at most 256 query tiles, at least 2048 keys), each over its own range of keys, and a second small kernel merges their partial results (deterministic).  4 MiB per 100 query tiles x splits is
+ * enough (bytes = query tiles x splits x 4 x (16 ceil(head_dim / 32) + 2) x 256); a smaller buffer, or none, runs the unsplit kernel.  The split-K scratch of
+ * GswMmExtras may be shared: both are free between launches of one stream. */
+int gsw_attention_ws(const void* q_dev, const void* k_dev, const void* vt_dev, void* out_dev, int B, int H, int head_dim, int Sq, int Sk,
+                     int Sk_valid, int ldq, int ldk, int ldo, float scale, int dtype, void* workspace_dev, int64_t workspace_bytes, void* stream);
 int gsw_attention_hd64(const void* q_dev, const void* k_dev, const void* vt_dev, void* out_dev, int B, int H, int Sq, int Sk, int Sk_valid,
                        int ldq, int ldk, int ldo, float scale, int dtype, void* stream);
 

@@ -339,3 +339,53 @@ torch.save(out, sys.argv[1])
         os.remove(path)
     for a, b in zip(*res):
         assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("B,H,Sq,Sk,D", [(1, 5, 4096, 4096, 64), (1, 10, 1024, 1024, 64), (2, 3, 128, 2112, 64), (1, 2, 256, 2752, 64), (1, 8, 1024, 2304, 40), (2, 5, 2048, 512, 64)])
+def test_attention_key_split_vs_unsplit_and_fp32(G, dtype, B, H, Sq, Sk, D):
+    """gsw_attention_ws: few query tiles against many key tiles (one image's self-attention) run as several workgroups per query tile over disjoint key ranges +
+    gsw_attn_combine_kernel, from 32 key tiles up.  Key-tile counts that do not divide by the split count (64 -> 21, 21, 22; 33, 43 and 36 tiles over 8 workgroups),
+    head_dim 40, both dtypes, two shapes below the threshold (same bits as unsplit); against the unsplit kernel (pf.ATTN_KEY_SPLIT = False) and fp32 torch; deterministic."""
+    pf = G.pf
+    g = torch.Generator().manual_seed(Sq + Sk + H)
+    q = (torch.randn(B, Sq, H * D, generator=g) * 2.0).to(dtype).cuda()
+    k = torch.randn(B, Sk, H * D, generator=g).to(dtype).cuda()
+    v = torch.randn(B, Sk, H * D, generator=g).to(dtype).cuda()
+    vt = v.transpose(1, 2).contiguous()
+    assert pf.ATTN_KEY_SPLIT
+    a = pf.attention(q, k, vt, H)
+    a2 = pf.attention(q, k, vt, H)
+    pf.ATTN_KEY_SPLIT = False
+    try:
+        b = pf.attention(q, k, vt, H)
+    finally:
+        pf.ATTN_KEY_SPLIT = True
+    qf, kf, vf = (t.float().view(B, t.shape[1], H, D).transpose(1, 2) for t in (q, k, v))
+    ref = (torch.softmax(qf @ kf.transpose(-1, -2) * D ** -0.5, dim=-1) @ vf).transpose(1, 2).reshape(B, Sq, H * D)
+    tol = (4e-3 if dtype == torch.float16 else 2e-2) * max(1.0, ref.abs().max().item())
+    assert torch.equal(a, a2)
+    assert (a.float() - ref).abs().max().item() <= tol and (b.float() - ref).abs().max().item() <= tol
+    assert (a.float() - b.float()).abs().max().item() <= tol
+    if Sk >= 2048:
+        assert not torch.equal(a, b) or dtype == torch.bfloat16          # the split path really ran (another summation order; bf16 may round both to the same bits)
+    else:
+        assert torch.equal(a, b)
+
+
+def test_attention_ws_validation_and_small_workspace_falls_back(G):
+    lib = G.N.lib()
+    q = torch.randn(1, 1024, 640, device="cuda").half()
+    vt = q.transpose(1, 2).contiguous()
+    out = torch.empty_like(q)
+    ws = torch.empty(1 << 20, dtype=torch.uint8, device="cuda")
+    args = (q.data_ptr(), q.data_ptr(), vt.data_ptr(), out.data_ptr(), 1, 10, 64, 1024, 1024, 1024, 640, 640, 640, 0.125, G.N.GSW_F16)
+    assert lib.gsw_attention_ws(*args, None, 16, None) == G.N.GSW_ERR_BAD_ARG and lib.gsw_attention_ws(*args, ws.data_ptr() + 8, 1024, None) == G.N.GSW_ERR_BAD_ARG
+    assert lib.gsw_attention_ws(*args, ws.data_ptr(), -1, None) == G.N.GSW_ERR_BAD_ARG
+    # a shape below the key-tile threshold (and a buffer too small for any split of it): the unsplit kernel -- same bits as no buffer at all
+    assert lib.gsw_attention_ws(*args, ws.data_ptr(), ws.numel(), None) == 0
+    torch.cuda.synchronize()
+    small = out.clone()
+    assert lib.gsw_attention_ws(*args, None, 0, None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(small, out)
