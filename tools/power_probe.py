@@ -1,7 +1,7 @@
 """Clock and power while a kernel family runs for seconds: is a kernel's time set by a unit's throughput or by the board's power limit?
 A sampler thread reads the GPU's sysfs sensors (hwmon power1_average / power1_input, freq1_input = shader clock; falls back to `rocm-smi --json`) every 20 ms while
 the main thread replays one workload back to back; per workload: kernel time, mean / min shader clock, mean / max power.
-usage: python tools/power_probe.py [attn|conv|dense|mm|all]      (mm: the convolution and dense lines on random operands only)
+usage: python tools/power_probe.py [attn|conv|dense|geglu|mm|all]      (mm: the convolution and dense lines on random operands only)
       (GSWM_LIB selects an ablation build of the attention kernel, tools/attn_ablate.sh)"""
 import os
 import sys
@@ -64,6 +64,15 @@ if what in ("conv", "all", "mm"):
             continue
         xz = pf.PF.from_nchw(torch.zeros(B, C, Hh, Hh, device="cuda", dtype=dt)); wz = torch.zeros_like(w)
         run(f"conv3x3 {Hh}x{Hh} C={C} N={N} B={B} (all-zero operands)", lambda: pf.conv_pf(xz, wz, b), flops=2.0 * B * Hh * Hh * 9 * C * N)
+if what in ("geglu", "all"):
+    # the transformer's GEGLU projection at 64 x 64 / 32 x 32 (five K stages, then the gelu epilogue with the matrix pipe idle): is THIS one at the power limit?
+    for (M, K, I) in ((524288, 320, 1280), (131072, 640, 2560), (32768, 1280, 5120)):
+        x = torch.randn(M, K, device="cuda", dtype=dt)
+        w = (torch.randn(2 * I, K, device="cuda") * K ** -0.5).to(dt); b = torch.randn(2 * I, device="cuda", dtype=dt)
+        wp, bp = pf.pack_geglu_weight(w, b)
+        out = torch.empty(M, I, device="cuda", dtype=dt)
+        run(f"geglu M={M} K={K} N={2 * I} (random operands)", lambda: pf.gemm(x, wp, bp, mode="geglu", out=out), flops=2.0 * M * K * 2 * I)
+        del x, out
 if what in ("dense", "all", "mm"):
     for (M, K, N) in ((524288, 320, 320), (32768, 5120, 1280)):
         x = torch.randn(M, K, device="cuda", dtype=dt); w = (torch.randn(N, K, device="cuda") * K ** -0.5).to(dt)
