@@ -92,12 +92,13 @@ def load_component_state_dict(model_dir: str, component: str) -> Dict[str, torch
     dirs = [os.path.join(model_dir, component), model_dir]
     stems = [stem] + (["pytorch_model"] if stem != "pytorch_model" else [])
     tried = []
+    # every safetensors candidate (single file, fp16 variant, their sharded indexes) of a directory is tried before any pickle-format .bin
     for d in dirs:
         if not os.path.isdir(d):
             continue
-        for st in stems:
-            for variant in ("", ".fp16"):
-                for ext in (".safetensors", ".bin"):
+        for ext in (".safetensors", ".bin"):
+            for st in stems:
+                for variant in ("", ".fp16"):
                     single = os.path.join(d, st + variant + ext)
                     index = single + ".index.json"
                     tried.append(single)

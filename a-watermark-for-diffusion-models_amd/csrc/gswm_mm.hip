@@ -56,6 +56,10 @@ __device__ unsigned long long* g_mm_trace_buf;
 #define MM_STAMP(k) do { } while (0)
 #endif
 
+#ifndef MM_ABL_READ
+#define MM_ABL_READ(stmt) stmt
+#define MM_ABL_MMA(a, b, c) MM<T>::mma(a, b, c)
+#endif
 #define MM_BARRIER() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
 // epilogue barrier: LDS image traffic only -- the DMA prefetch of the next tile stays in flight (no vmcnt wait)
 #define MM_LDS_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); MM_BARRIER(); } while (0)
@@ -76,15 +80,26 @@ __device__ __forceinline__ void mm_lds_read5_b64(uint32_t a, uint2 (&o)[5]) {
     for (int i = 0; i < 5; ++i) o[i] = make_uint2((uint32_t)r[i], (uint32_t)(r[i] >> 32));
 }
 // LayerNorm fold: u and v (1 KiB apart) of a lane's four columns in each of the five column blocks, and (rstd, nrm) of its MT rows (16 rows apart)
+template <uint32_t VOFF>      // VOFF: byte offset of v behind u (1 KiB; 2 KiB for the 320-column tile)
 __device__ __forceinline__ void mm_lds_read_uv(uint32_t a, mm_f4 (&u)[5], mm_f4 (&v)[5]) {
     asm volatile("ds_read_b128 %0, %10\n\tds_read_b128 %1, %10 offset:64\n\tds_read_b128 %2, %10 offset:128\n\tds_read_b128 %3, %10 offset:192\n\tds_read_b128 %4, %10 offset:256\n\t"
-                 "ds_read_b128 %5, %10 offset:1024\n\tds_read_b128 %6, %10 offset:1088\n\tds_read_b128 %7, %10 offset:1152\n\tds_read_b128 %8, %10 offset:1216\n\t"
-                 "ds_read_b128 %9, %10 offset:1280\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(u[0]), "=&v"(u[1]), "=&v"(u[2]), "=&v"(u[3]), "=&v"(u[4]), "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]) : "v"(a) : "memory");
+                 "ds_read_b128 %5, %10 offset:%11\n\tds_read_b128 %6, %10 offset:%12\n\tds_read_b128 %7, %10 offset:%13\n\tds_read_b128 %8, %10 offset:%14\n\t"
+                 "ds_read_b128 %9, %10 offset:%15\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(u[0]), "=&v"(u[1]), "=&v"(u[2]), "=&v"(u[3]), "=&v"(u[4]), "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4])
+                 : "v"(a), "n"(VOFF), "n"(VOFF + 64u), "n"(VOFF + 128u), "n"(VOFF + 192u), "n"(VOFF + 256u) : "memory");
+}
+// one column block's u and v (the wide tile reads them block by block: all five at once do not fit beside 160 accumulators)
+template <uint32_t VOFF>
+__device__ __forceinline__ void mm_lds_read_uv1(uint32_t a, mm_f4& u, mm_f4& v) {
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:%3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(u), "=&v"(v) : "v"(a), "n"(VOFF) : "memory");
 }
 template <int MT>
 __device__ __forceinline__ void mm_lds_read_rows(uint32_t a, mm_f2 (&r)[MT]) {
-    if constexpr (MT == 4)
+    if constexpr (MT == 8)
+        asm volatile("ds_read_b64 %0, %8\n\tds_read_b64 %1, %8 offset:128\n\tds_read_b64 %2, %8 offset:256\n\tds_read_b64 %3, %8 offset:384\n\t"
+                     "ds_read_b64 %4, %8 offset:512\n\tds_read_b64 %5, %8 offset:640\n\tds_read_b64 %6, %8 offset:768\n\tds_read_b64 %7, %8 offset:896\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7]) : "v"(a) : "memory");
+    else if constexpr (MT == 4)
         asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:128\n\tds_read_b64 %2, %4 offset:256\n\tds_read_b64 %3, %4 offset:384\n\ts_waitcnt lgkmcnt(0)"
                      : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]) : "v"(a) : "memory");
     else
@@ -119,37 +134,49 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
     // workspace slab; gsw_mm_reduce_kernel sums the slabs of a tile in a fixed order and runs the epilogue of the launch's mode
     constexpr bool PART = EPI == 4;
     static_assert(!PART || SPLIT, "split-K partial launches use the producer-wave variant");
-    constexpr int WM = 4;                            // waves along M; 2 groups of 4 waves along N
-    constexpr int BM = 64 * MT, BN = 160;
+    // WIDE (MT == 8): the 256 x 320 tile -- 8 multiplying waves as 2 (M) x 4 (N), a wave owns 128 x 80 outputs = 8 x 5 accumulators (160 registers).  Per MFMA it
+    // moves 31 % fewer LDS-DMA bytes and 28 % fewer fragment bytes than the 256 x 160 tile: under the board's power limit the engine's
+    // time follows its energy, and operand movement is ~40 % of it (profiles/r04h_power_cap_probe.txt section 5).  A stage is 72 KiB, so the ring has TWO slots
+    // and the step is scheduled differently (step8 below): fragments are streamed (W sets double-buffered, A fragments through a ring of four) instead of
+    // held twice, ONE barrier per stage sits inside the odd phase, and the DMA of stage s + 2 is issued behind it.
+    constexpr bool WIDE = MT == 8;
+    constexpr int WM = WIDE ? 2 : 4;                 // waves along M; NG groups of WM waves along N
+    constexpr int NG = 8 / WM;
+    constexpr int BM = WM * 16 * MT, BN = NG * 80;
     constexpr int NPR = MT / 2;                      // pairs of row tiles per wave (the epilogue's unit)
-    static_assert(MT == 4 || MT == 2, "wave tile of 64 or 32 rows");
+    static_assert(MT == 8 || MT == 4 || MT == 2, "wave tile of 128, 64 or 32 rows");
+    static_assert(!WIDE || (!SPLIT && EPI != 3 && EPI != 4 && EPI != 5), "the wide tile: 8-wave form, dense rows / PF rows / GEGLU; no split-K, no transposed output, no fused q | k | v");
     constexpr int NPROD = SPLIT ? 4 : 8;             // waves that issue DMA
     constexpr int NPA = BM / 8 / NPROD;              // A pieces (8 rows x 128 B = 1 KiB) per producing wave per stage: 4 (8 with SPLIT)
     constexpr int NPW = BN / 8 / NPROD;              // full rounds of W pieces per producing wave: 2 (5 with SPLIT)
     constexpr int NEXTRA = BN / 8 - NPROD * NPW;     // waves that issue one more W piece: 4 (0 with SPLIT)
     constexpr int NDMA = NPA + NPW;                  // pieces per stage of a wave without the extra one: 6 (13 with SPLIT)
     constexpr uint32_t STAGE = (uint32_t)(BM + BN) * 128u;     // one stage = 64 k-values of every tile row: 52 KiB
-    constexpr uint32_t RING = 3u * STAGE;
-    constexpr int HC = BN / 2;                       // columns owned by a group
+    constexpr uint32_t RING = (WIDE ? 2u : 3u) * STAGE;
+    constexpr int HC = 80;                           // columns owned by a group
     // STG (8-wave dense-row / GEGLU epilogues): the epilogue's per-column / per-row parameters (bias; LayerNorm fold: u, v, the rows' (rstd, nrm)) are
     // staged in the 4 KiB of LDS behind the ring by LDS-DMA pieces wave 7 issues in the tile's first step.  Fetched by the epilogue itself they are
     // vector-memory loads BEHIND the next tile's prefetched stages, i.e. the epilogue's arithmetic starts a full HBM latency late
     // (profiles/r03w_epilogue_param_wait.txt: the GEGLU launches are 6-13 % faster without a bias vector).
     // (not the LayerNorm-folded dense-row epilogue: it sits at the 256-register cap)
-    constexpr bool STG = !SPLIT && !SWAP && !QKV && (EPI == 2 || (EPI == 0 && !LNF));
+    constexpr bool STG = !SPLIT && !SWAP && !QKV && (EPI == 2 || (EPI == 0 && (!LNF || WIDE)));
     constexpr uint32_t PARAM = RING;                 // [0, 1 KiB): bias (fp16) or u (fp32) of the tile's 160 columns; [1, 2): v; [2, 4): (rstd, nrm) of its rows
-    constexpr int NPAR = LNF ? 2 + (BM + 127) / 128 : 1;
+                                                     // (WIDE: 320 columns -- u [0, 2), v [2, 4), rows [4, 6) KiB)
+    constexpr uint32_t PAR_V = WIDE ? 2048u : 1024u, PAR_ROWS = WIDE ? 4096u : 2048u;
+    constexpr int NPCOL = WIDE ? 2 : 1;              // LDS-DMA pieces per fp32 column vector (256 floats each)
+    constexpr int NPAR = LNF ? 2 * NPCOL + (BM + 127) / 128 : 1;
     typedef typename MM<T>::frag frag;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
-    const uint32_t grp = (wave >> 2) & 1u, wm = wave & 3u;
+    const uint32_t grp = WIDE ? (wave >> 1) & 3u : (wave >> 2) & 1u, wm = WIDE ? wave & 1u : wave & 3u;
     const uint32_t pid = SPLIT ? (wave & 3u) : wave;          // index among the producing waves (SPLIT: waves 8..11)
     const bool extra = pid < (uint32_t)NEXTRA;
     // (three steps: the pieces are issued in step 0 and published by the barrier of step 2)
     // with fewer than three steps per tile the pieces are issued inside the epilogue, between two barriers
-    const bool stg = STG && p.P >= 3 && (LNF || p.bias != nullptr);
+    // (WIDE: issued behind the barrier of step 0, covered by the wait in front of the barrier of step 1)
+    const bool stg = STG && p.P >= (WIDE ? 2 : 3) && (LNF || p.bias != nullptr);
     const bool stg7 = stg && wave == 7u;
 
     // LDS rows are 128 B (64 k-values); 16-byte chunks are XOR-swizzled with (row >> 1) & 7.
@@ -297,6 +324,110 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
                                          (__attribute__((address_space(3))) void*)(lds + pr_slot + (uint32_t)BM * 128u + (pid + (uint32_t)NPROD * i) * 1024u), 16, 0, 0);
         pw[i] += w_step;
     };
+    // ---------------------------------------------------------------- WIDE producer: the same walk with BUFFER addressing.  160 accumulators leave no room for
+    // nine 64-bit lane pointers + nine row indices: a piece's address is (buffer base in SGPRs) + (32-bit lane offset) + (scalar offset), and what a stage
+    // advances is the scalar offset only.  Activations: one lane offset per piece (row of this lane x row stride + its swizzled chunk), recomputed when the
+    // segment changes (the row stride does); the segment's tap base is folded into the buffer base so every offset stays non-negative.  Weights: ONE lane offset
+    // for the whole kernel ((8 pid + lane row) rows + chunk); tile column, piece (64 rows apart), tap and channel block live in the scalar offset.  Needs
+    // N % 320 == 0 (no weight-row clamp) and operands below 4 GiB (host-checked).
+    // EPI 0 / 2 (dense operands only, M % 256 == 0 host-checked): the four activation pieces are 64 rows apart too -- one lane offset, scalar piece offsets
+    constexpr bool AFF = EPI == 0 || EPI == 2;
+    uint32_t vo_a[4] = {0u, 0u, 0u, 0u}, vo_w = 0u, so_a = 0u, so_w = 0u, st_a = 0u, st_w = 0u, w_piece = 0u, a_piece = 0u;
+    int32_t seg_rows = -1;                                    // segment vo_a was computed for
+    __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, -1, 0x00020000);
+    int32_t tile_m8 = 0, tile_n8 = 0;
+    auto setup_tile8 = [&](uint32_t it) {
+        decode_tile(it * G + slotx, tile_m8, tile_n8);
+        seg_rows = -1;
+    };
+    auto begin_run8 = [&]() {
+        const MMSeg& s0 = p.seg[0]; const MMSeg& s1 = p.seg[1]; const MMSeg& s2 = p.seg[2];
+        const int32_t sg = pr_seg;
+        const T* x = reinterpret_cast<const T*>(sg == 0 ? s0.x : sg == 1 ? s1.x : s2.x);
+        const int32_t ld = sg == 0 ? s0.ld : sg == 1 ? s1.ld : s2.ld;
+        const int32_t kb = sg == 0 ? s0.kblocks : sg == 1 ? s1.kblocks : s2.kblocks;
+        const int32_t nt = sg == 0 ? s0.ntaps : sg == 1 ? s1.ntaps : s2.ntaps;
+        const int32_t tw = sg == 0 ? s0.tw : sg == 1 ? s1.tw : s2.tw;
+        const int32_t trow = sg == 0 ? s0.tap_row : sg == 1 ? s1.tap_row : s2.tap_row;
+        const int32_t tbase = sg == 0 ? s0.tap_base : sg == 1 ? s1.tap_base : s2.tap_base;
+        const int32_t wk0 = sg == 0 ? s0.wk0 : sg == 1 ? s1.wk0 : s2.wk0;
+        if (seg_rows != sg) {                                 // new tile or new segment: lane offsets of the four activation pieces
+            seg_rows = sg;
+            // (lane row and swizzled chunk are recomputed HERE, behind an empty asm: kept from the kernel's start they are long-lived values the
+            // allocator spills around the main loop)
+            uint32_t l8 = threadIdx.x & 63u;
+            asm volatile("" : "+v"(l8));
+            const uint32_t prow = l8 >> 3;
+            const uint32_t chunk8 = ((l8 & 7u) ^ ((4u * (pid & 1u) + (l8 >> 4)) & 7u)) * 8u;
+            rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(x + (int64_t)tbase * ld), 0, -1, 0x00020000);
+            const int32_t m0 = tile_m8 * BM;
+            if constexpr (AFF) {
+                vo_a[0] = ((uint32_t)(m0 + 8 * (int32_t)pid + (int32_t)prow) * (uint32_t)ld + chunk8) * 2u;
+            } else {
+#pragma unroll
+                for (int i = 0; i < NPA; ++i) {
+                    const int32_t m = m0 + 8 * (int32_t)(pid + (uint32_t)NPROD * i) + (int32_t)prow;
+                    const int32_t mc = m < p.M ? m : p.M - 1;
+                    int32_t b_, y_, x_, row = mc;
+                    if (compact) {
+                        row = pf_row(mc, b_, y_, x_);
+                        if (p.stride == 2) row = b_ * (p.in_Hp * p.in_Wp) + 2 * (y_ - 1) * p.in_Wp + 2 * (x_ - 1);
+                    }
+                    vo_a[i] = ((uint32_t)row * (uint32_t)ld + chunk8) * 2u;
+                }
+            }
+        }
+        so_a = (uint32_t)(pr_kh * trow * ld + pr_kc * 64) * 2u;
+        so_w = (uint32_t)(tile_n8 * BN * p.ldw + wk0 + pr_kh * tw * (kb * 64) + pr_kc * 64) * 2u;
+        if (nt == 1) { pr_run = kb; st_a = 128u; st_w = 128u; }
+        else { pr_run = tw; st_a = (uint32_t)ld * 2u; st_w = (uint32_t)(kb * 64) * 2u; }
+    };
+    auto end_run8 = [&]() {                                  // slow path: next tap row / channel block / segment / tile
+        const MMSeg& s0 = p.seg[0]; const MMSeg& s1 = p.seg[1]; const MMSeg& s2 = p.seg[2];
+        const int32_t sg = pr_seg;
+        const int32_t kb = sg == 0 ? s0.kblocks : sg == 1 ? s1.kblocks : s2.kblocks;
+        const int32_t nt = sg == 0 ? s0.ntaps : sg == 1 ? s1.ntaps : s2.ntaps;
+        const int32_t tw = sg == 0 ? s0.tw : sg == 1 ? s1.tw : s2.tw;
+        bool seg_done = nt == 1;
+        if (!seg_done && ++pr_kh * tw == nt) { pr_kh = 0; seg_done = ++pr_kc == kb; }
+        if (seg_done) {
+            pr_kc = 0; pr_kh = 0;
+            if (++pr_seg == p.nseg) {
+                pr_seg = 0;
+                if (++pr_it == nt_mine) {
+                    // no stage left: the (unconditional) DMA of the remaining steps re-reads the last stage (valid, cached) into ring slots nobody reads
+                    pr_run = 0x7FFFFFFF; st_a = 0u; st_w = 0u;
+                    so_a -= 128u; so_w -= 128u;               // (back inside the last K block: the offsets were already advanced past it)
+                    return;
+                }
+                setup_tile8(pr_it);
+            }
+        }
+        begin_run8();
+    };
+    // piece j = 0 .. 8 of the stage being issued (four activation pieces, then five weight pieces 64 rows apart); the last one completes the stage
+    auto dma_piece8 = [&](int j) {
+        if (j < NPA) {
+            if constexpr (AFF) {
+                if (j == 0) a_piece = so_a;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(lds + pr_slot + (pid + (uint32_t)NPROD * j) * 1024u), 16, (int)vo_a[0], (int)a_piece, 0, 0);
+                a_piece += 64u * 2u * (uint32_t)p.seg[0].ld;
+            } else {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(lds + pr_slot + (pid + (uint32_t)NPROD * j) * 1024u), 16, (int)vo_a[j], (int)so_a, 0, 0);
+            }
+        } else {
+            if (j == NPA) w_piece = so_w;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(lds + pr_slot + (uint32_t)BM * 128u + (pid + (uint32_t)NPROD * (j - NPA)) * 1024u), 16,
+                                                     (int)vo_w, (int)w_piece, 0, 0);
+            w_piece += 64u * 2u * (uint32_t)p.ldw;
+        }
+        if (j == NDMA - 1) {
+            so_a += st_a; so_w += st_w;
+            pr_slot = pr_slot + STAGE == RING ? 0u : pr_slot + STAGE;
+            if (--pr_run == 0) end_run8();
+        }
+    };
     auto dma_h1 = [&]() {
 #pragma unroll
         for (int i = 0; i < NPA / 2; ++i) dma_piece_a(i);
@@ -402,6 +533,20 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // nothing may land in LDS after the workgroup is gone
             return;
         }
+    } else if constexpr (WIDE) {
+        // prologue: stage 0 and the first three pieces of stage 1 (what the tail of an odd phase issues); wait for stage 0
+        {
+            uint32_t l8 = threadIdx.x & 63u;
+            asm volatile("" : "+v"(l8));
+            vo_w = (((8u * pid + (l8 >> 3)) * (uint32_t)p.ldw) + ((l8 & 7u) ^ ((4u * (pid & 1u) + (l8 >> 4)) & 7u)) * 8u) * 2u;
+        }
+        setup_tile8(0);
+        begin_run8();
+#pragma unroll
+        for (int j = 0; j < NDMA; ++j) dma_piece8(j);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) dma_piece8(j);
+        asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     } else {
         static_assert(SPLIT || ((NPA == 4 || NPA == 2) && NPW == 2), "the half-stage split assumes 4 (2) + 2 (+1) pieces per wave");
         // prologue: stages 0 and 1 and the first half of stage 2; wait for stage 0 (counted: the newer pieces stay in flight; exact for waves
@@ -444,19 +589,25 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
         int32_t tm, tn;
         decode_tile(c_it * G + slotx, tm, tn);
         const int32_t m0 = tm * BM, n0 = tn * BN;
-        auto piece = [&](const void* src, uint32_t k) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(lds + PARAM + k * 1024u), 16, 0, 0);
+        uint32_t lane_p = threadIdx.x & 63u;                   // (WIDE: nothing derived from the lane index may be hoisted out of here into the main loop's registers)
+        if constexpr (WIDE) asm volatile("" : "+v"(lane_p));
+        const uint32_t lane = lane_p;
+        auto piece = [&](const void* src, uint32_t byte_off) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(lds + PARAM + byte_off), 16, 0, 0);
         };
         // lanes past the end of a vector / of the rows re-read its last 16 bytes: their LDS positions belong to columns / rows that are never stored
         if constexpr (LNF) {
-            const int32_t nc = min(n0 + 4 * (int32_t)lane, p.N - 4);
-            piece(p.ln_u + nc, 0u);
-            piece(p.ln_v + nc, 1u);
+#pragma unroll
+            for (int k = 0; k < NPCOL; ++k) {
+                const int32_t nc = min(n0 + 256 * k + 4 * (int32_t)lane, p.N - 4);
+                piece(p.ln_u + nc, (uint32_t)k * 1024u);
+                piece(p.ln_v + nc, PAR_V + (uint32_t)k * 1024u);
+            }
             const float2* st = reinterpret_cast<const float2*>(p.ln_stat);
 #pragma unroll
-            for (int k = 0; k < (BM + 127) / 128; ++k) piece(st + min(m0 + 128 * k + 2 * (int32_t)lane, p.M - 2), 2u + (uint32_t)k);
+            for (int k = 0; k < (BM + 127) / 128; ++k) piece(st + min(m0 + 128 * k + 2 * (int32_t)lane, p.M - 2), PAR_ROWS + (uint32_t)k * 1024u);
         } else {
-            piece(reinterpret_cast<const uint16_t*>(p.bias) + min(n0 + 8 * (int32_t)lane, p.N - 8), 0u);
+            piece(reinterpret_cast<const uint16_t*>(p.bias) + min(n0 + 8 * (int32_t)lane, p.N - 8), 0u);        // 512 columns per piece: one covers either tile
         }
     };
 
@@ -475,6 +626,11 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
         int32_t tile_m, tile_n;
         decode_tile(PART ? slotx % ntiles : c_it * G + slotx, tile_m, tile_n);
         const int32_t m0 = tile_m * BM, n0 = tile_n * BN;
+        // (WIDE: the lane index goes through an empty asm so that nothing derived from it -- row / column offsets of ten stores -- is hoisted above the tile
+        // loop: the main loop has no register to spare for it)
+        uint32_t lane_e = threadIdx.x & 63u;
+        if constexpr (WIDE) asm volatile("" : "+v"(lane_e));
+        const uint32_t lane = lane_e;
         const uint32_t q = lane >> 4, li = lane & 15u;
         MM_STAMP(13);
         const bool vtile = QKV && n0 >= p.n_rows;                 // (wave-uniform) this tile belongs to the transposed part
@@ -509,11 +665,13 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
                         if (wave == 7u) { dma_params(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
                         MM_BARRIER();
                     }
-                    mm_f2 rw[MT];
-                    mm_lds_read_rows<MT>(mm_lds_addr(lds + PARAM + 2048u) + (wm * (16u * MT) + li) * 8u, rw);
+                    if constexpr (!(WIDE && EPI == 0)) {           // (WIDE dense rows: lnf_rows, per row pair)
+                        mm_f2 rw[MT];
+                        mm_lds_read_rows<MT>(mm_lds_addr(lds + PARAM + PAR_ROWS) + (wm * (16u * MT) + li) * 8u, rw);
 #pragma unroll
-                    for (int im = 0; im < MT; ++im) { ln_r[im] = rw[im][0]; ln_n[im] = rw[im][1]; }
-                    mm_lds_read_uv(mm_lds_addr(lds + PARAM) + (grp * HC + q * 4u) * 4u, ln_u4, ln_v4);
+                        for (int im = 0; im < MT; ++im) { ln_r[im] = rw[im][0]; ln_n[im] = rw[im][1]; }
+                    }
+                    if constexpr (!WIDE) mm_lds_read_uv<PAR_V>(mm_lds_addr(lds + PARAM) + (grp * HC + q * 4u) * 4u, ln_u4, ln_v4);      // (WIDE: lnf_cols, per block)
                 } else {
 #pragma unroll
                 for (int im = 0; im < MT; ++im) {
@@ -547,6 +705,18 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
                 }
             }
         }
+        // WIDE dense rows: (rstd, nrm) of the two row tiles of row pair `pr`, read when the pair is processed
+        auto lnf_rows = [&](int pr) {
+            if constexpr (LNF && WIDE && STG && EPI == 0) {
+                mm_f2 rw[2];
+                mm_lds_read_rows<2>(mm_lds_addr(lds + PARAM + PAR_ROWS) + (wm * (16u * MT) + (uint32_t)(2 * pr) * 16u + li) * 8u, rw);
+                ln_r[2 * pr] = rw[0][0]; ln_n[2 * pr] = rw[0][1]; ln_r[2 * pr + 1] = rw[1][0]; ln_n[2 * pr + 1] = rw[1][1];
+            }
+        };
+        // WIDE: u and v of column block `in`, read when the block is processed
+        auto lnf_cols = [&](int in) {
+            if constexpr (LNF && WIDE && STG) mm_lds_read_uv1<PAR_V>(mm_lds_addr(lds + PARAM) + (grp * HC + (uint32_t)in * 16u + q * 4u) * 4u, ln_u4[in], ln_v4[in]);
+        };
         // the four values of accumulator (in, im) as they are rounded and stored: acc + bias, or the LayerNorm-folded form
         auto vals4 = [&](int in, int im, const float (&b)[4], float (&o)[4]) {
             const mm_f4& a = acc[in][im];
@@ -609,79 +779,108 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
         };
         if (EPI == 0 || (QKV && !vtile)) {
             // dense rows: out[m, n] (+ resid[m, n]); row pointers hoisted, ten 16-byte stores per lane at immediate column offsets
-            uint16_t* yrow[2];
-            const uint16_t* rrow[2];
-            bool live[2];
+            uint16_t* yrow[NPR];
+            const uint16_t* rrow[NPR];
+            bool live[NPR];
             const int32_t colb = n0 + (int32_t)(grp * HC + (q >> 1) * 8u);
-#pragma unroll
-            for (int pr = 0; pr < NPR; ++pr) {
+            auto row_setup = [&](int pr) {
                 const int32_t m = m0 + (int32_t)(wm * (16u * MT) + (uint32_t)(2 * pr + (int)(q & 1u)) * 16u + li);
                 live[pr] = m < p.M;
                 const int64_t mm = live[pr] ? m : 0;
                 yrow[pr] = Y + mm * p.ldy + colb;
                 rrow[pr] = resid ? resid + mm * p.ldr + colb : nullptr;
-            }
+            };
             // residual chunks are fetched RSD column blocks ahead of their use: all five up front on the 8-wave variant, two on the 12-wave one
             // (168 registers: 80 accumulators + the next tile's 36 fragment registers are live here)
             const bool rstat = EPI == 0 && p.rowstats != nullptr;
-            float rs_s[2] = {0.f, 0.f}, rs_q[2] = {0.f, 0.f};
-            constexpr int RSD = SPLIT ? 2 : 5;
-            uint4 rs[5][2];
+            float rs_s[NPR], rs_q[NPR];
+#pragma unroll
+            for (int pr = 0; pr < NPR; ++pr) { rs_s[pr] = 0.f; rs_q[pr] = 0.f; }
+            constexpr int RSD = SPLIT ? 2 : (WIDE ? 2 : 5);
+            uint4 rs[5][NPR];
+            auto load_rs1 = [&](int in, int pr) {
+                rs[in][pr] = make_uint4(0, 0, 0, 0);
+                if (colb + in * 16 < p.N) rs[in][pr] = *reinterpret_cast<const uint4*>(rrow[pr] + in * 16);
+            };
             auto load_rs = [&](int in) {
 #pragma unroll
-                for (int pr = 0; pr < NPR; ++pr) {
-                    rs[in][pr] = make_uint4(0, 0, 0, 0);
-                    if (colb + in * 16 < p.N) rs[in][pr] = *reinterpret_cast<const uint4*>(rrow[pr] + in * 16);
+                for (int pr = 0; pr < NPR; ++pr) load_rs1(in, pr);
+            };
+            auto block = [&](int in, int pr, const float (&bq)[4]) {
+                uint32_t a0, a1, b0, b1;
+                pack4(in, 2 * pr, bq, a0, a1);
+                pack4(in, 2 * pr + 1, bq, b0, b1);
+                swap16(a0, b0);
+                swap16(a1, b1);
+                uint32_t w4[4] = {a0, a1, b0, b1};
+                if (resid) {
+                    const uint32_t rsw[4] = {rs[in][pr].x, rs[in][pr].y, rs[in][pr].z, rs[in][pr].w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) w4[k] = MM<T>::add2(w4[k], rsw[k]);           // one rounding of the exact sum, as before
+                }
+                if (live[pr] && colb + in * 16 < p.N) {
+                    *reinterpret_cast<uint4*>(yrow[pr] + in * 16) = make_uint4(w4[0], w4[1], w4[2], w4[3]);      // the last N tile may be partial
+                    if (rstat) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) MM<T>::stat2(w4[k], rs_s[pr], rs_q[pr]);
+                    }
                 }
             };
-            if (resid) {
-#pragma unroll
-                for (int in = 0; in < RSD; ++in) load_rs(in);
-            }
-#pragma unroll
-            for (int in = 0; in < 5; ++in) {
-                float bq[4];
-                bias4(in, bq);
-                if (resid && in + RSD < 5) load_rs(in + RSD);
-#pragma unroll
-                for (int pr = 0; pr < NPR; ++pr) {
-                    uint32_t a0, a1, b0, b1;
-                    pack4(in, 2 * pr, bq, a0, a1);
-                    pack4(in, 2 * pr + 1, bq, b0, b1);
-                    swap16(a0, b0);
-                    swap16(a1, b1);
-                    uint32_t w4[4] = {a0, a1, b0, b1};
-                    if (resid) {
-                        const uint32_t rsw[4] = {rs[in][pr].x, rs[in][pr].y, rs[in][pr].z, rs[in][pr].w};
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) w4[k] = MM<T>::add2(w4[k], rsw[k]);           // one rounding of the exact sum, as before
-                    }
-                    if (live[pr] && colb + in * 16 < p.N) {
-                        *reinterpret_cast<uint4*>(yrow[pr] + in * 16) = make_uint4(w4[0], w4[1], w4[2], w4[3]);      // the last N tile may be partial
-                        if (rstat) {
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) MM<T>::stat2(w4[k], rs_s[pr], rs_q[pr]);
-                        }
-                    }
-                }
-            }
             // Row statistics for the LayerNorm that consumes this output (p.rowstats): (sum, sum of squares) of the stored values of each row over this
             // wave's 80 columns; one v_permlane32_swap + add folds the two 8-column halves of a lane pair, lanes < 32 then hold sums, lanes >= 32 squares
-            if (rstat) {
+            auto flush_stat = [&](int pr) {
+                uint32_t a = __float_as_uint(rs_s[pr]), b = __float_as_uint(rs_q[pr]);
+                swap32(a, b);
+                const float t = __uint_as_float(a) + __uint_as_float(b);
+                const int32_t m = m0 + (int32_t)(wm * (16u * MT) + (uint32_t)(2 * pr + (int)(q & 1u)) * 16u + li);
+                if (m < p.M) p.rowstats[((int64_t)m * (NG * p.tiles_n) + NG * tile_n + (int32_t)grp) * 2 + (int32_t)(lane >> 5)] = t;
+            };
+            if constexpr (WIDE) {
+                // row pair by row pair (one pair's pointers, residual chunks and sums live at a time: the 160 accumulators leave room for no more)
 #pragma unroll
                 for (int pr = 0; pr < NPR; ++pr) {
-                    uint32_t a = __float_as_uint(rs_s[pr]), b = __float_as_uint(rs_q[pr]);
-                    swap32(a, b);
-                    const float t = __uint_as_float(a) + __uint_as_float(b);
-                    const int32_t m = m0 + (int32_t)(wm * (16u * MT) + (uint32_t)(2 * pr + (int)(q & 1u)) * 16u + li);
-                    if (m < p.M) p.rowstats[((int64_t)m * (2 * p.tiles_n) + 2 * tile_n + (int32_t)grp) * 2 + (int32_t)(lane >> 5)] = t;
+                    row_setup(pr);
+                    lnf_rows(pr);
+                    if (resid) {
+#pragma unroll
+                        for (int in = 0; in < RSD; ++in) load_rs1(in, pr);
+                    }
+#pragma unroll
+                    for (int in = 0; in < 5; ++in) {
+                        float bq[4];
+                        bias4(in, bq);
+                        lnf_cols(in);
+                        if (resid && in + RSD < 5) load_rs1(in + RSD, pr);
+                        block(in, pr, bq);
+                    }
+                    if (rstat) flush_stat(pr);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+#pragma unroll
+                for (int pr = 0; pr < NPR; ++pr) row_setup(pr);
+                if (resid) {
+#pragma unroll
+                    for (int in = 0; in < RSD; ++in) load_rs(in);
+                }
+#pragma unroll
+                for (int in = 0; in < 5; ++in) {
+                    float bq[4];
+                    bias4(in, bq);
+                    if (resid && in + RSD < 5) load_rs(in + RSD);
+#pragma unroll
+                    for (int pr = 0; pr < NPR; ++pr) block(in, pr, bq);
+                }
+                if (rstat) {
+#pragma unroll
+                    for (int pr = 0; pr < NPR; ++pr) flush_stat(pr);
                 }
             }
         } else if (EPI == 1) {
             // per row pair p: this lane's output row and its addressing
-            int64_t orow[2];
-            int32_t img_b[2];
-            bool live[2], border[2];
+            int64_t orow[NPR];
+            int32_t img_b[NPR];
+            bool live[NPR], border[NPR];
 #pragma unroll
             for (int pr = 0; pr < NPR; ++pr) {
                 const int32_t m = m0 + (int32_t)(wm * (16u * MT) + (uint32_t)(2 * pr + (int)(q & 1u)) * 16u + li);
@@ -765,7 +964,7 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
                     }
                     if (li == 15u && col < p.N) {
                         // records [block][plane: sums | sums of squares][N / 2 column pairs]
-                        float* dst = p.colstats + (((int64_t)tile_m * 4 + wm) * 2 + (q & 1u)) * (int64_t)(p.N >> 1) + (col >> 1);
+                        float* dst = p.colstats + (((int64_t)tile_m * WM + wm) * 2 + (q & 1u)) * (int64_t)(p.N >> 1) + (col >> 1);
                         *reinterpret_cast<mm_f4*>(dst) = mm_f4{rec[0], rec[1], rec[2], rec[3]};
                     }
                 }
@@ -778,11 +977,12 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
             // with (values, gates) of two outputs, the gate pair goes through gelu in fp32, is rounded like torch's F.gelu output, and the product is
             // one packed multiply (v_pk_mul_f16: the correctly rounded product of the two rounded operands).  33 instead of 52 instructions per accumulator.
             const uint32_t qv = q & 1u;
-            uint32_t D[5][2][2];                              // [in][row pair][2 registers]: 4 consecutive outputs 4 qv .. of row tile 2p + (lane >> 5)
+            uint32_t D[5][NPR][2];                            // [in][row pair][2 registers]: 4 consecutive outputs 4 qv .. of row tile 2p + (lane >> 5)
 #pragma unroll
             for (int in = 0; in < 5; ++in) {
                 float bq[4];
                 bias4(in, bq);
+                lnf_cols(in);
                 uint32_t Wv[MT];                              // per row tile im: outputs 4 qv + 2 (lane >> 5) + {0, 1}, packed
 #pragma unroll
                 for (int im = 0; im < MT; ++im) {
@@ -953,6 +1153,67 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
         rd_slot = nx_slot;
     };
 
+    if constexpr (WIDE) {
+        // ------------------------------------------------------------ the 256 x 320 tile: a wave multiplies 128 x 80 outputs, 40 MFMAs per phase.
+        // Registers: 160 accumulators, so fragments cannot be held twice.  W fragments (5 per phase) are double-buffered across phases; the 8 activation
+        // blocks of a phase stream through a ring of four registers sets, block im + 3 read while block im multiplies (the last three reads of a phase fetch
+        // blocks 0..2 of the next one).  Ring of TWO stage slots, ONE barrier per stage, inside the odd phase behind block 4: by then every wave has read the
+        // last fragment of stage s (block 7 of k-half 1 is fetched in group 4) and waited for its own pieces of stage s + 1, so the barrier both publishes
+        // stage s + 1 (read from group 5 on) and frees the slot of stage s, into which groups 5..7 and the next even phase issue stage s + 2: a whole stage
+        // of lead, in cycles what the three-slot ring of the narrower tile has.
+        // fragment addresses: ONE persistent lane offset; a phase derives the three bases it reads from (this phase's activation blocks, the next phase's
+        // activation blocks and W set) behind an empty asm -- left to itself hipcc hoists all eight (slot, k-half, operand) combinations into registers
+        auto rd_at = [&](uint32_t base, int blk) -> frag { return *reinterpret_cast<const frag*>(lds + base + blk * 2048); };
+        frag wA[5], wB[5], xr[4];
+        // LAST (the odd phase of a tile's last step): no fragment of the next tile is fetched -- 32 registers the epilogue needs; they are read afresh behind it
+        auto phase = [&](auto odd_tag, auto last_tag, frag (&wc)[5], frag (&wn)[5], const uint32_t slot_c, const uint32_t slot_n, const int32_t step_i) {
+            constexpr bool ODD = decltype(odd_tag)::value, LAST = decltype(last_tag)::value;
+            constexpr uint32_t kh_c = ODD ? 1u : 0u, kh_n = ODD ? 0u : 1u;
+            uint32_t lrd = lane_rd0;
+            asm volatile("" : "+v"(lrd));
+            const uint32_t a_c = (lrd ^ (kh_c * 64u)) + (wm * (16u * MT) * 128u + slot_c);
+            const uint32_t a_n = (lrd ^ (kh_n * 64u)) + (wm * (16u * MT) * 128u + slot_n);
+            const uint32_t w_n = (lrd ^ (kh_n * 64u)) + ((uint32_t)BM * 128u + grp * (uint32_t)HC * 128u + slot_n);
+#pragma unroll
+            for (int im = 0; im < 8; ++im) {
+                // activation block im + 3 of this phase, or block im - 5 of the next one, into the ring entry block im - 1 has left
+                if (im + 3 < 8) { MM_ABL_READ(xr[(im + 3) & 3] = rd_at(a_c, im + 3)); }
+                else if (!LAST) { MM_ABL_READ(xr[(im + 3) & 3] = rd_at(a_n, im - 5)); }
+                if (!LAST && im == 5) { MM_ABL_READ(wn[0] = rd_at(w_n, 0)); MM_ABL_READ(wn[1] = rd_at(w_n, 1)); MM_ABL_READ(wn[2] = rd_at(w_n, 2)); }
+                if (!LAST && im == 6) { MM_ABL_READ(wn[3] = rd_at(w_n, 3)); MM_ABL_READ(wn[4] = rd_at(w_n, 4)); }
+                // the nine pieces of a stage: three behind the barrier of the odd phase, six in the even phase that follows
+                if (!ODD && im < 6) dma_piece8(3 + im);
+                if (ODD && im >= 5) dma_piece8(im - 5);
+                if constexpr (STG && ODD) { if (stg7 && step_i == 0 && im == 7) dma_params(); }
+#pragma unroll
+                for (int in = 0; in < 5; ++in) acc[in][im] = MM_ABL_MMA(wc[in], xr[im & 3], acc[in][im]);
+                if (ODD && im == 4) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's pieces of stage s + 1 (issued a stage ago)
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // its last fragment reads of stage s
+                    MM_BARRIER();
+                } else {
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        };
+#pragma unroll
+        for (int in = 0; in < 5; ++in) wA[in] = rd_at(w_rd0, in);
+#pragma unroll
+        for (int im = 0; im < 3; ++im) xr[im] = rd_at(a_rd0, im);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (uint32_t it = 0; it < nt_mine; ++it) {
+            for (int32_t i = 0; i < P_mine; ++i) {
+                const uint32_t nx_slot = rd_slot + STAGE == RING ? 0u : rd_slot + STAGE;
+                phase(std::false_type{}, std::false_type{}, wA, wB, rd_slot, rd_slot, i);
+                phase(std::true_type{}, std::false_type{}, wB, wA, rd_slot, nx_slot, i);
+                rd_slot = nx_slot;
+            }
+            epilogue();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the filler DMA of the last steps
+        return;
+    }
     // The step loop is a loop of its own (not one flat loop with the epilogue inside): hipcc then places the wait for the epilogue's
     // loads / stores once in front of it instead of inside the steady state.
     frag xa[MT], wa[5], xb[MT], wb[5];
@@ -1108,7 +1369,9 @@ __global__ __launch_bounds__(256) void gsw_mm_reduce_kernel(const MMArgs p, cons
 template <typename T, int EPI, bool SPLIT, int MT, bool LNF = false>
 int mm_launch_k(const MMArgs& a, uint32_t grid, hipStream_t st) {
     static bool attr_done = false;          // benign race: setting the attribute twice is harmless
-    constexpr size_t ldsb = 3u * (size_t)(64 * MT + 160) * 128u + (!SPLIT && (EPI == 2 || (EPI == 0 && !LNF)) ? 4096u : 0u);   // the three-stage ring (+ the staged epilogue parameters)
+    constexpr bool wide = MT == 8;          // the 256 x 320 tile: two stage slots of 72 KiB
+    constexpr size_t ldsb = (wide ? 2u * 576u : 3u * (size_t)(64 * MT + 160)) * 128u
+                            + (!SPLIT && (EPI == 2 || (EPI == 0 && (!LNF || wide))) ? (wide ? 6144u : 4096u) : 0u);   // the ring (+ the staged epilogue parameters)
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)gsw_mm_kernel<T, EPI, SPLIT, MT, LNF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
@@ -1122,10 +1385,12 @@ int mm_launch_t(const MMArgs& a, uint32_t grid, int mt, hipStream_t st) {
     if constexpr (EPI == 5) return mt == 4 ? mm_launch_k<T, 5, false, 4>(a, grid, st) : mm_launch_k<T, 5, false, 2>(a, grid, st);      // dense epilogues: 8-wave form
     else {
     if (a.ln_stat) {                      // LayerNorm folded into the epilogue: dense rows / GEGLU / transposed, 8-wave form
+        if constexpr (EPI == 0 || EPI == 2) { if (mt == 8) return mm_launch_k<T, EPI, false, 8, true>(a, grid, st); }
         if constexpr (EPI == 0 || EPI == 2 || EPI == 3)
             return mt == 4 ? mm_launch_k<T, EPI, false, 4, true>(a, grid, st) : mm_launch_k<T, EPI, false, 2, true>(a, grid, st);
         else return (int)hipErrorInvalidValue;
     }
+    if constexpr (EPI == 0 || EPI == 1 || EPI == 2) { if (mt == 8) return mm_launch_k<T, EPI, false, 8>(a, grid, st); }
     // bit e of the split mask set = epilogue kind e runs the 12-wave variant whose waves 8-11 own the LDS-DMA (gsw_mm_config / GSW_MM_SPLIT: A/B switch)
     const bool split = (g_mm_split_mask.load(std::memory_order_relaxed) >> EPI) & 1;
     // (dense rows, 256-row tile: the 12-wave form does not fit its 168 registers -- 32-40 bytes of scratch per lane -- so that combination is not
@@ -1233,7 +1498,7 @@ int gsw_mm_last_colstats(int* rows_per_block, int* blocks) {
 }
 
 int gsw_mm_config(int tile_rows, int split_mask) {
-    if (tile_rows != 0 && tile_rows != 128 && tile_rows != 256 && tile_rows != -1) return GSW_ERR_BAD_ARG;
+    if (tile_rows != 0 && tile_rows != 128 && tile_rows != 256 && tile_rows != 512 && tile_rows != -1) return GSW_ERR_BAD_ARG;      // 512: the 256 x 320 tile wherever it is legal
     if (split_mask < -1 || split_mask > 15) return GSW_ERR_BAD_ARG;
     if (tile_rows != -1) g_mm_tile_rows.store(tile_rows, std::memory_order_relaxed);
     if (split_mask != -1) g_mm_split_mask.store(split_mask, std::memory_order_relaxed);
@@ -1366,24 +1631,55 @@ int gsw_mm_launch(MMArgs& a, int dtype, void* stream, GswMmExtras* ex) {
             return GSW_OK;
         }
     }
-    const int64_t tiles_m = ((int64_t)a.M + BM - 1) / BM;
-    if (tiles_m * tiles_n > 0x7FFFFFFF) return GSW_ERR_UNSUPPORTED;
-    a.tiles_n = (int32_t)tiles_n;
-    a.ntiles = (int32_t)(tiles_m * tiles_n);
+    // The wide tile (256 x 320, MT = 8): launches with enough of those tiles to keep every CU busy for several rounds and a K loop long enough to amortise
+    // the longer fill (two 72 KiB stages).  Fewer operand bytes per MFMA is what pays under the board's power limit.
+    // GSW_MM_WIDE=0 / gsw_mm_config(tile_rows = 256 or 128) keep the narrower tiles (A/B, tests); tile_rows = 512 forces the wide tile wherever it is legal.
+    bool wide = false;
+    {
+        static const int wide_mask = getenv("GSW_MM_WIDE") ? atoi(getenv("GSW_MM_WIDE")) : 2;       // bit e: epilogue kind e may take the wide tile (default: the convolutions, EPI 1)
+        const int epi_k = a.mode == MM_MODE_GEGLU ? 2 : (a.mode == MM_MODE_DENSE && !a.rowbias) ? 0 : 1;
+        const int wide_env = (wide_mask >> epi_k) & 1;
+        const int bm_cfg = g_mm_tile_rows.load(std::memory_order_relaxed);
+        const bool mode_ok = a.mode == MM_MODE_DENSE || a.mode == MM_MODE_PF || a.mode == MM_MODE_TOK2PF || a.mode == MM_MODE_UP2X || a.mode == MM_MODE_GEGLU;
+        const int64_t tn_w = (a.N + 319) / 320, tm_w = ((int64_t)a.M + 255) / 256;
+        // buffer addressing of the wide producer: no weight-row clamp (N % 320 == 0), every activation segment below 4 GiB
+        int64_t rows_in = a.M;
+        if (a.mode == MM_MODE_PF || a.mode == MM_MODE_UP2X) {
+            const int64_t per_img = (a.flags & MM_FLAG_COMPACT) ? (int64_t)std::max(1, (a.Hp - 2) * (a.Wp - 2)) : (int64_t)a.Hp * a.Wp;
+            rows_in = ((int64_t)a.M / per_img + 1) * (int64_t)a.in_Hp * a.in_Wp + 2 * (int64_t)a.in_Wp + 4;
+        }
+        int64_t ld_max = 0;
+        for (int i = 0; i < a.nseg; ++i) ld_max = std::max<int64_t>(ld_max, a.seg[i].ld);
+        const bool legal = mode_ok && a.N >= 320 && a.N % 320 == 0 && (!(a.mode == MM_MODE_GEGLU || (a.mode == MM_MODE_DENSE && !a.rowbias)) || a.M % 256 == 0) && rows_in * ld_max * 2 < ((int64_t)1 << 32) - (1 << 20) && (int64_t)a.N * a.ldw * 2 < ((int64_t)1 << 32) - (1 << 20);
+        // a partial last column tile costs a whole one: at most 1/8 of the column tiles' work wasted
+        const bool fits = (tn_w * 320 - a.N) * 8 <= a.N && tm_w * tn_w >= 2 * 256 && a.P >= 8 && a.M >= 2048;
+        wide = legal && (bm_cfg == 512 || (bm_cfg == 0 && wide_env != 0 && fits));
+    }
+    const int BMt = wide ? 256 : BM, BNt = wide ? 320 : BN;
+    const int64_t tiles_nt = (a.N + BNt - 1) / BNt;
+    const int64_t tiles_m = ((int64_t)a.M + BMt - 1) / BMt;
+    if (tiles_m * tiles_nt > 0x7FFFFFFF) return GSW_ERR_UNSUPPORTED;
+    a.tiles_n = (int32_t)tiles_nt;
+    a.ntiles = (int32_t)(tiles_m * tiles_nt);
+    if (wide) {          // panel of the tile order for 320-column tiles: 4 (the same 1280 columns), or all of them under the same L2 budget
+        a.panel = 4;
+        if (tiles_nt > 4 && tiles_nt <= 16 && tiles_nt * 320 * (int64_t)a.P * 64 * 2 <= (2 << 20)) a.panel = (int32_t)tiles_nt;
+    }
     const uint32_t grid = (uint32_t)std::min<int64_t>(256, (a.ntiles + 7) / 8 * 8);
+    const int ngrp = wide ? 4 : 2, wmv = wide ? 2 : 4;        // 80-column groups per tile, waves along M
     // row statistics: plain dense-row launches (EPI 0), unsplit
-    if (rs_req && a.mode == MM_MODE_DENSE && !a.rowbias && !a.ln_stat && (int64_t)a.M * 2 * tiles_n * 2 <= rs_cap) {
+    if (rs_req && a.mode == MM_MODE_DENSE && !a.rowbias && !a.ln_stat && (int64_t)a.M * ngrp * tiles_nt * 2 <= rs_cap) {
         a.rowstats = rs_req;
-        ex->rowstats_slots = (int)(2 * tiles_n);
+        ex->rowstats_slots = (int)(ngrp * tiles_nt);
     }
     // column statistics: EPI 1 launches whose M dimension enumerates real pixels / tokens (interior enumeration or the token scatter), unsplit
     if (cs_req && (a.mode == MM_MODE_TOK2PF || ((a.mode == MM_MODE_PF || a.mode == MM_MODE_UP2X) && (a.flags & MM_FLAG_COMPACT)))
-        && tiles_m * 4 * (int64_t)a.N <= cs_cap) {
+        && tiles_m * wmv * (int64_t)a.N <= cs_cap) {
         a.colstats = cs_req;
-        ex->colstats_rows_per_block = BM / 4; ex->colstats_blocks = (int)(tiles_m * 4);
+        ex->colstats_rows_per_block = BMt / wmv; ex->colstats_blocks = (int)(tiles_m * wmv);
     }
     const int epi = a.mode == MM_MODE_QKV ? 5 : a.mode == MM_MODE_TRANS ? 3 : a.mode == MM_MODE_GEGLU ? 2 : (a.mode == MM_MODE_DENSE && !a.rowbias) ? 0 : 1;
-    const int e = dtype == GSW_F16 ? mm_launch_e<_Float16>(a, epi, grid, BM / 64, st) : mm_launch_e<__bf16>(a, epi, grid, BM / 64, st);
+    const int e = dtype == GSW_F16 ? mm_launch_e<_Float16>(a, epi, grid, wide ? 8 : BM / 64, st) : mm_launch_e<__bf16>(a, epi, grid, wide ? 8 : BM / 64, st);
     if (e != 0) { g_last_hip_error = e; return GSW_ERR_HIP; }
     return GSW_OK;
 }

@@ -58,6 +58,10 @@ class DDIMSchedule:
         self.ratio = self.num_train_timesteps // self.num_inference_steps
         ts = (np.arange(self.num_inference_steps) * self.ratio).round().astype(np.int64) + self.steps_offset
         self.timesteps_desc = ts[::-1].copy()      # sampling order: 981, 961, ..., 1 for 50 steps
+        if self.num_inference_steps < 1 or int(ts.min()) < 0 or int(ts.max()) >= self.num_train_timesteps:
+            # the eps model tabulates its time embedding over [0, num_train_timesteps) (unet.TEMB_TABLE): a timestep outside it has no row
+            raise ValueError(f"DDIMSchedule: timesteps {int(ts.min())}..{int(ts.max())} leave [0, {self.num_train_timesteps}) "
+                             f"({self.num_inference_steps} steps, steps_offset {self.steps_offset})")
 
     def _alpha(self, t: int) -> float:
         return float(self.alphas_cumprod[t]) if t >= 0 else self.final_alpha

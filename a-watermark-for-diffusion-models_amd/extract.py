@@ -173,6 +173,7 @@ class Models:
             if os.path.exists(scfg):
                 self.scheduler = _read_json(scfg)
                 checkpoint.validate_scheduler_config(self.scheduler)
+        self.unet.num_train_timesteps = int(self.scheduler.get("num_train_timesteps", 1000)) if self.scheduler else 1000      # length of the time-embedding table (unet.TEMB_TABLE)
         self.unet.to(self.device, dtype).eval()
         self.vae.to(self.device, dtype).eval()
         from .graph import graphed
@@ -595,7 +596,7 @@ def main(argv=None):
     if args.preflight:
         from . import dist as gdist
         if "WORLD_SIZE" not in os.environ:
-            os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29532"))
+            os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT") or str(launch._free_port()))
         backend = os.environ.get("GSW_DIST_BACKEND", "nccl" if torch.cuda.is_available() else "gloo")
         raise SystemExit(gdist.preflight_main(backend, float(os.environ.get("GSW_PREFLIGHT_TIMEOUT_S", "120"))))
     args.key = bytes.fromhex(args.key_hex)

@@ -41,6 +41,17 @@ def _env_mode() -> str:
 # hidden behind it; the graph would only pin a second copy of the activation memory)
 AUTO_MAX_ROWS = 32
 CHECK_EVERY = 32        # replays of an entry between two checks of the parameters' versions (~0.3 ms per check: ~700 parameters)
+# Staleness window: an IN-PLACE edit of a parameter tensor (p.data.add_(...), a hand-rolled LoRA merge) under an unchanged context is noticed at the next of
+# those periodic checks, i.e. up to CHECK_EVERY - 1 replays later.  Everything that goes through the usual entry points is seen AT ONCE: load_state_dict on the
+# wrapped module (a post-hook bumps the epoch below), unet / vae.load_diffusers_state_dict, extract.Models -- and anyone editing weights by hand calls
+# graph.weights_changed() (or GraphedEpsModel.reset()).  The epoch is one integer compare per replay.
+_WEIGHTS_EPOCH = [0]
+
+
+def weights_changed() -> None:
+    """Tell every GraphedEpsModel of the process that parameters were edited: the next call re-checks the versions before it replays anything."""
+    _WEIGHTS_EPOCH[0] += 1
+
 MAX_ENTRIES = 8         # captured (shape, dtype, context shape, switches) entries kept; the least recently used one is dropped beyond that
 
 
@@ -90,6 +101,9 @@ class GraphedEpsModel:
         self.capture_fallbacks: Dict[str, int] = {}        # unet.FALLBACKS counted while capturing: a library kernel baked into a graph is invisible at replay
         self._entries: "OrderedDict[Tuple, _Entry]" = OrderedDict()
         self._weights_key = None
+        self._epoch = _WEIGHTS_EPOCH[0]
+        if hasattr(model, "register_load_state_dict_post_hook"):
+            model.register_load_state_dict_post_hook(lambda _m, _keys: weights_changed())
         self._failed: Dict[Tuple, str] = {}
         self.stats = {"captures": 0, "replays": 0, "eager": 0, "context_refreshes": 0}
 
@@ -163,8 +177,10 @@ class GraphedEpsModel:
             return self.model(x, t, ctx, **kw)
         e = self._entries.get(key)
         cid = _ctx_identity(ctx)
-        if e is None or not _same_ctx(cid, e.ctx_id) or e.replays % CHECK_EVERY == 0:
-            # (checked when a graph is captured, whenever the context changes, and every CHECK_EVERY replays: ~700 parameters, ~0.3 ms)
+        if e is None or not _same_ctx(cid, e.ctx_id) or e.replays % CHECK_EVERY == 0 or self._epoch != _WEIGHTS_EPOCH[0]:
+            # (checked when a graph is captured, whenever the context changes, every CHECK_EVERY replays, and at once after weights_changed():
+            # ~700 parameters, ~0.3 ms)
+            self._epoch = _WEIGHTS_EPOCH[0]
             wk = self._params_key()
             if wk != self._weights_key:         # parameters replaced / edited: every captured address or packed copy may be stale
                 self._entries.clear()

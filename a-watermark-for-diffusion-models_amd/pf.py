@@ -548,7 +548,7 @@ def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
         if rs_buf is not None and ex.rowstats_slots > 0:
             y._gsw_rowstats = (rs_buf, int(ex.rowstats_slots))          # rides on the output tensor; in-place edits of y must drop it
         if tm is not None:
-            tm.stop(e0, ("gsw_mm_kernel", M, K, Nn, mode) if tm.by_shape else "gsw_mm_kernel", 2.0 * M * K * Nn)
+            tm.stop(e0, ("gsw_mm_kernel", M, K, Nn, mode + ("+res" if resid is not None and mode == "plain" else "")) if tm.by_shape else "gsw_mm_kernel", 2.0 * M * K * Nn)
     return y
 
 
@@ -755,14 +755,22 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, sc
         out = torch.empty((B, Sq, inner), dtype=q.dtype, device=q.device)
     elif tuple(out.shape) != (B, Sq, inner) or out.dtype != q.dtype or out.device != q.device or not out.is_contiguous():
         raise ValueError("attention: out must be a contiguous [B, Sq, heads * d] tensor like q")
+    tm = CONV_TIMER
     with torch.cuda.device(q.device):
+        e0 = tm.start() if tm is not None else None
         # the split-K scratch of this stream doubles as the key-split scratch (few query tiles against many key tiles: one image's self-attention); both are
         # free between two launches of a stream
-        ws = _workspace(q.device) if ATTN_KEY_SPLIT else None
+        # (only for launches the key-split form can take -- whole 128-query / 64-key tiles, >= 32 key tiles, at most 256 query tiles, no padded keys: a
+        # 77-key cross-attention or a ragged launch must not pin a scratch buffer on its stream)
+        ks_ok = (ATTN_KEY_SPLIT and d in (40, 64) and Sq % 128 == 0 and Sk % 64 == 0 and Sk // 64 >= 32 and (valid_keys is None or int(valid_keys) == Sk)
+                 and (Sq // 128) * B * heads <= 256)
+        ws = _workspace(q.device) if ks_ok else None
         N.check(N.lib().gsw_attention_ws(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), B, heads, d, Sq, Sk,
                                          Sk if valid_keys is None else int(valid_keys), ldq, ldk, inner,
                                          float(scale if scale is not None else d ** -0.5), _dt(q.dtype), 0 if ws is None else ws.data_ptr(),
                                          0 if ws is None else ws.numel(), _stream_ptr()))
+        if tm is not None:
+            tm.stop(e0, ("gsw_attn_fwd_kernel", B, Sq, Sk, heads, d) if tm.by_shape else "gsw_attn_fwd_kernel", 4.0 * B * heads * Sq * (Sk if valid_keys is None else int(valid_keys)) * d)
     return out
 
 

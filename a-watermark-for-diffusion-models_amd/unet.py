@@ -721,12 +721,14 @@ def _temb_rows(self, temb: torch.Tensor):
 TEMB_TABLE = True     # integer timesteps: the whole time-embedding chain (sinusoid -> linear -> SiLU -> linear -> SiLU -> every resnet's time_emb_proj) is a
                       # function of t alone -- tabulated once over the training timesteps, a forward gathers its rows (one launch instead of ~20, and the
                       # 50 MB of projection weights are not streamed per forward)
-NUM_TRAIN_TIMESTEPS = 1000
+NUM_TRAIN_TIMESTEPS = 1000   # default length of the table; a model built from a checkpoint carries its scheduler's value as `model.num_train_timesteps`
+                             # (extract.Models sets it from scheduler/scheduler_config.json), and ddim.DDIMSchedule refuses timesteps outside the range on the host
 
 
 def _temb_rows_from_table(self, t: torch.Tensor, x: torch.Tensor):
     """TembRows gathered from the per-model table [num_train_timesteps, sum of the resnets' channels], or None when t is not an integer tensor / the
-    projections do not run on the engine.  Timesteps outside [0, num_train_timesteps) are clamped (the reference's schedulers never produce them)."""
+    projections do not run on the engine.  The table is as long as the model's `num_train_timesteps` (the scheduler config's; 1000 by default).  The
+    schedules of ddim.py validate their timesteps against that range on the host; a device tensor outside it would be clamped by gsw_gather_rows."""
     if t.dtype not in (torch.int64, torch.int32) or not t.is_cuda or t.numel() not in (1, x.shape[0]):
         return None
     resnets = getattr(self, "_gsw_resnets", None)
@@ -744,7 +746,7 @@ def _temb_rows_from_table(self, t: torch.Tensor, x: torch.Tensor):
 
     def build():
         with torch.no_grad():
-            tt = torch.arange(NUM_TRAIN_TIMESTEPS, device=x.device)
+            tt = torch.arange(int(getattr(self, "num_train_timesteps", NUM_TRAIN_TIMESTEPS)), device=x.device)
             temb = F.silu(te(timestep_embedding(tt, self.c0).to(x.dtype)))
             rows = _temb_rows(self, temb)
             if not isinstance(rows, TembRows):
@@ -752,6 +754,9 @@ def _temb_rows_from_table(self, t: torch.Tensor, x: torch.Tensor):
             return rows.table.contiguous()
 
     table = cached(self, "_gsw_temb_table", params, build)
+    if table is not None and table.shape[0] != int(getattr(self, "num_train_timesteps", NUM_TRAIN_TIMESTEPS)):      # the scheduler length changed after the table was built
+        self._gsw_temb_table = None
+        table = cached(self, "_gsw_temb_table", params, build)
     if table is None:
         return None
     B, n_tot = x.shape[0], table.shape[1]
@@ -893,6 +898,8 @@ def load_diffusers_state_dict(model: nn.Module, weight_dir: str) -> nn.Module:
     missing, unexpected = model.load_state_dict(sd, strict=False)
     if missing or unexpected:
         raise RuntimeError(f"state dict mismatch: missing {missing[:5]}..., unexpected {unexpected[:5]}...")
+    from .graph import weights_changed
+    weights_changed()                            # captured graphs of this model (graph.GraphedEpsModel) re-check the parameters before their next replay
     return model
 
 

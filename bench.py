@@ -51,6 +51,9 @@ def parse():
                          "(BASELINE config 4's data path; synthetic VAE weights, so the inversion still consumes the latent)")
     ap.add_argument("--jpeg-qf", type=int, default=10)
     ap.add_argument("--vae-chunk", type=int, default=8, help="images per VAE call")
+    ap.add_argument("--workload", choices=["roundtrip", "txt2img"], default="roundtrip",
+                    help="e2e tier: roundtrip = embed -> sampling -> image stages -> inversion -> vote (the headline); txt2img = BASELINE configs[1] as named: "
+                         "embed -> 50-step CFG sampling -> VAE decode -> uint8 image, no extraction (use with --batch 8)")
     ap.add_argument("--unet", choices=["sd21", "sd15"], default="sd21", help="sd15 + --height 768 --width 768 = BASELINE config 5's shape")
     ap.add_argument("--preflight", action="store_true", help="every rank: device check, RCCL init, one broadcast + all_gather_into_tensor + all_reduce under a hard "
                                                              "time limit (GSW_PREFLIGHT_TIMEOUT_S, default 120); rank 0 prints ONE JSON line; a failing stage is named and exits 3")
@@ -337,7 +340,11 @@ def main():
         sys.exit(self_launch(args))
     if args.preflight:
         if "WORLD_SIZE" not in os.environ:                 # one GPU from a bare shell: a world of one, still through the same stages
-            os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29531"))
+            import importlib.util
+            spec = importlib.util.spec_from_file_location("gswm_launch", os.path.join(ROOT, "a-watermark-for-diffusion-models_amd", "launch.py"))
+            launch = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(launch)        # (a free port, not a fixed one: a busy port would read as a rendezvous failure)
+            os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT") or str(launch._free_port()))
         import gswm_amd
         from gswm_amd import dist as gdist
         sys.exit(gdist.preflight_main(os.environ.get("GSW_BENCH_BACKEND", "nccl"), float(os.environ.get("GSW_PREFLIGHT_TIMEOUT_S", "120"))))

@@ -48,7 +48,7 @@ class TimedModel:
                 "rows": rows, "rows_whose_context_free_prefix_was_shared": shared, "prefix_flops_per_row": self.prefix_flops_per_row}
 
 
-def cpu_baseline_e2e(unet_cfg, ddim_steps, M, h=64, w=64, with_vae=False):
+def cpu_baseline_e2e(unet_cfg, ddim_steps, M, h=64, w=64, with_vae=False, forwards_per_step=3):
     """Bounded CPU sample of the same workload: the oracle's reference-shaped codec port on 1 image + ONE fp32 UNet forward
     of one image on the host cores (torch CPU), extrapolated to the 3*S forwards an image needs (2S with CFG + S inversion)."""
     import types
@@ -74,7 +74,7 @@ def cpu_baseline_e2e(unet_cfg, ddim_steps, M, h=64, w=64, with_vae=False):
         for _ in range(n_fw):
             m(x, t, c)
         t_fw = (time.perf_counter() - t1) / n_fw
-    per_image = t_codec + 3 * ddim_steps * t_fw
+    per_image = t_codec + forwards_per_step * ddim_steps * t_fw
     vae_note = ""
     if with_vae:
         from gswm_amd import vae as V
@@ -87,10 +87,10 @@ def cpu_baseline_e2e(unet_cfg, ddim_steps, M, h=64, w=64, with_vae=False):
         per_image += t_vae
         vae_note = f" + 1 full fp32 VAE decode+encode ({t_vae:.2f} s, timed whole)"
     return {"value": 1.0 / per_image, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port", "extrapolated": True,
-            "measured_s": {"codec_1_image": t_codec, "unet_forward_fp32": t_fw, "unet_forwards_timed": n_fw, "forwards_per_image": 3 * ddim_steps},
+            "measured_s": {"codec_1_image": t_codec, "unet_forward_fp32": t_fw, "unet_forwards_timed": n_fw, "forwards_per_image": forwards_per_step * ddim_steps},
             "sample": f"EXTRAPOLATED from 1 image: reference-shaped scalar codec port ({t_codec:.2f} s, 1 core) + {n_fw} fp32 forwards of THIS BUILD'S OWN torch "
                       f"UNet module (the reference's diffusers model is not available) on the host ({t_fw:.2f} s each, {torch.get_num_threads()} threads), "
-                      f"extrapolated to {3 * ddim_steps} forwards/image" + vae_note,
+                      f"extrapolated to {forwards_per_step * ddim_steps} forwards/image" + vae_note,
             "host_cpus": os.cpu_count()}
 
 
@@ -162,8 +162,21 @@ def run_e2e(args, rank, world, local_rank):
             outs.append(V.normalised_img_to_latents(xn, vae))
         return torch.cat(outs)
 
+    txt2img = getattr(args, "workload", "roundtrip") == "txt2img"
+    if txt2img and vae is None:
+        raise SystemExit("bench.py: --workload txt2img ends in the VAE decode: it needs --image-stages vae")
+
     def step(i):
         idx0 = (i * world + rank) * B
+        if txt2img:
+            # BASELINE configs[1]: the generation pipeline's call (modified_stable_diffusion_gs.pyc __call__; README.md:107-129) -- Z_s_T from the embed kernel,
+            # CFG sampling, decode_latents, numpy_to_pil's uint8 conversion; nothing is extracted
+            z_T = pipe.embed(B, seed=params["seed"], image_index0=idx0)
+            x0 = pipe.generate(z_T, ctx_text, 7.5)
+            with torch.no_grad():
+                for chunk in x0.split(args.vae_chunk):
+                    imaging.tensor_to_image(V.latents_to_img(chunk, vae))
+            return z_T, x0, None, None
         if vae is None:
             return pipe.roundtrip(B, ctx_text, seed=params["seed"], image_index0=idx0, guidance_scale=7.5)
         z_T = pipe.embed(B, seed=params["seed"], image_index0=idx0)
@@ -192,8 +205,9 @@ def run_e2e(args, rank, world, local_rank):
     marks[0].record()
     for i in range(args.steps):
         z_T, x0, bits, flags = step(args.warmup + i)
-        matched += codec.bit_matches(bits, M, params["message"]).sum()
-        flagged += (flags != 0).sum()
+        if bits is not None:
+            matched += codec.bit_matches(bits, M, params["message"]).sum()
+            flagged += (flags != 0).sum()
         marks[i + 1].record()
     torch.cuda.synchronize()
     if world > 1:
@@ -201,6 +215,11 @@ def run_e2e(args, rank, world, local_rank):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     board.__exit__()
+    if txt2img:
+        # nothing was extracted inside the region: the lossless gate of this workload is the embedded Z_s_T of the last step read back by the extract kernel
+        bits, flags = codec.extract_batch(z_T, params["key"], params["nonce"], M)
+        matched += codec.bit_matches(bits, M, params["message"]).sum() * args.steps
+        flagged += (flags != 0).sum()
     fallbacks = dict(U.FALLBACKS)
     if vae is not None:
         fallbacks.update({"vae: " + k: v for k, v in V.FALLBACKS.items()})
@@ -244,9 +263,11 @@ def run_e2e(args, rank, world, local_rank):
             "value": total_images / dt, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"e2e: gsw_embed -> {S}-step DDIM sampling (CFG 7.5, 2B-row UNet) -> {S}-step DDIM inversion -> "
-                                   f"fused last step + {M}-bit vote; {'SD2.1-base' if args.unet == 'sd21' else 'SD1.5'}-shaped UNet ({sum(p.numel() for p in model.parameters()) / 1e6:.1f} M params, synthetic weights; convolutions on the hand-written MFMA implicit GEMM), "
-                                   + ("no VAE" if vae is None else f"image stages per image: VAE decode -> uint8 -> {'JPEG QF ' + str(args.jpeg_qf) + ' -> ' if args.image_stages == 'vae+jpeg' else ''}ToTensor -> VAE encode (timed; synthetic VAE, inversion consumes the latent)"),
+            "config": {"workload": (f"txt2img (BASELINE configs[1]): gsw_embed -> {S}-step DDIM sampling (CFG 7.5, 2B-row UNet) -> VAE decode -> uint8 image, no "
+                                    f"extraction (bit accuracy = the embedded Z_s_T read back after the timed region); " if txt2img else
+                                    f"e2e: gsw_embed -> {S}-step DDIM sampling (CFG 7.5, 2B-row UNet) -> {S}-step DDIM inversion -> "
+                                    f"fused last step + {M}-bit vote; ") + f"{'SD2.1-base' if args.unet == 'sd21' else 'SD1.5'}-shaped UNet ({sum(p.numel() for p in model.parameters()) / 1e6:.1f} M params, synthetic weights; convolutions on the hand-written MFMA implicit GEMM), "
+                                   + ("no VAE" if vae is None else "image stage per image: VAE decode -> uint8 (timed)" if txt2img else f"image stages per image: VAE decode -> uint8 -> {'JPEG QF ' + str(args.jpeg_qf) + ' -> ' if args.image_stages == 'vae+jpeg' else ''}ToTensor -> VAE encode (timed; synthetic VAE, inversion consumes the latent)"),
                        "batch_per_gpu": B, "global_batch": world * B, "lattice": [4, h, w], "message_bits": M, "ddim_steps": S,
                        "parallelism": f"dp{world} (images sharded, UNet replicated, no data-path collective)"},
             "bit_accuracy": bit_acc, "lossless": bit_acc == 1.0 and int(flagged.item()) == 0, "flagged_images": int(flagged.item()),
@@ -301,7 +322,7 @@ def run_e2e(args, rank, world, local_rank):
             for key in ("roofline", "roofline_unet"):
                 out[key] = dict(out[key], frac_of_peak_at_sustained_clock=out[key]["frac"] / out["board"]["sclk_fraction_of_nominal"])
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline_e2e(unet_cfg, S, M, h, w, with_vae=vae is not None)
+            out["cpu_baseline"] = cpu_baseline_e2e(unet_cfg, S, M, h, w, with_vae=vae is not None, forwards_per_step=2 if txt2img else 3)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         else:
             out["cpu_baseline"] = None

@@ -22,7 +22,7 @@ def G():
     pf.SMALL_GEMM_MAX_ROWS = old
 
 
-@pytest.fixture(params=[256, 128], ids=["BM256", "BM128"])
+@pytest.fixture(params=[256, 128, 512], ids=["BM256", "BM128", "WIDE256x320"])      # 512: the 256 x 320 tile wherever it is legal (N % 320 == 0, dense / PF / GEGLU epilogues)
 def tile_rows(request, G):
     assert G.lib.gsw_mm_config(request.param, -1) == 0
     yield request.param
