@@ -31,6 +31,7 @@ class GswMmExtras(C.Structure):
 
 _PROTOTYPES = {
     "gsw_version": (C.c_int, []),
+    "gsw_build_flags": (C.c_int, []),
     "gsw_strerror": (C.c_char_p, [C.c_int]),
     "gsw_last_hip_error": (C.c_int, []),
     "gsw_keystream": (C.c_int, [C.c_char_p, C.c_char_p, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -141,6 +142,11 @@ def lib() -> C.CDLL:
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
+        flags = l.gsw_build_flags()
+        if flags != 0 and os.environ.get("GSWM_LIB") is None:
+            # a side build with measurement switches (csrc/gswm_ablate.inc) computes wrong results by design: only an explicit GSWM_LIB may load one
+            raise ImportError(f"{LIB_PATH} was compiled with measurement switches (gsw_build_flags() = {flags:#x}): not a production build; rebuild it "
+                              "(__graft_entry__.build()) or select the side build explicitly with GSWM_LIB")
         _lib = l
     return _lib
 

@@ -25,9 +25,10 @@
 // Tried and dropped: row sums of P on the matrix pipe (one more MFMA per 16-key slice with an all-ones A operand instead of 32 v_add_f32 per tile and
 // query block -- the pipe idles half the time): 813 vs 831 TFLOP/s at 4096 keys.
 // What sets the time (round 4, profiles/r04h_power_cap_probe.txt): on random operands the kernel runs at 1.99 GHz / 1.36 kW of the board's 1.4 kW, on all-zero operands
-// at 2.39 GHz and finishes 28 % sooner -- the power management, not an issue port.  A/B macros kept for that measurement (tools/attn_ablate.sh): ATTN_ABL_PK (packed
-// v_pk_fma_f32 / v_pk_add_f32 softmax arithmetic), ATTN_ABL_DOT (row sums by v_dot2c_f32_f16 on the converted pairs) -- together 16-18 % fewer VALU instructions per
-// tile, same time to the percent -- and ATTN_ABL_PRIO (s_setprio around the MFMA blocks: 3-4 % slower).
+// at 2.39 GHz and finishes 28 % sooner -- the power management, not an issue port.  Measured in round 4 with ablation / A-B builds of this kernel (parts of the loop
+// compiled out; packed v_pk_fma_f32 / v_pk_add_f32 softmax arithmetic and row sums by v_dot2c_f32_f16: 16-18 % fewer VALU instructions per tile, same time to the
+// percent; s_setprio around the MFMA blocks: 3-4 % slower).  Those switches were removed from the product source in round 5: the builds are reproducible from the
+// round-4 tree (git: 81b654b, tools/attn_ablate.sh there), their results are profiles/r04g_* and profiles/r04h_*.
 // Tried and dropped: software pipelining over 32-key blocks (S^T of block u+1 issued before the softmax of block u, 3 LDS stages,
 // one barrier per tile): 790 vs 831 TFLOP/s -- the per-block max / exchange / rescale overhead doubles and hipcc does not interleave
 // the two streams any better than the wave scheduler already does across the 2-4 resident waves.
@@ -96,10 +97,8 @@ constexpr uint32_t VP = 136;                               // V^T LDS row pitch 
 // the two blocks' softmax / MFMA chains are independent instruction streams the scheduler can interleave inside one wave).
 // DU = head_dim / 8 (5, 8, 10 <-> head_dim 40, 64, 80): the contraction over head_dim runs in KC = ceil(DU/2) MFMA k-slices and the
 // output in DB = ceil(head_dim/32) row blocks; the padding lanes of Q are zero registers and the padding rows of V^T zero LDS rows.
-// PIPE (QB = 1; an A/B switch, GSW_ATTN_PIPE=1 -- measured slower than the plain loop, see launch_attn_cfg): software pipeline ACROSS tiles inside every wave -- the S^T MFMAs of tile t + 1 are issued in front of the softmax arithmetic of tile t and run
-// under it (the two are independent; measured: MFMA and VALU streams of one wave overlap completely, tools/ubench/mfma_valu_overlap.hip), so a wave no longer walks
-// the dependent chain K fragments -> MFMAs -> max / exp / sum -> convert -> V^T fragments -> MFMAs once per tile (profiles/r04g_attention_ablation_and_isa_mix.txt:
-// its parts were nearly additive).  Three LDS stages, one barrier per tile; S of two tiles in registers.
+// (A cross-tile software pipeline of the QB = 1 form -- the S^T MFMAs of tile t + 1 issued in front of the softmax arithmetic of tile t, three LDS stages -- was
+// written in round 4, bit-identical and 3 % SLOWER at 4096 keys (3.74 vs 3.63 ms; profiles/r04g_attention_ablation_and_isa_mix.txt); removed in round 5.)
 // PAIR: four LDS stages and ONE barrier per two 64-key tiles (half the barriers; 4 x 17.5 KiB of dynamic LDS at head_dim 64).
 // RAGGED: Sq is not a multiple of the workgroup tile and / or Sk not a multiple of 64 (the mid block: 64 tokens at 512x512, 144 at 768x768;
 // 576 tokens at the SD 1.5 third level).  Query lanes past Sq read row 0 and store nothing; key rows / V^T columns past Sk are fetched
@@ -107,20 +106,16 @@ constexpr uint32_t VP = 136;                               // V^T LDS row pitch 
 // KVS (QB = 1, whole tiles; one image's self-attention: 160 workgroups for 256 CUs, each walking 64 key tiles): `ksplit` workgroups share a query tile, each over its
 // own range of key tiles; they leave their unnormalised accumulators, running maximum and partial row sum in a workspace and gsw_attn_combine_kernel merges them
 // (the usual rescaling by 2^(m_s - m)).  One image at 64 x 64: 62 -> ~30 us per launch.
-template <typename T, int QB, int DU, bool PAIR, bool RAGGED, bool PIPE = false, bool KVS = false>
-#ifndef ATTN_MINWAVES
-#define ATTN_MINWAVES 2          // (tools/attn_ablate.sh builds side libraries with 3 / 4: occupancy experiments)
-#endif
-__global__ __launch_bounds__(256, (DU > 10 ? 1 : (QB == 1 ? ATTN_MINWAVES : 2))) void gsw_attn_fwd_kernel(AttnArgs p) {
+template <typename T, int QB, int DU, bool PAIR, bool RAGGED, bool KVS = false>
+__global__ __launch_bounds__(256, (DU > 10 ? 1 : 2)) void gsw_attn_fwd_kernel(AttnArgs p) {
     using v8 = typename AT<T>::v8;
     using v4 = typename AT<T>::v4;
     constexpr int D = DU * 8, KC = (DU + 1) / 2, DB = (D + 31) / 32;
     constexpr uint32_t KP = KC * 32 + 16;                         // K LDS row pitch: odd number of 16-byte slots -> conflict-free ds_read_b128
     constexpr uint32_t STAGE = 64 * KP + DB * 32 * VP;            // one 64-key K tile + one V^T tile
     constexpr int NU = (64 * DU + 255) / 256;                     // 16-byte staging units per thread, tile and operand
-    constexpr uint32_t NSTG = PIPE ? 3 : (PAIR ? 4 : 2);
-    static_assert(!PIPE || (QB == 1 && !RAGGED && !PAIR), "the cross-tile pipeline: 32 queries per wave, whole tiles");
-    static_assert(!KVS || (QB == 1 && !RAGGED && !PAIR && !PIPE), "key-split form: 32 queries per wave, whole tiles, the plain two-stage loop");
+    constexpr uint32_t NSTG = PAIR ? 4 : 2;
+    static_assert(!KVS || (QB == 1 && !RAGGED && !PAIR), "key-split form: 32 queries per wave, whole tiles, the plain two-stage loop");
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];          // NSTG * STAGE bytes
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u, h = lane >> 5, c32 = lane & 31u;
     constexpr uint32_t QW = 32u * QB, QWG = 4u * QW;          // queries per wave / per workgroup
@@ -229,30 +224,15 @@ __global__ __launch_bounds__(256, (DU > 10 ? 1 : (QB == 1 ? ATTN_MINWAVES : 2)))
         for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
             for (int i = 0; i < 16; ++i) { s[qb][0][i] = 0.f; s[qb][1][i] = 0.f; }
-#ifdef ATTN_ABL_PRIO
-        __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc) {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
-#ifdef ATTN_ABL_NOLDSR
-                const v8 a = qreg[0][kc];                                                    // (ablation: no K fragment read)
-#else
                 const v8 a = *reinterpret_cast<const v8*>(Kl + (uint32_t)(kb * 32 + (int)c32) * KP + (uint32_t)kc * 32u + h * 16u);
-#endif
-#ifndef ATTN_ABL_NOQK
 #pragma unroll
                 for (int qb = 0; qb < QB; ++qb) s[qb][kb] = AT<T>::mfma(a, qreg[qb][kc], s[qb][kb]);
-#else
-#pragma unroll
-                for (int qb = 0; qb < QB; ++qb) s[qb][kb][kc] += (float)a[0] + (float)qreg[qb][kc][1];      // (ablation: keeps the LDS read and the registers alive)
-#endif
             }
         }
-#ifdef ATTN_ABL_PRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
         if ((t + 1) * 64 > p.Sk_valid) {            // padded keys of the last tile(s) (cross-attention, 77 context tokens): score -inf
             asm volatile("; masked tile");             // (a wave-uniform branch the steady state jumps over; the comment marks the block for tools/isa_loop_mix.py)
 #pragma unroll
@@ -269,15 +249,6 @@ __global__ __launch_bounds__(256, (DU > 10 ? 1 : (QB == 1 ? ATTN_MINWAVES : 2)))
 
         // ---- online softmax (base-2 domain); a query lives in lanes c32 and c32 + 32
         v8 pb[QB][2][2];
-#ifdef ATTN_ABL_NOSOFTMAX
-#pragma unroll
-        for (int qb = 0; qb < QB; ++qb)
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) pb[qb][kb][i >> 3][i & 7] = (T)s[qb][kb][i];
-        l_i[0] += cs;
-#else
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
             float mx = s[qb][0][0];
@@ -290,65 +261,25 @@ __global__ __launch_bounds__(256, (DU > 10 ? 1 : (QB == 1 ? ATTN_MINWAVES : 2)))
             const float alpha = __builtin_amdgcn_exp2f(m_i[qb] - m_new);      // raw v_exp_f32: arguments are <= 0, underflow to 0 is the intent
             m_i[qb] = m_new;
             float rs = 0.f;
-#ifdef ATTN_ABL_PK
-            // two scores per VALU instruction where the ISA has a packed fp32 form: v_pk_fma_f32 for s * scale - m, v_pk_add_f32 for the row sum (even / odd partial sums)
-            f32x2 rs2 = f32x2{0.f, 0.f};
-            const f32x2 cs2 = f32x2{cs, cs}, nm2 = f32x2{-m_new, -m_new};
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-                for (int i = 0; i < 16; i += 2) {
-                    const f32x2 a2 = __builtin_elementwise_fma(f32x2{s[qb][kb][i], s[qb][kb][i + 1]}, cs2, nm2);
-                    const f32x2 e2 = f32x2{__builtin_amdgcn_exp2f(a2[0]), __builtin_amdgcn_exp2f(a2[1])};
-#ifdef ATTN_ABL_DOT
-                    if constexpr (sizeof(T) == 2 && !__is_same(T, __bf16)) {
-                        // row sum from the ROUNDED probabilities (the ones the second product multiplies V with): one v_dot2_f32_f16 per converted pair
-                        const f16x2 pr = f16x2{(_Float16)e2[0], (_Float16)e2[1]};
-                        rs = __builtin_amdgcn_fdot2(pr, f16x2{(_Float16)1.0f, (_Float16)1.0f}, rs, false);
-                        pb[qb][kb][i >> 3][i & 7] = (T)pr[0];
-                        pb[qb][kb][i >> 3][(i & 7) + 1] = (T)pr[1];
-                        continue;
-                    }
-#endif
-                    rs2 += e2;
-                    pb[qb][kb][i >> 3][i & 7] = (T)e2[0];
-                    pb[qb][kb][i >> 3][(i & 7) + 1] = (T)e2[1];
-                }
-            }
-            rs += rs2[0] + rs2[1];
-#else
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-#ifdef ATTN_ABL_NOEXP
-                    const float e = fmaf(s[qb][kb][i], cs, -m_new);                 // (ablation: one full-rate op instead of v_exp_f32)
-#else
                     const float e = __builtin_amdgcn_exp2f(fmaf(s[qb][kb][i], cs, -m_new));
-#endif
                     rs += e;
                     pb[qb][kb][i >> 3][i & 7] = (T)e;
                 }
             }
-#endif
             l_i[qb] = fmaf(l_i[qb], alpha, rs);
-#ifdef ATTN_ABL_NORESCALE
-            if (false) {
-#else
             if (__any(alpha != 1.0f)) {                 // once the running maxima have settled the whole wave skips the rescale
-#endif
 #pragma unroll
                 for (int db = 0; db < DB; ++db)
 #pragma unroll
                     for (int i = 0; i < 16; ++i) o[qb][db][i] *= alpha;
             }
         }
-#endif
 
         // ---- O^T += V^T P^T
-#ifdef ATTN_ABL_PRIO
-        __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
@@ -356,205 +287,22 @@ __global__ __launch_bounds__(256, (DU > 10 ? 1 : (QB == 1 ? ATTN_MINWAVES : 2)))
 #pragma unroll
                 for (int db = 0; db < DB; ++db) {
                     const uint8_t* vp = Vl + (uint32_t)(db * 32 + (int)c32) * VP + (uint32_t)(kb * 32 + tt * 16 + (int)h * 4) * 2u;
-#ifdef ATTN_ABL_NOLDSR
-                    const v4 lo = __builtin_shufflevector(qreg[0][0], qreg[0][0], 0, 1, 2, 3), hi = __builtin_shufflevector(qreg[0][0], qreg[0][0], 4, 5, 6, 7);
-                    (void)vp;
-#else
                     const v4 lo = *reinterpret_cast<const v4*>(vp);
                     const v4 hi = *reinterpret_cast<const v4*>(vp + 16);
-#endif
                     const v8 a = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-#ifndef ATTN_ABL_NOPV
 #pragma unroll
                     for (int qb = 0; qb < QB; ++qb) o[qb][db] = AT<T>::mfma(a, pb[qb][kb][tt], o[qb][db]);
-#else
-#pragma unroll
-                    for (int qb = 0; qb < QB; ++qb) o[qb][db][kb * 2 + tt] += (float)a[0] + (float)pb[qb][kb][tt][1];
-#endif
                 }
             }
         }
-#ifdef ATTN_ABL_PRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
     };
-    if constexpr (PIPE) {
-        // ---- the three parts of a tile as separate pieces: S^T of a staged tile, the online softmax of a finished S^T, O^T += V^T P^T
-        auto qk_part = [&](uint32_t stage, f32x16 (&sc)[2]) {
-            const uint8_t* Kl = lds + stage * STAGE;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { sc[0][i] = 0.f; sc[1][i] = 0.f; }
-#pragma unroll
-            for (int kc = 0; kc < KC; ++kc)
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb) {
-                    const v8 a = *reinterpret_cast<const v8*>(Kl + (uint32_t)(kb * 32 + (int)c32) * KP + (uint32_t)kc * 32u + h * 16u);
-                    sc[kb] = AT<T>::mfma(a, qreg[0][kc], sc[kb]);
-                }
-        };
-        auto sm_part = [&](f32x16 (&sc)[2], int32_t t, v8 (&pb)[2][2]) {
-            if ((t + 1) * 64 > p.Sk_valid) {        // padded keys of the last tile(s): score -inf (a wave-uniform branch the steady state jumps over)
-                asm volatile("; masked tile");
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const int32_t key = t * 64 + kb * 32 + (i >> 2) * 8 + (int32_t)h * 4 + (i & 3);
-                        if (key >= p.Sk_valid) sc[kb][i] = -INFINITY;
-                    }
-            }
-            float mx = sc[0][0];
-#pragma unroll
-            for (int i = 1; i < 16; ++i) mx = fmaxf(mx, sc[0][i]);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sc[1][i]);
-            mx = xhalf_max(mx);
-            const float m_new = fmaxf(m_i[0], mx * cs);
-            const float alpha = __builtin_amdgcn_exp2f(m_i[0] - m_new);
-            m_i[0] = m_new;
-            float rs = 0.f;
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const float e = __builtin_amdgcn_exp2f(fmaf(sc[kb][i], cs, -m_new));
-                    rs += e;
-                    pb[kb][i >> 3][i & 7] = (T)e;
-                }
-            l_i[0] = fmaf(l_i[0], alpha, rs);
-            if (__any(alpha != 1.0f)) {
-#pragma unroll
-                for (int db = 0; db < DB; ++db)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) o[0][db][i] *= alpha;
-            }
-        };
-        auto pv_part = [&](uint32_t stage, v8 (&pb)[2][2]) {
-            const uint8_t* Vl = lds + stage * STAGE + 64u * KP;
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-                    for (int db = 0; db < DB; ++db) {
-                        const uint8_t* vp = Vl + (uint32_t)(db * 32 + (int)c32) * VP + (uint32_t)(kb * 32 + tt * 16 + (int)h * 4) * 2u;
-                        const v4 lo = *reinterpret_cast<const v4*>(vp);
-                        const v4 hi = *reinterpret_cast<const v4*>(vp + 16);
-                        const v8 a = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                        o[0][db] = AT<T>::mfma(a, pb[kb][tt], o[0][db]);
-                    }
-        };
-        // one pipeline step: tiles t (its S^T finished in `sa`) and t + 1 (S^T goes to `sb`); stages: tile j lives in stage j % 3.
-        // Issue order inside a wave (in-order issue: what is written first is issued first):
-        //   1. the eight K fragment reads of tile t + 1 (LDS, 1 KiB each) -- their latency passes under step 2
-        //   2. row maximum of tile t, new reference point, alpha (VALU on `sa` only)
-        //   3. the eight S^T MFMAs of tile t + 1, one in front of every fourth of the exponential block of tile t (fma, v_exp_f32, add, convert): the matrix
-        //      pipe works through them while the VALU does the exponentials
-        //   4. running sum, O rescale (only when some row's maximum moved), then V^T fragments + the eight O^T MFMAs of tile t
-        auto step = [&](int32_t t, uint32_t st, f32x16 (&sa)[2], f32x16 (&sb)[2]) {
-            const uint32_t st1 = st + 1 == 3 ? 0u : st + 1, st2 = st1 + 1 == 3 ? 0u : st1 + 1;
-            GSW_ATTN_GLOAD((t + 2 < nt ? t + 2 : nt - 1) << 6)                 // tile t + 2 -> registers (re-fetches the last tile at the end: no branch around loads)
-            const bool more = t + 1 < nt;                                       // (wave-uniform)
-            const uint8_t* Kl = lds + (more ? st1 : st) * STAGE;                // (the last step reads a valid stage and discards the products)
-            v8 kf[KC][2];
-#pragma unroll
-            for (int kc = 0; kc < KC; ++kc)
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-                    kf[kc][kb] = *reinterpret_cast<const v8*>(Kl + (uint32_t)(kb * 32 + (int)c32) * KP + (uint32_t)kc * 32u + h * 16u);
-            __builtin_amdgcn_sched_barrier(0);
-            if ((t + 1) * 64 > p.Sk_valid) {        // padded keys of the last tile(s): score -inf (a wave-uniform branch the steady state jumps over)
-                asm volatile("; masked tile");
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const int32_t key = t * 64 + kb * 32 + (i >> 2) * 8 + (int32_t)h * 4 + (i & 3);
-                        if (key >= p.Sk_valid) sa[kb][i] = -INFINITY;
-                    }
-            }
-            float mx = sa[0][0];
-#pragma unroll
-            for (int i = 1; i < 16; ++i) mx = fmaxf(mx, sa[0][i]);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sa[1][i]);
-            mx = xhalf_max(mx);
-            const float m_new = fmaxf(m_i[0], mx * cs);
-            const float alpha = __builtin_amdgcn_exp2f(m_i[0] - m_new);
-            m_i[0] = m_new;
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- S^T(t + 1) under the exponentials of tile t
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { sb[0][i] = 0.f; sb[1][i] = 0.f; }
-            v8 pb[2][2];
-            float rs = 0.f;
-#pragma unroll
-            for (int kc = 0; kc < KC; ++kc)
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb) {
-                    sb[kb] = AT<T>::mfma(kf[kc][kb], qreg[0][kc], sb[kb]);
-                    constexpr int PER = 32 / (KC * 2);                           // exponentials behind each MFMA (4 at head_dim 64)
-                    const int e0 = (kc * 2 + kb) * PER;
-#pragma unroll
-                    for (int j = e0; j < e0 + PER; ++j) {
-                        const float e = __builtin_amdgcn_exp2f(fmaf(sa[j >> 4][j & 15], cs, -m_new));
-                        rs += e;
-                        pb[j >> 4][(j & 15) >> 3][j & 7] = (T)e;
-                    }
-                }
-            if constexpr (32 % (KC * 2) != 0) {                                  // (head_dim 40: 6 MFMAs, 5 exponentials behind each, 2 left over)
-#pragma unroll
-                for (int j = (32 / (KC * 2)) * KC * 2; j < 32; ++j) {
-                    const float e = __builtin_amdgcn_exp2f(fmaf(sa[j >> 4][j & 15], cs, -m_new));
-                    rs += e;
-                    pb[j >> 4][(j & 15) >> 3][j & 7] = (T)e;
-                }
-            }
-            // pin the interleaving: one MFMA, then its share of the VALU work (per exponential: fma, v_exp_f32, add, half a convert)
-#pragma unroll
-            for (int i = 0; i < KC * 2; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 4 * (32 / (KC * 2)) - 2, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            l_i[0] = fmaf(l_i[0], alpha, rs);
-            if (__any(alpha != 1.0f)) {
-#pragma unroll
-                for (int db = 0; db < DB; ++db)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) o[0][db][i] *= alpha;
-            }
-            pv_part(st, pb);
-            GSW_ATTN_LSTORE(st2)                                                // -> the stage tile t - 1 left (every wave is past its PV: barrier of the previous step)
-            __syncthreads();
-        };
-        GSW_ATTN_GLOAD(0)
-        GSW_ATTN_LSTORE(0u)
-        GSW_ATTN_GLOAD((nt > 1 ? 1 : 0) << 6)
-        GSW_ATTN_LSTORE(1u)
-        __syncthreads();
-        f32x16 s0[2], s1[2];
-        qk_part(0u, s0);
-        uint32_t st = 0;
-        int32_t t = 0;
-        for (; t + 1 < nt; t += 2) {                                           // two steps per trip: the two S^T register sets swap roles without moves
-            step(t, st, s0, s1);
-            st = st + 1 == 3 ? 0u : st + 1;
-            step(t + 1, st, s1, s0);
-            st = st + 1 == 3 ? 0u : st + 1;
-        }
-        if (t < nt) step(t, st, s0, s1);
-    } else if (PAIR) {
+    if (PAIR) {
         GSW_ATTN_GLOAD(0)
         GSW_ATTN_LSTORE(0u)
         GSW_ATTN_GLOAD((nt > 1 ? 1 : 0) << 6)
         GSW_ATTN_LSTORE(1u)
         __syncthreads();
         for (int32_t t = 0; t < nt; t += 2) {
-#ifdef ATTN_ABL_NOSTAGE
-            tile((uint32_t)(t & 1), t);                  // (ablation: no global loads, no LDS writes, no barrier inside the loop)
-            if (t + 1 < nt) tile((uint32_t)((t + 1) & 1), t + 1);
-#else
             // tiles t and t+1 are visible; t+2 and t+3 are fetched, written into the two idle stages, and published by ONE barrier
             GSW_ATTN_GLOAD((t + 2 < nt ? t + 2 : nt - 1) << 6)
             __builtin_amdgcn_sched_barrier(0);
@@ -567,7 +315,6 @@ __global__ __launch_bounds__(256, (DU > 10 ? 1 : (QB == 1 ? ATTN_MINWAVES : 2)))
                 GSW_ATTN_LSTORE((uint32_t)((t + 3) & 3))
             }
             __syncthreads();
-#endif
         }
     } else {
         // (KVS: this workgroup's share of the key tiles)
@@ -678,10 +425,6 @@ __global__ __launch_bounds__(256) void gsw_attn_combine_kernel(AttnArgs p) {
 
 }  // namespace
 
-#ifndef ATTN_PIPE_MIN_TILES
-#define ATTN_PIPE_MIN_TILES (1 << 30)   // key tiles from which the pipelined form would be the default: never -- measured SLOWER than the plain loop (4096 keys, B = 128:
-                                        // 3.74 vs 3.63 ms in the QB = 1 form, 3.28 ms for QB = 2; profiles/r04g_attention_ablation_and_isa_mix.txt), kept as an A/B switch (GSW_ATTN_PIPE=1)
-#endif
 template <typename T, int QB, int DU>
 static int launch_attn_cfg(const AttnArgs& a, uint32_t grid, bool ragged, float* ws, int64_t ws_bytes, hipStream_t st) {
     constexpr int KC = (DU + 1) / 2, DB = (DU * 8 + 31) / 32;
@@ -699,7 +442,7 @@ static int launch_attn_cfg(const AttnArgs& a, uint32_t grid, bool ragged, float*
             if (ksplit >= 2 && need <= ws_bytes) {
                 AttnArgs k = a;
                 k.ksplit = ksplit; k.part = ws;
-                hipLaunchKernelGGL((gsw_attn_fwd_kernel<T, 1, DU, false, false, false, true>), dim3(a.total * ksplit), dim3(256), 2 * stage, st, k);
+                hipLaunchKernelGGL((gsw_attn_fwd_kernel<T, 1, DU, false, false, true>), dim3(a.total * ksplit), dim3(256), 2 * stage, st, k);
                 hipLaunchKernelGGL((gsw_attn_combine_kernel<T, DU>), dim3(a.total), dim3(256), 0, st, k);
                 return GSW_OK;
             }
@@ -707,20 +450,6 @@ static int launch_attn_cfg(const AttnArgs& a, uint32_t grid, bool ragged, float*
     }
     static const int pair_env = getenv("GSW_ATTN_PAIR") ? atoi(getenv("GSW_ATTN_PAIR")) : 1;      // A/B switch for profiling
     const bool pair = !ragged && pair_env && 4 * stage <= 80 * 1024 && (a.Sk >> 6) >= 16;      // long key sequences only: +2 % at 4096 keys, a loss at 256
-    // the cross-tile pipeline (QB = 1 form only): GSW_ATTN_PIPE=0 / 1 forces it off / on where it applies
-    static const int pipe_env = getenv("GSW_ATTN_PIPE") ? atoi(getenv("GSW_ATTN_PIPE")) : -1;
-    if constexpr (QB == 1 && (DU == 8 || DU == 5)) {
-        if (!ragged && pipe_env != 0 && (a.Sk >> 6) >= 2 && (pipe_env == 1 || (a.Sk >> 6) >= ATTN_PIPE_MIN_TILES)) {
-            const uint32_t lds3 = 3 * stage;
-            const void* fnp = (const void*)gsw_attn_fwd_kernel<T, 1, DU, false, false, true>;
-            if (lds3 > 64 * 1024) {
-                hipError_t e = hipFuncSetAttribute(fnp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
-                if (e != hipSuccess) { g_last_hip_error = (int)e; return GSW_ERR_HIP; }
-            }
-            hipLaunchKernelGGL((gsw_attn_fwd_kernel<T, 1, DU, false, false, true>), dim3(grid), dim3(256), lds3, st, a);
-            return GSW_OK;
-        }
-    }
     const uint32_t lds = (pair ? 4 : 2) * stage;
     const void* fn = pair ? (const void*)gsw_attn_fwd_kernel<T, QB, DU, true, false>
                           : (ragged ? (const void*)gsw_attn_fwd_kernel<T, 1, DU, false, true> : (const void*)gsw_attn_fwd_kernel<T, QB, DU, false, false>);

@@ -39,6 +39,7 @@
 #include "../../include/gswm.h"
 #include "gswm_mm.h"
 #include "gswm_mmtypes.h"
+#include "gswm_ablate.inc"
 
 // Process-wide tuning knobs of the engine (tests and A/B runs force a tiling; production leaves both on "auto").  Initialised from the environment
 // (GSW_MM_BM = 128 | 256, GSW_MM_SPLIT = bit mask over epilogue kinds) and settable through the C ABI (gsw_mm_config).
@@ -47,19 +48,10 @@ static std::atomic<int> g_mm_split_mask{getenv("GSW_MM_SPLIT") ? atoi(getenv("GS
 
 namespace {
 
-// MM_TRACE (tools/ubench/mm_trace.hip only): cycles between consecutive stamps, summed per interval kind in scalar registers (no memory
-// traffic inside the loop); workgroup 0's waves write their sums when the kernel ends
-#ifdef MM_TRACE
-__device__ unsigned long long* g_mm_trace_buf;
-#define MM_STAMP(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tr_acc[k] += t_ - tr_last; tr_last = t_; } while (0)
-#else
-#define MM_STAMP(k) do { } while (0)
-#endif
-
-#ifndef MM_ABL_READ
-#define MM_ABL_READ(stmt) stmt
-#define MM_ABL_MMA(a, b, c) MM<T>::mma(a, b, c)
-#endif
+// measurement switches (cycle stamps, ablations): every one of them lives in gswm_ablate.inc; a production build defines none (gsw_build_flags() == 0)
+__device__ unsigned long long* g_mm_trace_buf;                // (MM_TRACE builds: tools/ubench/mm_trace.hip points it at its buffer)
+template <typename F>
+__device__ __forceinline__ mm_f4 mm_abl_touch(F a, F b, mm_f4 c) { c[0] = fmaf((float)a[0], (float)b[0], c[0]); return c; }      // (MM_ABL_NOMFMA builds)
 #define MM_BARRIER() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
 // epilogue barrier: LDS image traffic only -- the DMA prefetch of the next tile stays in flight (no vmcnt wait)
 #define MM_LDS_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); MM_BARRIER(); } while (0)
@@ -411,15 +403,15 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
         if (j < NPA) {
             if constexpr (AFF) {
                 if (j == 0) a_piece = so_a;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(lds + pr_slot + (pid + (uint32_t)NPROD * j) * 1024u), 16, (int)vo_a[0], (int)a_piece, 0, 0);
+                MM_ABL_DMA_A(__builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(lds + pr_slot + (pid + (uint32_t)NPROD * j) * 1024u), 16, (int)vo_a[0], (int)a_piece, 0, 0));
                 a_piece += 64u * 2u * (uint32_t)p.seg[0].ld;
             } else {
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(lds + pr_slot + (pid + (uint32_t)NPROD * j) * 1024u), 16, (int)vo_a[j], (int)so_a, 0, 0);
+                MM_ABL_DMA_A(__builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(lds + pr_slot + (pid + (uint32_t)NPROD * j) * 1024u), 16, (int)vo_a[j], (int)so_a, 0, 0));
             }
         } else {
             if (j == NPA) w_piece = so_w;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(lds + pr_slot + (uint32_t)BM * 128u + (pid + (uint32_t)NPROD * (j - NPA)) * 1024u), 16,
-                                                     (int)vo_w, (int)w_piece, 0, 0);
+            MM_ABL_DMA_W(__builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(lds + pr_slot + (uint32_t)BM * 128u + (pid + (uint32_t)NPROD * (j - NPA)) * 1024u), 16,
+                                                                  (int)vo_w, (int)w_piece, 0, 0));
             w_piece += 64u * 2u * (uint32_t)p.ldw;
         }
         if (j == NDMA - 1) {
@@ -445,25 +437,11 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
             // Barrier k (k = 0 .. stages) is the consumers' "stage k is in LDS and the slot of stage k-1 is free": stage s+2 is issued after
             // barrier s-1... i.e. right after the barrier that retired the slot's previous tenant, and stage s+1 has landed before barrier s.
             int32_t pr_left = 0x7FFFFFFF;                                    // (PART) stages of this workgroup's K range still to issue
-#ifdef MM_ABL_A9
-            uint32_t abl_i = 0;                                  // (ablation: activation pieces on one stage in nine -- the DMA volume of a halo tile reused by the nine taps)
-            bool abl_a = true;
-#endif
             auto dma_stage = [&]() {
-#ifdef MM_ABL_A9
-                abl_a = abl_i == 0; abl_i = abl_i == 8 ? 0 : abl_i + 1;
-                if (abl_a) {
 #pragma unroll
-                    for (int i = 0; i < NPA; ++i) dma_piece_a(i);
-                }
-#elif !defined(MM_ABL_NOA)                                      // (ablation builds of tools/ubench/mm_trace.hip: results wrong by design)
+                for (int i = 0; i < NPA; ++i) MM_ABL_DMA_A(dma_piece_a(i));
 #pragma unroll
-                for (int i = 0; i < NPA; ++i) dma_piece_a(i);
-#endif
-#ifndef MM_ABL_NOW
-#pragma unroll
-                for (int i = 0; i < NPW; ++i) dma_piece_w(i);
-#endif
+                for (int i = 0; i < NPW; ++i) MM_ABL_DMA_W(dma_piece_w(i));
                 pr_slot = pr_slot + STAGE == RING ? 0u : pr_slot + STAGE;
                 if constexpr (PART) {
                     if (--pr_left == 0) {                        // the K range of this workgroup is issued: filler reads from here on (see end_run)
@@ -477,13 +455,7 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
                 }
                 if (--pr_run == 0) end_run();
             };
-#if defined(MM_ABL_NOW) && defined(MM_ABL_NOA)
-            constexpr int NWAIT = 0;
-#elif defined(MM_ABL_NOW)
-            constexpr int NWAIT = NPA;
-#else
-            constexpr int NWAIT = NDMA;
-#endif
+            constexpr int NWAIT = MM_ABL_NPA(NPA) + MM_ABL_NPW(NPW);             // pieces of a stage this wave has in flight (= NDMA in a production build)
             setup_tile(0);
             if constexpr (PART) {
                 // enter the tile's stage sequence at stage k_lo: segment, channel block, tap row, and the position inside the run
@@ -509,27 +481,16 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
             asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NWAIT) : "memory");         // stage 0 has landed
             MM_BARRIER();
             const uint32_t total = nt_mine * (uint32_t)P_mine;
-#ifdef MM_TRACE
-            unsigned long long tr_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tr_last = __builtin_amdgcn_s_memtime();
-#endif
+            MM_TRACE_DECL();
             for (uint32_t sidx = 0; sidx < total; ++sidx) {
                 dma_stage();                                                     // stage sidx + 2 (a cached dummy location once the work is issued)
                 MM_STAMP(0);
-#ifdef MM_ABL_A9
-                if (abl_a) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NDMA) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NPW) : "memory");
-#else
                 asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NWAIT) : "memory");     // stage sidx + 1 has landed
-#endif
                 MM_STAMP(1);
                 MM_BARRIER();
                 MM_STAMP(2);
             }
-#ifdef MM_TRACE
-            if (blockIdx.x == 0 && lane == 0) {
-                for (int k = 0; k < 16; ++k) g_mm_trace_buf[wave * 16 + k] = tr_acc[k];
-            }
-#endif
+            MM_TRACE_DUMP();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // nothing may land in LDS after the workgroup is gone
             return;
         }
@@ -546,7 +507,7 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
         for (int j = 0; j < NDMA; ++j) dma_piece8(j);
 #pragma unroll
         for (int j = 0; j < 3; ++j) dma_piece8(j);
-        asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(MM_ABL_NPA(3)) : "memory");
     } else {
         static_assert(SPLIT || ((NPA == 4 || NPA == 2) && NPW == 2), "the half-stage split assumes 4 (2) + 2 (+1) pieces per wave");
         // prologue: stages 0 and 1 and the first half of stage 2; wait for stage 0 (counted: the newer pieces stay in flight; exact for waves
@@ -572,9 +533,7 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
 #pragma unroll
         for (int b = 0; b < MT; ++b) acc[a][b] = mm_f4{0.f, 0.f, 0.f, 0.f};
     uint32_t c_it = 0, rd_slot = 0;                           // rd_slot: ring offset of the stage being multiplied
-#ifdef MM_TRACE
-    unsigned long long tr_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tr_last = __builtin_amdgcn_s_memtime();
-#endif
+    MM_TRACE_DECL();
 
     auto read_frags = [&](frag (&xf)[MT], frag (&wf)[5], uint32_t slot, uint32_t khalf) {
         const uint8_t* ap = lds + ((khalf ? a_rd1 : a_rd0) + slot);
@@ -1057,7 +1016,7 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
         for (int in = 0; in < 5; ++in)
 #pragma unroll
             for (int im = 0; im < MT; ++im)
-                acc[in][im] = SW ? MM<T>::mma(xc[im], wc[in], acc[in][im]) : MM<T>::mma(wc[in], xc[im], acc[in][im]);
+                acc[in][im] = SW ? MM_ABL_MMA(xc[im], wc[in], acc[in][im]) : MM_ABL_MMA(wc[in], xc[im], acc[in][im]);
     };
     // issue order of a phase's main block: three DMA pieces, each behind three MFMAs, then the nine fragment reads one per MFMA
     auto pin_order = [&]() {
@@ -1087,29 +1046,14 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
             __builtin_amdgcn_sched_group_barrier(0x008, NM - per * NV - NR, 0);
         }
     };
-#ifdef MM_ABL_NOMFMA
-    // (ablation builds, tools/mm_ablate.sh: one cheap VALU consumer per fragment instead of the 20 MFMAs, so that the LDS reads stay alive)
-    auto touch20 = [&](frag (&xf)[MT], frag (&wf)[5]) {
-#pragma unroll
-        for (int im = 0; im < MT; ++im) acc[0][im][0] += (float)xf[im][0];
-#pragma unroll
-        for (int in = 0; in < 5; ++in) acc[in][0][1] += (float)wf[in][0];
-    };
-#endif
     // X holds the fragments of (stage s, k-half 0) on entry; Y is filled with (s, k-half 1), then X with (s+1, k-half 0)
     auto step = [&](auto swap_tag, frag (&xX)[MT], frag (&wX)[5], frag (&xY)[MT], frag (&wY)[5], const int32_t step_i) {
         const uint32_t nx_slot = rd_slot + STAGE == RING ? 0u : rd_slot + STAGE;
         // ---- even phase: second half of stage s+2 (its slot held stage s-1, whose last reads completed before the previous barrier)
         MM_STAMP(0);
         if constexpr (!SPLIT) { dma_extra(); dma_h2(); }
-#ifndef MM_ABL_NOREADS
-        read_frags(xY, wY, rd_slot, 1u);
-#endif
-#ifndef MM_ABL_NOMFMA
+        MM_ABL_READ(read_frags(xY, wY, rd_slot, 1u));
         mfma20(swap_tag, xX, wX);
-#else
-        touch20(xX, wX);
-#endif
         pin_order();
         if constexpr (!SPLIT) { if (--pr_run == 0) end_run(); }
         MM_STAMP(1);
@@ -1129,26 +1073,15 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
             if (stg7 && step_i == 0) dma_params();
         }
         if constexpr (!SPLIT) dma_h1();
-#ifndef MM_ABL_NOREADS
-        read_frags(xX, wX, nx_slot, 0u);
-#endif
-#ifndef MM_ABL_NOMFMA
+        MM_ABL_READ(read_frags(xX, wX, nx_slot, 0u));
         mfma20(swap_tag, xY, wY);
-#else
-        touch20(xY, wY);
-#endif
         pin_order();
         MM_STAMP(4);
-#ifdef MM_ODD_BARRIER
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        MM_BARRIER();
-#else
         // no lgkmcnt(0) either: the compiler's own counted waits let the next phase's first MFMAs start as soon as THEIR fragments are in,
         // and the slot these reads come from is only released by the next barrier, which drains them
         // no barrier here: the next even phase only writes the slot freed by the barrier above and only reads the stage that barrier
         // published, so the waves of a SIMD are free to drift by up to one phase -- one's DMA / fragment reads under the other's MFMAs
         __builtin_amdgcn_sched_barrier(0);
-#endif
         MM_STAMP(5);
         rd_slot = nx_slot;
     };
@@ -1231,11 +1164,7 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
         epilogue();
         MM_STAMP(6);
     }
-#ifdef MM_TRACE
-    if (blockIdx.x == 0 && lane == 0) {
-        for (int k = 0; k < 16; ++k) g_mm_trace_buf[wave * 16 + k] = tr_acc[k];
-    }
-#endif
+    MM_TRACE_DUMP();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the filler DMA of the last steps
 }
 
@@ -1497,6 +1426,8 @@ int gsw_mm_last_colstats(int* rows_per_block, int* blocks) {
     return dropped ? GSW_WARN_NO_RECORDS : GSW_OK;
 }
 
+int gsw_build_flags(void) { return GSW_MM_BUILD_FLAGS; }
+
 int gsw_mm_config(int tile_rows, int split_mask) {
     if (tile_rows != 0 && tile_rows != 128 && tile_rows != 256 && tile_rows != 512 && tile_rows != -1) return GSW_ERR_BAD_ARG;      // 512: the 256 x 320 tile wherever it is legal
     if (split_mask < -1 || split_mask > 15) return GSW_ERR_BAD_ARG;
@@ -1636,7 +1567,7 @@ int gsw_mm_launch(MMArgs& a, int dtype, void* stream, GswMmExtras* ex) {
     // GSW_MM_WIDE=0 / gsw_mm_config(tile_rows = 256 or 128) keep the narrower tiles (A/B, tests); tile_rows = 512 forces the wide tile wherever it is legal.
     bool wide = false;
     {
-        static const int wide_mask = getenv("GSW_MM_WIDE") ? atoi(getenv("GSW_MM_WIDE")) : 2;       // bit e: epilogue kind e may take the wide tile (default: the convolutions, EPI 1)
+        static const int wide_mask = getenv("GSW_MM_WIDE") ? atoi(getenv("GSW_MM_WIDE")) : 7;       // bit e: epilogue kind e (0 dense rows, 1 PF rows, 2 GEGLU) may take the wide tile; 0 = never (A/B)
         const int epi_k = a.mode == MM_MODE_GEGLU ? 2 : (a.mode == MM_MODE_DENSE && !a.rowbias) ? 0 : 1;
         const int wide_env = (wide_mask >> epi_k) & 1;
         const int bm_cfg = g_mm_tile_rows.load(std::memory_order_relaxed);
@@ -1652,7 +1583,16 @@ int gsw_mm_launch(MMArgs& a, int dtype, void* stream, GswMmExtras* ex) {
         for (int i = 0; i < a.nseg; ++i) ld_max = std::max<int64_t>(ld_max, a.seg[i].ld);
         const bool legal = mode_ok && a.N >= 320 && a.N % 320 == 0 && (!(a.mode == MM_MODE_GEGLU || (a.mode == MM_MODE_DENSE && !a.rowbias)) || a.M % 256 == 0) && rows_in * ld_max * 2 < ((int64_t)1 << 32) - (1 << 20) && (int64_t)a.N * a.ldw * 2 < ((int64_t)1 << 32) - (1 << 20);
         // a partial last column tile costs a whole one: at most 1/8 of the column tiles' work wasted
-        const bool fits = (tn_w * 320 - a.N) * 8 <= a.N && tm_w * tn_w >= 2 * 256 && a.P >= 8 && a.M >= 2048;
+        // measured per shape at 128 rows (profiles/r05c_unet_forward_b128_wide_vs_narrow.txt): the dense-row and GEGLU launches win from K = 640 on (-5 ... -23 %);
+        // the PF-row epilogue (convolutions, token scatter: per-row residual / row-bias fetches, twice as long per wave on the wide tile) needs a longer K loop
+        // to pay for itself -- 3 x 3 convolutions win from K = 5760 (-4 ... -7 %) and lose 2 % at K = 2880, the token scatter (K <= 1280) loses 10-15 %
+        static const int pmin_dense = getenv("GSW_MM_WIDE_PMIN") ? atoi(getenv("GSW_MM_WIDE_PMIN")) : 8;          // (A/B knobs: stages from which the dense-row / GEGLU
+        static const int pmin_pf = getenv("GSW_MM_WIDE_PMIN_PF") ? atoi(getenv("GSW_MM_WIDE_PMIN_PF")) : 64;      //  and the PF-row launches take the wide tile)
+        const int p_min = epi_k == 1 ? pmin_pf : pmin_dense;
+        // tiles per round of 256 workgroups: the wide tiling must fill its last round about as well as the narrow one does
+        auto fill = [](int64_t t) { return (double)t / (double)(((t + 255) / 256) * 256); };
+        const int64_t t_w = tm_w * tn_w, t_n = (((int64_t)a.M + 255) / 256) * tiles_n;
+        const bool fits = t_w >= 256 && fill(t_w) >= fill(t_n) - 0.04 && a.P >= p_min && a.M >= 2048;
         wide = legal && (bm_cfg == 512 || (bm_cfg == 0 && wide_env != 0 && fits));
     }
     const int BMt = wide ? 256 : BM, BNt = wide ? 320 : BN;

@@ -64,6 +64,9 @@ typedef enum gsw_status {
 #define GSW_FLAG_NAN 2u       /* some z is NaN (int(nan) raises ValueError at extract.py:84)            */
 
 int gsw_version(void);
+/* Measurement switches the library was COMPILED with (csrc/gswm_ablate.inc: cycle stamps, ablations of the matmul engine's main loop -- builds that compute
+ * wrong results by design).  A shippable library returns 0; tests/test_kernel_metadata.py and the loader (_native.lib) refuse anything else. */
+int gsw_build_flags(void);
 const char* gsw_strerror(int status);
 int gsw_last_hip_error(void); /* thread-local hipError_t of the last GSW_ERR_HIP on this thread */
 
@@ -270,7 +273,9 @@ int gsw_gemm_strided(const void* x_dev, int64_t ldx, const void* w_dev, int64_t 
 
 /* Process-wide tuning knobs of the matmul engine, for parity tests and A/B measurements only (production leaves both on "auto"; this is the
  * one piece of global state behind the ABI, also settable through the environment as GSW_MM_BM / GSW_MM_SPLIT before the first launch):
- *   tile_rows  : 0 = automatic (256-row output tiles unless they would leave CUs without one, then 128), 128 or 256 = forced; -1 = keep
+ *   tile_rows  : 0 = automatic (the 256 x 320 tile for long-K launches with several rounds of such tiles -- GSW_MM_WIDE is its per-epilogue bit mask --, else
+ *                256 x 160 tiles unless they would leave CUs without one, then 128 x 160), 128 or 256 = forced narrow tiles, 512 = the 256 x 320 tile
+ *                wherever it is legal (N % 320 == 0, dense rows / PF rows / GEGLU epilogues, operands below 4 GiB); -1 = keep
  *   split_mask : bit e set = epilogue kind e (0 dense rows -- 128-row tiles only: the 256-row dense-row tile has no 12-wave form --, 1 PF / convolution, 2 GEGLU, 3 transposed) runs the 12-wave variant whose
  *                waves 8-11 own the LDS-DMA; -1 = keep (default 10: convolutions and the transposed projection) */
 int gsw_mm_config(int tile_rows, int split_mask);

@@ -68,3 +68,28 @@ def test_every_kernel_is_gfx950_and_none_uses_scratch():
            if k.get(".private_segment_fixed_size", 0) or k.get(".vgpr_spill_count", 0)]
     assert not bad, bad
     assert all(k.get(".wavefront_size") == 64 for k in kernels)
+
+
+@pytest.mark.skipif(not os.path.isfile(LIB), reason="libgswm.so is not built (python __graft_entry__.py)")
+def test_production_library_has_no_measurement_switches():
+    """The shipped libgswm.so must be compiled with none of the measurement switches of csrc/gswm_ablate.inc (MM_TRACE, MM_ABL_*): those builds carry
+    cycle stamps or compile parts of the main loop out and compute wrong results by design.  gsw_build_flags() is a plain host symbol: no GPU needed."""
+    import ctypes
+    lib = ctypes.CDLL(LIB)
+    lib.gsw_build_flags.restype = ctypes.c_int
+    assert lib.gsw_build_flags() == 0
+
+
+def test_no_measurement_switch_outside_the_ablation_header():
+    """#ifdef-guarded experiment code stays out of the kernels: the switches are hook macros defined in csrc/gswm_ablate.inc and nowhere else."""
+    import re
+    csrc = os.path.join(ROOT, "a-watermark-for-diffusion-models_amd", "csrc")
+    pat = re.compile(r"^\s*#\s*(if|ifdef|ifndef|elif)\b.*\b(MM_ABL_|ATTN_ABL_|MM_TRACE|MM_ODD_BARRIER|ATTN_MINWAVES)")
+    bad = []
+    for name in sorted(os.listdir(csrc)):
+        if not name.endswith((".hip", ".h")):
+            continue
+        for i, line in enumerate(open(os.path.join(csrc, name), errors="replace"), 1):
+            if pat.search(line):
+                bad.append(f"{name}:{i}: {line.strip()}")
+    assert not bad, bad

@@ -2,7 +2,7 @@
 A sampler thread reads the GPU's sysfs sensors (hwmon power1_average / power1_input, freq1_input = shader clock; falls back to `rocm-smi --json`) every 20 ms while
 the main thread replays one workload back to back; per workload: kernel time, mean / min shader clock, mean / max power.
 usage: python tools/power_probe.py [attn|conv|dense|geglu|mm|all]      (mm: the convolution and dense lines on random operands only)
-      (GSWM_LIB selects an ablation build of the attention kernel, tools/attn_ablate.sh)"""
+      (GSWM_LIB selects a side build, e.g. an ablation build of the matmul engine: tools/mm_ablate.sh)"""
 import os
 import sys
 import time
