@@ -50,6 +50,7 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // value of the lane 32 positions away, combined: v_permlane32_swap_b32 exchanges the upper half of one register with the lower half of
@@ -58,6 +59,14 @@ __device__ __forceinline__ float xhalf_max(float v) {
     const uint32_t u = __float_as_uint(v);
     const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
     return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+// (x of the lane's query for queries 0-15 | for queries 16-31 of the 32-query block) in EVERY 16-lane row: the 16 x 16 MFMA tail keeps one query per lane of a
+// row, the 32 x 32 blocks one query per lane of a half -- one v_permlane16_swap moves a per-query scalar from the second layout to the first
+__device__ __forceinline__ void rows16_split(float x, float& lo16, float& hi16) {
+    const uint32_t u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);       // [0]: rows (0, 0, 2, 2) of x, [1]: rows (1, 1, 3, 3)
+    lo16 = __uint_as_float(r[0]);
+    hi16 = __uint_as_float(r[1]);
 }
 __device__ __forceinline__ float xhalf_sum(float v) {
     const uint32_t u = __float_as_uint(v);
@@ -70,11 +79,13 @@ template <> struct AT<_Float16> {
     using v8 = f16x8;
     using v4 = f16x4;
     static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ f32x4 mfma16(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 };
 template <> struct AT<__bf16> {
     using v8 = bf16x8;
     using v4 = bf16x4;
     static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ f32x4 mfma16(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 };
 
 struct AttnArgs {
@@ -88,7 +99,7 @@ struct AttnArgs {
     uint32_t nqt;       // query tiles per (batch, head)
     uint32_t total;     // nqt * B * H
     uint32_t ksplit;    // KVS kernels: workgroups that share a query tile, each over its own range of key tiles (1 elsewhere)
-    float* part;        // KVS kernels: partial results [total][ksplit][4 waves][DB * 16 + 2][64 lanes] floats (unnormalised O^T accumulators, running maximum, partial row sum)
+    float* part;        // KVS kernels: partial results [total][ksplit][4 waves][NACC + 2][64 lanes] floats (unnormalised O^T accumulators, running maximum, partial row sum)
 };
 
 constexpr uint32_t VP = 136;                               // V^T LDS row pitch in bytes (64 keys + 8 B: conflict-free ds_read_b64)
@@ -96,7 +107,12 @@ constexpr uint32_t VP = 136;                               // V^T LDS row pitch 
 // QB = 32-query blocks per wave (1: 128 queries per workgroup; 2: 256 -- every K / V^T fragment read from LDS feeds two MFMAs and
 // the two blocks' softmax / MFMA chains are independent instruction streams the scheduler can interleave inside one wave).
 // DU = head_dim / 8 (5, 8, 10 <-> head_dim 40, 64, 80): the contraction over head_dim runs in KC = ceil(DU/2) MFMA k-slices and the
-// output in DB = ceil(head_dim/32) row blocks; the padding lanes of Q are zero registers and the padding rows of V^T zero LDS rows.
+// output in DBF = head_dim / 32 row blocks of 32 (v_mfma_f32_32x32x16) plus, for head_dim 40 / 80, ONE block of 16 rows on v_mfma_f32_16x16x32 (TAIL): rows 32-39
+// (+ 8 zero rows) / 64-79.  Round 4 ran the remainder as a full 32-row block -- at head_dim 40 that was 60 % more second-product MFMAs than the head has rows
+// (SD 1.5 at 768 x 768: 9216-token self-attention, a third of that forward).  The tail's B operand (P^T with one QUERY per lane of a 16-lane row) is the S^T
+// accumulator layout (one query per lane of a 32-lane half) after four v_permlane16_swap per 32 keys; the key order inside its 32-wide k-slice is what those swaps
+// produce (keys 0-3 8-11 | 16-19 24-27 | 4-7 12-15 | 20-23 28-31 for the four lane rows) and the V^T fragment is read in the same order.  The padding lanes of Q are
+// zero registers and the padding rows of V^T zero LDS rows.
 // (A cross-tile software pipeline of the QB = 1 form -- the S^T MFMAs of tile t + 1 issued in front of the softmax arithmetic of tile t, three LDS stages -- was
 // written in round 4, bit-identical and 3 % SLOWER at 4096 keys (3.74 vs 3.63 ms; profiles/r04g_attention_ablation_and_isa_mix.txt); removed in round 5.)
 // PAIR: four LDS stages and ONE barrier per two 64-key tiles (half the barriers; 4 x 17.5 KiB of dynamic LDS at head_dim 64).
@@ -110,9 +126,12 @@ template <typename T, int QB, int DU, bool PAIR, bool RAGGED, bool KVS = false>
 __global__ __launch_bounds__(256, (DU > 10 ? 1 : 2)) void gsw_attn_fwd_kernel(AttnArgs p) {
     using v8 = typename AT<T>::v8;
     using v4 = typename AT<T>::v4;
-    constexpr int D = DU * 8, KC = (DU + 1) / 2, DB = (D + 31) / 32;
+    constexpr int D = DU * 8, KC = (DU + 1) / 2, DBF = D / 32, TR = D % 32;
+    constexpr bool TAIL = TR != 0;                                // head_dim 40 / 80: the last 8 / 16 output rows on 16 x 16 x 32 MFMAs
+    static_assert(TR == 0 || TR == 8 || TR == 16, "head_dim % 32 must be 0, 8 or 16");
+    constexpr int DB = DBF > 0 ? DBF : 1, VROWS = DBF * 32 + (TAIL ? 16 : 0), NACC = DBF * 16 + (TAIL ? 8 : 0);
     constexpr uint32_t KP = KC * 32 + 16;                         // K LDS row pitch: odd number of 16-byte slots -> conflict-free ds_read_b128
-    constexpr uint32_t STAGE = 64 * KP + DB * 32 * VP;            // one 64-key K tile + one V^T tile
+    constexpr uint32_t STAGE = 64 * KP + VROWS * VP;              // one 64-key K tile + one V^T tile
     constexpr int NU = (64 * DU + 255) / 256;                     // 16-byte staging units per thread, tile and operand
     constexpr uint32_t NSTG = PAIR ? 4 : 2;
     static_assert(!KVS || (QB == 1 && !RAGGED && !PAIR), "key-split form: 32 queries per wave, whole tiles, the plain two-stage loop");
@@ -200,9 +219,11 @@ __global__ __launch_bounds__(256, (DU > 10 ? 1 : 2)) void gsw_attn_fwd_kernel(At
     static_assert(NU <= 5, "staging code covers up to 5 units per thread");
 
     f32x16 o[QB][DB];
+    f32x4 ot[QB][2];          // TAIL: rows DBF*32 + 4 (lane >> 4) + j of queries 0-15 | 16-31 of the block (query = lane & 15)
     float m_i[QB], l_i[QB];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
+        ot[qb][0] = f32x4{0.f, 0.f, 0.f, 0.f}; ot[qb][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int db = 0; db < DB; ++db)
 #pragma unroll
@@ -273,9 +294,14 @@ __global__ __launch_bounds__(256, (DU > 10 ? 1 : 2)) void gsw_attn_fwd_kernel(At
             l_i[qb] = fmaf(l_i[qb], alpha, rs);
             if (__any(alpha != 1.0f)) {                 // once the running maxima have settled the whole wave skips the rescale
 #pragma unroll
-                for (int db = 0; db < DB; ++db)
+                for (int db = 0; db < DBF; ++db)
 #pragma unroll
                     for (int i = 0; i < 16; ++i) o[qb][db][i] *= alpha;
+                if constexpr (TAIL) {
+                    float a0, a1;
+                    rows16_split(alpha, a0, a1);
+                    ot[qb][0] *= a0; ot[qb][1] *= a1;
+                }
             }
         }
 
@@ -285,13 +311,34 @@ __global__ __launch_bounds__(256, (DU > 10 ? 1 : 2)) void gsw_attn_fwd_kernel(At
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
 #pragma unroll
-                for (int db = 0; db < DB; ++db) {
+                for (int db = 0; db < DBF; ++db) {
                     const uint8_t* vp = Vl + (uint32_t)(db * 32 + (int)c32) * VP + (uint32_t)(kb * 32 + tt * 16 + (int)h * 4) * 2u;
                     const v4 lo = *reinterpret_cast<const v4*>(vp);
                     const v4 hi = *reinterpret_cast<const v4*>(vp + 16);
                     const v8 a = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
                     for (int qb = 0; qb < QB; ++qb) o[qb][db] = AT<T>::mfma(a, pb[qb][kb][tt], o[qb][db]);
+                }
+            }
+            if constexpr (TAIL) {
+                // rows DBF*32 .. + 15 against all 32 keys of the half tile: one 16 x 16 x 32 MFMA per 16 queries.  Lane (row r = lane >> 4, m = lane & 15): V^T row
+                // DBF*32 + m, keys (r & 1) * 16 + (r >> 1) * 4 + {0..3, 8..11} -- the key order the swapped probabilities carry
+                const uint32_t r16 = lane >> 4, m16 = lane & 15u;
+                const uint8_t* vp = Vl + (uint32_t)(DBF * 32 + (int)m16) * VP + (uint32_t)(kb * 32 + (int)((r16 & 1u) * 16u + (r16 >> 1) * 4u)) * 2u;
+                const v4 lo = *reinterpret_cast<const v4*>(vp);
+                const v4 hi = *reinterpret_cast<const v4*>(vp + 16);
+                const v8 a = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) {
+                    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                    u32x4 b0 = __builtin_bit_cast(u32x4, pb[qb][kb][0]), b1 = __builtin_bit_cast(u32x4, pb[qb][kb][1]);
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const auto sw = __builtin_amdgcn_permlane16_swap(b0[w], b1[w], false, false);
+                        b0[w] = sw[0]; b1[w] = sw[1];
+                    }
+                    ot[qb][0] = AT<T>::mfma16(a, __builtin_bit_cast(v8, b0), ot[qb][0]);      // queries 0-15 of the block
+                    ot[qb][1] = AT<T>::mfma16(a, __builtin_bit_cast(v8, b1), ot[qb][1]);      // queries 16-31
                 }
             }
         }
@@ -337,13 +384,17 @@ __global__ __launch_bounds__(256, (DU > 10 ? 1 : 2)) void gsw_attn_fwd_kernel(At
 
     if constexpr (KVS) {
         // ---- partial result of this key range: accumulators as they are (one coalesced 256-byte store per register), then m and the lane's partial row sum
-        float* base = p.part + (((size_t)logical * p.ksplit + ks) * 4u + wave) * (size_t)((DB * 16 + 2) * 64) + lane;
+        float* base = p.part + (((size_t)logical * p.ksplit + ks) * 4u + wave) * (size_t)((NACC + 2) * 64) + lane;
 #pragma unroll
-        for (int db = 0; db < DB; ++db)
+        for (int db = 0; db < DBF; ++db)
 #pragma unroll
             for (int i = 0; i < 16; ++i) base[(db * 16 + i) * 64] = o[0][db][i];
-        base[(DB * 16) * 64] = m_i[0];
-        base[(DB * 16 + 1) * 64] = l_i[0];
+        if constexpr (TAIL) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) base[(DBF * 16 + i) * 64] = ot[0][i >> 2][i & 3];
+        }
+        base[NACC * 64] = m_i[0];
+        base[(NACC + 1) * 64] = l_i[0];
         return;
     }
 
@@ -356,16 +407,33 @@ __global__ __launch_bounds__(256, (DU > 10 ? 1 : 2)) void gsw_attn_fwd_kernel(At
         if (RAGGED && qi >= (uint32_t)p.Sq) continue;
         T* O = reinterpret_cast<T*>(p.o) + ((int64_t)b * p.Sq + qi) * p.ldo + hh * (uint32_t)D;
 #pragma unroll
-        for (int db = 0; db < DB; ++db) {
+        for (int db = 0; db < DBF; ++db) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int d0 = db * 32 + g * 8 + (int)h * 4;
-                if (db * 32 + g * 8 + 8 <= D || d0 < D) {          // rows >= head_dim are padding
-                    v4 w;
+                v4 w;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) w[j] = (T)(o[qb][db][g * 4 + j] * inv);
-                    *reinterpret_cast<v4*>(O + d0) = w;
-                }
+                for (int j = 0; j < 4; ++j) w[j] = (T)(o[qb][db][g * 4 + j] * inv);
+                *reinterpret_cast<v4*>(O + d0) = w;
+            }
+        }
+    }
+    if constexpr (TAIL) {
+        // the 16-row tail: lane (r = lane >> 4, n = lane & 15) holds rows DBF*32 + 4 r + j of query n (first MFMA) / 16 + n (second) of each 32-query block
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            float inv2[2];
+            rows16_split(1.0f / xhalf_sum(l_i[qb]), inv2[0], inv2[1]);
+            const int d0 = DBF * 32 + (int)(lane >> 4) * 4;
+#pragma unroll
+            for (int hq = 0; hq < 2; ++hq) {
+                const uint32_t qi = qt * QWG + wave * QW + 32u * qb + 16u * hq + (lane & 15u);
+                if ((RAGGED && qi >= (uint32_t)p.Sq) || d0 >= D) continue;
+                T* O = reinterpret_cast<T*>(p.o) + ((int64_t)b * p.Sq + qi) * p.ldo + hh * (uint32_t)D;
+                v4 w;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w[j] = (T)(ot[qb][hq][j] * inv2[hq]);
+                *reinterpret_cast<v4*>(O + d0) = w;
             }
         }
     }
@@ -381,17 +449,19 @@ __global__ __launch_bounds__(256, (DU > 10 ? 1 : 2)) void gsw_attn_fwd_kernel(At
 template <typename T, int DU>
 __global__ __launch_bounds__(256) void gsw_attn_combine_kernel(AttnArgs p) {
     using v4 = typename AT<T>::v4;
-    constexpr int D = DU * 8, DB = (D + 31) / 32;
+    constexpr int D = DU * 8, DBF = D / 32, TR = D % 32, DB = DBF > 0 ? DBF : 1, NACC = DBF * 16 + (TR ? 8 : 0);
+    constexpr bool TAIL = TR != 0;
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u, h = lane >> 5, c32 = lane & 31u;
     const uint32_t logical = blockIdx.x;
     const uint32_t bh = logical / p.nqt, qt = logical - bh * p.nqt;
     const uint32_t b = bh / (uint32_t)p.H, hh = bh - b * (uint32_t)p.H;
     const uint32_t qi = qt * 128u + wave * 32u + c32;
-    constexpr size_t REC = (size_t)(DB * 16 + 2) * 64;
+    constexpr size_t REC = (size_t)(NACC + 2) * 64;
     const float* base = p.part + ((size_t)logical * p.ksplit * 4u + wave) * REC + lane;
     float m = -INFINITY;
-    for (uint32_t s = 0; s < p.ksplit; ++s) m = fmaxf(m, base[(size_t)s * 4u * REC + (DB * 16) * 64]);
+    for (uint32_t s = 0; s < p.ksplit; ++s) m = fmaxf(m, base[(size_t)s * 4u * REC + NACC * 64]);
     f32x16 o[DB];
+    f32x4 ot[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
     for (int db = 0; db < DB; ++db)
 #pragma unroll
@@ -399,26 +469,45 @@ __global__ __launch_bounds__(256) void gsw_attn_combine_kernel(AttnArgs p) {
     float l = 0.f;
     for (uint32_t s = 0; s < p.ksplit; ++s) {
         const float* r = base + (size_t)s * 4u * REC;
-        const float sc = __builtin_amdgcn_exp2f(r[(DB * 16) * 64] - m);
-        l = fmaf(r[(DB * 16 + 1) * 64], sc, l);
+        const float sc = __builtin_amdgcn_exp2f(r[NACC * 64] - m);          // (m and the row sums are per query of the 32-lane-half layout)
+        l = fmaf(r[(NACC + 1) * 64], sc, l);
 #pragma unroll
-        for (int db = 0; db < DB; ++db)
+        for (int db = 0; db < DBF; ++db)
 #pragma unroll
             for (int i = 0; i < 16; ++i) o[db][i] = fmaf(r[(db * 16 + i) * 64], sc, o[db][i]);
+        if constexpr (TAIL) {
+            float s2[2];
+            rows16_split(sc, s2[0], s2[1]);                                  // the tail accumulators keep one query per lane of a 16-lane row
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ot[i >> 2][i & 3] = fmaf(r[(DBF * 16 + i) * 64], s2[i >> 2], ot[i >> 2][i & 3]);
+        }
     }
     const float inv = 1.0f / xhalf_sum(l);
     T* O = reinterpret_cast<T*>(p.o) + ((int64_t)b * p.Sq + qi) * p.ldo + hh * (uint32_t)D;
 #pragma unroll
-    for (int db = 0; db < DB; ++db) {
+    for (int db = 0; db < DBF; ++db) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int d0 = db * 32 + g * 8 + (int)h * 4;
-            if (db * 32 + g * 8 + 8 <= D || d0 < D) {          // rows >= head_dim are padding
-                v4 w;
+            v4 w;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) w[j] = (T)(o[db][g * 4 + j] * inv);
-                *reinterpret_cast<v4*>(O + d0) = w;
-            }
+            for (int j = 0; j < 4; ++j) w[j] = (T)(o[db][g * 4 + j] * inv);
+            *reinterpret_cast<v4*>(O + d0) = w;
+        }
+    }
+    if constexpr (TAIL) {
+        float inv2[2];
+        rows16_split(inv, inv2[0], inv2[1]);
+        const int d0 = DBF * 32 + (int)(lane >> 4) * 4;
+#pragma unroll
+        for (int hq = 0; hq < 2; ++hq) {
+            const uint32_t qh = qt * 128u + wave * 32u + 16u * hq + (lane & 15u);
+            if (d0 >= D) continue;
+            T* Oh = reinterpret_cast<T*>(p.o) + ((int64_t)b * p.Sq + qh) * p.ldo + hh * (uint32_t)D;
+            v4 w;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[j] = (T)(ot[hq][j] * inv2[hq]);
+            *reinterpret_cast<v4*>(Oh + d0) = w;
         }
     }
 }
@@ -427,8 +516,8 @@ __global__ __launch_bounds__(256) void gsw_attn_combine_kernel(AttnArgs p) {
 
 template <typename T, int QB, int DU>
 static int launch_attn_cfg(const AttnArgs& a, uint32_t grid, bool ragged, float* ws, int64_t ws_bytes, hipStream_t st) {
-    constexpr int KC = (DU + 1) / 2, DB = (DU * 8 + 31) / 32;
-    constexpr uint32_t stage = 64 * (KC * 32 + 16) + DB * 32 * 136;
+    constexpr int KC = (DU + 1) / 2, DBF = DU * 8 / 32, TR = DU * 8 % 32, NACC = DBF * 16 + (TR ? 8 : 0);
+    constexpr uint32_t stage = 64 * (KC * 32 + 16) + (DBF * 32 + (TR ? 16 : 0)) * 136;
     // Key-split form: few query tiles against many key tiles (one image's self-attention at 64 x 64: 62 -> 49 us).  As many splits as keep every workgroup
     // resident at once (2 per CU); only from 32 key tiles up -- the second launch and the partial results cost ~12 us, and at 16 tiles (32 x 32: 17.6 -> 21.4 us)
     // that is more than the split saves.  Needs the caller's workspace (gsw_attention_ws); GSW_ATTN_KVS=0 switches it off (A/B), k > 1 forces k ways from 8 tiles up.
@@ -438,7 +527,7 @@ static int launch_attn_cfg(const AttnArgs& a, uint32_t grid, bool ragged, float*
         if (!ragged && kvs_env && ws && a.Sk_valid == a.Sk && a.total <= 256u && nt >= (kvs_env > 1 ? 8 : 32)) {
             uint32_t ksplit = (uint32_t)std::min<int64_t>(std::min<int64_t>(512 / a.total, nt / 4), 8);
             if (kvs_env > 1) ksplit = (uint32_t)std::min<int>(kvs_env, nt);                                   // (tests: force a split count)
-            const int64_t need = (int64_t)a.total * ksplit * 4 * (DB * 16 + 2) * 64 * (int64_t)sizeof(float);
+            const int64_t need = (int64_t)a.total * ksplit * 4 * (NACC + 2) * 64 * (int64_t)sizeof(float);
             if (ksplit >= 2 && need <= ws_bytes) {
                 AttnArgs k = a;
                 k.ksplit = ksplit; k.part = ws;

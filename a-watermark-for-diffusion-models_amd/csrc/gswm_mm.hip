@@ -98,6 +98,13 @@ __device__ __forceinline__ void mm_lds_read_rows(uint32_t a, mm_f2 (&r)[MT]) {
         asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:128\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r[0]), "=&v"(r[1]) : "v"(a) : "memory");
 }
 
+// lane index of the calling lane, made on the spot (exec is all ones wherever this is called): two v_mbcnt in a VOLATILE asm -- unlike threadIdx.x & 63 it needs no
+// register kept alive across the main loop, and unlike the builtin it is not hoisted above it
+__device__ __forceinline__ uint32_t mm_lane_now() {
+    uint32_t l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
 // EPI: epilogue class the kernel is compiled for -- 0 dense rows (bias, optional residual), 1 generic (PF border / row bias / token scatter /
 // sub-pixel scatter), 2 GEGLU, 3 transposed output (MFMA operands swapped); mm_gelu: gswm_mmtypes.h
 // x + (the DPP-selected x of another lane; 0 where the selection has no source or the row is masked out)
@@ -318,7 +325,8 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
     };
     // ---------------------------------------------------------------- WIDE producer: the same walk with BUFFER addressing.  160 accumulators leave no room for
     // nine 64-bit lane pointers + nine row indices: a piece's address is (buffer base in SGPRs) + (32-bit lane offset) + (scalar offset), and what a stage
-    // advances is the scalar offset only.  Activations: one lane offset per piece (row of this lane x row stride + its swizzled chunk), recomputed when the
+    // advances is the scalar offset only.  (global_load_lds on base + 32-bit offsets selects the saddr form and needs no descriptor, but hipcc's waitcnt pass
+    // then turns every counted lgkmcnt wait of the fragment reads into lgkmcnt(0): measured in the ISA, not adopted.)  Activations: one lane offset per piece (row of this lane x row stride + its swizzled chunk), recomputed when the
     // segment changes (the row stride does); the segment's tap base is folded into the buffer base so every offset stays non-negative.  Weights: ONE lane offset
     // for the whole kernel ((8 pid + lane row) rows + chunk); tile column, piece (64 rows apart), tap and channel block live in the scalar offset.  Needs
     // N % 320 == 0 (no weight-row clamp) and operands below 4 GiB (host-checked).
@@ -328,6 +336,10 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
     int32_t seg_rows = -1;                                    // segment vo_a was computed for
     __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, -1, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, -1, 0x00020000);
+    // byte strides between the 64-row pieces of a stage, pinned in scalar registers: read from the kernel arguments where they are used, hipcc re-loads them
+    // with s_load INSIDE the main loop, and a scalar load in flight turns every counted lgkmcnt wait of the fragment reads into lgkmcnt(0)
+    uint32_t str_a8 = 128u * (uint32_t)p.seg[0].ld, str_w8 = 128u * (uint32_t)p.ldw;
+    if constexpr (WIDE) asm volatile("" : "+s"(str_a8), "+s"(str_w8));
     int32_t tile_m8 = 0, tile_n8 = 0;
     auto setup_tile8 = [&](uint32_t it) {
         decode_tile(it * G + slotx, tile_m8, tile_n8);
@@ -348,8 +360,8 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
             seg_rows = sg;
             // (lane row and swizzled chunk are recomputed HERE, behind an empty asm: kept from the kernel's start they are long-lived values the
             // allocator spills around the main loop)
-            uint32_t l8 = threadIdx.x & 63u;
-            asm volatile("" : "+v"(l8));
+            const uint32_t l8 = mm_lane_now();
+
             const uint32_t prow = l8 >> 3;
             const uint32_t chunk8 = ((l8 & 7u) ^ ((4u * (pid & 1u) + (l8 >> 4)) & 7u)) * 8u;
             rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(x + (int64_t)tbase * ld), 0, -1, 0x00020000);
@@ -388,9 +400,11 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
             if (++pr_seg == p.nseg) {
                 pr_seg = 0;
                 if (++pr_it == nt_mine) {
-                    // no stage left: the (unconditional) DMA of the remaining steps re-reads the last stage (valid, cached) into ring slots nobody reads
+                    // no stage left: the (unconditional) DMA of the remaining steps re-reads ONE valid, cached location (the first K block of the lanes' rows,
+                    // the first 320 weight rows) into ring slots nobody reads.  (Not "where the offsets stand": they were already advanced past the last stage --
+                    // for the last weight rows that is past the end of the matrix.)
                     pr_run = 0x7FFFFFFF; st_a = 0u; st_w = 0u;
-                    so_a -= 128u; so_w -= 128u;               // (back inside the last K block: the offsets were already advanced past it)
+                    so_a = 0u; so_w = 0u;
                     return;
                 }
                 setup_tile8(pr_it);
@@ -404,7 +418,7 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
             if constexpr (AFF) {
                 if (j == 0) a_piece = so_a;
                 MM_ABL_DMA_A(__builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(lds + pr_slot + (pid + (uint32_t)NPROD * j) * 1024u), 16, (int)vo_a[0], (int)a_piece, 0, 0));
-                a_piece += 64u * 2u * (uint32_t)p.seg[0].ld;
+                a_piece += str_a8;
             } else {
                 MM_ABL_DMA_A(__builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(lds + pr_slot + (pid + (uint32_t)NPROD * j) * 1024u), 16, (int)vo_a[j], (int)so_a, 0, 0));
             }
@@ -412,7 +426,7 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
             if (j == NPA) w_piece = so_w;
             MM_ABL_DMA_W(__builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(lds + pr_slot + (uint32_t)BM * 128u + (pid + (uint32_t)NPROD * (j - NPA)) * 1024u), 16,
                                                                   (int)vo_w, (int)w_piece, 0, 0));
-            w_piece += 64u * 2u * (uint32_t)p.ldw;
+            w_piece += str_w8;
         }
         if (j == NDMA - 1) {
             so_a += st_a; so_w += st_w;
@@ -495,19 +509,17 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
             return;
         }
     } else if constexpr (WIDE) {
-        // prologue: stage 0 and the first three pieces of stage 1 (what the tail of an odd phase issues); wait for stage 0
+        // prologue: stage 0; stage 1 is issued by the first even phase
         {
-            uint32_t l8 = threadIdx.x & 63u;
-            asm volatile("" : "+v"(l8));
+            const uint32_t l8 = mm_lane_now();
+
             vo_w = (((8u * pid + (l8 >> 3)) * (uint32_t)p.ldw) + ((l8 & 7u) ^ ((4u * (pid & 1u) + (l8 >> 4)) & 7u)) * 8u) * 2u;
         }
         setup_tile8(0);
         begin_run8();
 #pragma unroll
         for (int j = 0; j < NDMA; ++j) dma_piece8(j);
-#pragma unroll
-        for (int j = 0; j < 3; ++j) dma_piece8(j);
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(MM_ABL_NPA(3)) : "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
         static_assert(SPLIT || ((NPA == 4 || NPA == 2) && NPW == 2), "the half-stage split assumes 4 (2) + 2 (+1) pieces per wave");
         // prologue: stages 0 and 1 and the first half of stage 2; wait for stage 0 (counted: the newer pieces stay in flight; exact for waves
@@ -548,25 +560,32 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
         int32_t tm, tn;
         decode_tile(c_it * G + slotx, tm, tn);
         const int32_t m0 = tm * BM, n0 = tn * BN;
-        uint32_t lane_p = threadIdx.x & 63u;                   // (WIDE: nothing derived from the lane index may be hoisted out of here into the main loop's registers)
-        if constexpr (WIDE) asm volatile("" : "+v"(lane_p));
+        const uint32_t lane_p = WIDE ? mm_lane_now() : (threadIdx.x & 63u);      // (WIDE: nothing derived from the lane index may be hoisted into the main loop's registers)
         const uint32_t lane = lane_p;
-        auto piece = [&](const void* src, uint32_t byte_off) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(lds + PARAM + byte_off), 16, 0, 0);
+        // one 16-byte-per-lane LDS-DMA piece: `base` (wave-uniform) + this lane's byte offset -> the parameter area.  WIDE: the buffer form -- a global_load_lds
+        // inside the step loop (even behind a branch one wave takes once per tile) makes hipcc's waitcnt pass turn every counted lgkmcnt wait of the fragment
+        // reads into lgkmcnt(0) (seen in the ISA of the dense-row kernel); the buffer form does not
+        auto piece = [&](const void* base, uint32_t lane_bytes, uint32_t byte_off) {
+            if constexpr (WIDE) {
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, -1, 0x00020000);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(lds + PARAM + byte_off), 16, (int)lane_bytes, 0, 0, 0);
+            } else {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const uint8_t*>(base) + lane_bytes),
+                                                 (__attribute__((address_space(3))) void*)(lds + PARAM + byte_off), 16, 0, 0);
+            }
         };
         // lanes past the end of a vector / of the rows re-read its last 16 bytes: their LDS positions belong to columns / rows that are never stored
         if constexpr (LNF) {
 #pragma unroll
             for (int k = 0; k < NPCOL; ++k) {
-                const int32_t nc = min(n0 + 256 * k + 4 * (int32_t)lane, p.N - 4);
-                piece(p.ln_u + nc, (uint32_t)k * 1024u);
-                piece(p.ln_v + nc, PAR_V + (uint32_t)k * 1024u);
+                const uint32_t nc = (uint32_t)min(n0 + 256 * k + 4 * (int32_t)lane, p.N - 4) * 4u;
+                piece(p.ln_u, nc, (uint32_t)k * 1024u);
+                piece(p.ln_v, nc, PAR_V + (uint32_t)k * 1024u);
             }
-            const float2* st = reinterpret_cast<const float2*>(p.ln_stat);
 #pragma unroll
-            for (int k = 0; k < (BM + 127) / 128; ++k) piece(st + min(m0 + 128 * k + 2 * (int32_t)lane, p.M - 2), PAR_ROWS + (uint32_t)k * 1024u);
+            for (int k = 0; k < (BM + 127) / 128; ++k) piece(p.ln_stat, (uint32_t)min(m0 + 128 * k + 2 * (int32_t)lane, p.M - 2) * 8u, PAR_ROWS + (uint32_t)k * 1024u);
         } else {
-            piece(reinterpret_cast<const uint16_t*>(p.bias) + min(n0 + 8 * (int32_t)lane, p.N - 8), 0u);        // 512 columns per piece: one covers either tile
+            piece(p.bias, (uint32_t)min(n0 + 8 * (int32_t)lane, p.N - 8) * 2u, 0u);        // 512 columns per piece: one covers either tile
         }
     };
 
@@ -587,11 +606,66 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
         const int32_t m0 = tile_m * BM, n0 = tile_n * BN;
         // (WIDE: the lane index goes through an empty asm so that nothing derived from it -- row / column offsets of ten stores -- is hoisted above the tile
         // loop: the main loop has no register to spare for it)
-        uint32_t lane_e = threadIdx.x & 63u;
-        if constexpr (WIDE) asm volatile("" : "+v"(lane_e));
+        const uint32_t lane_e = WIDE ? mm_lane_now() : (threadIdx.x & 63u);
+
         const uint32_t lane = lane_e;
         const uint32_t q = lane >> 4, li = lane & 15u;
+        // zero-extension of a lane-dependent 32-bit offset to 64 bits with a zero made HERE (volatile asm: not hoisted): hipcc otherwise keeps ONE zero register for all
+        // such pairs, hoists it above the tile loop, and -- on the wide tile, where the main loop needs every register -- spills it around the loop
+        uint32_t zero_hi = 0u;
+        if constexpr (WIDE) asm volatile("v_mov_b32 %0, 0" : "=v"(zero_hi));
+        auto zx = [&](uint32_t v) -> int64_t { return WIDE ? (int64_t)(((uint64_t)zero_hi << 32) | (uint64_t)v) : (int64_t)v; };
         MM_STAMP(13);
+        // output row of tile row m for the PF-row epilogues (EPI 1): padded-flat row of the interior pixel / of the up-sampled pixel / of the token; image, border flag
+        auto out_row = [&](int32_t m, int32_t& img, bool& brd, bool& lv) -> int64_t {
+            lv = m < p.M; brd = false; img = 0;
+            int64_t orow_ = m;
+            const int32_t mc = lv ? m : 0;
+            if (p.mode == MM_MODE_PF || p.mode == MM_MODE_UP2X) {
+                int32_t b, yy, xx;
+                if (compact) {
+                    orow_ = pf_row(mc, b, yy, xx);
+                } else {
+                    b = mc / HpWp;
+                    const int32_t r = mc - b * HpWp;
+                    yy = r / p.Wp; xx = r - yy * p.Wp;
+                    brd = (yy == 0) | (yy == p.Hp - 1) | (xx == 0) | (xx == p.Wp - 1);
+                }
+                img = b;
+                if (p.mode == MM_MODE_UP2X) {             // low-resolution pixel (yy-1, xx-1) -> pixel (2(yy-1)+dy, 2(xx-1)+dx) of a [B, 2H+2, 2W+2] PF tensor
+                    const int32_t dy = (p.up - 1) >> 1, dx = (p.up - 1) & 1;
+                    orow_ = ((int64_t)b * (2 * p.Hp - 2) + (2 * (yy - 1) + dy + 1)) * (2 * p.Wp - 2) + (2 * (xx - 1) + dx + 1);
+                    lv = lv && !brd;
+                }
+            } else if (p.mode == MM_MODE_TOK2PF) {        // token (b, y, x) -> interior row of the PF tensor [B, H+2, W+2]
+                const int32_t b = mc / p.S, ii = mc - b * p.S;
+                const int32_t yy = ii / p.Wimg, xx = ii - yy * p.Wimg;
+                img = b;
+                orow_ = (int64_t)b * HpWp + (int64_t)(yy + 1) * p.Wp + (xx + 1);
+            }
+            return orow_;
+        };
+        // WIDE, launches with a residual operand: the epilogue walks 20 (column block, row pair) blocks per wave, each a load -> add -> store chain, and with 160
+        // accumulators live it can keep ONE block's load in flight -- twenty HBM round trips in a row, ~12 us per tile with the matrix pipe idle (the fixed cost per
+        // launch of the first build: 293 us against 194 for the narrow tile on the 64 x 64 convolutions).  So the wave first TOUCHES every 128-byte line of its
+        // 128 x 80 residual block: four 4-byte LDS-DMA loads (64 lines each, no destination register; they land in a dummy LDS area) bring the lines into L2 / L1 in
+        // ONE round trip, and the chunk loads behind them hit.
+        if constexpr (WIDE && (EPI == 0 || EPI == 1)) {
+            if (resid) {
+                // (buffer form like every LDS-DMA of the wide kernel: see dma_params; the residual tensor is below 4 GiB, host-checked)
+                const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(resid), 0, -1, 0x00020000);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int32_t m = m0 + (int32_t)(wm * (16u * MT) + (uint32_t)k * 32u + (lane >> 1));
+                    int32_t img_; bool brd_, lv_ = m < p.M;
+                    int64_t row_ = m;
+                    if constexpr (EPI == 1) row_ = out_row(m, img_, brd_, lv_);
+                    const int64_t col_ = (int64_t)n0 + grp * (uint32_t)HC + (lane & 1u) * 64u;
+                    if (lv_ && col_ < p.N)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_r, (__attribute__((address_space(3))) void*)(lds + RING + 6144u), 4, (int)(uint32_t)((row_ * p.ldr + col_) * 2), 0, 0, 0);
+                }
+            }
+        }
         const bool vtile = QKV && n0 >= p.n_rows;                 // (wave-uniform) this tile belongs to the transposed part
         const bool transposed = SWAP || vtile;
         if constexpr (PART) {
@@ -754,11 +828,11 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
             const bool rstat = EPI == 0 && p.rowstats != nullptr;
             float rs_s[NPR], rs_q[NPR];
 #pragma unroll
-            for (int pr = 0; pr < NPR; ++pr) { rs_s[pr] = 0.f; rs_q[pr] = 0.f; }
+            for (int pr = 0; pr < NPR; ++pr) { rs_s[pr] = __uint_as_float(zero_hi); rs_q[pr] = __uint_as_float(zero_hi); }
             constexpr int RSD = SPLIT ? 2 : (WIDE ? 2 : 5);
             uint4 rs[5][NPR];
             auto load_rs1 = [&](int in, int pr) {
-                rs[in][pr] = make_uint4(0, 0, 0, 0);
+                rs[in][pr] = make_uint4(zero_hi, zero_hi, zero_hi, zero_hi);
                 if (colb + in * 16 < p.N) rs[in][pr] = *reinterpret_cast<const uint4*>(rrow[pr] + in * 16);
             };
             auto load_rs = [&](int in) {
@@ -792,7 +866,7 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
                 swap32(a, b);
                 const float t = __uint_as_float(a) + __uint_as_float(b);
                 const int32_t m = m0 + (int32_t)(wm * (16u * MT) + (uint32_t)(2 * pr + (int)(q & 1u)) * 16u + li);
-                if (m < p.M) p.rowstats[((int64_t)m * (NG * p.tiles_n) + NG * tile_n + (int32_t)grp) * 2 + (int32_t)(lane >> 5)] = t;
+                if (m < p.M) p.rowstats[((int64_t)m * (NG * p.tiles_n) + NG * tile_n + (int32_t)grp) * 2 + zx(lane >> 5)] = t;
             };
             if constexpr (WIDE) {
                 // row pair by row pair (one pair's pointers, residual chunks and sums live at a time: the 160 accumulators leave room for no more)
@@ -837,36 +911,14 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
             }
         } else if (EPI == 1) {
             // per row pair p: this lane's output row and its addressing
-            int64_t orow[NPR];
+            using orow_t = std::conditional_t<WIDE, int32_t, int64_t>;      // (WIDE: row indices fit 32 bits -- M does -- and four registers matter there)
+            orow_t orow[NPR];
             int32_t img_b[NPR];
             bool live[NPR], border[NPR];
 #pragma unroll
             for (int pr = 0; pr < NPR; ++pr) {
                 const int32_t m = m0 + (int32_t)(wm * (16u * MT) + (uint32_t)(2 * pr + (int)(q & 1u)) * 16u + li);
-                live[pr] = m < p.M; border[pr] = false; img_b[pr] = 0; orow[pr] = m;
-                const int32_t mc = live[pr] ? m : 0;
-                if (p.mode == MM_MODE_PF || p.mode == MM_MODE_UP2X) {
-                    int32_t b, yy, xx;
-                    if (compact) {
-                        orow[pr] = pf_row(mc, b, yy, xx);
-                    } else {
-                        b = mc / HpWp;
-                        const int32_t r = mc - b * HpWp;
-                        yy = r / p.Wp; xx = r - yy * p.Wp;
-                        border[pr] = (yy == 0) | (yy == p.Hp - 1) | (xx == 0) | (xx == p.Wp - 1);
-                    }
-                    img_b[pr] = b;
-                    if (p.mode == MM_MODE_UP2X) {             // low-resolution pixel (yy-1, xx-1) -> pixel (2(yy-1)+dy, 2(xx-1)+dx) of a [B, 2H+2, 2W+2] PF tensor
-                        const int32_t dy = (p.up - 1) >> 1, dx = (p.up - 1) & 1;
-                        orow[pr] = ((int64_t)b * (2 * p.Hp - 2) + (2 * (yy - 1) + dy + 1)) * (2 * p.Wp - 2) + (2 * (xx - 1) + dx + 1);
-                        live[pr] = live[pr] && !border[pr];
-                    }
-                } else if (p.mode == MM_MODE_TOK2PF) {        // token (b, y, x) -> interior row of the PF tensor [B, H+2, W+2]
-                    const int32_t b = mc / p.S, ii = mc - b * p.S;
-                    const int32_t yy = ii / p.Wimg, xx = ii - yy * p.Wimg;
-                    img_b[pr] = b;
-                    orow[pr] = (int64_t)b * HpWp + (int64_t)(yy + 1) * p.Wp + (xx + 1);
-                }
+                orow[pr] = (orow_t)out_row(m, img_b[pr], border[pr], live[pr]);
             }
             // Column statistics for the GroupNorm that consumes this output (p.colstats): every lane adds the values it STORES -- as packed column pairs,
             // two v_dot2_f32_f16 per pair -- into 4 (sum, sum of squares) pairs; one v_permlane16_swap + add folds the two row tiles and leaves the sums
@@ -874,6 +926,20 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
             // is reproducible -- and lanes 15 / 31 / 47 / 63 each write one 16-byte record (4 column pairs of one plane) for this wave's block of 16 MT rows.
             const bool cstat = p.colstats != nullptr;
             MM_STAMP(14);
+            // WIDE: the row-bias / residual chunks of block (in, pr) are fetched one block AHEAD (two register sets): 20 blocks per wave, each a dependent
+            // load -> add -> store chain otherwise, with the matrix pipe idle
+            // (ONE prefetched operand: the residual when there is one, else the row bias -- no launch of the eps model or the VAE has both; a launch that
+            // does fetches its row bias in place)
+            uint4 prev[2];
+            auto fetch = [&](int in, int pr, int sl) {
+                const int64_t col = (int64_t)n0 + grp * (uint32_t)HC + (uint32_t)in * 16u + (q >> 1) * 8u;
+                prev[sl] = make_uint4(0, 0, 0, 0);
+                if (live[pr] && col < p.N && !border[pr]) {
+                    if (resid) prev[sl] = *reinterpret_cast<const uint4*>(resid + (int64_t)orow[pr] * p.ldr + col);
+                    else prev[sl] = *reinterpret_cast<const uint4*>(rowbias + (int64_t)img_b[pr] * p.ldrb + col);
+                }
+            };
+            if constexpr (WIDE) { if (rowbias || resid) fetch(0, 0, 0); }
 #pragma unroll
             for (int in = 0; in < 5; ++in) {
                 float bq[4];
@@ -882,6 +948,9 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
                 float cs_s[4] = {0.f, 0.f, 0.f, 0.f}, cs_q[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int pr = 0; pr < NPR; ++pr) {
+                    constexpr int NB = 5 * NPR;
+                    const int j = in * NPR + pr;
+                    if constexpr (WIDE) { if ((rowbias || resid) && j + 1 < NB) fetch((j + 1) / NPR, (j + 1) % NPR, (j + 1) & 1); }
                     uint32_t a0, a1, b0, b1;
                     pack4(in, 2 * pr, bq, a0, a1);
                     pack4(in, 2 * pr + 1, bq, b0, b1);
@@ -892,8 +961,13 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
                     if (border[pr]) { w4[0] = w4[1] = w4[2] = w4[3] = 0u; }
                     else if (rowbias || resid) {
                         uint4 rb = make_uint4(0, 0, 0, 0), rs = make_uint4(0, 0, 0, 0);
+                        if constexpr (WIDE) {
+                            if (resid) { rs = prev[j & 1]; if (rowbias) rb = *reinterpret_cast<const uint4*>(rowbias + (int64_t)img_b[pr] * p.ldrb + col); }
+                            else rb = prev[j & 1];
+                        } else {
                         if (rowbias) rb = *reinterpret_cast<const uint4*>(rowbias + (int64_t)img_b[pr] * p.ldrb + col);
-                        if (resid) rs = *reinterpret_cast<const uint4*>(resid + orow[pr] * p.ldr + col);
+                        if (resid) rs = *reinterpret_cast<const uint4*>(resid + (int64_t)orow[pr] * p.ldr + col);
+                        }
                         const uint32_t rbw[4] = {rb.x, rb.y, rb.z, rb.w}, rsw[4] = {rs.x, rs.y, rs.z, rs.w};
                         // packed adds, rounded like the separate tensor adds they replace (conv1 has the row bias, conv2 / the token scatter the residual)
 #pragma unroll
@@ -902,7 +976,7 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
                             if (resid) w4[k] = MM<T>::add2(w4[k], rsw[k]);
                         }
                     }
-                    *reinterpret_cast<uint4*>(Y + orow[pr] * p.ldy + col) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+                    *reinterpret_cast<uint4*>(Y + (int64_t)orow[pr] * p.ldy + col) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
                     if (cstat && !border[pr]) {
 #pragma unroll
                         for (int k = 0; k < 4; ++k) MM<T>::stat2(w4[k], cs_s[k], cs_q[k]);
@@ -937,8 +1011,7 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
             // one packed multiply (v_pk_mul_f16: the correctly rounded product of the two rounded operands).  33 instead of 52 instructions per accumulator.
             const uint32_t qv = q & 1u;
             uint32_t D[5][NPR][2];                            // [in][row pair][2 registers]: 4 consecutive outputs 4 qv .. of row tile 2p + (lane >> 5)
-#pragma unroll
-            for (int in = 0; in < 5; ++in) {
+            auto gate_block = [&](int in) {                   // value * gelu(gate) of column block `in`, all row tiles of the wave
                 float bq[4];
                 bias4(in, bq);
                 lnf_cols(in);
@@ -958,24 +1031,41 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
                     D[in][pr][0] = a;
                     D[in][pr][1] = b;
                 }
-            }
+            };
             const int64_t obase = (int64_t)tile_n * (BN / 2) + grp * 40u;
+            // n-tile pairs (0,1) and (2,3): one more swap round -> 8 consecutive outputs (16 bytes) per lane
+            auto store_pair = [&](int ip) {
 #pragma unroll
-            for (int pr = 0; pr < NPR; ++pr) {
-                // n-tile pairs (0,1) and (2,3): one more swap round -> 8 consecutive outputs (16 bytes) per lane
-#pragma unroll
-                for (int ip = 0; ip < 2; ++ip) {
+                for (int pr = 0; pr < NPR; ++pr) {
                     uint32_t a0 = D[2 * ip][pr][0], a1 = D[2 * ip][pr][1], b0 = D[2 * ip + 1][pr][0], b1 = D[2 * ip + 1][pr][1];
                     swap16(a0, b0);
                     swap16(a1, b1);
                     const int32_t m = m0 + (int32_t)(wm * (16u * MT) + (uint32_t)(2 * pr + (int)(q >> 1)) * 16u + li);
                     if (m < p.M)
-                        *reinterpret_cast<uint4*>(Y + (int64_t)m * p.ldy + obase + (uint32_t)(2 * ip + (int)(q & 1u)) * 8u) = make_uint4(a0, a1, b0, b1);
+                        *reinterpret_cast<uint4*>(Y + (int64_t)m * p.ldy + obase + zx((uint32_t)(2 * ip + (int)(q & 1u)) * 8u)) = make_uint4(a0, a1, b0, b1);
                 }
-                // n-tile 4 has no partner: 8-byte stores (4 outputs per lane)
-                const int32_t m = m0 + (int32_t)(wm * (16u * MT) + (uint32_t)(2 * pr + (int)(lane >> 5)) * 16u + li);
-                if (m < p.M)
-                    *reinterpret_cast<uint2*>(Y + (int64_t)m * p.ldy + obase + 32u + qv * 4u) = make_uint2(D[4][pr][0], D[4][pr][1]);
+            };
+            // n-tile 4 has no partner: 8-byte stores (4 outputs per lane)
+            auto store_last = [&]() {
+#pragma unroll
+                for (int pr = 0; pr < NPR; ++pr) {
+                    const int32_t m = m0 + (int32_t)(wm * (16u * MT) + (uint32_t)(2 * pr + (int)(lane >> 5)) * 16u + li);
+                    if (m < p.M)
+                        *reinterpret_cast<uint2*>(Y + (int64_t)m * p.ldy + obase + zx(32u + qv * 4u)) = make_uint2(D[4][pr][0], D[4][pr][1]);
+                }
+            };
+            if constexpr (WIDE) {
+                // a pair of column blocks at a time (2 x 4 row pairs x 2 registers live instead of 5 x 4 x 2 beside the accumulators still to come)
+                gate_block(0); gate_block(1); store_pair(0);
+                __builtin_amdgcn_sched_barrier(0);
+                gate_block(2); gate_block(3); store_pair(1);
+                __builtin_amdgcn_sched_barrier(0);
+                gate_block(4); store_last();
+            } else {
+#pragma unroll
+                for (int in = 0; in < 5; ++in) gate_block(in);
+                store_pair(0); store_pair(1);
+                store_last();
             }
         } else {
             // transposed output Y[image][n][token]: lane (q, i) holds tokens 16 im + 4 q + j of output row 16 in + i
@@ -1114,9 +1204,11 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
                 else if (!LAST) { MM_ABL_READ(xr[(im + 3) & 3] = rd_at(a_n, im - 5)); }
                 if (!LAST && im == 5) { MM_ABL_READ(wn[0] = rd_at(w_n, 0)); MM_ABL_READ(wn[1] = rd_at(w_n, 1)); MM_ABL_READ(wn[2] = rd_at(w_n, 2)); }
                 if (!LAST && im == 6) { MM_ABL_READ(wn[3] = rd_at(w_n, 3)); MM_ABL_READ(wn[4] = rd_at(w_n, 4)); }
-                // the nine pieces of a stage: three behind the barrier of the odd phase, six in the even phase that follows
-                if (!ODD && im < 6) dma_piece8(3 + im);
-                if (ODD && im >= 5) dma_piece8(im - 5);
+                // the nine pieces of a stage: all in the even phase that follows the barrier which freed the slot (two with block 0, one with each other block).
+                // Not in the tail of the odd phase (blocks 5..7, right behind the barrier): hipcc's waitcnt pass puts s_waitcnt vmcnt(0) in front of the first
+                // fragment read after the loop's back edge whenever an LDS-DMA may be in flight there -- with nothing issued since the barrier's own vmcnt(0)
+                // that wait is free, with three pieces in flight it stalled every stage (found in the ISA of the first build)
+                if (!ODD) { if (im == 0) dma_piece8(0); dma_piece8(1 + im); }
                 if constexpr (STG && ODD) { if (stg7 && step_i == 0 && im == 7) dma_params(); }
 #pragma unroll
                 for (int in = 0; in < 5; ++in) acc[in][im] = MM_ABL_MMA(wc[in], xr[im & 3], acc[in][im]);
@@ -1299,8 +1391,8 @@ template <typename T, int EPI, bool SPLIT, int MT, bool LNF = false>
 int mm_launch_k(const MMArgs& a, uint32_t grid, hipStream_t st) {
     static bool attr_done = false;          // benign race: setting the attribute twice is harmless
     constexpr bool wide = MT == 8;          // the 256 x 320 tile: two stage slots of 72 KiB
-    constexpr size_t ldsb = (wide ? 2u * 576u : 3u * (size_t)(64 * MT + 160)) * 128u
-                            + (!SPLIT && (EPI == 2 || (EPI == 0 && (!LNF || wide))) ? (wide ? 6144u : 4096u) : 0u);   // the ring (+ the staged epilogue parameters)
+    constexpr size_t ldsb = wide ? 2u * 576u * 128u + 6144u + 256u          // two stage slots + the staged epilogue parameters + the landing area of the residual touches
+                                 : 3u * (size_t)(64 * MT + 160) * 128u + (!SPLIT && (EPI == 2 || (EPI == 0 && !LNF)) ? 4096u : 0u);   // the ring (+ the staged epilogue parameters)
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)gsw_mm_kernel<T, EPI, SPLIT, MT, LNF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
@@ -1453,29 +1545,46 @@ int gsw_mm_get_config(int* tile_rows, int* split_mask) {
 // keeps 256-row tiles (a half tile re-fetches the weight tile twice as often).
 // Split: at most 128 tiles, at least 8 stages, up to 32 ways (one image at 8 x 8: 8 tiles x 32 = the whole chip, 19.9 vs 21.1 us at 16 ways) and 256 workgroups, 128- or 256-row tiles, taken for a predicted gain of 5 % or more.  Forced splits
 // (max_splits > 1: tests) use 128 rows unless gsw_mm_config forces the 256-row tile.
+// compute units of the current device (256 on MI355X; the persistent grid, the plan's "rounds" and its half-chip threshold are counted in them).  The XCD
+// interleave of the tile order assumes 8 XCDs: the count is rounded down to a multiple of 8.
+static int mm_cus() {
+    static thread_local int dev_cached = -1, cus = 256;
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && dev != dev_cached) {
+        hipDeviceProp_t pr;
+        if (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount >= 8) cus = pr.multiProcessorCount / 8 * 8;
+        dev_cached = dev;
+    }
+    return cus;
+}
 struct MMPlan { int bm; int splits; double t_us; };
+// (the stage costs were fitted on ONE box of the pool in round 4 -- profiles/r04i_splitk_tile_sweep.txt: MI355X, 256 CUs, 1400 W board limit, HBM-cold weights,
+// the deep levels at 4-64 images, board at 1.1-1.3 kW; boxes of the pool differ by +-4 %.  W = busy workgroups; the costs are functions of the busy FRACTION
+// of the chip, so a different CU count rescales W, not the constants.)
 static inline double mm_stage_us(int bm, double W) {
-    const double over = W > 128.0 ? (W - 128.0) / 128.0 : 0.0;
-    return bm == 128 ? 0.56 + 0.11 * over : 0.79 + 0.02 * std::min(1.0, W / 128.0) + 0.32 * over;
+    const double half = 0.5 * (double)mm_cus();
+    const double over = W > half ? (W - half) / half : 0.0;
+    return bm == 128 ? 0.56 + 0.11 * over : 0.79 + 0.02 * std::min(1.0, W / half) + 0.32 * over;
 }
 static MMPlan mm_plan(int64_t M, int64_t tiles_n, int32_t P, bool can_split, int max_splits) {
     const int bm_env = g_mm_tile_rows.load(std::memory_order_relaxed);          // GSW_MM_BM / gsw_mm_config: 128 / 256 forces a tiling (A/B runs, tests)
+    const int64_t CU = mm_cus();
     const int64_t nt256 = ((M + 255) / 256) * tiles_n, nt128 = ((M + 127) / 128) * tiles_n;
     auto t_unsplit = [&](int bm) {
-        const int64_t nt = bm == 256 ? nt256 : nt128, rounds = (nt + 255) / 256;
-        return 2.5 + mm_stage_us(bm, rounds == 1 ? (double)nt : 256.0) * (double)P * (double)rounds;
+        const int64_t nt = bm == 256 ? nt256 : nt128, rounds = (nt + CU - 1) / CU;
+        return 2.5 + mm_stage_us(bm, rounds == 1 ? (double)nt : (double)CU) * (double)P * (double)rounds;
     };
     int BM;
     if (bm_env == 128 || bm_env == 256) BM = bm_env;
     else if (M <= 128) BM = 256;
-    else if (P >= 40 && nt256 <= 256) BM = t_unsplit(128) < t_unsplit(256) ? 128 : 256;
-    else BM = nt256 < (P >= 64 ? 128 : 256) ? 128 : 256;
+    else if (P >= 40 && nt256 <= CU) BM = t_unsplit(128) < t_unsplit(256) ? 128 : 256;
+    else BM = nt256 < (P >= 64 ? CU / 2 : CU) ? 128 : 256;
     MMPlan pl{BM, 1, t_unsplit(BM)};
     if (!can_split) return pl;
     if (max_splits > 1) {
         const int bm_s = bm_env == 256 && M > 128 ? 256 : 128;
         const int64_t nt_f = ((M + bm_s - 1) / bm_s) * tiles_n;
-        const int sp = (int)std::min<int64_t>(std::min<int64_t>(max_splits, P), 256 / std::max<int64_t>(nt_f, 1));
+        const int sp = (int)std::min<int64_t>(std::min<int64_t>(max_splits, P), CU / std::max<int64_t>(nt_f, 1));
         if (sp >= 2) { pl.bm = bm_s; pl.splits = sp; }
         return pl;
     }
@@ -1485,8 +1594,8 @@ static MMPlan mm_plan(int64_t M, int64_t tiles_n, int32_t P, bool can_split, int
         if (bm_c == 256 && (M <= 128 || bm_env == 128)) continue;
         if (bm_c == 128 && bm_env == 256) continue;
         const int64_t nt_c = bm_c == 256 ? nt256 : nt128;
-        if (nt_c > 128) continue;
-        for (int s_ = 2; s_ <= 32 && s_ * nt_c <= 256 && 2 * s_ <= P; ++s_) {
+        if (nt_c > CU / 2) continue;
+        for (int s_ = 2; s_ <= 32 && s_ * nt_c <= CU && 2 * s_ <= P; ++s_) {
             const double t = 12.5 + mm_stage_us(bm_c, (double)(s_ * nt_c)) * (double)((P + s_ - 1) / s_) + 0.014 * (double)(s_ * nt_c * (bm_c / 128));
             if (t < best) { best = t; pl.bm = bm_c; pl.splits = s_; pl.t_us = t; }
         }
@@ -1581,7 +1690,12 @@ int gsw_mm_launch(MMArgs& a, int dtype, void* stream, GswMmExtras* ex) {
         }
         int64_t ld_max = 0;
         for (int i = 0; i < a.nseg; ++i) ld_max = std::max<int64_t>(ld_max, a.seg[i].ld);
-        const bool legal = mode_ok && a.N >= 320 && a.N % 320 == 0 && (!(a.mode == MM_MODE_GEGLU || (a.mode == MM_MODE_DENSE && !a.rowbias)) || a.M % 256 == 0) && rows_in * ld_max * 2 < ((int64_t)1 << 32) - (1 << 20) && (int64_t)a.N * a.ldw * 2 < ((int64_t)1 << 32) - (1 << 20);
+        // rows of the output / residual row space (the residual touches address it through a buffer descriptor too)
+        int64_t rows_out = a.M;
+        if (a.mode == MM_MODE_PF || a.mode == MM_MODE_TOK2PF) rows_out = ((int64_t)a.M / std::max<int64_t>(1, (a.mode == MM_MODE_TOK2PF ? a.S : ((a.flags & MM_FLAG_COMPACT) ? (int64_t)(a.Hp - 2) * (a.Wp - 2) : (int64_t)a.Hp * a.Wp))) + 1) * (int64_t)a.Hp * a.Wp;
+        if (a.mode == MM_MODE_UP2X) rows_out = rows_in * 4 + 8;
+        const bool res_ok = !a.resid || rows_out * (int64_t)a.ldr * 2 < ((int64_t)1 << 32) - (1 << 20);
+        const bool legal = mode_ok && res_ok && a.N >= 320 && a.N % 320 == 0 && (!(a.mode == MM_MODE_GEGLU || (a.mode == MM_MODE_DENSE && !a.rowbias)) || a.M % 256 == 0) && rows_in * ld_max * 2 < ((int64_t)1 << 32) - (1 << 20) && (int64_t)a.N * a.ldw * 2 < ((int64_t)1 << 32) - (1 << 20);
         // a partial last column tile costs a whole one: at most 1/8 of the column tiles' work wasted
         // measured per shape at 128 rows (profiles/r05c_unet_forward_b128_wide_vs_narrow.txt): the dense-row and GEGLU launches win from K = 640 on (-5 ... -23 %);
         // the PF-row epilogue (convolutions, token scatter: per-row residual / row-bias fetches, twice as long per wave on the wide tile) needs a longer K loop
@@ -1590,9 +1704,10 @@ int gsw_mm_launch(MMArgs& a, int dtype, void* stream, GswMmExtras* ex) {
         static const int pmin_pf = getenv("GSW_MM_WIDE_PMIN_PF") ? atoi(getenv("GSW_MM_WIDE_PMIN_PF")) : 64;      //  and the PF-row launches take the wide tile)
         const int p_min = epi_k == 1 ? pmin_pf : pmin_dense;
         // tiles per round of 256 workgroups: the wide tiling must fill its last round about as well as the narrow one does
-        auto fill = [](int64_t t) { return (double)t / (double)(((t + 255) / 256) * 256); };
+        const int64_t cus = mm_cus();
+        auto fill = [cus](int64_t t) { return (double)t / (double)(((t + cus - 1) / cus) * cus); };
         const int64_t t_w = tm_w * tn_w, t_n = (((int64_t)a.M + 255) / 256) * tiles_n;
-        const bool fits = t_w >= 256 && fill(t_w) >= fill(t_n) - 0.04 && a.P >= p_min && a.M >= 2048;
+        const bool fits = t_w >= cus && fill(t_w) >= fill(t_n) - 0.04 && a.P >= p_min && a.M >= 2048;
         wide = legal && (bm_cfg == 512 || (bm_cfg == 0 && wide_env != 0 && fits));
     }
     const int BMt = wide ? 256 : BM, BNt = wide ? 320 : BN;
@@ -1605,7 +1720,7 @@ int gsw_mm_launch(MMArgs& a, int dtype, void* stream, GswMmExtras* ex) {
         a.panel = 4;
         if (tiles_nt > 4 && tiles_nt <= 16 && tiles_nt * 320 * (int64_t)a.P * 64 * 2 <= (2 << 20)) a.panel = (int32_t)tiles_nt;
     }
-    const uint32_t grid = (uint32_t)std::min<int64_t>(256, (a.ntiles + 7) / 8 * 8);
+    const uint32_t grid = (uint32_t)std::min<int64_t>(mm_cus(), (a.ntiles + 7) / 8 * 8);
     const int ngrp = wide ? 4 : 2, wmv = wide ? 2 : 4;        // 80-column groups per tile, waves along M
     // row statistics: plain dense-row launches (EPI 0), unsplit
     if (rs_req && a.mode == MM_MODE_DENSE && !a.rowbias && !a.ln_stat && (int64_t)a.M * ngrp * tiles_nt * 2 <= rs_cap) {

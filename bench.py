@@ -39,6 +39,10 @@ def parse():
     ap.add_argument("--batch", type=int, default=64, help="e2e: images per GPU per step (north-star batch 64)")
     ap.add_argument("--codec-batch", type=int, default=16384, help="codec tier: images per GPU per step (HBM-bound regime)")
     ap.add_argument("--codec-steps", type=int, default=50, help="codec tier steps when it rides along with e2e")
+    ap.add_argument("--codec-streams", type=int, choices=[1, 2], default=1,
+                    help="codec tier: 1 (default) = embed, then extract on one stream; 2 = the embed (a pure HBM write stream) and the extract (a pure read stream) of a "
+                         "step on two HIP streams sharing the HBM interface -- measured in round 5 and NOT faster (4.93e7 vs 5.00e7 images/s, "
+                         "profiles/r05e_codec_one_vs_two_streams.txt), kept as a switch.  The per-kernel roofline durations always come from single-stream launches")
     ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--width", type=int, default=512)
     ap.add_argument("--message-length", type=int, default=256)
@@ -236,8 +240,21 @@ def run_codec(args, rank, world, local_rank, steps, warmup, cpu_codec=None):
     z16 = codec.embed_batch(key, nonce, k, B, shape, seed=params["seed"], image_index0=rank * B, dtype=torch.float16, fast=fast, device=dev)
     bits_all = torch.empty((world, B, M // 8), dtype=torch.uint8, device=dev) if world > 1 else None
 
+    two = args.codec_streams == 2
+    side = torch.cuda.Stream(device=dev) if two else None
+
     def step(i, ev=None):
         idx0 = (i * world + rank) * B                                         # global image index: independent of the GPU count
+        if two and ev is None:
+            # the two kernels of a step touch disjoint buffers (embed writes z32, extract reads z16): the embed goes to a side stream, the extract stays on the
+            # current one, and the step ends when both have (the side stream joins the current stream again)
+            cur = torch.cuda.current_stream(dev)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                codec.embed_batch(key, nonce, k, B, shape, seed=params["seed"], image_index0=idx0, fast=fast, out=z32)
+            bits, flags = codec.extract_batch(z16, key, nonce, M)
+            cur.wait_stream(side)
+            return bits, flags
         if ev: ev[0].record()
         codec.embed_batch(key, nonce, k, B, shape, seed=params["seed"], image_index0=idx0, fast=fast, out=z32)
         if ev: ev[1].record()
@@ -255,7 +272,7 @@ def run_codec(args, rank, world, local_rank, steps, warmup, cpu_codec=None):
     handles = []
     t0 = time.perf_counter()
     for i in range(steps):
-        bits, flags = step(warmup + i, events[i])
+        bits, flags = step(warmup + i, None if two else events[i])
         if world > 1:  # gather of the recovered bitstrings (1 KiB-class, latency-bound), overlapped with the next step
             handles.append(dist.all_gather_into_tensor(bits_all.view(-1), bits.view(-1), async_op=True))
     for hd in handles:
@@ -285,6 +302,11 @@ def run_codec(args, rank, world, local_rank, steps, warmup, cpu_codec=None):
             ok_bits &= bool((bits_all == want[None, None]).all())
     bit_acc = float(matches.item()) / (world * B * M)
 
+    if two:
+        # per-kernel durations for the roofline: the same launches one after the other on ONE stream, HIP events around each, outside the timed region
+        for i in range(steps):
+            step(warmup + steps + i, events[i])
+        torch.cuda.synchronize()
     t_embed = sum(e[0].elapsed_time(e[1]) for e in events) / steps * 1e-3   # s per launch
     t_extract = sum(e[1].elapsed_time(e[2]) for e in events) / steps * 1e-3
     bytes_embed = 4.0 * n * B               # fp32 Z_s_T written (in-kernel RNG: nothing read)
@@ -314,12 +336,15 @@ def run_codec(args, rank, world, local_rank, steps, warmup, cpu_codec=None):
             "dtype": "f32" if fast else "f64", "data": "synthetic",
             "config": {"workload": f"codec tier: gsw_embed (fp32 out, Philox u, {'fp32 fast' if fast else 'fp64 Cephes'} ndtri) + gsw_extract "
                                    f"(fp16 in, {M}-bit vote) on {shape[0]}x{shape[1]}x{shape[2]} lattices, inputs resident in HBM",
-                       "batch_per_gpu": B, "global_batch": world * B, "lattice": list(shape), "message_bits": M,
+                       "batch_per_gpu": B, "global_batch": world * B, "lattice": list(shape), "message_bits": M, "hip_streams_per_step": args.codec_streams,
                        "parallelism": f"dp{world} (images sharded, no data-path collective; async all-gather of recovered bits)"},
             "bit_accuracy": bit_acc, "lossless": ok_bits,
             "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": dom[1] / dom[2] / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": dom[1] / dom[2] / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": dom[1], "avg_launch_us": dom[2] * 1e6,
+                         "measured_in": ("single-stream launches after the timed region (the timed steps overlap embed and extract on two streams)" if two
+                                         else "the timed region"),
+                         "step_GBps": (bytes_embed + bytes_extract) * steps / dt / 1e9,
                          "kernels": {"gsw_embed_kernel": {"bytes": bytes_embed, "avg_us": t_embed * 1e6, "GBps": bytes_embed / t_embed / 1e9},
                                      "gsw_extract_wave_kernel": {"bytes": bytes_extract, "avg_us": t_extract * 1e6, "GBps": bytes_extract / t_extract / 1e9}}},
         }
