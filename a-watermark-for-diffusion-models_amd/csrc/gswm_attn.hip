@@ -102,7 +102,11 @@ struct AttnArgs {
     float* part;        // KVS kernels: partial results [total][ksplit][4 waves][NACC + 2][64 lanes] floats (unnormalised O^T accumulators, running maximum, partial row sum)
 };
 
-constexpr uint32_t VP = 136;                               // V^T LDS row pitch in bytes (64 keys + 8 B: conflict-free ds_read_b64)
+constexpr uint32_t VP = 144;                               // V^T LDS row pitch in bytes (64 keys + 16 B: an odd number of 16-byte slots -> conflict-free ds_read_b128)
+// V^T rows are stored with the four 4-key groups of every 16 keys in the order (0, 2, 1, 3): the 16-wide MFMA k-slice of the second product wants keys
+// {0-3, 8-11} in lanes 0-31 and {4-7, 12-15} in lanes 32-63 (the S^T accumulator layout), and in that order each half is ONE 16-byte read (round 4 read it as two
+// ds_read_b64 from key-ordered rows: 16 instead of 8 V^T fragment reads per 64-key tile).  The permutation costs the staging nothing: it already wrote a 16-byte unit
+// as two 8-byte halves (rows are only 8-byte aligned for them at the old pitch), now 16 bytes apart.
 
 // QB = 32-query blocks per wave (1: 128 queries per workgroup; 2: 256 -- every K / V^T fragment read from LDS feeds two MFMAs and
 // the two blocks' softmax / MFMA chains are independent instruction streams the scheduler can interleave inside one wave).
@@ -189,7 +193,7 @@ __global__ __launch_bounds__(256, (DU > 10 ? 1 : 2)) void gsw_attn_fwd_kernel(At
     const T* kg##i = K + (int64_t)kr##i * p.ldk + kcol##i * 8u;                                         \
     const uint32_t kst##i = kr##i * KP + kcol##i * 16u;                                                 \
     const T* vg##i = VT + (int64_t)(uu##i >> 3) * p.Sk + (uu##i & 7u) * 8u;                             \
-    const uint32_t vst##i = 64u * KP + (uu##i >> 3) * VP + (uu##i & 7u) * 16u;
+    const uint32_t vst##i = 64u * KP + (uu##i >> 3) * VP + ((uu##i & 7u) >> 1) * 32u + (uu##i & 1u) * 8u;      /* unit j (keys 8j..8j+7) of 16-key block j >> 1: groups at slots (j & 1), (j & 1) + 2 */
     GSW_ATTN_UNIT_DECL(0)
     GSW_ATTN_UNIT_DECL(1)
     GSW_ATTN_UNIT_DECL(2)
@@ -212,8 +216,8 @@ __global__ __launch_bounds__(256, (DU > 10 ? 1 : 2)) void gsw_attn_fwd_kernel(At
     if (NU > i && (ALLV || uv##i)) {                                                                    \
         uint8_t* base_ = lds + (st) * STAGE;                                                            \
         *reinterpret_cast<uint4*>(base_ + kst##i) = kreg##i;                                            \
-        *reinterpret_cast<uint2*>(base_ + vst##i) = make_uint2(vreg##i.x, vreg##i.y);      /* V^T rows are 136 B apart: */ \
-        *reinterpret_cast<uint2*>(base_ + vst##i + 8u) = make_uint2(vreg##i.z, vreg##i.w); /* 8-byte aligned only      */ \
+        *reinterpret_cast<uint2*>(base_ + vst##i) = make_uint2(vreg##i.x, vreg##i.y);       /* keys 8j .. 8j+3   -> slot (j & 1)     */ \
+        *reinterpret_cast<uint2*>(base_ + vst##i + 16u) = make_uint2(vreg##i.z, vreg##i.w); /* keys 8j+4 .. 8j+7 -> slot (j & 1) + 2 */ \
     }
 #define GSW_ATTN_LSTORE(st) GSW_ATTN_LSTORE1(0, st) GSW_ATTN_LSTORE1(1, st) GSW_ATTN_LSTORE1(2, st) GSW_ATTN_LSTORE1(3, st) GSW_ATTN_LSTORE1(4, st)
     static_assert(NU <= 5, "staging code covers up to 5 units per thread");
@@ -312,10 +316,7 @@ __global__ __launch_bounds__(256, (DU > 10 ? 1 : 2)) void gsw_attn_fwd_kernel(At
             for (int tt = 0; tt < 2; ++tt) {
 #pragma unroll
                 for (int db = 0; db < DBF; ++db) {
-                    const uint8_t* vp = Vl + (uint32_t)(db * 32 + (int)c32) * VP + (uint32_t)(kb * 32 + tt * 16 + (int)h * 4) * 2u;
-                    const v4 lo = *reinterpret_cast<const v4*>(vp);
-                    const v4 hi = *reinterpret_cast<const v4*>(vp + 16);
-                    const v8 a = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    const v8 a = *reinterpret_cast<const v8*>(Vl + (uint32_t)(db * 32 + (int)c32) * VP + (uint32_t)(kb * 32 + tt * 16) * 2u + h * 16u);
 #pragma unroll
                     for (int qb = 0; qb < QB; ++qb) o[qb][db] = AT<T>::mfma(a, pb[qb][kb][tt], o[qb][db]);
                 }
@@ -324,10 +325,7 @@ __global__ __launch_bounds__(256, (DU > 10 ? 1 : 2)) void gsw_attn_fwd_kernel(At
                 // rows DBF*32 .. + 15 against all 32 keys of the half tile: one 16 x 16 x 32 MFMA per 16 queries.  Lane (row r = lane >> 4, m = lane & 15): V^T row
                 // DBF*32 + m, keys (r & 1) * 16 + (r >> 1) * 4 + {0..3, 8..11} -- the key order the swapped probabilities carry
                 const uint32_t r16 = lane >> 4, m16 = lane & 15u;
-                const uint8_t* vp = Vl + (uint32_t)(DBF * 32 + (int)m16) * VP + (uint32_t)(kb * 32 + (int)((r16 & 1u) * 16u + (r16 >> 1) * 4u)) * 2u;
-                const v4 lo = *reinterpret_cast<const v4*>(vp);
-                const v4 hi = *reinterpret_cast<const v4*>(vp + 16);
-                const v8 a = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                const v8 a = *reinterpret_cast<const v8*>(Vl + (uint32_t)(DBF * 32 + (int)m16) * VP + (uint32_t)(kb * 32 + (int)((r16 & 1u) * 16u)) * 2u + (r16 >> 1) * 16u);
 #pragma unroll
                 for (int qb = 0; qb < QB; ++qb) {
                     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -517,7 +515,7 @@ __global__ __launch_bounds__(256) void gsw_attn_combine_kernel(AttnArgs p) {
 template <typename T, int QB, int DU>
 static int launch_attn_cfg(const AttnArgs& a, uint32_t grid, bool ragged, float* ws, int64_t ws_bytes, hipStream_t st) {
     constexpr int KC = (DU + 1) / 2, DBF = DU * 8 / 32, TR = DU * 8 % 32, NACC = DBF * 16 + (TR ? 8 : 0);
-    constexpr uint32_t stage = 64 * (KC * 32 + 16) + (DBF * 32 + (TR ? 16 : 0)) * 136;
+    constexpr uint32_t stage = 64 * (KC * 32 + 16) + (DBF * 32 + (TR ? 16 : 0)) * VP;
     // Key-split form: few query tiles against many key tiles (one image's self-attention at 64 x 64: 62 -> 49 us).  As many splits as keep every workgroup
     // resident at once (2 per CU); only from 32 key tiles up -- the second launch and the partial results cost ~12 us, and at 16 tiles (32 x 32: 17.6 -> 21.4 us)
     // that is more than the split saves.  Needs the caller's workspace (gsw_attention_ws); GSW_ATTN_KVS=0 switches it off (A/B), k > 1 forces k ways from 8 tiles up.

@@ -226,7 +226,29 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
     // The border rows of the output are not this kernel's business then (gsw_pf_zero_border writes them).
     const bool compact = (p.flags & MM_FLAG_COMPACT) != 0;
     const int32_t HpWp = p.Hp * p.Wp;
+    // (WIDE: a divisor goes through an empty asm where it is used -- hipcc otherwise hoists the reciprocal it divides with above the tile loop, one VGPR per
+    // divisor kept alive, i.e. spilled, across the main loop)
+    auto opaque = [&](int32_t v) -> int32_t { if constexpr (WIDE) asm volatile("" : "+s"(v)); return v; };
+    // WIDE: the two divisions by wave-uniform divisors as multiply-high by floor((2^32 - 1) / d) plus ONE correction step (the estimate is the quotient or one
+    // less for any 32-bit dividend): six VALU instructions and two temporaries instead of hipcc's ~20-instruction float-reciprocal sequence, whose temporaries
+    // do not fit beside 160 accumulators and the fragment sets where the producer's slow path runs (the tail of an odd phase)
+    // (the two multipliers are recomputed where they are used -- a scalar division in a slow path -- rather than kept: the scalar registers are all taken too)
+    auto udiv = [&](uint32_t m, uint32_t d, uint32_t mg) -> uint32_t {
+        uint32_t q = __umulhi(m, mg);
+        if (m - q * d >= d) ++q;
+        return q;
+    };
     auto pf_row = [&](int32_t m, int32_t& b, int32_t& yy, int32_t& xx) -> int32_t {      // interior index -> (image, padded y, padded x), row
+        if constexpr (WIDE) {
+            const int32_t Wi = opaque(p.Wp - 2), HW = opaque((p.Hp - 2) * (p.Wp - 2));
+            const uint32_t mg_hw = 0xFFFFFFFFu / (uint32_t)HW, mg_wi = 0xFFFFFFFFu / (uint32_t)Wi;
+            b = (int32_t)udiv((uint32_t)m, (uint32_t)HW, mg_hw);
+            const int32_t r = m - b * HW;
+            yy = (int32_t)udiv((uint32_t)r, (uint32_t)Wi, mg_wi);
+            xx = r - yy * Wi + 1;
+            yy += 1;
+            return b * HpWp + yy * p.Wp + xx;
+        }
         const int32_t Wi = p.Wp - 2, HW = (p.Hp - 2) * Wi;
         b = m / HW;
         const int32_t r = m - b * HW;
@@ -334,6 +356,7 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
     constexpr bool AFF = EPI == 0 || EPI == 2;
     uint32_t vo_a[4] = {0u, 0u, 0u, 0u}, vo_w = 0u, so_a = 0u, so_w = 0u, st_a = 0u, st_w = 0u, w_piece = 0u, a_piece = 0u;
     int32_t seg_rows = -1;                                    // segment vo_a was computed for
+    bool pr_end = false;                                      // a stage completed its run: end_run8() pending
     __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, -1, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, -1, 0x00020000);
     // byte strides between the 64-row pieces of a stage, pinned in scalar registers: read from the kernel arguments where they are used, hipcc re-loads them
@@ -431,7 +454,8 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
         if (j == NDMA - 1) {
             so_a += st_a; so_w += st_w;
             pr_slot = pr_slot + STAGE == RING ? 0u : pr_slot + STAGE;
-            if (--pr_run == 0) end_run8();
+            pr_end = --pr_run == 0;          // the run is exhausted: end_run8() is due before the next stage is issued (the caller decides where -- there are three
+                                             // issue sites and the slow path is inlined at each place that calls it: kept to two)
         }
     };
     auto dma_h1 = [&]() {
@@ -509,7 +533,7 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
             return;
         }
     } else if constexpr (WIDE) {
-        // prologue: stage 0; stage 1 is issued by the first even phase
+        // prologue: stages 0 and 1 (both slots are free); the first even phase of a tile issues nothing (below)
         {
             const uint32_t l8 = mm_lane_now();
 
@@ -519,7 +543,10 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
         begin_run8();
 #pragma unroll
         for (int j = 0; j < NDMA; ++j) dma_piece8(j);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (pr_end) { end_run8(); pr_end = false; }
+#pragma unroll
+        for (int j = 0; j < NDMA; ++j) dma_piece8(j);          // (its end_run8, if due, runs behind the first barrier)
+        __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0) as a builtin: hipcc's waitcnt pass must know that no LDS-DMA is in flight when the tile loop is entered
     } else {
         static_assert(SPLIT || ((NPA == 4 || NPA == 2) && NPW == 2), "the half-stage split assumes 4 (2) + 2 (+1) pieces per wave");
         // prologue: stages 0 and 1 and the first half of stage 2; wait for stage 0 (counted: the newer pieces stay in flight; exact for waves
@@ -626,9 +653,10 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
                 if (compact) {
                     orow_ = pf_row(mc, b, yy, xx);
                 } else {
-                    b = mc / HpWp;
+                    const int32_t d1 = opaque(HpWp), d2 = opaque(p.Wp);
+                    b = mc / d1;
                     const int32_t r = mc - b * HpWp;
-                    yy = r / p.Wp; xx = r - yy * p.Wp;
+                    yy = r / d2; xx = r - yy * p.Wp;
                     brd = (yy == 0) | (yy == p.Hp - 1) | (xx == 0) | (xx == p.Wp - 1);
                 }
                 img = b;
@@ -638,8 +666,9 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
                     lv = lv && !brd;
                 }
             } else if (p.mode == MM_MODE_TOK2PF) {        // token (b, y, x) -> interior row of the PF tensor [B, H+2, W+2]
-                const int32_t b = mc / p.S, ii = mc - b * p.S;
-                const int32_t yy = ii / p.Wimg, xx = ii - yy * p.Wimg;
+                const int32_t d1 = opaque(p.S), d2 = opaque(p.Wimg);
+                const int32_t b = mc / d1, ii = mc - b * p.S;
+                const int32_t yy = ii / d2, xx = ii - yy * p.Wimg;
                 img = b;
                 orow_ = (int64_t)b * HpWp + (int64_t)(yy + 1) * p.Wp + (xx + 1);
             }
@@ -851,6 +880,7 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
 #pragma unroll
                     for (int k = 0; k < 4; ++k) w4[k] = MM<T>::add2(w4[k], rsw[k]);           // one rounding of the exact sum, as before
                 }
+                if constexpr (WIDE) { if (in == 0 && pr == 0) __builtin_amdgcn_s_waitcnt(0x0F70); }      // vmcnt(0), as a BUILTIN (hipcc's waitcnt pass must see it: see the main loop): the next tile's stage 1 has landed
                 if (live[pr] && colb + in * 16 < p.N) {
                     *reinterpret_cast<uint4*>(yrow[pr] + in * 16) = make_uint4(w4[0], w4[1], w4[2], w4[3]);      // the last N tile may be partial
                     if (rstat) {
@@ -933,11 +963,11 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
             uint4 prev[2];
             auto fetch = [&](int in, int pr, int sl) {
                 const int64_t col = (int64_t)n0 + grp * (uint32_t)HC + (uint32_t)in * 16u + (q >> 1) * 8u;
-                prev[sl] = make_uint4(0, 0, 0, 0);
-                if (live[pr] && col < p.N && !border[pr]) {
-                    if (resid) prev[sl] = *reinterpret_cast<const uint4*>(resid + (int64_t)orow[pr] * p.ldr + col);
-                    else prev[sl] = *reinterpret_cast<const uint4*>(rowbias + (int64_t)img_b[pr] * p.ldrb + col);
-                }
+                // UNCONDITIONAL (lanes without a block read element 0, always there) and unconditionally consumed below: a load some path never uses is one
+                // hipcc must assume in flight when its register is written next -- it then waits vmcnt(0), i.e. for this epilogue's stores, in the next tile's first phase
+                const bool okl = live[pr] && col < p.N && !border[pr];
+                if (resid) prev[sl] = *reinterpret_cast<const uint4*>(resid + (okl ? (int64_t)orow[pr] * p.ldr + col : (int64_t)0));
+                else prev[sl] = *reinterpret_cast<const uint4*>(rowbias + (okl ? (int64_t)img_b[pr] * p.ldrb + col : (int64_t)0));
             };
             if constexpr (WIDE) { if (rowbias || resid) fetch(0, 0, 0); }
 #pragma unroll
@@ -956,18 +986,38 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
                     pack4(in, 2 * pr + 1, bq, b0, b1);
                     swap16(a0, b0);
                     swap16(a1, b1);
+                    if constexpr (WIDE) { if (j == 0) __builtin_amdgcn_s_waitcnt(0x0F70); }      // vmcnt(0), as a BUILTIN (hipcc's waitcnt pass must see it: see the main loop): the next tile's stage 1 has landed
+                    if constexpr (WIDE) {
+                        // the same block with every load consumed on every path (see fetch): arithmetic for all lanes, store and statistics for the live ones
+                        uint32_t w4[4] = {a0, a1, b0, b1};
+                        if (rowbias || resid) {
+                            uint4 rb = make_uint4(0, 0, 0, 0), rs = make_uint4(0, 0, 0, 0);
+                            if (resid) { rs = prev[j & 1]; if (rowbias) rb = *reinterpret_cast<const uint4*>(rowbias + (int64_t)img_b[pr] * p.ldrb + (col < p.N ? col : 0)); }
+                            else rb = prev[j & 1];
+                            const uint32_t rbw[4] = {rb.x, rb.y, rb.z, rb.w}, rsw[4] = {rs.x, rs.y, rs.z, rs.w};
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                if (rowbias) w4[k] = MM<T>::add2(w4[k], rbw[k]);
+                                if (resid) w4[k] = MM<T>::add2(w4[k], rsw[k]);
+                            }
+                        }
+                        if (border[pr]) { w4[0] = w4[1] = w4[2] = w4[3] = 0u; }
+                        if (live[pr] && col < p.N) {
+                            *reinterpret_cast<uint4*>(Y + (int64_t)orow[pr] * p.ldy + col) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+                            if (cstat && !border[pr]) {
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) MM<T>::stat2(w4[k], cs_s[k], cs_q[k]);
+                            }
+                        }
+                        continue;
+                    }
                     if (!live[pr] || col >= p.N) continue;
                     uint32_t w4[4] = {a0, a1, b0, b1};
                     if (border[pr]) { w4[0] = w4[1] = w4[2] = w4[3] = 0u; }
                     else if (rowbias || resid) {
                         uint4 rb = make_uint4(0, 0, 0, 0), rs = make_uint4(0, 0, 0, 0);
-                        if constexpr (WIDE) {
-                            if (resid) { rs = prev[j & 1]; if (rowbias) rb = *reinterpret_cast<const uint4*>(rowbias + (int64_t)img_b[pr] * p.ldrb + col); }
-                            else rb = prev[j & 1];
-                        } else {
                         if (rowbias) rb = *reinterpret_cast<const uint4*>(rowbias + (int64_t)img_b[pr] * p.ldrb + col);
                         if (resid) rs = *reinterpret_cast<const uint4*>(resid + (int64_t)orow[pr] * p.ldr + col);
-                        }
                         const uint32_t rbw[4] = {rb.x, rb.y, rb.z, rb.w}, rsw[4] = {rs.x, rs.y, rs.z, rs.w};
                         // packed adds, rounded like the separate tensor adds they replace (conv1 has the row bias, conv2 / the token scatter the residual)
 #pragma unroll
@@ -1003,6 +1053,9 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
                 }
                 MM_STAMP(8 + in);
             }
+            // (WIDE: both prefetch registers are read once more HERE, so that on every path hipcc has placed its wait for their loads inside the epilogue -- a load
+            // it must assume in flight when the register is written next costs a vmcnt(0), i.e. a wait for this epilogue's stores, in the next tile's first phase)
+            if constexpr (WIDE) { if (rowbias || resid) asm volatile("" :: "v"(prev[0].x), "v"(prev[1].x)); }
         } else if (EPI == 2) {
             // GEGLU: accumulator columns of an n-tile are [8 value | 8 gate] of outputs 8 in .. 8 in + 7 (within the group's 40 outputs): lanes < 32
             // hold values, lanes >= 32 the gates of the same four outputs 4 qv .. 4 qv + 3.  The projection is rounded to the storage dtype as torch
@@ -1056,7 +1109,9 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
             };
             if constexpr (WIDE) {
                 // a pair of column blocks at a time (2 x 4 row pairs x 2 registers live instead of 5 x 4 x 2 beside the accumulators still to come)
-                gate_block(0); gate_block(1); store_pair(0);
+                gate_block(0); gate_block(1);
+                __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0), as a builtin: the next tile's stage 1 has landed
+                store_pair(0);
                 __builtin_amdgcn_sched_barrier(0);
                 gate_block(2); gate_block(3); store_pair(1);
                 __builtin_amdgcn_sched_barrier(0);
@@ -1179,18 +1234,33 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
     if constexpr (WIDE) {
         // ------------------------------------------------------------ the 256 x 320 tile: a wave multiplies 128 x 80 outputs, 40 MFMAs per phase.
         // Registers: 160 accumulators, so fragments cannot be held twice.  W fragments (5 per phase) are double-buffered across phases; the 8 activation
-        // blocks of a phase stream through a ring of four registers sets, block im + 3 read while block im multiplies (the last three reads of a phase fetch
+        // blocks of a phase stream through a ring of four register sets, block im + 3 read while block im multiplies (the last three reads of a phase fetch
         // blocks 0..2 of the next one).  Ring of TWO stage slots, ONE barrier per stage, inside the odd phase behind block 4: by then every wave has read the
         // last fragment of stage s (block 7 of k-half 1 is fetched in group 4) and waited for its own pieces of stage s + 1, so the barrier both publishes
-        // stage s + 1 (read from group 5 on) and frees the slot of stage s, into which groups 5..7 and the next even phase issue stage s + 2: a whole stage
-        // of lead, in cycles what the three-slot ring of the narrower tile has.
-        // fragment addresses: ONE persistent lane offset; a phase derives the three bases it reads from (this phase's activation blocks, the next phase's
+        // stage s + 1 (read from group 5 on) and frees the slot of stage s.
+        // Where the DMA goes: the nine pieces of stage s + 2, into that freed slot, one per group over the TAIL of the odd phase (groups 5..7) and the first six
+        // groups of the following even phase -- a piece holds its wave at issue for 60-185 cycles, three per group (measured: all nine in the tail) cost the long-K
+        // convolutions half of what the tile gains.  Only the tail in front of an EPILOGUE issues all nine (stage 1 of the next tile; once per tile).
+        // The step sequence is rotated around the barrier -- per tile: [even 0 | odd head 0 | barrier] { odd tail s + DMA | even s + 1 | odd head s + 1 |
+        // vmcnt(0) | barrier } [odd tail P - 1 + DMA | epilogue] -- for three reasons that all come from gfx9's single vmcnt:
+        //  * hipcc's waitcnt pass puts s_waitcnt vmcnt(0) in front of the first fragment read behind a loop's back edge whenever an LDS-DMA may be in flight there:
+        //    the back edge sits right behind the barrier, where this wave's vmcnt(0) has just drained everything, so that wait is free (in the first build, with
+        //    pieces in flight across the back edge, it stalled every stage);
+        //  * the DMA behind the last step of a tile is stage 1 of the NEXT tile, issued in front of the epilogue and waited for in front of the epilogue's first
+        //    store; the first barrier of a tile (peeled out of the loop) therefore needs NO vmcnt wait.  A wait there is a wait for the epilogue's stores (stores
+        //    count in vmcnt, and nothing orders a load's return against them but vmcnt(0)): with every CU leaving its epilogue at the same time that is a ~40 MB
+        //    write burst, ~9 us per tile with the matrix pipe idle -- the intercept of time against K that the 12-wave form, whose multiplying waves never wait on
+        //    vmcnt, does not have;
+        //  * no step-dependent branch is left inside the loop (parameter staging, the first-step exception: all in the peeled part).
+        // fragment addresses: ONE persistent lane offset; a segment derives the three bases it reads from (this phase's activation blocks, the next phase's
         // activation blocks and W set) behind an empty asm -- left to itself hipcc hoists all eight (slot, k-half, operand) combinations into registers
         auto rd_at = [&](uint32_t base, int blk) -> frag { return *reinterpret_cast<const frag*>(lds + base + blk * 2048); };
         frag wA[5], wB[5], xr[4];
-        // LAST (the odd phase of a tile's last step): no fragment of the next tile is fetched -- 32 registers the epilogue needs; they are read afresh behind it
-        auto phase = [&](auto odd_tag, auto last_tag, frag (&wc)[5], frag (&wn)[5], const uint32_t slot_c, const uint32_t slot_n, const int32_t step_i) {
-            constexpr bool ODD = decltype(odd_tag)::value, LAST = decltype(last_tag)::value;
+        // groups IM0 .. IM1 - 1 of a phase (8 groups of 5 MFMAs: one activation block against the phase's five W fragments)
+        // DMA: 0 = this segment issues nothing, 1 = the steady state (tail: pieces 0..2, even phase: pieces 3..8), 2 = the tail in front of an epilogue (all nine)
+        auto seg = [&](auto odd_tag, auto im0_tag, auto im1_tag, auto dma_tag, frag (&wc)[5], frag (&wn)[5], const uint32_t slot_c, const uint32_t slot_n) {
+            constexpr bool ODD = decltype(odd_tag)::value;
+            constexpr int IM0 = decltype(im0_tag)::value, IM1 = decltype(im1_tag)::value, DMA = decltype(dma_tag)::value;
             constexpr uint32_t kh_c = ODD ? 1u : 0u, kh_n = ODD ? 0u : 1u;
             uint32_t lrd = lane_rd0;
             asm volatile("" : "+v"(lrd));
@@ -1198,43 +1268,53 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
             const uint32_t a_n = (lrd ^ (kh_n * 64u)) + (wm * (16u * MT) * 128u + slot_n);
             const uint32_t w_n = (lrd ^ (kh_n * 64u)) + ((uint32_t)BM * 128u + grp * (uint32_t)HC * 128u + slot_n);
 #pragma unroll
-            for (int im = 0; im < 8; ++im) {
+            for (int im = IM0; im < IM1; ++im) {
                 // activation block im + 3 of this phase, or block im - 5 of the next one, into the ring entry block im - 1 has left
                 if (im + 3 < 8) { MM_ABL_READ(xr[(im + 3) & 3] = rd_at(a_c, im + 3)); }
-                else if (!LAST) { MM_ABL_READ(xr[(im + 3) & 3] = rd_at(a_n, im - 5)); }
-                if (!LAST && im == 5) { MM_ABL_READ(wn[0] = rd_at(w_n, 0)); MM_ABL_READ(wn[1] = rd_at(w_n, 1)); MM_ABL_READ(wn[2] = rd_at(w_n, 2)); }
-                if (!LAST && im == 6) { MM_ABL_READ(wn[3] = rd_at(w_n, 3)); MM_ABL_READ(wn[4] = rd_at(w_n, 4)); }
-                // the nine pieces of a stage: all in the even phase that follows the barrier which freed the slot (two with block 0, one with each other block).
-                // Not in the tail of the odd phase (blocks 5..7, right behind the barrier): hipcc's waitcnt pass puts s_waitcnt vmcnt(0) in front of the first
-                // fragment read after the loop's back edge whenever an LDS-DMA may be in flight there -- with nothing issued since the barrier's own vmcnt(0)
-                // that wait is free, with three pieces in flight it stalled every stage (found in the ISA of the first build)
-                if (!ODD) { if (im == 0) dma_piece8(0); dma_piece8(1 + im); }
-                if constexpr (STG && ODD) { if (stg7 && step_i == 0 && im == 7) dma_params(); }
+                else { MM_ABL_READ(xr[(im + 3) & 3] = rd_at(a_n, im - 5)); }
+                if (im == 5) { MM_ABL_READ(wn[0] = rd_at(w_n, 0)); MM_ABL_READ(wn[1] = rd_at(w_n, 1)); MM_ABL_READ(wn[2] = rd_at(w_n, 2)); }
+                if (im == 6) { MM_ABL_READ(wn[3] = rd_at(w_n, 3)); MM_ABL_READ(wn[4] = rd_at(w_n, 4)); }
+                if (DMA == 2 && ODD && im >= 5) { dma_piece8(3 * (im - 5)); dma_piece8(3 * (im - 5) + 1); dma_piece8(3 * (im - 5) + 2); }
+                if (DMA == 1 && ODD && im >= 5) dma_piece8(im - 5);
+                if (DMA == 1 && !ODD && im < 6) dma_piece8(3 + im);
 #pragma unroll
                 for (int in = 0; in < 5; ++in) acc[in][im] = MM_ABL_MMA(wc[in], xr[im & 3], acc[in][im]);
-                if (ODD && im == 4) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's pieces of stage s + 1 (issued a stage ago)
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // its last fragment reads of stage s
-                    MM_BARRIER();
-                } else {
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         };
+        // the producer's slow path (next tap row / channel block / segment / tile), due when the stage just issued ended its run: right BEHIND a barrier, where one
+        // fragment set is dead -- in the tail of the odd phase, beside both W sets, its temporaries spilled fragments
+        auto run_end = [&]() { if (pr_end) { end_run8(); pr_end = false; } };
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+        using I5 = std::integral_constant<int, 5>; using I8 = std::integral_constant<int, 8>;
 #pragma unroll
         for (int in = 0; in < 5; ++in) wA[in] = rd_at(w_rd0, in);
 #pragma unroll
         for (int im = 0; im < 3; ++im) xr[im] = rd_at(a_rd0, im);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         for (uint32_t it = 0; it < nt_mine; ++it) {
-            for (int32_t i = 0; i < P_mine; ++i) {
-                const uint32_t nx_slot = rd_slot + STAGE == RING ? 0u : rd_slot + STAGE;
-                phase(std::false_type{}, std::false_type{}, wA, wB, rd_slot, rd_slot, i);
-                phase(std::true_type{}, std::false_type{}, wB, wA, rd_slot, nx_slot, i);
+            uint32_t nx_slot = rd_slot + STAGE == RING ? 0u : rd_slot + STAGE;
+            // step 0 up to its barrier: stage 1 landed long ago (prologue / top of the previous epilogue) -- no vmcnt wait
+            seg(std::false_type{}, I0{}, I8{}, I0{}, wA, wB, rd_slot, rd_slot);
+            seg(std::true_type{}, I0{}, I5{}, I0{}, wB, wA, rd_slot, nx_slot);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // this wave's last fragment reads of stage 0
+            MM_BARRIER();
+            run_end();
+            if constexpr (STG) { if (stg7) dma_params(); }                // every wave is past the previous tile's epilogue (its parameter reads): covered by the next vmcnt(0)
+            for (int32_t i = 1; i < P_mine; ++i) {
+                seg(std::true_type{}, I5{}, I8{}, I1{}, wB, wA, rd_slot, nx_slot);    // tail of step i - 1: next fragments + pieces 0..2 of stage i + 1
                 rd_slot = nx_slot;
+                nx_slot = rd_slot + STAGE == RING ? 0u : rd_slot + STAGE;
+                seg(std::false_type{}, I0{}, I8{}, I1{}, wA, wB, rd_slot, rd_slot);   // + pieces 3..8
+                seg(std::true_type{}, I0{}, I5{}, I0{}, wB, wA, rd_slot, nx_slot);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's pieces of stage i + 1 (issued a stage ago)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // its last fragment reads of stage i
+                MM_BARRIER();
+                run_end();
             }
-            epilogue();
+            seg(std::true_type{}, I5{}, I8{}, I2{}, wB, wA, rd_slot, nx_slot);        // tail of the last step: the next tile's first fragments + ALL of its stage 1
+            rd_slot = nx_slot;
+            epilogue();                                                               // (waits for those pieces in front of its first store)
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the filler DMA of the last steps
         return;
@@ -1697,12 +1777,14 @@ int gsw_mm_launch(MMArgs& a, int dtype, void* stream, GswMmExtras* ex) {
         const bool res_ok = !a.resid || rows_out * (int64_t)a.ldr * 2 < ((int64_t)1 << 32) - (1 << 20);
         const bool legal = mode_ok && res_ok && a.N >= 320 && a.N % 320 == 0 && (!(a.mode == MM_MODE_GEGLU || (a.mode == MM_MODE_DENSE && !a.rowbias)) || a.M % 256 == 0) && rows_in * ld_max * 2 < ((int64_t)1 << 32) - (1 << 20) && (int64_t)a.N * a.ldw * 2 < ((int64_t)1 << 32) - (1 << 20);
         // a partial last column tile costs a whole one: at most 1/8 of the column tiles' work wasted
-        // measured per shape at 128 rows (profiles/r05c_unet_forward_b128_wide_vs_narrow.txt): the dense-row and GEGLU launches win from K = 640 on (-5 ... -23 %);
-        // the PF-row epilogue (convolutions, token scatter: per-row residual / row-bias fetches, twice as long per wave on the wide tile) needs a longer K loop
-        // to pay for itself -- 3 x 3 convolutions win from K = 5760 (-4 ... -7 %) and lose 2 % at K = 2880, the token scatter (K <= 1280) loses 10-15 %
-        static const int pmin_dense = getenv("GSW_MM_WIDE_PMIN") ? atoi(getenv("GSW_MM_WIDE_PMIN")) : 8;          // (A/B knobs: stages from which the dense-row / GEGLU
+        // measured per shape at 128 rows (profiles/r05g_unet_forward_b128_wide_thresholds.txt): the dense-row and GEGLU launches win at every K of the eps model,
+        // K = 320 included (-5 ... -24 %: a 320-column tile reads the activations once where two 160-column tiles read them twice) -- except the K = 320 launches
+        // WITH a residual operand (+6 %: five stages do not pay for the longer epilogue), which stay narrow; the PF-row epilogue (convolutions, token scatter:
+        // per-row residual / row-bias fetches, twice as long per wave on the wide tile) needs a longer K loop -- 3 x 3 convolutions win from K = 5760 on
+        // (-3 ... -7 %) and lose 2-6 % at K = 2880
+        static const int pmin_dense = getenv("GSW_MM_WIDE_PMIN") ? atoi(getenv("GSW_MM_WIDE_PMIN")) : 5;          // (A/B knobs: stages from which the dense-row / GEGLU
         static const int pmin_pf = getenv("GSW_MM_WIDE_PMIN_PF") ? atoi(getenv("GSW_MM_WIDE_PMIN_PF")) : 64;      //  and the PF-row launches take the wide tile)
-        const int p_min = epi_k == 1 ? pmin_pf : pmin_dense;
+        const int p_min = epi_k == 1 ? pmin_pf : (a.resid ? std::max(pmin_dense, 8) : pmin_dense);
         // tiles per round of 256 workgroups: the wide tiling must fill its last round about as well as the narrow one does
         const int64_t cus = mm_cus();
         auto fill = [cus](int64_t t) { return (double)t / (double)(((t + cus - 1) / cus) * cus); };

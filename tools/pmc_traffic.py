@@ -25,9 +25,10 @@ def load(d, counter):
 
 
 def short(name):
-    m = re.search(r"gsw_mm_kernelIDF16(b?)_Li(\d)ELb([01])E", name)
+    m = re.search(r"gsw_mm_kernelIDF16(b?)_Li(\d)ELb([01])ELi(\d)E", name)
     if m:
-        return f"gsw_mm_kernel<{'bf16' if m.group(1) else 'f16'}, EPI {m.group(2)}, {'12 waves' if m.group(3) == '1' else '8 waves'}>"
+        tile = {"8": "256x320 tile", "4": "256x160 tile", "2": "128x160 tile"}.get(m.group(4), "MT " + m.group(4))
+        return f"gsw_mm_kernel<{'bf16' if m.group(1) else 'f16'}, EPI {m.group(2)}, {'12 waves' if m.group(3) == '1' else '8 waves'}, {tile}>"
     m = re.search(r"(gsw_[a-z0-9_]+)", name)
     return m.group(1) if m else name[:60]
 
