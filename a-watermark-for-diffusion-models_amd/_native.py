@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("GSWM_LIB", os.path.join(_HERE, "libgswm.so"))     # G
 GSW_F32, GSW_F16, GSW_BF16, GSW_F64 = 0, 1, 2, 3
 GSW_OK, GSW_ERR_BAD_ARG, GSW_ERR_UNSUPPORTED, GSW_ERR_RAGGED, GSW_ERR_HIP, GSW_WARN_NO_RECORDS = 0, 1, 2, 3, 4, 5
 GSW_EMBED_EXACT_F64, GSW_EMBED_FAST_F32 = 0, 1
+GSW_MM_GN_ONLY = 1
 GSW_FLAG_SATURATED, GSW_FLAG_NAN = 1, 2
 GSW_MSG_INLINE_MAX = 256
 GSW_IMG_U8_HWC, GSW_IMG_F16_CHW, GSW_IMG_F32_CHW = 0, 1, 2
@@ -26,7 +27,7 @@ class GswMmExtras(C.Structure):
     """include/gswm.h: everything an engine launch needs besides its operands (records requested, split-K scratch), and what it did"""
     _fields_ = [("colstats_dev", C.c_void_p), ("colstats_capacity", C.c_int64), ("rowstats_dev", C.c_void_p), ("rowstats_capacity", C.c_int64),
                 ("workspace_dev", C.c_void_p), ("workspace_bytes", C.c_int64), ("max_splits", C.c_int),
-                ("colstats_rows_per_block", C.c_int), ("colstats_blocks", C.c_int), ("rowstats_slots", C.c_int), ("splits", C.c_int)]
+                ("colstats_rows_per_block", C.c_int), ("colstats_blocks", C.c_int), ("rowstats_slots", C.c_int), ("splits", C.c_int), ("flags", C.c_int)]
 
 
 _PROTOTYPES = {

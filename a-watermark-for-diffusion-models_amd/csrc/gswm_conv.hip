@@ -582,8 +582,12 @@ static int launch_engine(const ConvArgs& a, int64_t M, int N, int dtype, void* s
     m.ldy = N; m.ldr = N; m.ldrb = a.ldrb;
     m.mode = a.up ? MM_MODE_UP2X : MM_MODE_PF;
     m.Hp = a.Hp; m.Wp = a.Wp; m.in_Hp = a.in_Hp; m.in_Wp = a.in_Wp; m.stride = a.stride; m.S = 1; m.Wimg = 1; m.up = a.up;
-    if (!a.up && !whole) zero_border(a.y, B, a.Hp, a.Wp, N, (hipStream_t)stream);
-    return gsw_mm_launch(m, dtype, stream, ex);
+    const int rc = gsw_mm_launch(m, dtype, stream, ex);
+    // the border of the output: zeroed by a small kernel of its own (it touches rows the engine launch does not) -- unless the caller declared the output
+    // GroupNorm-only (GSW_MM_GN_ONLY) AND this launch wrote the column records that GroupNorm will take its statistics from: nothing reads the border then
+    const bool gn_only = ex && (ex->flags & GSW_MM_GN_ONLY) && ex->colstats_rows_per_block > 0;
+    if (rc == GSW_OK && !a.up && !whole && !gn_only) zero_border(a.y, B, a.Hp, a.Wp, N, (hipStream_t)stream);
+    return rc;
 }
 
 static bool use_engine(const ConvArgs& a, int N) {

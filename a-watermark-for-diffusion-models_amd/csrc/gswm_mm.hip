@@ -1294,11 +1294,14 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         for (uint32_t it = 0; it < nt_mine; ++it) {
             uint32_t nx_slot = rd_slot + STAGE == RING ? 0u : rd_slot + STAGE;
+            MM_STAMP(6);                                                  // (MM_TRACE builds; interval 6: the epilogue of the previous tile)
             // step 0 up to its barrier: stage 1 landed long ago (prologue / top of the previous epilogue) -- no vmcnt wait
             seg(std::false_type{}, I0{}, I8{}, I0{}, wA, wB, rd_slot, rd_slot);
             seg(std::true_type{}, I0{}, I5{}, I0{}, wB, wA, rd_slot, nx_slot);
+            MM_STAMP(0);                                                  // interval 0: step 0 up to its barrier (issue)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // this wave's last fragment reads of stage 0
             MM_BARRIER();
+            MM_STAMP(1);                                                  // interval 1: the wait at the first barrier
             run_end();
             if constexpr (STG) { if (stg7) dma_params(); }                // every wave is past the previous tile's epilogue (its parameter reads): covered by the next vmcnt(0)
             for (int32_t i = 1; i < P_mine; ++i) {
@@ -1307,15 +1310,21 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
                 nx_slot = rd_slot + STAGE == RING ? 0u : rd_slot + STAGE;
                 seg(std::false_type{}, I0{}, I8{}, I1{}, wA, wB, rd_slot, rd_slot);   // + pieces 3..8
                 seg(std::true_type{}, I0{}, I5{}, I0{}, wB, wA, rd_slot, nx_slot);
+                MM_STAMP(2);                                              // interval 2: a steady-state step's issue (tail + even + odd head)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's pieces of stage i + 1 (issued a stage ago)
+                MM_STAMP(3);                                              // interval 3: its vmcnt wait
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // its last fragment reads of stage i
                 MM_BARRIER();
+                MM_STAMP(4);                                              // interval 4: its barrier wait
                 run_end();
             }
             seg(std::true_type{}, I5{}, I8{}, I2{}, wB, wA, rd_slot, nx_slot);        // tail of the last step: the next tile's first fragments + ALL of its stage 1
+            MM_STAMP(5);                                                              // interval 5: that tail
             rd_slot = nx_slot;
             epilogue();                                                               // (waits for those pieces in front of its first store)
         }
+        MM_STAMP(6);
+        MM_TRACE_DUMP();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the filler DMA of the last steps
         return;
     }
@@ -1785,11 +1794,13 @@ int gsw_mm_launch(MMArgs& a, int dtype, void* stream, GswMmExtras* ex) {
         static const int pmin_dense = getenv("GSW_MM_WIDE_PMIN") ? atoi(getenv("GSW_MM_WIDE_PMIN")) : 5;          // (A/B knobs: stages from which the dense-row / GEGLU
         static const int pmin_pf = getenv("GSW_MM_WIDE_PMIN_PF") ? atoi(getenv("GSW_MM_WIDE_PMIN_PF")) : 64;      //  and the PF-row launches take the wide tile)
         const int p_min = epi_k == 1 ? pmin_pf : (a.resid ? std::max(pmin_dense, 8) : pmin_dense);
-        // tiles per round of 256 workgroups: the wide tiling must fill its last round about as well as the narrow one does
+        // rounds of 256 workgroups: a stage of a wide tile costs 1.77 x a stage of a 256 x 160 tile for 2 x its outputs (1.70 vs 0.96 us, the slopes of time against K on
+        // the 64 x 64 convolutions) -- wide wins when its rounds, at that price, are fewer than the narrow tiling's (a half-empty last round can eat the gain:
+        // 4.5 rounds of wide tiles against 9 of narrow ones still win, 2.25 against 4.5 do not)
         const int64_t cus = mm_cus();
-        auto fill = [cus](int64_t t) { return (double)t / (double)(((t + cus - 1) / cus) * cus); };
         const int64_t t_w = tm_w * tn_w, t_n = (((int64_t)a.M + 255) / 256) * tiles_n;
-        const bool fits = t_w >= cus && fill(t_w) >= fill(t_n) - 0.04 && a.P >= p_min && a.M >= 2048;
+        const double cost_w = 1.77 * (double)((t_w + cus - 1) / cus), cost_n = (double)((t_n + cus - 1) / cus);
+        const bool fits = t_w >= cus && cost_w <= 0.995 * cost_n && a.P >= p_min && a.M >= 2048;
         wide = legal && (bm_cfg == 512 || (bm_cfg == 0 && wide_env != 0 && fits));
     }
     const int BMt = wide ? 256 : BM, BNt = wide ? 320 : BN;

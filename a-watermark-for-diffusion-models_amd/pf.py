@@ -16,13 +16,15 @@ from .codec import _dt, _stream_ptr
 
 
 class PF:
-    __slots__ = ("buf", "B", "H", "W", "C", "stats")
+    __slots__ = ("buf", "B", "H", "W", "C", "stats", "border_valid")
 
     def __init__(self, buf: torch.Tensor, B: int, H: int, W: int, C: int):
         self.buf, self.B, self.H, self.W, self.C = buf, B, H, W, C
         # column records of the launch that produced the payload (ColStats) -- GroupNorm statistics without a pass over the tensor; anything
         # that writes the payload by other means must leave it None
         self.stats: Optional["ColStats"] = None
+        # False: the one-pixel border was left unwritten (conv_pf(gn_only=True) whose launch wrote column records); only a record-fed GroupNorm may read the tensor
+        self.border_valid = True
 
     @property
     def G(self) -> int:
@@ -78,6 +80,7 @@ class PF:
 # ---- split-K workspace of the matmul engine (gsw_mm_set_workspace): one scratch buffer per (device, stream), handed to the library whenever the
 # calling thread's (device, stream) changes.  Launches on one stream share it (a launch and its reduce kernel are stream-ordered).
 SPLITK_BYTES = 40 << 20        # 256 slabs of 160 KiB (256-row tiles; 80 KiB for 128-row tiles): every launch that splits fits
+GN_ONLY_SKIPS_BORDER = True    # conv_pf(gn_only=True): no border zeroing behind a convolution whose output only a record-fed GroupNorm reads (A/B switch)
 ATTN_KEY_SPLIT = True          # self-attention with few query tiles (one image) splits its keys over several workgroups (gsw_attention_ws)
 LAUNCH_LOG = None              # a list: every engine launch appends its GswMmExtras (tests: which launches split, and how)
 SPLITK_MAX = 0                 # 0 automatic, 1 never split, k > 1: force k-way splits wherever K allows (parity tests)
@@ -247,8 +250,10 @@ def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
 
 def conv_pf(x: PF, w_packed: torch.Tensor, bias: Optional[torch.Tensor], *, ksize: int = 3, stride: int = 1,
             rowbias: Optional[torch.Tensor] = None, resid: Optional[PF] = None, cin: Optional[int] = None, cin_offset: int = 0,
-            pad_after_only: bool = False) -> PF:
+            pad_after_only: bool = False, gn_only: bool = False) -> PF:
     """y = conv(x) (+ bias + rowbias[b] + resid) as one MFMA implicit GEMM; border rows of y are zero.
+    gn_only: the caller promises that nothing but a GroupNorm reads y (a resnet's conv1 -> norm2).  When the launch wrote that GroupNorm's column records the
+    border zeroing is then skipped (`y.border_valid = False`; `groupnorm_pf*` zero it first if they ever have to fall back to the statistics pass).
     pad_after_only (stride 2): the asymmetric F.pad(x, (0, 1, 0, 1)) + padding-0 convolution of the SD VAE downsampler -- in the PF
     layout that is the same tap table read one row and one column further on, i.e. a shifted base pointer."""
     C = x.C if cin is None else cin
@@ -271,11 +276,14 @@ def conv_pf(x: PF, w_packed: torch.Tensor, bias: Optional[torch.Tensor], *, ksiz
         e0 = tm.start() if tm is not None else None
         armed = _colstats_arm(x.B * Ho * Wo, Nn, x.buf.device, geom=(x.B, Ho, Wo)) if Nn >= 128 else None
         ex = _extras(x.buf.device, colstats=None if armed is None else armed[0])
+        if gn_only and GN_ONLY_SKIPS_BORDER:
+            ex.flags = N.GSW_MM_GN_ONLY
         N.check(N.lib().gsw_conv_pf_ex(xp, w_packed.data_ptr(), bias.data_ptr() if bias is not None else None,
                                        rowbias.data_ptr() if rowbias is not None else None, ldrb,
                                        resid.rows.data_ptr() if resid is not None else None, y.rows.data_ptr(),
                                        x.B, Ho, Wo, C, Nn, ksize, stride, x.C, _dt(x.buf.dtype), _C.byref(ex), _stream_ptr()))
         y.stats = _colstats_collect(armed, ex)
+        y.border_valid = not (ex.flags & N.GSW_MM_GN_ONLY and ex.colstats_rows_per_block > 0)
         if tm is not None:
             name = _conv_kernel_name(Wo, Nn, ksize, stride)
             tm.stop(e0, (name, x.B, Ho, Wo, ksize * ksize * C, Nn, stride) if tm.by_shape else name, 2.0 * x.B * Ho * Wo * Nn * ksize * ksize * C)
@@ -399,12 +407,21 @@ def _groupnorm_fused(x: PF, x2: Optional[PF], gamma, beta, groups, eps, act, tok
     return res
 
 
+def _ensure_border(x: PF) -> None:
+    """A tensor whose border was left unwritten is about to be read by a kernel that looks at the border (the statistics pass): write the zeros now."""
+    if not x.border_valid:
+        g = x.grid
+        g[:, 0].zero_(); g[:, -1].zero_(); g[:, :, 0].zero_(); g[:, :, -1].zero_()
+        x.border_valid = True
+
+
 def groupnorm_pf(x: PF, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float, *, act: bool = True, tokens: bool = False):
     """act(GroupNorm(x)) on a PF tensor -> PF (zero border) or dense tokens [B, H*W, C] (tokens=True)."""
     dev = x.buf.device
     _same(gamma, x.buf, "gamma", x.C)
     _same(beta, x.buf, "beta", x.C)
     if _gn_fused_ok(x.B, x.H, x.W, x.C, groups):
+        _ensure_border(x)
         return _groupnorm_fused(x, None, gamma, beta, groups, eps, act, tokens)
     ws = _gn_workspace(dev, x.B, groups, x.C)
     if tokens:
@@ -420,6 +437,7 @@ def groupnorm_pf(x: PF, gamma: torch.Tensor, beta: torch.Tensor, groups: int, ep
                                                 gamma.data_ptr(), beta.data_ptr(), optr, ws.data_ptr(), x.B, x.H, x.W, x.C, groups, eps,
                                                 1 if act else 0, 1 if tokens else 0, _dt(x.buf.dtype), _stream_ptr()))
         return res
+    _ensure_border(x)
     with torch.cuda.device(dev):
         N.check(N.lib().gsw_groupnorm_pf(x.rows.data_ptr(), gamma.data_ptr(), beta.data_ptr(), optr, ws.data_ptr(), x.B, x.H, x.W, x.C, groups,
                                          eps, 1 if act else 0, 1 if tokens else 0, _dt(x.buf.dtype), _stream_ptr()))
@@ -656,6 +674,7 @@ def groupnorm_pf2(x: PF, x2: Optional[PF], gamma: torch.Tensor, beta: torch.Tens
     if (x2.B, x2.H, x2.W) != (x.B, x.H, x.W):
         raise ValueError("groupnorm_pf2: the two sources differ in geometry")
     if x.C % 8 == 0 and _gn_fused_ok(x.B, x.H, x.W, C, groups):
+        _ensure_border(x); _ensure_border(x2)
         return _groupnorm_fused(x, x2, gamma, beta, groups, eps, act, False)
     ws = _gn_workspace(dev, x.B, groups, C)
     y = PF.empty(x.B, x.H, x.W, C, x.buf.dtype, dev)
@@ -666,6 +685,7 @@ def groupnorm_pf2(x: PF, x2: Optional[PF], gamma: torch.Tensor, beta: torch.Tens
                                                 s2.buf.data_ptr(), s2.rows, s2.npar, s2.blocks, gamma.data_ptr(), beta.data_ptr(), y.rows.data_ptr(),
                                                 ws.data_ptr(), x.B, x.H, x.W, C, groups, eps, 1 if act else 0, 0, _dt(x.buf.dtype), _stream_ptr()))
         return y
+    _ensure_border(x); _ensure_border(x2)
     with torch.cuda.device(dev):
         N.check(N.lib().gsw_groupnorm_pf2(x.rows.data_ptr(), x2.rows.data_ptr(), x.C, gamma.data_ptr(), beta.data_ptr(), y.rows.data_ptr(),
                                           ws.data_ptr(), x.B, x.H, x.W, C, groups, eps, 1 if act else 0, 0, _dt(x.buf.dtype), _stream_ptr()))

@@ -185,7 +185,7 @@ class ResnetBlock2D(nn.Module):
             x, x2 = PF(torch.cat([x.buf, x2.buf], dim=1), x.B, x.H, x.W, x.C + x2.C), None
         n1 = groupnorm_pf2(x, x2, self.norm1.weight, self.norm1.bias, self.norm1.num_groups, self.norm1.eps, act=True)
         rowbias = temb_act.rows[id(self)] if isinstance(temb_act, TembRows) else _lin(temb_act, self.time_emb_proj).contiguous()
-        h = conv_pf(n1, _pw(self.conv1), self.conv1.bias, rowbias=rowbias)
+        h = conv_pf(n1, _pw(self.conv1), self.conv1.bias, rowbias=rowbias, gn_only=True)       # read by norm2 and nothing else: no border zeroing when it wrote records
         h = _gn_pf(h, self.norm2)
         if self.conv_shortcut is None:
             return conv_pf(h, _pw(self.conv2), self.conv2.bias, resid=x)                 # residual add in the GEMM epilogue

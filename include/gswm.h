@@ -33,7 +33,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define GSW_VERSION 400 /* 0.4.0: explicit-argument launches (GswMmExtras, gsw_*_ex); the one-shot side channels (gsw_mm_next_colstats / gsw_mm_next_rowstats / gsw_mm_set_workspace) are deprecated shims over them; gsw_mm_last_colstats / gsw_mm_last_rowstats return GSW_WARN_NO_RECORDS for a dropped request; small-batch kernels (gsw_groupnorm_pf_fused, gsw_gather_rows, gsw_nchw_to_pf, gsw_conv3x3_pf_nchw, gsw_gemm_small).  0.3.1: 0.3.1: gsw_gemm / gsw_gemm_strided (PLAIN, GEGLU) want a 16-byte aligned bias.  0.3.0: gsw_conv_pf / gsw_conv3x3_res_pf take ld_rowbias; gsw_mm_set_workspace (split-K).  0.2.0: GEGLU weights packed per 16-row block (see gsw_gemm) */
+#define GSW_VERSION 401 /* 0.4.0: explicit-argument launches (GswMmExtras, gsw_*_ex); the one-shot side channels (gsw_mm_next_colstats / gsw_mm_next_rowstats / gsw_mm_set_workspace) are deprecated shims over them; gsw_mm_last_colstats / gsw_mm_last_rowstats return GSW_WARN_NO_RECORDS for a dropped request; small-batch kernels (gsw_groupnorm_pf_fused, gsw_gather_rows, gsw_nchw_to_pf, gsw_conv3x3_pf_nchw, gsw_gemm_small).  0.3.1: 0.3.1: gsw_gemm / gsw_gemm_strided (PLAIN, GEGLU) want a 16-byte aligned bias.  0.3.0: gsw_conv_pf / gsw_conv3x3_res_pf take ld_rowbias; gsw_mm_set_workspace (split-K).  0.2.0: GEGLU weights packed per 16-row block (see gsw_gemm) */
 
 #define GSW_MSG_INLINE_MAX 256 /* message bytes carried inside the kernel arguments (2048 bit) */
 
@@ -168,7 +168,12 @@ int gsw_groupnorm_pf2(const void* x_dev, const void* x2_dev, int Ca, const void*
  *   workspace_dev / workspace_bytes / max_splits : in -- split-K scratch and policy, as gsw_mm_set_workspace (NULL: the launch runs unsplit)
  *   colstats_rows_per_block, colstats_blocks : out -- 0 / 0 when the launch wrote no column records (it split K, enumerated whole tensors, ...)
  *   rowstats_slots : out -- records per row written (0: none)
- *   splits         : out -- K splits of the launch (1: unsplit) */
+ *   splits         : out -- K splits of the launch (1: unsplit)
+ *   flags          : in  -- 0, or GSW_MM_GN_ONLY (ABI 0.4.1; the word sits in what was tail padding: zero-initialise the struct): the PF output of this convolution
+ *                           is read by nothing but a GroupNorm that takes its statistics from the column records requested here.  The launch then leaves the
+ *                           one-pixel border of the output UNWRITTEN when (and only when) it wrote those records: the GroupNorm kernels never read it (the apply
+ *                           kernel writes zeros to its own output's border whatever the input's holds) -- one small launch less per resnet. */
+#define GSW_MM_GN_ONLY 1
 typedef struct GswMmExtras {
     float* colstats_dev;
     int64_t colstats_capacity;
@@ -178,6 +183,7 @@ typedef struct GswMmExtras {
     int64_t workspace_bytes;
     int max_splits;
     int colstats_rows_per_block, colstats_blocks, rowstats_slots, splits;
+    int flags;
 } GswMmExtras;
 
 /* gsw_gemm_strided / gsw_gemm_ln / gsw_conv_pf / gsw_conv3x3_res_pf / gsw_conv_up2x_pf with explicit extras (ex may be NULL). */

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"libgswm.so does not export {s}"
     assert sorted(N.exported_symbols()) == syms            # the ctypes prototypes cover the whole header
-    assert lib.gsw_version() == 400
+    assert lib.gsw_version() == 401
     assert lib.gsw_strerror(0) == b"ok" and b"IndexError" in lib.gsw_strerror(N.GSW_ERR_RAGGED)
 
 

@@ -212,3 +212,33 @@ def test_a_split_producer_writes_no_records_and_groupnorm_takes_the_separate_pas
     a = G.pf.groupnorm_pf2(y, None, gamma, beta, 32, 1e-5, act=True)
     ref = _gn_ref(y.to_nchw(), gamma, beta, 32, 1e-5, True)
     assert (a.to_nchw().float() - ref).abs().max().item() <= 4e-3 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("B,C,N,H,W", [(8, 320, 320, 32, 32), (20, 640, 1280, 16, 16)])
+def test_gn_only_convolution_skips_the_border_and_groupnorm_does_not_care(G, B, C, N, H, W):
+    """conv_pf(gn_only=True) (a resnet's conv1 -> norm2): the launch that wrote column records leaves the output's border unwritten (border_valid False, one launch
+    less); the record-fed GroupNorm gives the same bits as behind a zero-bordered producer, and a GroupNorm that has to take the statistics pass zeroes the border first."""
+    pf = G.pf
+    g = torch.Generator().manual_seed(B + C + N)
+    x = torch.randn(B, C, H, W, generator=g).half().cuda()
+    w = (torch.randn(N, C, 3, 3, generator=g) * (9 * C) ** -0.5).half().cuda()
+    b = torch.randn(N, generator=g).half().cuda()
+    gamma, beta = torch.randn(N, generator=g).half().cuda(), torch.randn(N, generator=g).half().cuda()
+    X, Wp = pf.PF.from_nchw(x), pf.pack_conv_weight(w)
+    y0 = pf.conv_pf(X, Wp, b)
+    assert y0.border_valid and y0.stats is not None
+    ref = pf.groupnorm_pf(y0, gamma, beta, 32, 1e-5)
+    # poison fresh allocations so that an unwritten border is not accidentally zero
+    junk = torch.full((y0.buf.numel(),), float("nan"), dtype=torch.float16, device="cuda")
+    del junk
+    y1 = pf.conv_pf(X, Wp, b, gn_only=True)
+    assert y1.stats is not None and not y1.border_valid
+    assert torch.equal(y1.interior, y0.interior)
+    out = pf.groupnorm_pf(y1, gamma, beta, 32, 1e-5)
+    assert torch.equal(out.rows, ref.rows)                            # interior AND (zero) border of the GroupNorm output
+    # statistics-pass fall-back: drop the records -> the border is zeroed before the pass reads it
+    y1.stats = None
+    out2 = pf.groupnorm_pf(y1, gamma, beta, 32, 1e-5)
+    assert y1.border_valid and y1.grid[:, 0].abs().max() == 0 and y1.grid[:, :, -1].abs().max() == 0
+    r = _gn_ref(y0.to_nchw(), gamma, beta, 32, 1e-5, True)
+    assert (out2.to_nchw().float() - r).abs().max().item() <= 2e-2 * max(1.0, r.abs().max().item())

@@ -2,13 +2,11 @@
 # Round-5 evidence run on the GPU box (from the repo root): attention with the permuted V^T rows, the bench lines of every configuration, rocprofv3 kernel
 # statistics of the default and the SD 1.5 / 768 x 768 runs, PMC traffic of the engine family.  Outputs under gpurun_out/r05h/.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/r05h
+O=$R/gpurun_out/r05l
 mkdir -p $O
 cd $R
-timeout 900 python3 -m pytest tests -m gpu -x -q -k "attn or attention or unet or fullsize" > $O/pytest_attn.txt 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest_attn.txt
-timeout 300 python3 tools/attn_accuracy.py > $O/attn_accuracy.txt 2>&1; tail -12 $O/attn_accuracy.txt
+timeout 1800 python3 -m pytest tests -m gpu -x -q > $O/pytest_gpu.txt 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest_gpu.txt
 timeout 600 python3 tools/attn_shapes_bench.py 32 all > $O/attn_shapes_b32.txt 2>&1; cat $O/attn_shapes_b32.txt
-timeout 300 python3 tools/attn_bench.py 128 > $O/attn_bench_b128.txt 2>&1; head -5 $O/attn_bench_b128.txt
 timeout 1200 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc=$?"
 timeout 600 python3 bench.py --tier e2e --batch 1 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_e2e_b1.json 2> $O/bench_e2e_b1.err; echo "b1 rc=$?"
 timeout 600 python3 bench.py --tier e2e --batch 8 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_e2e_b8.json 2> $O/bench_e2e_b8.err; echo "b8 rc=$?"
