@@ -196,6 +196,17 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
     const uint32_t nvirt = PART ? ntiles * (uint32_t)p.splits : ntiles;      // split-K: (tile, K range) pairs, at most one per workgroup
     const uint32_t nt_mine = nvirt > slotx ? (nvirt - slotx + G - 1u) / G : 0u;
     if (nt_mine == 0u) return;
+    // Start stagger (gsw_mm_launch decides): every workgroup of a launch runs the same tile sequence at the same pace, so all 256 epilogues store at the same
+    // time and that burst drains at the HBM write rate with every matrix pipe idle; group k of the workgroups starts k steps late and keeps that phase.
+    if constexpr (!PART) {
+        if (p.stagger_step != 0) {
+            const uint32_t k = (blockIdx.x >> 3) & (uint32_t)p.stagger_mask;
+            if (k != 0u) {
+                const uint64_t t0 = __builtin_amdgcn_s_memrealtime(), d = (uint64_t)k * (uint32_t)p.stagger_step;
+                while (__builtin_amdgcn_s_memrealtime() - t0 < d) __builtin_amdgcn_s_sleep(8);
+            }
+        }
+    }
     // split-K: virtual tile v = split * ntiles + tile; stages [k_lo, k_hi) of the tile's P
     const uint32_t part_split = PART ? slotx / ntiles : 0u;
     const int32_t k_lo = PART ? (int32_t)(((int64_t)part_split * p.P) / p.splits) : 0;
@@ -1731,7 +1742,7 @@ int gsw_mm_launch(MMArgs& a, int dtype, void* stream, GswMmExtras* ex) {
     const MMPlan plan = mm_plan(a.M, tiles_n, a.P, ws_dev && max_splits != 1 && !a.ln_stat, max_splits);       // tiling and split-K policy: see mm_plan
     const int BM = plan.splits >= 2 ? mm_plan(a.M, tiles_n, a.P, false, 1).bm : plan.bm;      // the tile of the UNSPLIT launch (also taken when a split plan does not fit the workspace)
     hipStream_t st = (hipStream_t)stream;
-    a.splits = 1; a.ws = nullptr;
+    a.splits = 1; a.ws = nullptr; a.stagger_step = 0; a.stagger_mask = 0;
     // the dense-row / GEGLU epilogues fetch the bias by 16-byte LDS-DMA pieces (STG in the kernel)
     if ((a.mode == MM_MODE_DENSE || a.mode == MM_MODE_GEGLU) && ((uintptr_t)a.bias & 15u)) return GSW_ERR_BAD_ARG;
     float* const cs_req = ex->colstats_capacity > 0 ? ex->colstats_dev : nullptr;
@@ -1827,6 +1838,19 @@ int gsw_mm_launch(MMArgs& a, int dtype, void* stream, GswMmExtras* ex) {
         ex->colstats_rows_per_block = BMt / wmv; ex->colstats_blocks = (int)(tiles_m * wmv);
     }
     const int epi = a.mode == MM_MODE_QKV ? 5 : a.mode == MM_MODE_TRANS ? 3 : a.mode == MM_MODE_GEGLU ? 2 : (a.mode == MM_MODE_DENSE && !a.rowbias) ? 0 : 1;
+    {
+        // start stagger (experiment switch): GSW_MM_STAGGER = groups (2, 4, 8), GSW_MM_STAGGER_TBPS = the drain rate the burst length is computed with
+        static const int stag = getenv("GSW_MM_STAGGER") ? atoi(getenv("GSW_MM_STAGGER")) : 0;
+        static const double tbps = getenv("GSW_MM_STAGGER_TBPS") ? atof(getenv("GSW_MM_STAGGER_TBPS")) : 5.5;
+        static const int stag_epi = getenv("GSW_MM_STAGGER_EPI") ? atoi(getenv("GSW_MM_STAGGER_EPI")) : 0x3F;
+        const int64_t rounds = (a.ntiles + grid - 1) / grid;
+        if (stag >= 2 && (stag & (stag - 1)) == 0 && rounds >= 2 && ((stag_epi >> epi) & 1)) {
+            const double tile_bytes = (double)BMt * (a.mode == MM_MODE_GEGLU ? BNt / 2 : BNt) * 2.0 * (a.resid ? 2.0 : 1.0);
+            const double burst_ns = tile_bytes * (double)grid / (tbps * 1e3);
+            a.stagger_step = std::max(1, (int)(burst_ns / stag / 10.0));
+            a.stagger_mask = stag - 1;
+        }
+    }
     const int e = dtype == GSW_F16 ? mm_launch_e<_Float16>(a, epi, grid, wide ? 8 : BM / 64, st) : mm_launch_e<__bf16>(a, epi, grid, wide ? 8 : BM / 64, st);
     if (e != 0) { g_last_hip_error = e; return GSW_ERR_HIP; }
     return GSW_OK;
