@@ -50,8 +50,6 @@ struct MMArgs {
     const float* ln_u;    // [N]
     const float* ln_v;    // [N]
     float* rowstats;      // EPI 0 only, or null: per output row and 80-column half tile the (sum, sum of squares) of the STORED values, [M][2 tiles_n][2] floats
-    int32_t stagger_step; // filled by gsw_mm_launch: start delay of workgroup group k = (block >> 3) & stagger_mask, in 10 ns ticks of s_memrealtime per k (0: none) --
-    int32_t stagger_mask; // groups - 1: takes the workgroups of a launch out of lockstep so that their epilogues' store bursts do not all hit HBM at once
     float* ws;            // filled by gsw_mm_launch: split-K workspace, [splits][ntiles][8 waves][5 * MT accumulators][64 lanes] float4
 };
 

@@ -165,6 +165,7 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
     constexpr int NPCOL = WIDE ? 2 : 1;              // LDS-DMA pieces per fp32 column vector (256 floats each)
     constexpr int NPAR = LNF ? 2 * NPCOL + (BM + 127) / 128 : 1;
     typedef typename MM<T>::frag frag;
+    typedef unsigned int mm_u4 __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
@@ -196,17 +197,6 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
     const uint32_t nvirt = PART ? ntiles * (uint32_t)p.splits : ntiles;      // split-K: (tile, K range) pairs, at most one per workgroup
     const uint32_t nt_mine = nvirt > slotx ? (nvirt - slotx + G - 1u) / G : 0u;
     if (nt_mine == 0u) return;
-    // Start stagger (gsw_mm_launch decides): every workgroup of a launch runs the same tile sequence at the same pace, so all 256 epilogues store at the same
-    // time and that burst drains at the HBM write rate with every matrix pipe idle; group k of the workgroups starts k steps late and keeps that phase.
-    if constexpr (!PART) {
-        if (p.stagger_step != 0) {
-            const uint32_t k = (blockIdx.x >> 3) & (uint32_t)p.stagger_mask;
-            if (k != 0u) {
-                const uint64_t t0 = __builtin_amdgcn_s_memrealtime(), d = (uint64_t)k * (uint32_t)p.stagger_step;
-                while (__builtin_amdgcn_s_memrealtime() - t0 < d) __builtin_amdgcn_s_sleep(8);
-            }
-        }
-    }
     // split-K: virtual tile v = split * ntiles + tile; stages [k_lo, k_hi) of the tile's P
     const uint32_t part_split = PART ? slotx / ntiles : 0u;
     const int32_t k_lo = PART ? (int32_t)(((int64_t)part_split * p.P) / p.splits) : 0;
@@ -685,12 +675,12 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
             }
             return orow_;
         };
-        // WIDE, launches with a residual operand: the epilogue walks 20 (column block, row pair) blocks per wave, each a load -> add -> store chain, and with 160
+        // WIDE PF rows, launches with a residual operand (dense rows: the queue of RD chunk loads further down): the epilogue walks 20 (column block, row pair) blocks per wave, each a load -> add -> store chain, and with 160
         // accumulators live it can keep ONE block's load in flight -- twenty HBM round trips in a row, ~12 us per tile with the matrix pipe idle (the fixed cost per
         // launch of the first build: 293 us against 194 for the narrow tile on the 64 x 64 convolutions).  So the wave first TOUCHES every 128-byte line of its
         // 128 x 80 residual block: four 4-byte LDS-DMA loads (64 lines each, no destination register; they land in a dummy LDS area) bring the lines into L2 / L1 in
         // ONE round trip, and the chunk loads behind them hit.
-        if constexpr (WIDE && (EPI == 0 || EPI == 1)) {
+        if constexpr (WIDE && EPI == 1) {
             if (resid) {
                 // (buffer form like every LDS-DMA of the wide kernel: see dma_params; the residual tensor is below 4 GiB, host-checked)
                 const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(resid), 0, -1, 0x00020000);
@@ -891,7 +881,7 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
 #pragma unroll
                     for (int k = 0; k < 4; ++k) w4[k] = MM<T>::add2(w4[k], rsw[k]);           // one rounding of the exact sum, as before
                 }
-                if constexpr (WIDE) { if (in == 0 && pr == 0) __builtin_amdgcn_s_waitcnt(0x0F70); }      // vmcnt(0), as a BUILTIN (hipcc's waitcnt pass must see it: see the main loop): the next tile's stage 1 has landed
+                if constexpr (WIDE) { if (in == 0 && pr == 0) { MM_STAMP(7); if (!resid) __builtin_amdgcn_s_waitcnt(0x0F70); MM_STAMP(8); } }      // vmcnt(0), as a BUILTIN (hipcc's waitcnt pass must see it: see the main loop): the next tile's stage 1 has landed
                 if (live[pr] && colb + in * 16 < p.N) {
                     *reinterpret_cast<uint4*>(yrow[pr] + in * 16) = make_uint4(w4[0], w4[1], w4[2], w4[3]);      // the last N tile may be partial
                     if (rstat) {
@@ -910,26 +900,85 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
                 if (m < p.M) p.rowstats[((int64_t)m * (NG * p.tiles_n) + NG * tile_n + (int32_t)grp) * 2 + zx(lane >> 5)] = t;
             };
             if constexpr (WIDE) {
-                // row pair by row pair (one pair's pointers, residual chunks and sums live at a time: the 160 accumulators leave room for no more)
+                // Row pair by row pair, STRAIGHT-LINE: the wide tile only takes launches with M % 256 == 0 and N % 320 == 0 (gsw_mm_launch), so no lane and no column
+                // block is ever masked, and the two launch-wide switches (residual operand, row records) select one of four copies of the body up front.  That matters
+                // for more than the branches: behind ANY branch that contains a store hipcc's waitcnt pass gives up counting and waits vmcnt(0) for the next loaded
+                // value -- with loads and stores in gfx9's ONE in-order counter that is a wait for every store issued so far, a full write round trip per block,
+                // twenty per wave: the epilogue was 33-64 % of a tile on the residual launches (profiles/r05o_mm_trace_wide_*.txt).
+                // The residual operand is a QUEUE of RD chunk loads in flight across the 20 (row pair, column block) blocks of the wave: the counted wait for block b's
+                // chunk leaves the RD younger loads and the stores of the last RD blocks outstanding.  Registers: the main loop's fragment sets are dead here (the next
+                // tile's first fragments are read at the top of the tile loop, not in front of the epilogue), and every block retires 8 accumulator registers.
+                // Addresses: buffer descriptors, ONE lane offset per tensor for all 20 blocks, the block's offset in a scalar register.
+                auto body = [&](auto res_tag, auto stat_tag) {
+                    constexpr bool RES = decltype(res_tag)::value, STAT = decltype(stat_tag)::value;
+                    constexpr int RD = LNF ? 10 : 8;          // (the plain epilogue holds the bias of all five column blocks: ten registers)
+                    const uint32_t lrow = (q & 1u) * 16u + li, lcol = grp * (uint32_t)HC + (q >> 1) * 8u;
+                    const uint32_t y_voff = (lrow * (uint32_t)p.ldy + lcol) * 2u;
+                    const uint32_t y_s0 = (uint32_t)(((int64_t)(m0 + (int32_t)(wm * (16u * MT))) * p.ldy + n0) * 2);
+                    mm_u4 rq[4 * 5];
+                    const __amdgpu_buffer_rsrc_t rs_q = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(RES ? resid : Y), 0, -1, 0x00020000);
+                    uint32_t r_voff = 0u, r_s0 = 0u;
+                    auto rq_issue = [&](int b) {
+                        const int pr = b / 5, in = b % 5;
+                        rq[b] = __builtin_amdgcn_raw_buffer_load_b128(rs_q, (int)r_voff, (int)(r_s0 + (uint32_t)(pr * 32) * (uint32_t)p.ldr * 2u + (uint32_t)(in * 32)), 0);
+                    };
+                    if constexpr (RES) {
+                        r_voff = (lrow * (uint32_t)p.ldr + lcol) * 2u;
+                        r_s0 = (uint32_t)(((int64_t)(m0 + (int32_t)(wm * (16u * MT))) * p.ldr + n0) * 2);
 #pragma unroll
-                for (int pr = 0; pr < NPR; ++pr) {
-                    row_setup(pr);
-                    lnf_rows(pr);
-                    if (resid) {
-#pragma unroll
-                        for (int in = 0; in < RSD; ++in) load_rs1(in, pr);
+                        for (int b = 0; b < RD; ++b) rq_issue(b);
                     }
 #pragma unroll
-                    for (int in = 0; in < 5; ++in) {
-                        float bq[4];
-                        bias4(in, bq);
-                        lnf_cols(in);
-                        if (resid && in + RSD < 5) load_rs1(in + RSD, pr);
-                        block(in, pr, bq);
+                    for (int pr = 0; pr < NPR; ++pr) {
+                        lnf_rows(pr);
+                        float ss = __uint_as_float(zero_hi), sq = __uint_as_float(zero_hi);
+#pragma unroll
+                        for (int in = 0; in < 5; ++in) {
+                            const int b = pr * 5 + in;
+                            float bq[4];
+                            bias4(in, bq);
+                            lnf_cols(in);
+                            if constexpr (RES) { if (b + RD < 20) rq_issue(b + RD); }
+                            uint32_t a0, a1, b0, b1;
+                            pack4(in, 2 * pr, bq, a0, a1);
+                            pack4(in, 2 * pr + 1, bq, b0, b1);
+                            swap16(a0, b0);
+                            swap16(a1, b1);
+                            mm_u4 w4 = {a0, a1, b0, b1};
+                            if constexpr (RES) {
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) w4[k] = MM<T>::add2(w4[k], rq[b][k]);          // one rounding of the exact sum, as before
+                            }
+                            if (b == 0) {
+                                MM_STAMP(7);
+                                // vmcnt(0), as a BUILTIN (hipcc's waitcnt pass must see it: see the main loop): the next tile's stage 1 has landed.  (With a residual
+                                // operand the counted wait for chunk 0 -- in order behind those pieces -- has already said so.)
+                                if constexpr (!RES) __builtin_amdgcn_s_waitcnt(0x0F70);
+                                MM_STAMP(8);
+                            }
+                            // (a GLOBAL store -- scalar base + this lane's 32-bit offset -- not a buffer store: on gfx950 a VALU write to the data registers of a
+                            // buffer_store_dwordx4 that follows it too closely lands in the stored data, SGPR soffset or not; measured: lanes 12-15 / 44-47 of the
+                            // second dword carried the next block's fp32 sums, fixed by wait states BEHIND the store or by this form, not by wait states in front)
+                            *reinterpret_cast<mm_u4*>(reinterpret_cast<uint8_t*>(Y) + (size_t)(y_s0 + (uint32_t)(pr * 32) * (uint32_t)p.ldy * 2u + (uint32_t)(in * 32)) + (size_t)y_voff) = w4;
+                            if constexpr (STAT) {
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) MM<T>::stat2(w4[k], ss, sq);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);                 // (the queue's depth is what the registers allow: no load moves up past a block)
+                        }
+                        if constexpr (STAT) {
+                            // (sum, sum of squares) of the stored values of each row over this wave's 80 columns: see flush_stat
+                            uint32_t a = __float_as_uint(ss), bb = __float_as_uint(sq);
+                            swap32(a, bb);
+                            const float t = __uint_as_float(a) + __uint_as_float(bb);
+                            const int32_t m = m0 + (int32_t)(wm * (16u * MT) + (uint32_t)(2 * pr + (int)(q & 1u)) * 16u + li);
+                            p.rowstats[((int64_t)m * (NG * p.tiles_n) + NG * tile_n + (int32_t)grp) * 2 + zx(lane >> 5)] = t;
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-                    if (rstat) flush_stat(pr);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+                };
+                if (resid) { if (rstat) body(std::true_type{}, std::true_type{}); else body(std::true_type{}, std::false_type{}); }
+                else { if (rstat) body(std::false_type{}, std::true_type{}); else body(std::false_type{}, std::false_type{}); }
             } else {
 #pragma unroll
                 for (int pr = 0; pr < NPR; ++pr) row_setup(pr);
@@ -967,11 +1016,13 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
             // is reproducible -- and lanes 15 / 31 / 47 / 63 each write one 16-byte record (4 column pairs of one plane) for this wave's block of 16 MT rows.
             const bool cstat = p.colstats != nullptr;
             MM_STAMP(14);
-            // WIDE: the row-bias / residual chunks of block (in, pr) are fetched one block AHEAD (two register sets): 20 blocks per wave, each a dependent
-            // load -> add -> store chain otherwise, with the matrix pipe idle
+            // WIDE: the row-bias / residual chunks of block (in, pr) are fetched PD blocks AHEAD (PD + 1 register sets): 20 blocks per wave, each a dependent
+            // load -> add -> store chain otherwise, with the matrix pipe idle -- and, loads and stores sharing gfx9's in-order vmcnt, a chunk fetched one block
+            // ahead still waits for the previous block's store to retire (see the dense-row epilogue: the queue there is ten deep)
             // (ONE prefetched operand: the residual when there is one, else the row bias -- no launch of the eps model or the VAE has both; a launch that
             // does fetches its row bias in place)
-            uint4 prev[2];
+            constexpr int PD = WIDE ? 6 : 1;
+            uint4 prev[PD + 1];
             auto fetch = [&](int in, int pr, int sl) {
                 const int64_t col = (int64_t)n0 + grp * (uint32_t)HC + (uint32_t)in * 16u + (q >> 1) * 8u;
                 // UNCONDITIONAL (lanes without a block read element 0, always there) and unconditionally consumed below: a load some path never uses is one
@@ -980,7 +1031,12 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
                 if (resid) prev[sl] = *reinterpret_cast<const uint4*>(resid + (okl ? (int64_t)orow[pr] * p.ldr + col : (int64_t)0));
                 else prev[sl] = *reinterpret_cast<const uint4*>(rowbias + (okl ? (int64_t)img_b[pr] * p.ldrb + col : (int64_t)0));
             };
-            if constexpr (WIDE) { if (rowbias || resid) fetch(0, 0, 0); }
+            if constexpr (WIDE) {
+                if (rowbias || resid) {
+#pragma unroll
+                    for (int j0 = 0; j0 < PD; ++j0) fetch(j0 / NPR, j0 % NPR, j0);
+                }
+            }
 #pragma unroll
             for (int in = 0; in < 5; ++in) {
                 float bq[4];
@@ -991,20 +1047,20 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
                 for (int pr = 0; pr < NPR; ++pr) {
                     constexpr int NB = 5 * NPR;
                     const int j = in * NPR + pr;
-                    if constexpr (WIDE) { if ((rowbias || resid) && j + 1 < NB) fetch((j + 1) / NPR, (j + 1) % NPR, (j + 1) & 1); }
+                    if constexpr (WIDE) { if ((rowbias || resid) && j + PD < NB) fetch((j + PD) / NPR, (j + PD) % NPR, (j + PD) % (PD + 1)); }
                     uint32_t a0, a1, b0, b1;
                     pack4(in, 2 * pr, bq, a0, a1);
                     pack4(in, 2 * pr + 1, bq, b0, b1);
                     swap16(a0, b0);
                     swap16(a1, b1);
-                    if constexpr (WIDE) { if (j == 0) __builtin_amdgcn_s_waitcnt(0x0F70); }      // vmcnt(0), as a BUILTIN (hipcc's waitcnt pass must see it: see the main loop): the next tile's stage 1 has landed
+                    if constexpr (WIDE) { if (j == 0 && !(rowbias || resid)) __builtin_amdgcn_s_waitcnt(0x0F70); }      // vmcnt(0), as a BUILTIN (hipcc's waitcnt pass must see it: see the main loop): the next tile's stage 1 has landed
                     if constexpr (WIDE) {
                         // the same block with every load consumed on every path (see fetch): arithmetic for all lanes, store and statistics for the live ones
                         uint32_t w4[4] = {a0, a1, b0, b1};
                         if (rowbias || resid) {
                             uint4 rb = make_uint4(0, 0, 0, 0), rs = make_uint4(0, 0, 0, 0);
-                            if (resid) { rs = prev[j & 1]; if (rowbias) rb = *reinterpret_cast<const uint4*>(rowbias + (int64_t)img_b[pr] * p.ldrb + (col < p.N ? col : 0)); }
-                            else rb = prev[j & 1];
+                            if (resid) { rs = prev[j % (PD + 1)]; if (rowbias) rb = *reinterpret_cast<const uint4*>(rowbias + (int64_t)img_b[pr] * p.ldrb + (col < p.N ? col : 0)); }
+                            else rb = prev[j % (PD + 1)];
                             const uint32_t rbw[4] = {rb.x, rb.y, rb.z, rb.w}, rsw[4] = {rs.x, rs.y, rs.z, rs.w};
 #pragma unroll
                             for (int k = 0; k < 4; ++k) {
@@ -1066,7 +1122,12 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
             }
             // (WIDE: both prefetch registers are read once more HERE, so that on every path hipcc has placed its wait for their loads inside the epilogue -- a load
             // it must assume in flight when the register is written next costs a vmcnt(0), i.e. a wait for this epilogue's stores, in the next tile's first phase)
-            if constexpr (WIDE) { if (rowbias || resid) asm volatile("" :: "v"(prev[0].x), "v"(prev[1].x)); }
+            if constexpr (WIDE) {
+                if (rowbias || resid) {
+#pragma unroll
+                    for (int k = 0; k <= PD; ++k) asm volatile("" :: "v"(prev[k].x));
+                }
+            }
         } else if (EPI == 2) {
             // GEGLU: accumulator columns of an n-tile are [8 value | 8 gate] of outputs 8 in .. 8 in + 7 (within the group's 40 outputs): lanes < 32
             // hold values, lanes >= 32 the gates of the same four outputs 4 qv .. 4 qv + 3.  The projection is rounded to the storage dtype as torch
@@ -1121,7 +1182,9 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
             if constexpr (WIDE) {
                 // a pair of column blocks at a time (2 x 4 row pairs x 2 registers live instead of 5 x 4 x 2 beside the accumulators still to come)
                 gate_block(0); gate_block(1);
+                MM_STAMP(7);
                 __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0), as a builtin: the next tile's stage 1 has landed
+                MM_STAMP(8);
                 store_pair(0);
                 __builtin_amdgcn_sched_barrier(0);
                 gate_block(2); gate_block(3); store_pair(1);
@@ -1281,10 +1344,12 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
 #pragma unroll
             for (int im = IM0; im < IM1; ++im) {
                 // activation block im + 3 of this phase, or block im - 5 of the next one, into the ring entry block im - 1 has left
+                // (DMA == 2, the tail in front of an epilogue: the next phase is the next TILE's step 0 -- its fragments are read at the top of the tile loop instead:
+                // read here they would sit in 32 registers across the whole epilogue, which needs them for its queue of residual loads)
                 if (im + 3 < 8) { MM_ABL_READ(xr[(im + 3) & 3] = rd_at(a_c, im + 3)); }
-                else { MM_ABL_READ(xr[(im + 3) & 3] = rd_at(a_n, im - 5)); }
-                if (im == 5) { MM_ABL_READ(wn[0] = rd_at(w_n, 0)); MM_ABL_READ(wn[1] = rd_at(w_n, 1)); MM_ABL_READ(wn[2] = rd_at(w_n, 2)); }
-                if (im == 6) { MM_ABL_READ(wn[3] = rd_at(w_n, 3)); MM_ABL_READ(wn[4] = rd_at(w_n, 4)); }
+                else if (DMA != 2) { MM_ABL_READ(xr[(im + 3) & 3] = rd_at(a_n, im - 5)); }
+                if (DMA != 2 && im == 5) { MM_ABL_READ(wn[0] = rd_at(w_n, 0)); MM_ABL_READ(wn[1] = rd_at(w_n, 1)); MM_ABL_READ(wn[2] = rd_at(w_n, 2)); }
+                if (DMA != 2 && im == 6) { MM_ABL_READ(wn[3] = rd_at(w_n, 3)); MM_ABL_READ(wn[4] = rd_at(w_n, 4)); }
                 if (DMA == 2 && ODD && im >= 5) { dma_piece8(3 * (im - 5)); dma_piece8(3 * (im - 5) + 1); dma_piece8(3 * (im - 5) + 2); }
                 if (DMA == 1 && ODD && im >= 5) dma_piece8(im - 5);
                 if (DMA == 1 && !ODD && im < 6) dma_piece8(3 + im);
@@ -1298,14 +1363,19 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
         auto run_end = [&]() { if (pr_end) { end_run8(); pr_end = false; } };
         using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
         using I5 = std::integral_constant<int, 5>; using I8 = std::integral_constant<int, 8>;
-#pragma unroll
-        for (int in = 0; in < 5; ++in) wA[in] = rd_at(w_rd0, in);
-#pragma unroll
-        for (int im = 0; im < 3; ++im) xr[im] = rd_at(a_rd0, im);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         for (uint32_t it = 0; it < nt_mine; ++it) {
             uint32_t nx_slot = rd_slot + STAGE == RING ? 0u : rd_slot + STAGE;
             MM_STAMP(6);                                                  // (MM_TRACE builds; interval 6: the epilogue of the previous tile)
+            // the tile's first fragments (stage 0 landed before the previous epilogue's first store / in the prologue)
+            {
+                uint32_t lrd = lane_rd0;
+                asm volatile("" : "+v"(lrd));
+                const uint32_t a0_ = lrd + (wm * (16u * MT) * 128u + rd_slot), w0_ = lrd + ((uint32_t)BM * 128u + grp * (uint32_t)HC * 128u + rd_slot);
+#pragma unroll
+                for (int in = 0; in < 5; ++in) { MM_ABL_READ(wA[in] = rd_at(w0_, in)); }
+#pragma unroll
+                for (int im = 0; im < 3; ++im) { MM_ABL_READ(xr[im] = rd_at(a0_, im)); }
+            }
             // step 0 up to its barrier: stage 1 landed long ago (prologue / top of the previous epilogue) -- no vmcnt wait
             seg(std::false_type{}, I0{}, I8{}, I0{}, wA, wB, rd_slot, rd_slot);
             seg(std::true_type{}, I0{}, I5{}, I0{}, wB, wA, rd_slot, nx_slot);
@@ -1742,7 +1812,7 @@ int gsw_mm_launch(MMArgs& a, int dtype, void* stream, GswMmExtras* ex) {
     const MMPlan plan = mm_plan(a.M, tiles_n, a.P, ws_dev && max_splits != 1 && !a.ln_stat, max_splits);       // tiling and split-K policy: see mm_plan
     const int BM = plan.splits >= 2 ? mm_plan(a.M, tiles_n, a.P, false, 1).bm : plan.bm;      // the tile of the UNSPLIT launch (also taken when a split plan does not fit the workspace)
     hipStream_t st = (hipStream_t)stream;
-    a.splits = 1; a.ws = nullptr; a.stagger_step = 0; a.stagger_mask = 0;
+    a.splits = 1; a.ws = nullptr;
     // the dense-row / GEGLU epilogues fetch the bias by 16-byte LDS-DMA pieces (STG in the kernel)
     if ((a.mode == MM_MODE_DENSE || a.mode == MM_MODE_GEGLU) && ((uintptr_t)a.bias & 15u)) return GSW_ERR_BAD_ARG;
     float* const cs_req = ex->colstats_capacity > 0 ? ex->colstats_dev : nullptr;
@@ -1804,7 +1874,8 @@ int gsw_mm_launch(MMArgs& a, int dtype, void* stream, GswMmExtras* ex) {
         // (-3 ... -7 %) and lose 2-6 % at K = 2880
         static const int pmin_dense = getenv("GSW_MM_WIDE_PMIN") ? atoi(getenv("GSW_MM_WIDE_PMIN")) : 5;          // (A/B knobs: stages from which the dense-row / GEGLU
         static const int pmin_pf = getenv("GSW_MM_WIDE_PMIN_PF") ? atoi(getenv("GSW_MM_WIDE_PMIN_PF")) : 64;      //  and the PF-row launches take the wide tile)
-        const int p_min = epi_k == 1 ? pmin_pf : (a.resid ? std::max(pmin_dense, 8) : pmin_dense);
+        static const int pmin_res = getenv("GSW_MM_WIDE_PMIN_RES") ? atoi(getenv("GSW_MM_WIDE_PMIN_RES")) : 8;     //  (dense rows with a residual operand)
+        const int p_min = epi_k == 1 ? pmin_pf : (a.resid ? std::max(pmin_dense, pmin_res) : pmin_dense);
         // rounds of 256 workgroups: a stage of a wide tile costs 1.77 x a stage of a 256 x 160 tile for 2 x its outputs (1.70 vs 0.96 us, the slopes of time against K on
         // the 64 x 64 convolutions) -- wide wins when its rounds, at that price, are fewer than the narrow tiling's (a half-empty last round can eat the gain:
         // 4.5 rounds of wide tiles against 9 of narrow ones still win, 2.25 against 4.5 do not)
@@ -1838,19 +1909,6 @@ int gsw_mm_launch(MMArgs& a, int dtype, void* stream, GswMmExtras* ex) {
         ex->colstats_rows_per_block = BMt / wmv; ex->colstats_blocks = (int)(tiles_m * wmv);
     }
     const int epi = a.mode == MM_MODE_QKV ? 5 : a.mode == MM_MODE_TRANS ? 3 : a.mode == MM_MODE_GEGLU ? 2 : (a.mode == MM_MODE_DENSE && !a.rowbias) ? 0 : 1;
-    {
-        // start stagger (experiment switch): GSW_MM_STAGGER = groups (2, 4, 8), GSW_MM_STAGGER_TBPS = the drain rate the burst length is computed with
-        static const int stag = getenv("GSW_MM_STAGGER") ? atoi(getenv("GSW_MM_STAGGER")) : 0;
-        static const double tbps = getenv("GSW_MM_STAGGER_TBPS") ? atof(getenv("GSW_MM_STAGGER_TBPS")) : 5.5;
-        static const int stag_epi = getenv("GSW_MM_STAGGER_EPI") ? atoi(getenv("GSW_MM_STAGGER_EPI")) : 0x3F;
-        const int64_t rounds = (a.ntiles + grid - 1) / grid;
-        if (stag >= 2 && (stag & (stag - 1)) == 0 && rounds >= 2 && ((stag_epi >> epi) & 1)) {
-            const double tile_bytes = (double)BMt * (a.mode == MM_MODE_GEGLU ? BNt / 2 : BNt) * 2.0 * (a.resid ? 2.0 : 1.0);
-            const double burst_ns = tile_bytes * (double)grid / (tbps * 1e3);
-            a.stagger_step = std::max(1, (int)(burst_ns / stag / 10.0));
-            a.stagger_mask = stag - 1;
-        }
-    }
     const int e = dtype == GSW_F16 ? mm_launch_e<_Float16>(a, epi, grid, wide ? 8 : BM / 64, st) : mm_launch_e<__bf16>(a, epi, grid, wide ? 8 : BM / 64, st);
     if (e != 0) { g_last_hip_error = e; return GSW_ERR_HIP; }
     return GSW_OK;

@@ -67,25 +67,21 @@ template <> struct MM<__bf16> {
     }
 };
 
-// gelu(g) = g Phi(g) for the GEGLU epilogue WITHOUT transcendental instructions: Phi(g) = 1/2 + c Q(z), c = g clamped to [-5, 5], z = 2 c^2 / 25 - 1, Q a degree-12
-// polynomial fitted for the smallest maximum of |g| |Phi_fit - Phi| (tools/gelu_poly_fit.py prints these coefficients and the bounds: |error| <= 1.7e-6 absolute in
-// float32 Horner arithmetic for every g, <= 1.5e-6 relative for g > 0.01 -- the result is rounded to fp16 / bf16 next, eps 4.9e-4; tests/test_gelu_poly.py re-derives the
-// bound from the constants below).  Beyond the clamp Phi stays Phi(+-5) = 1 - 2.9e-7 / 2.9e-7, and the negative side multiplies max(g, -5), so a huge negative gate
-// gives -1.4e-6 instead of 0.  Every operation is an FMA / multiply / min / max: hipcc packs two values per v_pk_fma_f32, 40 issue cycles per value on a SIMD.
-// (Rounds 1-4: Abramowitz & Stegun 7.1.26 with a v_rcp_f32 and a v_exp_f32 -- quarter-rate instructions, 16 cycles each per wave: 66 cycles per value, and the
-// wide tile's GEGLU epilogue (80 values per lane) measured VALU-bound at 43 % of a K = 320 tile, profiles/r05m_mm_trace_wide.txt.)
-#define MM_GELU_CLAMP 5.0f
-#define MM_GELU_COEFFS { 0.0004929697024635971f, -0.001514154253527522f, 0.0020018599461764097f, -0.0029156720265746117f, 0.006165430881083012f, \
-                         -0.010973232798278332f, 0.0164976567029953f, -0.023336730897426605f, 0.03142622858285904f, -0.040432948619127274f, \
-                         0.0515214204788208f, -0.07029665261507034f, 0.14136378467082977f }      /* highest degree first */
+// Abramowitz & Stegun 7.1.26 for the GEGLU epilogue: erfc(x) = (a1 t + ... + a5 t^5) exp(-x^2), t = 1 / (1 + p x), |error| <= 1.5e-7 (three orders below the
+// fp16 / bf16 rounding of the gelu it feeds), branch-free.  The library erff (two polynomial branches, both executed in a wave) made the epilogue of the
+// L0 feed-forward projection (K = 320: five K slices per tile) VALU-bound.
+// gelu(g) = g Phi(g) for the GEGLU epilogue, from h = erfc(|g| / sqrt 2) / 2 (the same 7.1.26 polynomial with the 1/2 and the 1/sqrt 2 folded into
+// its constants): gelu = max(g, 0) - |g| h -- no sign transfer, no 1 + erf, 13 instructions with the v_rcp and the v_exp.
 __device__ __forceinline__ float mm_gelu(float g) {
-    constexpr float cf[13] = MM_GELU_COEFFS;
-    const float gm = fmaxf(g, -MM_GELU_CLAMP), c = fminf(gm, MM_GELU_CLAMP);
-    const float z = fmaf(c * c, 2.0f / (MM_GELU_CLAMP * MM_GELU_CLAMP), -1.0f);
-    float q = cf[0];
-#pragma unroll
-    for (int i = 1; i < 13; ++i) q = fmaf(q, z, cf[i]);
-    return gm * fmaf(c, q, 0.5f);
+    const float ag = fabsf(g);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752f, ag, 1.0f));
+    float pl = fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
+    pl = fmaf(pl, t, 0.5f * 1.421413741f);
+    pl = fmaf(pl, t, 0.5f * -0.284496736f);
+    pl = fmaf(pl, t, 0.5f * 0.254829592f);
+    const float y = 0.84932180028801904f * g;                          // sqrt(log2(e) / 2) g: exp(-g^2 / 2) = exp2(-y^2)
+    const float e = __builtin_amdgcn_exp2f(-y * y);
+    return fmaf(-ag, pl * t * e, fmaxf(g, 0.0f));
 }
 
 }  // namespace

@@ -33,11 +33,11 @@ int main(int argc, char** argv) {
     const long tiles = ((M + 255) / 256) * ((N + 319) / 320);
     const double nt = (double)((tiles + 255) / 256);            // tiles of workgroup 0 per launch (the last launch's sums are what the buffer holds)
     printf("M=%ld K=%d N=%d mode=%d bias=%d resid=%d: %.1f us per launch, %d steps per tile, %.0f tiles per workgroup\n", M, K, N, mode, use_bias, use_res, ms * 1e3 / reps, P, nt);
-    printf("cycles per tile: step 0 issue | first barrier | steady steps (P-1): issue + vmcnt wait + barrier wait | last tail | epilogue || sum\n");
-    for (int wv : {0, 1, 6, 7}) {
+    printf("cycles per tile: step 0 issue | first barrier | steady steps (P-1): issue + vmcnt wait + barrier wait | last tail | epilogue: up to its vmcnt(0) + that wait + the rest (stores) || sum\n");
+    for (int wv = 0; wv < 8; ++wv) {
         const unsigned long long* t = &h[wv * 16];
-        double s = 0; for (int k = 0; k < 7; ++k) s += t[k] / nt;
-        printf("wave %d: %7.0f | %6.0f | %7.0f + %6.0f + %6.0f | %6.0f | %7.0f || %8.0f per tile\n", wv, t[0] / nt, t[1] / nt, t[2] / nt, t[3] / nt, t[4] / nt, t[5] / nt, t[6] / nt, s);
+        double s = 0; for (int k = 0; k < 9; ++k) s += t[k] / nt;
+        printf("wave %d: %7.0f | %6.0f | %7.0f + %6.0f + %6.0f | %6.0f | %6.0f + %6.0f + %6.0f || %8.0f per tile\n", wv, t[0] / nt, t[1] / nt, t[2] / nt, t[3] / nt, t[4] / nt, t[5] / nt, t[7] / nt, t[8] / nt, t[6] / nt, s);
     }
     return 0;
 }
