@@ -2,7 +2,7 @@
 # Round-5 evidence run on the GPU box (from the repo root): attention with the permuted V^T rows, the bench lines of every configuration, rocprofv3 kernel
 # statistics of the default and the SD 1.5 / 768 x 768 runs, PMC traffic of the engine family.  Outputs under gpurun_out/r05h/.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/r05l
+O=$R/gpurun_out/r05s
 mkdir -p $O
 cd $R
 timeout 1800 python3 -m pytest tests -m gpu -x -q > $O/pytest_gpu.txt 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest_gpu.txt
@@ -19,6 +19,10 @@ timeout 300 python3 tools/unet_forward_bench.py 128 convs > $O/unet_forward_b128
 cd /tmp && export TMPDIR=/tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_e2e -o e2e -- python3 $R/bench.py --tier e2e --steps 1 --warmup 1 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err; echo "rocprof rc=$?"
 GSW_GRAPH=never timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_sd15 -o sd15 -- python3 $R/bench.py --tier e2e --batch 16 --steps 1 --warmup 1 --unet sd15 --height 768 --width 768 --no-cpu-baseline > $O/bench_sd15_under_rocprof.json 2> $O/bench_sd15_under_rocprof.err; echo "rocprof sd15 rc=$?"
+for rows in 1 16; do
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_rows$rows -o g -- python3 $R/tools/small_rows_profile.py $rows > $O/prof_rows$rows.log 2>&1; echo "graph rows $rows rc=$?"
+  f=$(find $O/prof_rows$rows -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/forward_${rows}rows_graph_kernel_stats.csv
+done
 for rows in 128 64; do
   for c in FETCH_SIZE WRITE_SIZE; do
     timeout 600 rocprofv3 --pmc $c --output-format csv -d $O/pmc_${rows}_$c -o p -- python3 $R/tools/unet_forward_bench.py $rows > $O/pmc_${rows}_$c.log 2>&1; echo "pmc $rows $c rc=$?"
