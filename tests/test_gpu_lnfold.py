@@ -20,7 +20,7 @@ def G():
     pf.SMALL_GEMM_MAX_ROWS = old
 
 
-@pytest.fixture(params=[0, 128, 256], ids=["auto", "BM128", "BM256"])
+@pytest.fixture(params=[0, 128, 256, 512], ids=["auto", "BM128", "BM256", "WIDE256x320"])      # 512: the 256 x 320 tile wherever it is legal (M % 256 == 0, N % 320 == 0)
 def tile_rows(request, G):
     assert G.lib.gsw_mm_config(request.param, -1) == 0
     prev = G.pf.FOLD_LN_MIN_ROWS
