@@ -1,11 +1,13 @@
 #!/bin/bash
 # Round-5 job 23: the straight-line dense-row epilogue (global stores, residual queue) and the tile-top fragment reads: parity, then a same-box A/B against the engine of
-# commit f48ec25 (tools/ubench/bin/libgswm_old.so = that gswm_mm.hip linked with today's other objects).
+# commit f48ec25 (tools/ubench/bin/libgswm_old.so = that gswm_mm.hip linked with today's other objects:
+#   mkdir -p /tmp/o/a/b /tmp/o/include; for f in gswm_mm.hip gswm_mm.h gswm_mmtypes.h gswm_ablate.inc; do git show f48ec25:a-watermark-for-diffusion-models_amd/csrc/$f > /tmp/o/a/b/$f; done; cp include/gswm.h /tmp/o/include/
+#   (cd /tmp/o/a/b && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -c gswm_mm.hip -o /tmp/mm_old.o)
+#   cd a-watermark-for-diffusion-models_amd/csrc && hipcc --offload-arch=gfx950 -shared -fPIC -Wl,--version-script=gswm.map build/gswm_{kernels,conv,image,attn}.o /tmp/mm_old.o build/gswm_small.o -o ../../tools/ubench/bin/libgswm_old.so ).
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/r05q
 mkdir -p $O
 cd $R
-python3 tools/debug_wide.py 2>&1 | grep -E "^bad"
 timeout 1500 python3 -m pytest tests/test_gpu_mm_production.py tests/test_gpu_gemm.py tests/test_gpu_lnfold.py tests/test_gpu_unet_fused.py tests/test_gpu_splitk.py tests/test_gpu_small.py tests/test_gpu_graph.py tests/test_gpu_gn_colstats.py -q -x > $O/pytest.txt 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest.txt
 OLD=$R/tools/ubench/bin/libgswm_old.so
 for rep in 1 2; do
