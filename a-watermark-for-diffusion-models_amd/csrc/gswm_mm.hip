@@ -956,9 +956,9 @@ __global__ __launch_bounds__(SPLIT ? 768 : 512, SPLIT ? 1 : 2) void gsw_mm_kerne
                                 if constexpr (!RES) __builtin_amdgcn_s_waitcnt(0x0F70);
                                 MM_STAMP(8);
                             }
-                            // (a GLOBAL store -- scalar base + this lane's 32-bit offset -- not a buffer store: on gfx950 a VALU write to the data registers of a
-                            // buffer_store_dwordx4 that follows it too closely lands in the stored data, SGPR soffset or not; measured: lanes 12-15 / 44-47 of the
-                            // second dword carried the next block's fp32 sums, fixed by wait states BEHIND the store or by this form, not by wait states in front)
+                            // (a GLOBAL store -- scalar base + this lane's 32-bit offset -- not a buffer store: on gfx950 a VALU write to the data registers in the
+                            // slot right behind a buffer_store_dwordx4 lands in the stored data even when soffset is an SGPR, the case hipcc's hazard recognizer
+                            // does not pad: lanes 12-15 mod 16 of the second dword carried the next block's fp32 sums; tools/ubench/buffer_store_hazard.hip)
                             *reinterpret_cast<mm_u4*>(reinterpret_cast<uint8_t*>(Y) + (size_t)(y_s0 + (uint32_t)(pr * 32) * (uint32_t)p.ldy * 2u + (uint32_t)(in * 32)) + (size_t)y_voff) = w4;
                             if constexpr (STAT) {
 #pragma unroll
