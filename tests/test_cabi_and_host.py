@@ -252,3 +252,30 @@ def test_argument_validation_of_eps_model_and_image_entry_points():
     key = (ctypes.c_uint32 * 624)()
     assert lib.gsw_mt19937_uniform(key, 625, p, 4, None, None) == BAD
     assert lib.gsw_mt19937_uniform(key, 624, p, 0, None, None) == N.GSW_OK
+
+
+def test_extras_struct_layout_matches_the_header(tmp_path):
+    """include/gswm.h is the boundary: the ctypes mirror of GswMmExtras must have the C compiler's size and field offsets (a silent mismatch would hand the
+    engine a workspace pointer where it expects a capacity).  gcc compiles a probe against the header itself; the header must also be plain C."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    names = [f[0] for f in N.GswMmExtras._fields_]
+    src = tmp_path / "probe.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "gswm.h"\nint main(void) {\n  printf("%zu\\n", sizeof(GswMmExtras));\n'
+                   + "".join(f'  printf("{n} %zu\\n", offsetof(GswMmExtras, {n}));\n' for n in names) + "  return 0;\n}\n")
+    exe = tmp_path / "probe"
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n")
+    assert int(out[0]) == ctypes.sizeof(N.GswMmExtras)
+    for line in out[1:]:
+        if line:
+            n, off = line.split()
+            assert getattr(N.GswMmExtras, n).offset == int(off), n
+    # every field of the C struct is mirrored (count the declarators between the braces of the typedef)
+    hdr = open(os.path.join(ROOT, "include", "gswm.h")).read()
+    body = re.search(r"typedef struct GswMmExtras \{(.*?)\} GswMmExtras;", hdr, re.S).group(1)
+    decl = [d.strip().split()[-1].lstrip("*") for stmt in body.split(";") if stmt.strip() for d in stmt.split(",")]
+    assert decl == names
