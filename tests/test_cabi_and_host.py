@@ -279,3 +279,38 @@ def test_extras_struct_layout_matches_the_header(tmp_path):
     body = re.search(r"typedef struct GswMmExtras \{(.*?)\} GswMmExtras;", hdr, re.S).group(1)
     decl = [d.strip().split()[-1].lstrip("*") for stmt in body.split(";") if stmt.strip() for d in stmt.split(",")]
     assert decl == names
+
+
+def test_ctypes_prototypes_match_the_header_declarations():
+    """Every declaration of include/gswm.h against its ctypes prototype: number of parameters, and per parameter pointer / int / int64 / uint32 / uint64 / float / double
+    (an int where the header says int64_t passes on x86-64 until a size crosses 2^31)."""
+    txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "gswm.h")).read(), flags=re.S)
+    txt = re.sub(r"//[^\n]*", "", txt)
+    decls = re.findall(r"([A-Za-z_][\w\s\*]*?)\b(gsw_[a-z0-9_]+)\s*\(([^()]*)\)\s*;", txt)
+    assert len(decls) == len(header_symbols())
+
+    def kind_of_c(t):
+        t = t.strip()
+        if "*" in t or "[" in t:            # (an array parameter is a pointer)
+            return "ptr"
+        for key, kind in (("uint64_t", "u64"), ("size_t", "u64"), ("int64_t", "i64"), ("uint32_t", "u32"), ("unsigned", "u32"), ("double", "f64"), ("float", "f32"), ("int", "i32")):
+            if re.search(rf"\b{key}\b", t):
+                return kind
+        raise AssertionError(f"unmapped C type {t!r}")
+
+    def kind_of_ctypes(t):
+        if t is None:
+            return "void"
+        if t in (ctypes.c_void_p, ctypes.c_char_p) or hasattr(t, "contents") or issubclass(t, ctypes._Pointer):
+            return "ptr"
+        return {ctypes.c_int: "i32", ctypes.c_int64: "i64", ctypes.c_uint64: "u64", ctypes.c_uint32: "u32", ctypes.c_float: "f32", ctypes.c_double: "f64",
+                ctypes.c_size_t: "u64", ctypes.c_long: "i64", ctypes.c_ulong: "u64", ctypes.c_longlong: "i64", ctypes.c_ulonglong: "u64", ctypes.c_uint: "u32"}[t]
+
+    for ret, name, params in decls:
+        res, args = N._PROTOTYPES[name]
+        plist = [p for p in (q.strip() for q in params.split(",")) if p and p != "void"]
+        # strip the parameter name (the last identifier) unless the declaration is type-only
+        ctypes_kinds = [kind_of_ctypes(a) for a in args]
+        c_kinds = [kind_of_c(p if "[" in p else (re.sub(r"\b[A-Za-z_]\w*$", "", p) if re.search(r"[\*\s][A-Za-z_]\w*$", p) else p)) for p in plist]
+        assert c_kinds == ctypes_kinds, (name, c_kinds, ctypes_kinds)
+        assert (kind_of_c(ret) if ret.strip() != "void" else "void") == kind_of_ctypes(res), (name, ret)
