@@ -1865,7 +1865,9 @@ int gsw_mm_launch(MMArgs& a, int dtype, void* stream, GswMmExtras* ex) {
         if (a.mode == MM_MODE_PF || a.mode == MM_MODE_TOK2PF) rows_out = ((int64_t)a.M / std::max<int64_t>(1, (a.mode == MM_MODE_TOK2PF ? a.S : ((a.flags & MM_FLAG_COMPACT) ? (int64_t)(a.Hp - 2) * (a.Wp - 2) : (int64_t)a.Hp * a.Wp))) + 1) * (int64_t)a.Hp * a.Wp;
         if (a.mode == MM_MODE_UP2X) rows_out = rows_in * 4 + 8;
         const bool res_ok = !a.resid || rows_out * (int64_t)a.ldr * 2 < ((int64_t)1 << 32) - (1 << 20);
-        const bool legal = mode_ok && res_ok && a.N >= 320 && a.N % 320 == 0 && (!(a.mode == MM_MODE_GEGLU || (a.mode == MM_MODE_DENSE && !a.rowbias)) || a.M % 256 == 0) && rows_in * ld_max * 2 < ((int64_t)1 << 32) - (1 << 20) && (int64_t)a.N * a.ldw * 2 < ((int64_t)1 << 32) - (1 << 20);
+        // (the dense-row epilogue of the wide tile addresses its OUTPUT by a 32-bit byte offset too)
+        const bool y_ok = !(a.mode == MM_MODE_DENSE && !a.rowbias) || (int64_t)a.M * a.ldy * 2 < ((int64_t)1 << 32) - (1 << 20);
+        const bool legal = mode_ok && res_ok && y_ok && a.N >= 320 && a.N % 320 == 0 && (!(a.mode == MM_MODE_GEGLU || (a.mode == MM_MODE_DENSE && !a.rowbias)) || a.M % 256 == 0) && rows_in * ld_max * 2 < ((int64_t)1 << 32) - (1 << 20) && (int64_t)a.N * a.ldw * 2 < ((int64_t)1 << 32) - (1 << 20);
         // a partial last column tile costs a whole one: at most 1/8 of the column tiles' work wasted
         // measured per shape at 128 rows (profiles/r05g_unet_forward_b128_wide_thresholds.txt): the dense-row and GEGLU launches win at every K of the eps model,
         // K = 320 included (-5 ... -24 %: a 320-column tile reads the activations once where two 160-column tiles read them twice) -- except the K = 320 launches
