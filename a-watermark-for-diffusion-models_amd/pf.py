@@ -577,6 +577,9 @@ FOLD_LN_MIN_ROWS = int(__import__("os").environ.get("GSW_FOLD_LN_MIN_ROWS", "102
 
 def ln_stat(x: torch.Tensor, eps: float) -> Optional[torch.Tensor]:
     """(rstd, -rstd * mean) per row of x [.., C] from the row records its producer left on it, or None when there are none."""
+    done = getattr(x, "_gsw_lnstat", None)      # the producer already left the finished statistics (xattn.fused: the whole row is in one wave there)
+    if done is not None and FOLD_LN and done[1] == float(eps):
+        return done[0]
     rs = getattr(x, "_gsw_rowstats", None)
     if rs is None or not FOLD_LN:
         return None

@@ -267,6 +267,13 @@ class Attention(nn.Module):
             o = attention(gemm_ln(x, stat, *fq), k_ctx, vt_ctx, self.heads, valid_keys=valid)
         return _lin(o, self.to_out[0], resid, rowstats=True)
 
+    def fused_sublayer(self, x, stat, norm: nn.LayerNorm, ctx, eps_next: Optional[float] = None):
+        """x + attn(LayerNorm(x), ctx) as ONE launch (xattn.py / csrc/gswm_xattn.hip): x [B, S, 320] raw residual stream, stat its (rstd, -rstd mean), ctx
+        [B or 2B, 77, D] (2B: classifier-free guidance on shared latents -> [2B, S, 320]).  eps_next: leave the statistics of the new rows for the next LayerNorm."""
+        from . import xattn
+        blob, uv, idx = xattn.context_operands(self, norm, ctx, x.dtype)
+        return xattn.fused(x, stat, blob, uv, idx, ctx.shape[0], self.heads, eps_out=eps_next)
+
     def cross_dup(self, x, ctx, *, stat=None, norm: Optional[nn.LayerNorm] = None):
         """Classifier-free guidance with shared latents: x [B, S, C] holds the queries' input ONCE, ctx [2B, 77, D] = (uncond | text) contexts.  The
         query projection runs on B rows; the 77-key attention once per context half, both writing one [2B, S, C] tensor; -> attention output (before
@@ -415,17 +422,24 @@ class BasicTransformerBlock(nn.Module):
             else:
                 _, n = add_layernorm(x, None, self.norm1.weight, self.norm1.bias, self.norm1.eps)
                 x = self.attn1(n, resid=x)
+            from . import xattn
+            one_launch = xattn.usable(x, self.attn2, ctx)      # the 320-channel level: norm2 + query projection + 77-key attention + output projection + residual in one kernel
             if dup:
-                st = ln_stat(x, self.norm2.eps) if self.attn2.ln_foldable(x, ctx[: x.shape[0]]) else None
-                if st is not None:
-                    o = self.attn2.cross_dup(x, ctx, stat=st, norm=self.norm2)
+                st = ln_stat(x, self.norm2.eps) if (one_launch or self.attn2.ln_foldable(x, ctx[: x.shape[0]])) else None
+                if st is not None and one_launch:
+                    x = self.attn2.fused_sublayer(x, st, self.norm2, ctx, eps_next=self.norm3.eps)      # from here on: 2B rows
                 else:
-                    _, n = add_layernorm(x, None, self.norm2.weight, self.norm2.bias, self.norm2.eps)
-                    o = self.attn2.cross_dup(n, ctx)
-                x = _lin(o, self.attn2.to_out[0], torch.cat([x, x], dim=0), rowstats=True)      # from here on: 2B rows
+                    if st is not None:
+                        o = self.attn2.cross_dup(x, ctx, stat=st, norm=self.norm2)
+                    else:
+                        _, n = add_layernorm(x, None, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+                        o = self.attn2.cross_dup(n, ctx)
+                    x = _lin(o, self.attn2.to_out[0], torch.cat([x, x], dim=0), rowstats=True)      # from here on: 2B rows
             else:
-                st = ln_stat(x, self.norm2.eps) if self.attn2.ln_foldable(x, ctx) else None
-                if st is not None:
+                st = ln_stat(x, self.norm2.eps) if (one_launch or self.attn2.ln_foldable(x, ctx)) else None
+                if st is not None and one_launch:
+                    x = self.attn2.fused_sublayer(x, st, self.norm2, ctx, eps_next=self.norm3.eps)
+                elif st is not None:
                     x = self.attn2.forward_ln(x, st, self.norm2, ctx, resid=x)
                 else:
                     _, n = add_layernorm(x, None, self.norm2.weight, self.norm2.bias, self.norm2.eps)
@@ -855,6 +869,9 @@ def _unet_prepare_context(self, ctx: torch.Tensor) -> None:
             a = blk.attn2
             if attention_ok(ctx, a.heads, a.to_q.out_features // a.heads, 1, src.shape[1]):
                 a.context_kv(src)
+            from . import xattn
+            if xattn.ENABLED and a.to_q.in_features == xattn.CHANNELS and ctx.shape[1] <= xattn.KEY_SLOTS and ctx.dtype in (torch.float16, torch.bfloat16):
+                xattn.context_operands(a, blk.norm2, ctx, ctx.dtype)      # the one-launch cross-attention's per-context fragment streams
 
 
 UNet2DCondition._cfg_dup_ok = _unet_cfg_dup_ok

@@ -1,0 +1,178 @@
+"""The cross-attention sublayer of a transformer block as ONE launch (csrc/gswm_xattn.hip, `gsw_xattn_fused`):
+
+    x' = x + to_out(softmax(to_q(LayerNorm(x)) K^T / sqrt(d)) V) + b_out,        K, V = to_k(ctx), to_v(ctx)
+
+Reference call site: extract.py:66-69 / modified_stable_diffusion_gs.pyc run diffusers' UNet2DConditionModel; this is its
+`BasicTransformerBlock.attn2` with `norm2` in front and the residual behind.
+
+Both sides of the softmax are linear in things that do not change from step to step of a sampling / inversion loop -- the weights and the
+context -- so per (context, head) the host derives two matrices ONCE (fp32 products of the fp16 weights, one rounding):
+
+    A_h = K_h Wq_h [keys, C]    scores      S_h = LayerNorm(x) A_h^T / sqrt(d)
+    B_h = Wo_h V_h^T [C, keys]  output      x'  = x + b_out + sum_h softmax(S_h) B_h^T
+
+LayerNorm is folded like pf.fold_ln_weights does it: A' = A diag(gamma) * scale * log2(e) (rounded), u = A' 1, v = (A beta) * scale * log2(e), so that
+S = rstd (x A'^T) + (-rstd mean) u + v in the exponent's base 2; padding keys get v = -inf.  `context_operands` stores A' and B in the order the kernel
+consumes them: a stream of 1 KiB MFMA fragments (110 per head); the layout algebra is in csrc/gswm_xattn.hip and restated by tests/test_xattn_host.py.
+"""
+from __future__ import annotations
+
+import ctypes as _C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _native as N
+from .codec import _dt, _stream_ptr
+
+CHANNELS = 320            # the level gsw_xattn_fused serves (SD 2.1: 64 x 64 latents; SD 1.5: the first level)
+KEY_SLOTS = 80            # 5 blocks of 16 keys; slot 80 of the second product carries the output bias
+HEAD_ELEMS = 11 * 5120    # 50 + 60 fragments of 512 elements
+UV_FLOATS = 2 * KEY_SLOTS
+LOG2E = 1.4426950408889634
+ENABLED = __import__("os").environ.get("GSW_XATTN_FUSED", "1") != "0"      # A/B switch: 0 = the three-launch path (query projection, attention kernel, output projection)
+
+
+def _column_of(nb: torch.Tensor, lab: torch.Tensor) -> torch.Tensor:
+    """output column of accumulator row `lab` (0..15) of column block `nb` (0..19): lane (row, g) then owns columns 32 q + 8 g .. + 7 of its rows"""
+    return 32 * (nb >> 1) + 8 * (lab >> 2) + 4 * (nb & 1) + (lab & 3)
+
+
+def _key_slot_of(kk: torch.Tensor, g: torch.Tensor, e: torch.Tensor) -> torch.Tensor:
+    """key slot (0..95) that element e of lane row g holds in key step kk of the second product: the S^T accumulator layout of two 16-key blocks"""
+    return 32 * kk + 16 * (e >> 2) + 4 * g + (e & 3)
+
+
+def fold_operands(wq: torch.Tensor, wk: torch.Tensor, wv: torch.Tensor, wo: torch.Tensor, bo: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor,
+                  ctx: torch.Tensor, heads: int, dtype: torch.dtype):
+    """-> (A' [Bc, H, 80, C] in `dtype`, u [Bc, H, 80] fp32, v [Bc, H, 80] fp32, B [Bc, H, C, 96] in `dtype`) of `ctx` [Bc, keys <= 80, D]: the matrices
+    of the module docstring, key slots padded (A' rows zero, u = 0, v = -inf, B columns zero), B's slot 80 = b_out for the last head."""
+    Bc, n, _ = ctx.shape
+    C = wq.shape[1]
+    inner = wq.shape[0]
+    d = inner // heads
+    if n > KEY_SLOTS:
+        raise ValueError(f"xattn: {n} context tokens, at most {KEY_SLOTS}")
+    f = torch.float32
+    c32 = ctx.to(f)
+    K = (c32 @ wk.detach().to(f).t()).view(Bc, n, heads, d).permute(0, 2, 1, 3)          # [Bc, H, n, d]
+    V = (c32 @ wv.detach().to(f).t()).view(Bc, n, heads, d).permute(0, 2, 1, 3)
+    A = torch.einsum("bhnd,hdc->bhnc", K, wq.detach().to(f).view(heads, d, C))           # [Bc, H, n, C]
+    sc = float(d) ** -0.5 * LOG2E
+    Ap = torch.zeros((Bc, heads, KEY_SLOTS, C), dtype=dtype, device=ctx.device)
+    Ap[:, :, :n] = (A * (gamma.detach().to(f) * sc)).to(dtype)
+    u = Ap.to(f).sum(dim=-1)
+    v = torch.full((Bc, heads, KEY_SLOTS), float("-inf"), dtype=f, device=ctx.device)
+    v[:, :, :n] = (A @ beta.detach().to(f)) * sc
+    Bm = torch.zeros((Bc, heads, C, 96), dtype=dtype, device=ctx.device)
+    Bm[..., :n] = torch.einsum("bhnd,chd->bhcn", V, wo.detach().to(f).view(C, heads, d)).to(dtype)
+    if bo is not None:
+        Bm[:, heads - 1, :, KEY_SLOTS] = bo.detach().to(dtype)
+    return Ap, u, v, Bm
+
+
+def pack_stream(Ap: torch.Tensor, u: torch.Tensor, v: torch.Tensor, Bm: torch.Tensor):
+    """fold_operands' matrices -> (blob [Bc, H * HEAD_ELEMS] in their dtype, uv [Bc, H * UV_FLOATS] fp32) in the kernel's consumption order"""
+    Bc, H, _, C = Ap.shape
+    if C != CHANNELS:
+        raise ValueError(f"xattn: C = {C}, the kernel serves {CHANNELS}")
+    dev = Ap.device
+    # first product: fragment (k-step ks, key block kb), lane (label, g), element e = A'[16 kb + label][32 ks + 8 g + e]
+    g1 = Ap.view(Bc, H, 5, 16, C // 32, 4, 8).permute(0, 1, 4, 2, 5, 3, 6).reshape(Bc, H, -1)      # [ks, kb, g, label, e]
+    # second product: fragment (key step kk, column block nb), lane (label, g), element e = B[column_of(nb, label)][key_slot_of(kk, g, e)]
+    ar = lambda k: torch.arange(k, device=dev)
+    cols = _column_of(ar(C // 16)[:, None], ar(16)[None, :])                                     # [nb, label]
+    slots = _key_slot_of(ar(3)[:, None, None], ar(4)[None, :, None], ar(8)[None, None, :])         # [kk, g, e]
+    g2 = Bm[:, :, cols[None, :, None, :, None], slots[:, None, :, None, :]].reshape(Bc, H, -1)    # [kk, nb, g, label, e]
+    blob = torch.cat([g1, g2], dim=2).reshape(Bc, H * HEAD_ELEMS).contiguous()
+    uv = torch.cat([u, v], dim=2).reshape(Bc, H * UV_FLOATS).contiguous()
+    return blob, uv
+
+
+def run_index(ctx: torch.Tensor) -> Optional[torch.Tensor]:
+    """int32 [Bc]: for every context row the first row of the run of identical rows it belongs to (classifier-free guidance hands over B copies of the
+    empty prompt's context: their images then share ONE fragment stream in L2).  Computed on the device, no host synchronisation.  None for one row."""
+    Bc = ctx.shape[0]
+    if Bc == 1:
+        return None
+    flat = ctx.reshape(Bc, -1)
+    new = torch.ones(Bc, dtype=torch.bool, device=ctx.device)
+    new[1:] = (flat[1:] != flat[:-1]).any(dim=1)
+    pos = torch.arange(Bc, device=ctx.device, dtype=torch.int32)
+    return torch.cummax(torch.where(new, pos, torch.zeros_like(pos)), dim=0).values.contiguous()
+
+
+def context_operands(attn, norm, ctx: torch.Tensor, dtype: torch.dtype):
+    """(blob, uv, index) of `ctx` [Bc, keys, D] for cross-attention module `attn` behind LayerNorm `norm`: computed once per (context tensor, layer) and
+    reused by every step of a loop.  The cache lives ON the context tensor and is keyed by the tensor's and the parameters' version counters; an in-place
+    edit recomputes INTO the existing buffers (a captured HIP graph of the forward reads them at fixed addresses)."""
+    src = ctx[:1] if (ctx.dim() == 3 and ctx.shape[0] > 1 and ctx.stride(0) == 0) else ctx           # .expand() of one context: one stream
+    store = getattr(ctx, "_gsw_xattn", None)
+    if store is None:
+        store = {}
+        ctx._gsw_xattn = store
+    params = (attn.to_q.weight, attn.to_k.weight, attn.to_v.weight, attn.to_out[0].weight, attn.to_out[0].bias, norm.weight, norm.bias)
+    ver = (ctx._version, str(dtype)) + tuple((q.data_ptr(), q._version) for q in params if q is not None)
+    ent = store.get(id(attn))
+    if ent is None or ent[0] != ver:
+        with torch.no_grad():
+            blob, uv = pack_stream(*fold_operands(attn.to_q.weight, attn.to_k.weight, attn.to_v.weight, attn.to_out[0].weight, attn.to_out[0].bias,
+                                                  norm.weight, norm.bias, src, attn.heads, dtype))
+            idx = run_index(src)
+        if ent is not None and ent[1].shape == blob.shape and ent[1].dtype == blob.dtype:
+            ent[1].copy_(blob)
+            ent[2].copy_(uv)
+            if idx is not None:
+                ent[3].copy_(idx)
+            ent = (ver, ent[1], ent[2], ent[3])
+        else:
+            ent = (ver, blob, uv, idx)
+        store[id(attn)] = ent
+    return ent[1], ent[2], ent[3]
+
+
+def usable(x: torch.Tensor, attn, ctx: torch.Tensor) -> bool:
+    """gsw_xattn_fused serves this call: 320 channels, whole 128-row tiles per image, at most 80 context tokens, no projection biases besides to_out's"""
+    return (ENABLED and x.is_cuda and x.dim() == 3 and x.dtype in (torch.float16, torch.bfloat16) and x.is_contiguous() and x.shape[-1] == CHANNELS
+            and x.shape[1] % 128 == 0 and ctx.dim() == 3 and ctx.shape[1] <= KEY_SLOTS and attn.to_q.bias is None and attn.to_k.bias is None
+            and attn.to_v.bias is None and attn.to_q.in_features == CHANNELS and attn.to_out[0].out_features == CHANNELS
+            and ctx.shape[0] % x.shape[0] == 0 and x.shape[0] * x.shape[1] < (1 << 31) // max(1, ctx.shape[0] // x.shape[0]))
+
+
+def fused(x: torch.Tensor, stat: torch.Tensor, blob: torch.Tensor, uv: torch.Tensor, index: Optional[torch.Tensor], out_images: int, heads: int,
+          eps_out: Optional[float] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x [xB, S, 320] raw residual stream, stat [xB * S, 2] = (rstd, -rstd mean) of its rows (pf.ln_stat) -> x' [out_images, S, 320]; output image i
+    reads x image i % xB and the context stream index[i] (None: stream 0; one stream: every image's).  eps_out: also leave the (rstd, -rstd mean) of the
+    NEW rows on the result (`_gsw_lnstat`, what pf.ln_stat returns for the LayerNorm that follows)."""
+    if not x.is_cuda:
+        raise RuntimeError("xattn.fused: device tensors only; there is no CPU fallback")
+    xB, S, C = x.shape
+    if C != CHANNELS or S % 128 or out_images % xB or x.dtype not in (torch.float16, torch.bfloat16) or not x.is_contiguous():
+        raise ValueError("xattn.fused: x must be a contiguous fp16 / bf16 [xB, S % 128 == 0, 320] tensor, out_images a multiple of xB")
+    if blob.dtype != x.dtype or blob.dim() != 2 or blob.shape[1] != heads * HEAD_ELEMS or uv.dtype != torch.float32 or uv.shape != (blob.shape[0], heads * UV_FLOATS):
+        raise ValueError("xattn.fused: blob / uv are not context_operands' output for this head count and dtype")
+    if stat.dtype != torch.float32 or stat.numel() != 2 * xB * S or not stat.is_contiguous():
+        raise ValueError("xattn.fused: stat must be fp32 [xB * S, 2]")
+    nctx = blob.shape[0]
+    if index is None and nctx not in (1, out_images):
+        raise ValueError("xattn.fused: one context stream, or one per output image, or an index")
+    if index is None and nctx == out_images and nctx > 1:
+        index = torch.arange(out_images, dtype=torch.int32, device=x.device)
+    if index is not None and (index.dtype != torch.int32 or index.numel() != out_images or not index.is_contiguous()):
+        raise ValueError("xattn.fused: index must be int32 [out_images]")
+    y = torch.empty((out_images, S, C), dtype=x.dtype, device=x.device) if out is None else out
+    ostat = torch.empty((out_images * S, 2), dtype=torch.float32, device=x.device) if eps_out is not None else None
+    from . import pf
+    tm = pf.CONV_TIMER
+    with torch.cuda.device(x.device):
+        e0 = tm.start() if tm is not None else None
+        N.check(N.lib().gsw_xattn_fused(x.data_ptr(), stat.data_ptr(), blob.data_ptr(), blob.shape[1] * blob.element_size(), uv.data_ptr(), uv.shape[1],
+                                        index.data_ptr() if index is not None else None, y.data_ptr(), ostat.data_ptr() if ostat is not None else None,
+                                        float(eps_out) if eps_out is not None else 0.0, xB, out_images, S, C, heads, _dt(x.dtype), _stream_ptr()))
+        if tm is not None:
+            keys = KEY_SLOTS
+            tm.stop(e0, ("gsw_xattn_kernel", out_images * S, C, heads * keys, "xattn") if tm.by_shape else "gsw_xattn_kernel",
+                    2.0 * out_images * S * C * heads * (keys + 96))
+    if ostat is not None:
+        y._gsw_lnstat = (ostat, float(eps_out))
+    return y

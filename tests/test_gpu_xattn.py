@@ -1,0 +1,128 @@
+"""GPU: the cross-attention sublayer as one launch (gsw_xattn_fused, csrc/gswm_xattn.hip; diffusers' BasicTransformerBlock.attn2 + norm2 + residual behind
+extract.py:66-69) against (a) the fp32 torch evaluation of the modules, (b) the three-launch path it replaces (LayerNorm-folded query projection, 77-key
+attention kernel, output projection + residual), (c) the lane-level restatement of tests/test_xattn_host.py.  Tolerances are absolute on outputs of scale ~1-3:
+fp16 4e-3 x max|ref| (the three-launch path is held to the same bound by tests/test_gpu_lnfold.py), bf16 3e-2."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from test_xattn_host import _module, emulate, reference  # noqa: E402
+
+
+def _stat(x, eps):
+    xf = x.float()
+    mean, var = xf.mean(-1), xf.var(-1, unbiased=False)
+    rstd = torch.rsqrt(var + eps)
+    return torch.stack([rstd, -rstd * mean], dim=-1).reshape(-1, 2).contiguous()
+
+
+def _case(heads, head_dim, ctx_dim, keys, dtype, xB, oB, S, seed, shared_ctx=False):
+    from gswm_amd import xattn
+    attn, norm = _module(heads, head_dim, ctx_dim, dtype, seed)
+    attn, norm = attn.cuda(), norm.cuda()
+    g = torch.Generator().manual_seed(seed + 100)
+    x = (torch.randn(xB, S, 320, generator=g) * 1.3 + 0.4).to(dtype).cuda()
+    if shared_ctx:
+        ctx = torch.randn(1, keys, ctx_dim, generator=g).to(dtype).cuda().expand(oB, -1, -1)
+    else:
+        ctx = torch.randn(oB, keys, ctx_dim, generator=g).to(dtype).cuda()
+    blob, uv, idx = xattn.context_operands(attn, norm, ctx, dtype)
+    y = xattn.fused(x, _stat(x, norm.eps), blob, uv, idx, oB, heads, eps_out=1e-5)
+    want = torch.cat([reference(x, norm, attn, ctx[i * xB:(i + 1) * xB]) for i in range(oB // xB)], dim=0)
+    return x, ctx, attn, norm, blob, uv, y, want
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+@pytest.mark.parametrize("heads,head_dim,ctx_dim,keys,xB,oB,S,shared", [
+    (5, 64, 1024, 77, 2, 2, 256, False),        # SD 2.1 level 0, one context per image
+    (5, 64, 1024, 77, 3, 3, 128, True),         # the empty prompt for every image (extract.py:66): one stream
+    (5, 64, 1024, 77, 2, 4, 384, False),        # classifier-free guidance on shared latents: 2 x, 4 contexts
+    (8, 40, 768, 77, 1, 1, 1152, False),        # SD 1.5 level 0: 8 heads of 40
+    (2, 64, 64, 80, 1, 1, 128, False),          # every key slot live
+    (3, 32, 96, 5, 2, 2, 128, False),           # almost all padding
+])
+def test_fused_vs_fp32_reference(heads, head_dim, ctx_dim, keys, xB, oB, S, shared, dtype):
+    x, ctx, attn, norm, blob, uv, y, want = _case(heads, head_dim, ctx_dim, keys, dtype, xB, oB, S, seed=heads + keys, shared_ctx=shared)
+    torch.cuda.synchronize()
+    assert y.shape == want.shape and torch.isfinite(y.float()).all()
+    tol = (4e-3 if dtype == torch.float16 else 3e-2) * max(1.0, want.abs().max().item())
+    assert (y.float() - want).abs().max().item() <= tol
+    # the statistics it leaves for the next LayerNorm are those of the rows it stored
+    ostat, eps = y._gsw_lnstat
+    ref = _stat(y, eps)
+    assert torch.allclose(ostat, ref, rtol=2e-3, atol=2e-3)
+
+
+def test_fused_equals_the_lane_level_restatement():
+    """one 16-row block, bit for bit up to fp32 summation order: the kernel and tests/test_xattn_host.emulate round at the same points"""
+    heads, dtype = 5, torch.float16
+    x, ctx, attn, norm, blob, uv, y, want = _case(heads, 64, 1024, 77, dtype, 1, 1, 128, seed=11)
+    st = _stat(x, norm.eps)
+    for blk in (0, 3, 7):
+        rows = slice(16 * blk, 16 * blk + 16)
+        emu = emulate(x[0, rows].cpu(), st[rows].cpu(), blob[0].cpu(), uv[0].cpu(), heads).to(dtype)
+        got = y[0, rows].cpu()
+        # identical rounding points; the exponentials (v_exp_f32 vs torch.exp2) and the fp32 summation order differ by ulps of fp32 -> at most one fp16 ulp apart
+        diff = (got.float() - emu.float()).abs()
+        assert diff.max().item() <= 2.0 ** -9 * max(1.0, emu.float().abs().max().item()) * 2
+        assert (diff > 0).float().mean().item() < 0.05
+
+
+@pytest.mark.parametrize("B", [16, 21])
+def test_fused_full_chip_xcd_order(B):
+    """more tiles than workgroups, >= 8 images: the XCD-ordered tile walk (images distributed over the 8 L2s) incl. an image count that is not a multiple of 8"""
+    heads, dtype, S = 5, torch.float16, 4096
+    x, ctx, attn, norm, blob, uv, y, want = _case(heads, 64, 1024, 77, dtype, B, B, S, seed=B)
+    tol = 4e-3 * max(1.0, want.abs().max().item())
+    assert (y.float() - want).abs().max().item() <= tol
+
+
+def test_block_one_launch_vs_three_launches():
+    """the whole BasicTransformerBlock with and without the one-launch cross-attention: same bound against fp32 torch, and close to each other"""
+    from gswm_amd import unet as U, xattn, pf
+    torch.manual_seed(0)
+    blk = U.BasicTransformerBlock(320, 1024, 5, 64)
+    for p_ in blk.parameters():
+        if p_.dim() == 2:
+            torch.nn.init.normal_(p_, std=1.2 * p_.shape[1] ** -0.5)
+    blk = blk.cuda().half().eval()
+    B, S = 2, 1024
+    x0 = torch.randn(B, S, 320, device="cuda").half()
+    ctx = torch.randn(B, 77, 1024, device="cuda").half()
+    w = (torch.randn(320, 320, device="cuda") * 320 ** -0.5).half()
+
+    def run(flag):
+        xattn.ENABLED = flag
+        with torch.no_grad():
+            x = pf.gemm(x0, w, None, rowstats=True)            # a producer that leaves row records, like proj_in
+            return blk(x, ctx), x
+    try:
+        y1, x = run(True)
+        y3, _ = run(False)
+    finally:
+        xattn.ENABLED = True
+    with torch.no_grad():
+        f = blk.float()
+        xf = x.float()
+        h = xf + f.attn1(f.norm1(xf))
+        h = h + f.attn2(f.norm2(h), ctx.float())
+        ref = h + f.ff(f.norm3(h))
+        blk.half()
+    scale = max(1.0, ref.abs().max().item())
+    assert (y1.float() - ref).abs().max().item() <= 1e-2 * scale
+    assert (y3.float() - ref).abs().max().item() <= 1e-2 * scale
+    assert (y1.float() - y3.float()).abs().max().item() <= 1e-2 * scale
+
+
+def test_unsupported_shapes_are_refused_not_computed():
+    from gswm_amd import xattn, _native
+    x = torch.zeros(1, 100, 320, device="cuda").half()
+    with pytest.raises(ValueError):
+        xattn.fused(x, torch.zeros(100, 2, device="cuda"), torch.zeros(1, 5 * xattn.HEAD_ELEMS, device="cuda").half(), torch.zeros(1, 5 * xattn.UV_FLOATS, device="cuda"), None, 1, 5)
+    lib = _native.lib()
+    z = torch.zeros(4096, device="cuda")
+    assert lib.gsw_xattn_fused(z.data_ptr(), z.data_ptr(), z.data_ptr(), 16, z.data_ptr(), 4, None, z.data_ptr(), None, 0.0, 1, 1, 128, 640, 5, 1, None) == _native.GSW_ERR_UNSUPPORTED
+    assert lib.gsw_xattn_fused(z.data_ptr(), z.data_ptr(), z.data_ptr(), 16, z.data_ptr(), 4, None, z.data_ptr(), None, 0.0, 1, 1, 100, 320, 5, 1, None) == _native.GSW_ERR_UNSUPPORTED
+    assert lib.gsw_xattn_fused(None, z.data_ptr(), z.data_ptr(), 16, z.data_ptr(), 4, None, z.data_ptr(), None, 0.0, 1, 1, 128, 320, 5, 1, None) == _native.GSW_ERR_BAD_ARG

@@ -1,0 +1,103 @@
+"""Where the one-launch cross-attention kernel's time goes: builds of csrc/gswm_xattn.hip with parts of the loop patched out (text patches applied to a COPY of the
+product source -- the product file has no measurement switches), each timed on the same operands.  Ablated builds compute wrong results by design.
+usage: python tools/xattn_ablate.py [B=128]"""
+import ctypes as C, os, subprocess, sys, tempfile, torch
+ROOT = os.environ.get('GRAFT_REPO_ROOT', os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import gswm_amd
+from gswm_amd import unet as U, xattn
+SRC = os.path.join(ROOT, "a-watermark-for-diffusion-models_amd", "csrc", "gswm_xattn.hip")
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+S, heads = 4096, 5
+
+PATCHES = {
+    "full": [],
+    "no_softmax": [("s[i] = __builtin_amdgcn_exp2f(s[i] - mx); l += s[i];", "l += s[i];"), ("mx = xq_max(mx);", ""), ("const float inv = __builtin_amdgcn_rcpf(xq_sum(l));", "const float inv = l;")],
+    "no_stream": [("if constexpr (m != 5) X_WR(m % 3, m % 3);", ""), ("X_LD(m % 3, base + (m < 5 ? m : m - 1) * XCHUNK);", "(void)base;")],
+    "no_ldswrite": [("if constexpr (m != 5) X_WR(m % 3, m % 3);", "if constexpr (m != 5) { if (((m % 3 == 0 ? sa0.x ^ sb0.x ^ sc0.x : m % 3 == 1 ? sa1.x ^ sb1.x ^ sc1.x : sa2.x ^ sb2.x ^ sc2.x)) == 0x12345u) ring[0] = 1; }")],
+    "no_mfma_g2": [("acc[nb0 + i][rb] = M_::mma(a, pf[kk][rb], acc[nb0 + i][rb]);", "acc[nb0 + i][rb][0] += __builtin_bit_cast(float, __builtin_bit_cast(uint4, a).x ^ __builtin_bit_cast(uint4, pf[kk][rb]).x);")],
+    "no_mfma_g1": [("S[kb][rb] = M_::mma(a, xf[rb][ks], ks == 0 ? zero4 : S[kb][rb]);", "{ S[kb][rb] = ks == 0 ? zero4 : S[kb][rb]; S[kb][rb][0] += __builtin_bit_cast(float, __builtin_bit_cast(uint4, a).x); }")],
+    "no_barrier": [("__builtin_amdgcn_s_barrier();", "")],
+    "no_fragread": [("fr[m & 1][i] = __builtin_bit_cast(frag, *reinterpret_cast<const uint4*>(sl + i * 1024));", "(void)sl;")],
+    "trace": [("    uint32_t oi, sub;\n    if (!xtile(p, 0, oi, sub)) return;", "    uint32_t oi, sub;\n    if (!xtile(p, 0, oi, sub)) return;\n    uint64_t* dbg = reinterpret_cast<uint64_t*>(p.ostat); uint32_t cnt = 0;\n#define X_STAMP() do { if (blockIdx.x == 0) { const uint64_t t_ = __builtin_amdgcn_s_memtime(); if (lane == 0 && cnt < 2000) dbg[wave * 2048 + cnt] = t_; ++cnt; } } while (0)"),
+              ("                X_BARRIER();\n                {   // chunk j + 1 (published", "                X_STAMP(); X_BARRIER(); X_STAMP();\n                {   // chunk j + 1 (published"),
+              ("        mm_f4 acc[XNB][2];", "        X_STAMP();\n        mm_f4 acc[XNB][2];"),
+              ("        for (uint32_t h = 0; h < p.heads; ++h) {", "        X_STAMP();\n        for (uint32_t h = 0; h < p.heads; ++h) {"),
+              ("        // epilogue: lane (r, g) holds", "        X_STAMP();\n        // epilogue: lane (r, g) holds"),
+              ("            if (p.ostat) {", "            if (false) {"),
+              ("        if (!more) break;", "        X_STAMP();\n        if (!more) break;")],
+    "no_store": [("*reinterpret_cast<uint4*>(orp + q * 32) = w;", "if (w.x == 0x12345678u) *reinterpret_cast<uint4*>(orp + q * 32) = w;")],
+}
+
+def build(name, patches):
+    s = open(SRC).read()
+    for old, new in patches:
+        assert old in s, (name, old)
+        s = s.replace(old, new)
+    s = s.replace('extern __attribute__((visibility("hidden"))) thread_local int g_last_hip_error;', 'thread_local int g_last_hip_error;')
+    s = s.replace('#include "../../include/gswm.h"', f'#include "{ROOT}/include/gswm.h"').replace('#include "gswm_mmtypes.h"', f'#include "{os.path.dirname(SRC)}/gswm_mmtypes.h"')
+    d = tempfile.mkdtemp()
+    f = os.path.join(d, name + ".hip")
+    open(f, "w").write(s)
+    so = os.path.join(d, name + ".so")
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", f, "-o", so])
+    return C.CDLL(so)
+
+if "compile" in sys.argv:
+    for name, patches in PATCHES.items():
+        build(name, patches); print("compiled", name, flush=True)
+    sys.exit(0)
+torch.manual_seed(0)
+blk = U.BasicTransformerBlock(320, 1024, heads, 64)
+for p_ in blk.parameters():
+    if p_.dim() == 2:
+        torch.nn.init.normal_(p_, std=p_.shape[1] ** -0.5)
+blk = blk.cuda().half().eval()
+x = torch.randn(B, S, 320, device="cuda").half()
+ctx = torch.randn(B, 77, 1024, device="cuda").half()
+xf = x.float(); mean = xf.mean(-1); rstd = torch.rsqrt(xf.var(-1, unbiased=False) + 1e-5)
+st = torch.stack([rstd, -rstd * mean], -1).reshape(-1, 2).contiguous(); del xf
+blob, uv, idx = xattn.context_operands(blk.attn2, blk.norm2, ctx, torch.float16)
+y = torch.empty_like(x); ost = torch.empty(B * S, 2, device="cuda")
+for combo in ("no_stream+no_barrier", "no_stream+no_barrier+no_softmax+no_store", "no_stream+no_barrier+no_softmax+no_store+no_fragread", "no_stream+no_fragread", "no_softmax+no_store"):
+    PATCHES[combo] = sum((PATCHES[k] for k in combo.split("+")), [])
+only = [a for a in sys.argv[2:] if a != "compile"]
+if "compile" in sys.argv:
+    for name, patches in PATCHES.items():
+        build(name, patches); print("compiled", name)
+    sys.exit(0)
+for name, patches in PATCHES.items():
+    if only and name not in only:
+        continue
+    lib = build(name, patches)
+    fn = lib.gsw_xattn_fused
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float] + [C.c_int] * 6 + [C.c_void_p]
+    def run():
+        rc = fn(x.data_ptr(), st.data_ptr(), blob.data_ptr(), blob.shape[1] * 2, uv.data_ptr(), uv.shape[1], idx.data_ptr(), y.data_ptr(), ost.data_ptr(), 1e-5, B, B, S, 320, heads, 1, None)
+        assert rc == 0, rc
+    for _ in range(3): run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(10): run()
+    e1.record(); torch.cuda.synchronize()
+    print(f"{name:60s} {e0.elapsed_time(e1) / 10 * 1e3:8.1f} us", flush=True)
+    if name == "trace":
+        dbg = torch.zeros(4 * 2048, dtype=torch.int64, device="cuda")
+        rc = fn(x.data_ptr(), st.data_ptr(), blob.data_ptr(), blob.shape[1] * 2, uv.data_ptr(), uv.shape[1], idx.data_ptr(), y.data_ptr(), dbg.data_ptr(), 1e-5, B, B, S, 320, heads, 1, None)
+        torch.cuda.synchronize()
+        d = dbg.cpu().view(4, 2048)
+        per_tile = 4 + 5 * 24
+        for w in (0, 3):
+            t = d[w]
+            n = int((t != 0).sum())
+            print(f"wave {w}: {n} stamps, {n // per_tile} tiles")
+            for tile in (0, 1, 5):
+                b = tile * per_tile
+                if b + per_tile > n: break
+                tt = (t[b:b + per_tile] - t[b]).tolist()
+                print(f"  tile {tile}: x landed +{tt[1]}, residual done +{tt[2]}, heads done +{tt[per_tile - 2]}, epilogue done +{tt[per_tile - 1]}; next tile starts +{int(t[b + per_tile] - t[b]) if b + per_tile < n else -1}")
+                for h in (0, 2):
+                    hb = 3 + h * 24
+                    steps = [(tt[hb + 2 * j + 1] - tt[hb + 2 * j], (tt[hb + 2 * j + 2] if hb + 2 * j + 2 < per_tile else tt[hb + 2*j+1]) - tt[hb + 2 * j + 1]) for j in range(12)]
+                    print(f"    head {h}: (barrier wait, step body) per step:", steps)
