@@ -85,46 +85,45 @@ def _load_bin(path: str) -> Dict[str, torch.Tensor]:
 
 
 def load_component_state_dict(model_dir: str, component: str) -> Dict[str, torch.Tensor]:
-    """State dict of `<model_dir>/<component>/` (or of `model_dir` itself when it IS the component directory).  Order: `<stem>.safetensors`,
-    `<stem>.fp16.safetensors`, sharded `<stem>[.fp16].safetensors.index.json`, `<stem>.bin` / `pytorch_model.bin` (+ fp16 variants, + their sharded
-    index)."""
+    """State dict of `<model_dir>/<component>/` (or of `model_dir` itself when it IS the component directory).  Order: `<stem>.safetensors`, `<stem>.bin` /
+    `pytorch_model.bin`, then the `.fp16` variants in the same order; each candidate as a single file or as its sharded `.index.json`."""
     stem = _STEMS.get(component, "diffusion_pytorch_model")
     dirs = [os.path.join(model_dir, component), model_dir]
     stems = [stem] + (["pytorch_model"] if stem != "pytorch_model" else [])
     tried = []
-    # every safetensors candidate (single file, fp16 variant, their sharded indexes) of a directory is tried before any pickle-format .bin
     for d in dirs:
         if not os.path.isdir(d):
             continue
-        for ext in (".safetensors", ".bin"):
+        # full-precision files of BOTH formats before any `.fp16` variant (a float32 load of a repository that ships `<stem>.bin` next to
+        # `<stem>.fp16.safetensors` must not silently get fp16-rounded weights); within a variant every safetensors candidate before any pickle-format .bin
+        for variant, ext in (("", ".safetensors"), ("", ".bin"), (".fp16", ".safetensors"), (".fp16", ".bin")):
             for st in stems:
-                for variant in ("", ".fp16"):
-                    single = os.path.join(d, st + variant + ext)
-                    index = single + ".index.json"
-                    tried.append(single)
-                    if os.path.isfile(single):
-                        if ext == ".safetensors":
+                single = os.path.join(d, st + variant + ext)
+                index = single + ".index.json"
+                tried.append(single)
+                if os.path.isfile(single):
+                    if ext == ".safetensors":
+                        from safetensors.torch import load_file
+                        return load_file(single)
+                    return _load_bin(single)
+                if os.path.isfile(index):
+                    with open(index) as f:
+                        wm = json.load(f)["weight_map"]
+                    sd: Dict[str, torch.Tensor] = {}
+                    for shard in sorted(set(wm.values())):
+                        sp = os.path.join(d, shard)
+                        if not os.path.isfile(sp):
+                            raise FileNotFoundError(f"{index} names the shard {shard}, which is missing")
+                        if shard.endswith(".safetensors"):
                             from safetensors.torch import load_file
-                            return load_file(single)
-                        return _load_bin(single)
-                    if os.path.isfile(index):
-                        with open(index) as f:
-                            wm = json.load(f)["weight_map"]
-                        sd: Dict[str, torch.Tensor] = {}
-                        for shard in sorted(set(wm.values())):
-                            sp = os.path.join(d, shard)
-                            if not os.path.isfile(sp):
-                                raise FileNotFoundError(f"{index} names the shard {shard}, which is missing")
-                            if shard.endswith(".safetensors"):
-                                from safetensors.torch import load_file
-                                part = load_file(sp)
-                            else:
-                                part = _load_bin(sp)
-                            sd.update(part)
-                        lost = [k for k in wm if k not in sd]
-                        if lost:
-                            raise RuntimeError(f"{index}: {len(lost)} tensors of the weight map are in no shard (first: {lost[:3]})")
-                        return sd
+                            part = load_file(sp)
+                        else:
+                            part = _load_bin(sp)
+                        sd.update(part)
+                    lost = [k for k in wm if k not in sd]
+                    if lost:
+                        raise RuntimeError(f"{index}: {len(lost)} tensors of the weight map are in no shard (first: {lost[:3]})")
+                    return sd
     raise FileNotFoundError(f"no weights for '{component}' under {model_dir} (looked for {', '.join(os.path.relpath(t, model_dir) for t in tried[:8])}, ...)")
 
 

@@ -1715,24 +1715,29 @@ int gsw_mm_get_config(int* tile_rows, int* split_mask) {
 // keeps 256-row tiles (a half tile re-fetches the weight tile twice as often).
 // Split: at most 128 tiles, at least 8 stages, up to 32 ways (one image at 8 x 8: 8 tiles x 32 = the whole chip, 19.9 vs 21.1 us at 16 ways) and 256 workgroups, 128- or 256-row tiles, taken for a predicted gain of 5 % or more.  Forced splits
 // (max_splits > 1: tests) use 128 rows unless gsw_mm_config forces the 256-row tile.
-// compute units of the current device (256 on MI355X; the persistent grid, the plan's "rounds" and its half-chip threshold are counted in them).  The XCD
-// interleave of the tile order assumes 8 XCDs: the count is rounded down to a multiple of 8.
+// Compute units the persistent grid, the plan's "rounds" and its half-chip threshold are counted in: 256, the MI355X the stage costs, the wide-tile thresholds and the 8-XCD
+// tile interleave were fitted and tested on.  A partition with fewer CUs still runs correctly with 256 workgroups (they queue); GSW_MM_CUS=<n> (a multiple of 8) or
+// GSW_MM_CUS=device opts into another count for experiments -- read once per process.
 static int mm_cus() {
-    static thread_local int dev_cached = -1, cus = 256;
-    int dev = 0;
-    if (hipGetDevice(&dev) == hipSuccess && dev != dev_cached) {
-        hipDeviceProp_t pr;
-        if (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount >= 8) cus = pr.multiProcessorCount / 8 * 8;
-        dev_cached = dev;
-    }
+    static const int cus = [] {
+        const char* e = getenv("GSW_MM_CUS");
+        if (!e || !*e) return 256;
+        int n = atoi(e);
+        if (n <= 0) {                                   // "device"
+            int dev = 0;
+            hipDeviceProp_t pr;
+            n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256;
+        }
+        return n >= 8 ? n / 8 * 8 : 256;
+    }();
     return cus;
 }
 struct MMPlan { int bm; int splits; double t_us; };
 // (the stage costs were fitted on ONE box of the pool in round 4 -- profiles/r04i_splitk_tile_sweep.txt: MI355X, 256 CUs, 1400 W board limit, HBM-cold weights,
 // the deep levels at 4-64 images, board at 1.1-1.3 kW; boxes of the pool differ by +-4 %.  W = busy workgroups; the costs are functions of the busy FRACTION
 // of the chip, so a different CU count rescales W, not the constants.)
-static inline double mm_stage_us(int bm, double W) {
-    const double half = 0.5 * (double)mm_cus();
+static inline double mm_stage_us(int bm, double W, int64_t CU) {
+    const double half = 0.5 * (double)CU;
     const double over = W > half ? (W - half) / half : 0.0;
     return bm == 128 ? 0.56 + 0.11 * over : 0.79 + 0.02 * std::min(1.0, W / half) + 0.32 * over;
 }
@@ -1742,7 +1747,7 @@ static MMPlan mm_plan(int64_t M, int64_t tiles_n, int32_t P, bool can_split, int
     const int64_t nt256 = ((M + 255) / 256) * tiles_n, nt128 = ((M + 127) / 128) * tiles_n;
     auto t_unsplit = [&](int bm) {
         const int64_t nt = bm == 256 ? nt256 : nt128, rounds = (nt + CU - 1) / CU;
-        return 2.5 + mm_stage_us(bm, rounds == 1 ? (double)nt : (double)CU) * (double)P * (double)rounds;
+        return 2.5 + mm_stage_us(bm, rounds == 1 ? (double)nt : (double)CU, CU) * (double)P * (double)rounds;
     };
     int BM;
     if (bm_env == 128 || bm_env == 256) BM = bm_env;
@@ -1766,7 +1771,7 @@ static MMPlan mm_plan(int64_t M, int64_t tiles_n, int32_t P, bool can_split, int
         const int64_t nt_c = bm_c == 256 ? nt256 : nt128;
         if (nt_c > CU / 2) continue;
         for (int s_ = 2; s_ <= 32 && s_ * nt_c <= CU && 2 * s_ <= P; ++s_) {
-            const double t = 12.5 + mm_stage_us(bm_c, (double)(s_ * nt_c)) * (double)((P + s_ - 1) / s_) + 0.014 * (double)(s_ * nt_c * (bm_c / 128));
+            const double t = 12.5 + mm_stage_us(bm_c, (double)(s_ * nt_c), CU) * (double)((P + s_ - 1) / s_) + 0.014 * (double)(s_ * nt_c * (bm_c / 128));
             if (t < best) { best = t; pl.bm = bm_c; pl.splits = s_; pl.t_us = t; }
         }
     }
@@ -1793,7 +1798,8 @@ int gsw_mm_launch(MMArgs& a, int dtype, void* stream, GswMmExtras* ex) {
     struct Done { GswMmExtras* e; bool legacy; ~Done() { if (legacy) gsw_mm_legacy_done(e); } } done{ex, is_legacy};
     if (dtype != GSW_F16 && dtype != GSW_BF16) return GSW_ERR_BAD_ARG;
     if (ex->colstats_capacity < 0 || ex->rowstats_capacity < 0 || ex->workspace_bytes < 0 || ex->max_splits < 0 || ex->max_splits > 64
-        || ((uintptr_t)ex->colstats_dev & 15) || ((uintptr_t)ex->rowstats_dev & 7) || ((uintptr_t)ex->workspace_dev & 15)) return GSW_ERR_BAD_ARG;
+        || ((uintptr_t)ex->colstats_dev & 15) || ((uintptr_t)ex->rowstats_dev & 7) || ((uintptr_t)ex->workspace_dev & 15)
+        || (ex->flags & ~GSW_MM_GN_ONLY)) return GSW_ERR_BAD_ARG;      // (unknown flag bits: a caller that filled the struct field by field without zeroing it)
     void* const ws_dev = ex->workspace_bytes > 0 ? ex->workspace_dev : nullptr;
     const int64_t ws_bytes = ws_dev ? ex->workspace_bytes : 0;
     const int max_splits = ex->max_splits;

@@ -88,6 +88,15 @@ __device__ __forceinline__ int64_t xuni(int64_t v) {
     return (int64_t)(((uint64_t)hi << 32) | lo);
 }
 
+// context of an output image, by an explicit SCALAR load: hipcc reads a uniform address in writable memory with a vector load and waits for it with vmcnt(0) -- at the
+// top of a tile that is a wait for the previous tile's 40 output stores
+__device__ __forceinline__ int64_t xctx(const int32_t* tab, uint32_t i) {
+    const int32_t* q = tab + __builtin_amdgcn_readfirstlane(i);
+    int32_t v;
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(q) : "memory");
+    return (int64_t)v;
+}
+
 // workgroup barrier behind this wave's LDS WRITES: LDS operations retire in order, so with the step's fragment reads issued behind its writes `lgkmcnt(N)` lets the N newest reads
 // stay in flight across the barrier (a read still in flight here is done long before its slot is written again, two barriers later)
 #define X_BARRIER(N) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(N) : "memory"); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -132,7 +141,7 @@ __global__ __launch_bounds__(256) void gsw_xattn_kernel(const XArgs p) {
 
     uint32_t oi, sub;
     if (!xtile(p, 0, oi, sub)) return;
-    int64_t cctx = p.bidx ? p.bidx[oi] : 0;                 // this tile's context
+    int64_t cctx = p.bidx ? xctx(p.bidx, oi) : 0;      // this tile's context
     const uint8_t* cur = p.blob + xuni(cctx * p.blob_stride);
 
     // three staging register sets, named (not an array: every use must be a compile-time choice for them to stay in registers)
@@ -159,15 +168,12 @@ __global__ __launch_bounds__(256) void gsw_xattn_kernel(const XArgs p) {
     for (int i = 0; i < 10; ++i) fr[0][i] = __builtin_bit_cast(frag, *reinterpret_cast<const uint4*>(ring + lane * 16u + i * 1024));
 
     const mm_f4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    for (uint32_t it = 0;; ++it) {
-        uint32_t noi = oi, nsub = sub;
-        const bool more = xtile(p, it + 1, noi, nsub);
-        const int64_t nctx = more ? (p.bidx ? p.bidx[noi] : 0) : cctx;      // the next tile's context: the fragment stream runs on into it
-
-        const int64_t xrow = (int64_t)(oi % p.xB) * p.S + sub * 128u + wave * 32u + r;
-        const int64_t orow = (int64_t)oi * p.S + sub * 128u + wave * 32u + r;
-        frag xf[2][XKS];
-        float2 st[2];
+    // the wave's 32 rows of x as B-operand fragments + their LayerNorm statistics.  They are loaded ONE TILE AHEAD: the last head's second product does not read them, so the
+    // next tile's rows are requested right behind that head's softmax -- under its 120 MFMAs and in front of this tile's output stores -- instead of at the top of the tile
+    frag xf[2][XKS];
+    float2 st[2];
+    auto load_x = [&](uint32_t oi_, uint32_t sub_) __attribute__((always_inline)) {
+        const int64_t xrow = (int64_t)(oi_ % p.xB) * p.S + sub_ * 128u + wave * 32u + r;
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
             const uint16_t* xr = p.x + (xrow + rb * 16) * XC + g * 8u;
@@ -175,13 +181,20 @@ __global__ __launch_bounds__(256) void gsw_xattn_kernel(const XArgs p) {
             for (int ks = 0; ks < XKS; ++ks) xf[rb][ks] = __builtin_bit_cast(frag, *reinterpret_cast<const uint4*>(xr + ks * 32));
             st[rb] = p.stat[xrow + rb * 16];
         }
+    };
+    load_x(oi, sub);
+    for (uint32_t it = 0;; ++it) {
+        uint32_t noi = oi, nsub = sub;
+        const bool more = xtile(p, it + 1, noi, nsub);
+        const int64_t nctx = more ? (p.bidx ? xctx(p.bidx, noi) : 0) : cctx;      // the next tile's context: the fragment stream runs on into it
+        const int64_t orow = (int64_t)oi * p.S + sub * 128u + wave * 32u + r;
         mm_f4 acc[XNB][2];
 #pragma unroll
         for (int nb = 0; nb < XNB; ++nb)
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb) acc[nb][rb] = M_::mma(pm[nb & 1], xf[rb][nb >> 1], zero4);
 
-        for (uint32_t h = 0; h < p.heads; ++h) {
+        auto head = [&](const uint32_t h, auto LAST) __attribute__((always_inline)) {
             const uint8_t* hb = p.blob + xuni(cctx * p.blob_stride + (int64_t)h * XHEAD);
             const uint8_t* hn = p.blob + xuni(h + 1 == p.heads ? nctx * p.blob_stride : cctx * p.blob_stride + (int64_t)(h + 1) * XHEAD);
             const float* huv = p.uv + xuni(cctx * p.uv_stride + h * XUV) + g * 4u;
@@ -262,6 +275,7 @@ __global__ __launch_bounds__(256) void gsw_xattn_kernel(const XArgs p) {
                             pf[kk][rb] = __builtin_bit_cast(frag, uint4{w[0], w[1], w[2], w[3]});
                         }
                     }
+                    if constexpr (decltype(LAST)::value) load_x(noi, nsub);      // (the last tile re-reads its own rows: harmless)
                 } else {
                     // x'^T[column block nb][rows] += B[16 columns x 32 key slots] P^T[32 key slots x 16 rows], ten column blocks per chunk
                     constexpr int kk = (j - 6) >> 1, nb0 = 10 * ((j - 6) & 1);
@@ -291,7 +305,9 @@ __global__ __launch_bounds__(256) void gsw_xattn_kernel(const XArgs p) {
             step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{}); step(std::integral_constant<int, 3>{});
             step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{}); step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{});
             step(std::integral_constant<int, 8>{}); step(std::integral_constant<int, 9>{}); step(std::integral_constant<int, 10>{}); step(std::integral_constant<int, 11>{});
-        }
+        };
+        for (uint32_t h = 0; h + 1 < p.heads; ++h) head(h, std::false_type{});
+        head(p.heads - 1, std::true_type{});      // (its own copy of the code: the x loads of the next tile sit in it unconditionally)
 
         // epilogue: lane (r, g) holds columns 32 q + 8 g .. + 7 of rows r and 16 + r
 #pragma unroll

@@ -55,10 +55,12 @@ class DDIMSchedule:
     def __post_init__(self):
         self.alphas_cumprod = sd_alphas_cumprod(self.num_train_timesteps, self.beta_start, self.beta_end)
         self.final_alpha = 1.0 if self.set_alpha_to_one else float(self.alphas_cumprod[0])
+        if not 1 <= self.num_inference_steps <= self.num_train_timesteps:      # (before the division: 0 steps would be a ZeroDivisionError, more steps than training timesteps a ratio of 0)
+            raise ValueError(f"DDIMSchedule: num_inference_steps must be in 1..{self.num_train_timesteps} (got {self.num_inference_steps})")
         self.ratio = self.num_train_timesteps // self.num_inference_steps
         ts = (np.arange(self.num_inference_steps) * self.ratio).round().astype(np.int64) + self.steps_offset
         self.timesteps_desc = ts[::-1].copy()      # sampling order: 981, 961, ..., 1 for 50 steps
-        if self.num_inference_steps < 1 or int(ts.min()) < 0 or int(ts.max()) >= self.num_train_timesteps:
+        if int(ts.min()) < 0 or int(ts.max()) >= self.num_train_timesteps:
             # the eps model tabulates its time embedding over [0, num_train_timesteps) (unet.TEMB_TABLE): a timestep outside it has no row
             raise ValueError(f"DDIMSchedule: timesteps {int(ts.min())}..{int(ts.max())} leave [0, {self.num_train_timesteps}) "
                              f"({self.num_inference_steps} steps, steps_offset {self.steps_offset})")

@@ -771,6 +771,8 @@ def _temb_rows_from_table(self, t: torch.Tensor, x: torch.Tensor):
     if table is not None and table.shape[0] != int(getattr(self, "num_train_timesteps", NUM_TRAIN_TIMESTEPS)):      # the scheduler length changed after the table was built
         self._gsw_temb_table = None
         table = cached(self, "_gsw_temb_table", params, build)
+        from . import graph
+        graph.weights_changed()      # a captured forward gathers from the OLD table's address: every graph entry must re-capture
     if table is None:
         return None
     B, n_tot = x.shape[0], table.shape[1]

@@ -13,14 +13,14 @@ S, heads = 4096, 5
 PATCHES = {
     "full": [],
     "no_softmax": [("s[i] = __builtin_amdgcn_exp2f(s[i] - mx); l += s[i];", "l += s[i];"), ("mx = xq_max(mx);", ""), ("const float inv = __builtin_amdgcn_rcpf(xq_sum(l));", "const float inv = l;")],
-    "no_stream": [("if constexpr (m != 5) X_WR(m % 3, m % 3);", ""), ("X_LD(m % 3, base + (m < 5 ? m : m - 1) * XCHUNK);", "(void)base;")],
+    "no_stream": [("if constexpr (m != 5) X_WR(m % 3, m % 3);", ""), ("if constexpr (m != 5) X_LD(m % 3, ((j + 5) >= 12 ? hn : hb) + (m < 5 ? m : m - 1) * XCHUNK);", "(void)hn;")],
     "no_ldswrite": [("if constexpr (m != 5) X_WR(m % 3, m % 3);", "if constexpr (m != 5) { if (((m % 3 == 0 ? sa0.x ^ sb0.x ^ sc0.x : m % 3 == 1 ? sa1.x ^ sb1.x ^ sc1.x : sa2.x ^ sb2.x ^ sc2.x)) == 0x12345u) ring[0] = 1; }")],
     "no_mfma_g2": [("acc[nb0 + i][rb] = M_::mma(a, pf[kk][rb], acc[nb0 + i][rb]);", "acc[nb0 + i][rb][0] += __builtin_bit_cast(float, __builtin_bit_cast(uint4, a).x ^ __builtin_bit_cast(uint4, pf[kk][rb]).x);")],
     "no_mfma_g1": [("S[kb][rb] = M_::mma(a, xf[rb][ks], ks == 0 ? zero4 : S[kb][rb]);", "{ S[kb][rb] = ks == 0 ? zero4 : S[kb][rb]; S[kb][rb][0] += __builtin_bit_cast(float, __builtin_bit_cast(uint4, a).x); }")],
-    "no_barrier": [("__builtin_amdgcn_s_barrier();", "")],
+    "no_barrier": [("__builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)", "__builtin_amdgcn_sched_barrier(0); } while (0)")],
     "no_fragread": [("fr[m & 1][i] = __builtin_bit_cast(frag, *reinterpret_cast<const uint4*>(sl + i * 1024));", "(void)sl;")],
     "trace": [("    uint32_t oi, sub;\n    if (!xtile(p, 0, oi, sub)) return;", "    uint32_t oi, sub;\n    if (!xtile(p, 0, oi, sub)) return;\n    uint64_t* dbg = reinterpret_cast<uint64_t*>(p.ostat); uint32_t cnt = 0;\n#define X_STAMP() do { if (blockIdx.x == 0) { const uint64_t t_ = __builtin_amdgcn_s_memtime(); if (lane == 0 && cnt < 2000) dbg[wave * 2048 + cnt] = t_; ++cnt; } } while (0)"),
-              ("                X_BARRIER();\n                {   // chunk j + 1 (published", "                X_STAMP(); X_BARRIER(); X_STAMP();\n                {   // chunk j + 1 (published"),
+              ("                X_BARRIER(j != 5 ? 3 : 0);", "                X_STAMP(); X_BARRIER(j != 5 ? 3 : 0);"),
               ("        mm_f4 acc[XNB][2];", "        X_STAMP();\n        mm_f4 acc[XNB][2];"),
               ("        for (uint32_t h = 0; h < p.heads; ++h) {", "        X_STAMP();\n        for (uint32_t h = 0; h < p.heads; ++h) {"),
               ("        // epilogue: lane (r, g) holds", "        X_STAMP();\n        // epilogue: lane (r, g) holds"),
@@ -87,7 +87,7 @@ for name, patches in PATCHES.items():
         rc = fn(x.data_ptr(), st.data_ptr(), blob.data_ptr(), blob.shape[1] * 2, uv.data_ptr(), uv.shape[1], idx.data_ptr(), y.data_ptr(), dbg.data_ptr(), 1e-5, B, B, S, 320, heads, 1, None)
         torch.cuda.synchronize()
         d = dbg.cpu().view(4, 2048)
-        per_tile = 4 + 5 * 24
+        per_tile = 4 + 5 * 12
         for w in (0, 3):
             t = d[w]
             n = int((t != 0).sum())
@@ -98,6 +98,6 @@ for name, patches in PATCHES.items():
                 tt = (t[b:b + per_tile] - t[b]).tolist()
                 print(f"  tile {tile}: x landed +{tt[1]}, residual done +{tt[2]}, heads done +{tt[per_tile - 2]}, epilogue done +{tt[per_tile - 1]}; next tile starts +{int(t[b + per_tile] - t[b]) if b + per_tile < n else -1}")
                 for h in (0, 2):
-                    hb = 3 + h * 24
-                    steps = [(tt[hb + 2 * j + 1] - tt[hb + 2 * j], (tt[hb + 2 * j + 2] if hb + 2 * j + 2 < per_tile else tt[hb + 2*j+1]) - tt[hb + 2 * j + 1]) for j in range(12)]
-                    print(f"    head {h}: (barrier wait, step body) per step:", steps)
+                    hb = 3 + h * 12
+                    steps = [tt[hb + j + 1] - tt[hb + j] for j in range(12)]
+                    print(f"    head {h}: cycles per step (stamp in front of each barrier):", steps)
