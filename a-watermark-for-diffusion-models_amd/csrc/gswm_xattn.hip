@@ -13,23 +13,26 @@
 //     o Wo = sum_h P_h V_h Wo_h^T        = sum_h P_h (Wo_h V_h^T)^T    =: sum_h P_h B_h^T       B_h [C, keys]
 // so a head is two small GEMMs against per-(context, head) matrices the host derives ONCE per sampling / inversion loop (xattn.py: fp32 products of the
 // fp16 weights, one rounding -- the query and the attention output are never rounded to fp16 at all), head_dim disappears, and the C-wide output
-// accumulators can stay in registers across the heads.  LayerNorm is folded as in gsw_gemm_ln: S = rstd (x A'^T) + nrm u + v with A' = A diag(gamma),
-// softmax scale and log2(e) folded in, u = A' 1, v = A beta (fp32, -inf for the padding keys: the mask costs nothing).
+// accumulators can stay in registers across the heads.  LayerNorm is folded: A' = A diag(gamma) with softmax scale and log2(e) folded in and every row CENTRED over
+// the channels, so that x A'^T = (x - mean(x)) A'^T and S = rstd (x A'^T) + v, v = A beta (fp32, -inf for the padding keys: the mask costs nothing).
 //
-// Kernel (C = 320, the 64 x 64 level of SD 2.1 and the 96 x 96 level of SD 1.5; <= 80 keys; any number of heads):
+// Kernel (C = 320, the 64 x 64 level of SD 2.1 and the 96 x 96 level of SD 1.5; <= 79 keys; any number of heads):
 //   * one workgroup = 128 token rows = 4 waves x 32 rows, ONE wave per SIMD with the whole 512-register file: 160 accumulators (32 rows x 320 columns of x'),
 //     the wave's rows of x as 20 B-operand fragments (80 registers, read from HBM once: they feed every head's first product AND the residual),
-//     40 score accumulators
-//   * every product is computed TRANSPOSED (weights = A operand from LDS, rows = B operand from registers, v_mfma_f32_16x16x32): the accumulator of
-//     S^T holds, per lane, four keys of one row -- exactly the B-operand layout of the second product, so P never moves between lanes; the contraction
-//     order over the keys (and the order of the output columns) is whatever that layout dictates and the host stores the matrices in it
+//     48 score accumulators
+//   * every product is computed TRANSPOSED (weights = A operand from LDS, rows = B operand from registers, v_mfma_f32_32x32x16: one MFMA per fragment read -- with one
+//     wave per SIMD nothing but this wave's own instruction stream overlaps the matrix pipe, and the 16 x 16 x 32 form of round-6's first build had too many instructions
+//     per MFMA to hide): the accumulator of S^T holds, per lane, keys of ONE row -- exactly the B-operand layout of the second product, so P never moves between lanes;
+//     the contraction order over the keys (and the order of the output columns) is whatever that layout dictates and the host stores the matrices in it
 //   * the residual and the output bias ride on the matrix pipe: x' accumulators start as (permutation matrix) x (the x fragments) -- exact in fp32 -- and the
-//     bias is the row of B_h for a 81st key whose probability is the constant 1.0 (last head only)
-//   * the per-(context, head) matrices arrive as a stream of 1 KiB MFMA fragments in consumption order (110 per head): global -> registers -> LDS in chunks of
-//     ten, three chunks of lead in registers, a three-slot LDS ring, ONE barrier per chunk (20-24 MFMAs per wave); the stream runs across heads and tiles
-//   * epilogue: one rounding, 16-byte stores, and the (rstd, -rstd mean) of the NEW rows for the LayerNorm that follows (norm3) -- the whole row is in the wave
+//     bias is the row of B_h for key slot 79, whose probability is the constant 1.0 (last head only)
+//   * the per-(context, head) matrices arrive as a stream of 1 KiB MFMA fragments in consumption order (60 + 50 per head): global -> registers -> LDS in chunks of
+//     ten, three chunks of lead in registers, a three-slot LDS ring, ONE barrier per chunk (10 MFMAs of 32 cycles per wave); a chunk's fragments are read from LDS one
+//     chunk ahead, each into the registers of the fragment the previous MFMA consumed; the stream runs across heads and tiles
+//   * the rows of x are loaded one tile ahead (behind the last head's softmax, under its second product, in front of the output stores)
+//   * epilogue: one rounding, 16-byte stores, and the (rstd, -rstd mean) of the NEW rows for the LayerNorm that follows (norm3) -- a row is two lanes of one wave
 //   * tiles of one image go to ONE XCD at a time (a context's matrices -- 550 KB -- are read from HBM once and shared through that XCD's L2)
-// Roofline: HBM (0.67 GB per launch at 128 images) / LDS fragment reads (every fragment feeds two MFMAs: 50 % of the LDS read rate at full MFMA rate).
+// Roofline: HBM (0.67 GB per launch at 128 images); measured and what bounds it: DESIGN.md section 4.9.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -43,19 +46,23 @@ extern __attribute__((visibility("hidden"))) thread_local int g_last_hip_error; 
 
 namespace {
 
+typedef float x_f16v __attribute__((ext_vector_type(16)));
+
 constexpr int XC = 320;                 // channels of the level this kernel serves
-constexpr int XKS = XC / 32;            // k-steps of the first product
-constexpr int XNB = XC / 16;            // 16-column blocks of the output
-constexpr int XKB = 5;                  // 16-key blocks: 80 key slots
+constexpr int XKS = XC / 16;            // 16-channel k-steps of the first product (v_mfma_f32_32x32x16)
+constexpr int XNB = XC / 32;            // 32-column blocks of the output
+constexpr int XKB = 3;                  // 32-key blocks of the first product: 96 key slots, of which the second product uses 80 (5 k-steps of 16)
+constexpr int XKK = 5;
+constexpr int XEMPTY = 6;               // the step of a head that carries the softmax instead of a chunk
 constexpr uint32_t XCHUNK = 10240;      // ten 1 KiB fragments
-constexpr uint32_t XHEAD = 11 * XCHUNK; // one head: 50 fragments of A' (k-step major, key block minor) + 60 of B (key step major, column block minor)
-constexpr int XUV = 2 * 16 * XKB;       // floats of (u | v) per head
+constexpr uint32_t XHEAD = 11 * XCHUNK; // one head: 60 fragments of A' (k-step major, key block minor) + 50 of B (key step major, column block minor)
+constexpr int XV = 32 * XKB;            // floats of v per head
 
 struct XArgs {
     const uint16_t* x;      // [xB * S, 320] raw residual stream
     const float2* stat;     // [xB * S] (rstd, -rstd mean) of its rows
-    const uint8_t* blob;    // per context: heads * XHEAD bytes of fragments (xattn.py: build_context_blob)
-    const float* uv;        // per context: heads * XUV floats
+    const uint8_t* blob;    // per context: heads * XHEAD bytes of fragments (xattn.py: pack_stream)
+    const float* uv;        // per context: heads * XV floats (v; -inf on padding keys)
     const int32_t* bidx;    // [oB] context of an output image (nullptr: all 0)
     uint16_t* out;          // [oB * S, 320]
     float2* ostat;          // [oB * S] (rstd, -rstd mean) of the output rows (nullptr: not wanted)
@@ -66,20 +73,24 @@ struct XArgs {
     uint32_t heads, ntiles, xcd;
 };
 
-// rows 0-1 and 2-3 of the four 16-lane rows combined, then the two halves: every lane ends up with the reduction over lanes (l & 15) + 16 k
-__device__ __forceinline__ float xq_max(float v) {
-    uint32_t u = __float_as_uint(v);
-    auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-    u = __float_as_uint(fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1])));
-    auto b = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+template <typename T> struct XM;
+template <> struct XM<_Float16> {
+    static __device__ __forceinline__ x_f16v mma(mm_h8 a, mm_h8 b, x_f16v c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+template <> struct XM<__bf16> {
+    static __device__ __forceinline__ x_f16v mma(mm_b8 a, mm_b8 b, x_f16v c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+
+// the value of the lane 32 positions away, combined (v_permlane32_swap: no LDS round trip)
+__device__ __forceinline__ float xh_max(float v) {
+    const uint32_t u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
-__device__ __forceinline__ float xq_sum(float v) {
-    uint32_t u = __float_as_uint(v);
-    auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-    u = __float_as_uint(__uint_as_float(a[0]) + __uint_as_float(a[1]));
-    auto b = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+__device__ __forceinline__ float xh_sum(float v) {
+    const uint32_t u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
 // a wave-uniform 64-bit offset, said so: a global load then addresses (kernel-argument pointer + it) as an SGPR pair + a 32-bit lane offset instead of a 64-bit add per lane
@@ -89,7 +100,7 @@ __device__ __forceinline__ int64_t xuni(int64_t v) {
 }
 
 // context of an output image, by an explicit SCALAR load: hipcc reads a uniform address in writable memory with a vector load and waits for it with vmcnt(0) -- at the
-// top of a tile that is a wait for the previous tile's 40 output stores
+// top of a tile that is a wait for the previous tile's 20 output stores
 __device__ __forceinline__ int64_t xctx(const int32_t* tab, uint32_t i) {
     const int32_t* q = tab + __builtin_amdgcn_readfirstlane(i);
     int32_t v;
@@ -124,20 +135,21 @@ template <typename T>
 __global__ __launch_bounds__(256) void gsw_xattn_kernel(const XArgs p) {
     using M_ = MM<T>;
     using frag = typename M_::frag;
-    __shared__ __attribute__((aligned(16))) uint8_t ring[3 * XCHUNK];
+    __shared__ __attribute__((aligned(16))) uint8_t ring0[XCHUNK], ring1[XCHUNK], ring2[XCHUNK];      // three slots, three objects: a slot's writes may pass another slot's reads
+#define X_SLOT(k) ((k) == 0 ? ring0 : (k) == 1 ? ring1 : ring2)
     const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane((uint32_t)(threadIdx.x >> 6));
-    const uint32_t r = lane & 15u, g = lane >> 4;
+    const uint32_t r = lane & 31u, hlf = lane >> 5;       // the lane's row of the wave's 32, and which 8 of a k-step's 16 values / which rows of an accumulator block it holds
     // this lane's share of a chunk: two whole fragments' 16 bytes and 8 bytes of a fragment shared with the neighbouring wave
     const uint32_t o0 = wave * 1024u + lane * 16u, o1 = o0 + 4096u, o2 = (8u + (wave >> 1)) * 1024u + (wave & 1u) * 512u + lane * 8u;
     constexpr uint32_t ONE = std::is_same<T, _Float16>::value ? 0x3C00u : 0x3F80u;      // 1.0 in the storage dtype
-    // residual as a product: A[label][k] = 1 where k = 8 (label >> 2) + 4 e + (label & 3) picks column n(block 2 q + e, label) = 32 q + 8 (label >> 2) + 4 e + (label & 3) of k-step q
+    // the residual as a product: accumulator row m of column block nb is output column 32 nb + 16 (m >> 4) + 8 ((m >> 2) & 1) + 4 ((m >> 3) & 1) + (m & 3), i.e. value
+    // 8 ((m >> 2) & 1) + 4 ((m >> 3) & 1) + (m & 3) of k-step 2 nb + (m >> 4): A[m][k] = 1 there (a lane holds A[m = its row][8 hlf ..])
     frag pm[2];
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const uint32_t idx = 4u * e + (r & 3u), one = g == (r >> 2) ? ONE << (16u * (idx & 1u)) : 0u;
-        pm[e] = __builtin_bit_cast(frag, uint4{(idx >> 1) == 0u ? one : 0u, (idx >> 1) == 1u ? one : 0u, (idx >> 1) == 2u ? one : 0u, (idx >> 1) == 3u ? one : 0u});
+    for (int j = 0; j < 2; ++j) {
+        const uint32_t e = 4u * ((r >> 3) & 1u) + (r & 3u), one = ((r >> 4) == (uint32_t)j && ((r >> 2) & 1u) == hlf) ? ONE << (16u * (e & 1u)) : 0u;
+        pm[j] = __builtin_bit_cast(frag, uint4{(e >> 1) == 0u ? one : 0u, (e >> 1) == 1u ? one : 0u, (e >> 1) == 2u ? one : 0u, (e >> 1) == 3u ? one : 0u});
     }
-    const uint32_t pad_one = g == 0u ? ONE : 0u;          // key slot 80 (lane row 0, element 4 of the third key step): probability 1.0 for the bias row
 
     uint32_t oi, sub;
     if (!xtile(p, 0, oi, sub)) return;
@@ -150,12 +162,12 @@ __global__ __launch_bounds__(256) void gsw_xattn_kernel(const XArgs p) {
 #define X_LD(st, cp) do { const uint8_t* cp_ = (cp); const uint4 a_ = *reinterpret_cast<const uint4*>(cp_ + o0), b_ = *reinterpret_cast<const uint4*>(cp_ + o1); \
                           const uint2 c_ = *reinterpret_cast<const uint2*>(cp_ + o2);                                                                             \
                           if constexpr ((st) == 0) { sa0 = a_; sb0 = b_; sc0 = c_; } else if constexpr ((st) == 1) { sa1 = a_; sb1 = b_; sc1 = c_; } else { sa2 = a_; sb2 = b_; sc2 = c_; } } while (0)
-#define X_WR(st, slot) do { uint8_t* sp_ = ring + (slot) * XCHUNK;                                                                                                \
+#define X_WR(st, slot) do { uint8_t* sp_ = X_SLOT(slot);                                                                                                \
                             *reinterpret_cast<uint4*>(sp_ + o0) = (st) == 0 ? sa0 : (st) == 1 ? sa1 : sa2; *reinterpret_cast<uint4*>(sp_ + o1) = (st) == 0 ? sb0 : (st) == 1 ? sb1 : sb2; \
                             *reinterpret_cast<uint2*>(sp_ + o2) = (st) == 0 ? sc0 : (st) == 1 ? sc1 : sc2; } while (0)
-    // invariant at the top of step j: the ten fragments of chunk j are in registers (fr[j & 1]), chunk j + 1 is in LDS slot (j + 1) % 3 (written a step ago, published by
+    // invariant at the top of step j: the ten fragments of chunk j are in registers (fr), chunk j + 1 is in LDS slot (j + 1) % 3 (written a step ago, published by
     // this step's barrier), chunks j + 2 .. j + 4 are in staging register sets (j + 2 .. j + 4) % 3
-    frag fr[2][10];
+    frag fr[10];
     X_LD(0, cur);
     X_LD(1, cur + XCHUNK);
     X_LD(2, cur + 2 * XCHUNK);
@@ -165,22 +177,20 @@ __global__ __launch_bounds__(256) void gsw_xattn_kernel(const XArgs p) {
     X_LD(1, cur + 4 * XCHUNK);
     X_BARRIER(0);
 #pragma unroll
-    for (int i = 0; i < 10; ++i) fr[0][i] = __builtin_bit_cast(frag, *reinterpret_cast<const uint4*>(ring + lane * 16u + i * 1024));
+    for (int i = 0; i < 10; ++i) fr[i] = __builtin_bit_cast(frag, *reinterpret_cast<const uint4*>(ring0 + lane * 16u + i * 1024));
 
-    const mm_f4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    // the wave's 32 rows of x as B-operand fragments + their LayerNorm statistics.  They are loaded ONE TILE AHEAD: the last head's second product does not read them, so the
-    // next tile's rows are requested right behind that head's softmax -- under its 120 MFMAs and in front of this tile's output stores -- instead of at the top of the tile
-    frag xf[2][XKS];
-    float2 st[2];
+    const x_f16v zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // the lane's row of x as B-operand fragments (lane (row, hlf) holds channels 16 ks + 8 hlf .. + 7 of k-step ks) + its LayerNorm statistics.  They are loaded ONE TILE
+    // AHEAD: the last head's second product does not read them, so the next tile's rows are requested right behind that head's softmax -- under its 50 MFMAs and in front
+    // of this tile's output stores -- instead of at the top of the tile
+    frag xf[XKS];
+    float2 st;
     auto load_x = [&](uint32_t oi_, uint32_t sub_) __attribute__((always_inline)) {
         const int64_t xrow = (int64_t)(oi_ % p.xB) * p.S + sub_ * 128u + wave * 32u + r;
+        const uint16_t* xr = p.x + xrow * XC + hlf * 8u;
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
-            const uint16_t* xr = p.x + (xrow + rb * 16) * XC + g * 8u;
-#pragma unroll
-            for (int ks = 0; ks < XKS; ++ks) xf[rb][ks] = __builtin_bit_cast(frag, *reinterpret_cast<const uint4*>(xr + ks * 32));
-            st[rb] = p.stat[xrow + rb * 16];
-        }
+        for (int ks = 0; ks < XKS; ++ks) xf[ks] = __builtin_bit_cast(frag, *reinterpret_cast<const uint4*>(xr + ks * 16));
+        st = p.stat[xrow];
     };
     load_x(oi, sub);
     for (uint32_t it = 0;; ++it) {
@@ -188,117 +198,95 @@ __global__ __launch_bounds__(256) void gsw_xattn_kernel(const XArgs p) {
         const bool more = xtile(p, it + 1, noi, nsub);
         const int64_t nctx = more ? (p.bidx ? xctx(p.bidx, noi) : 0) : cctx;      // the next tile's context: the fragment stream runs on into it
         const int64_t orow = (int64_t)oi * p.S + sub * 128u + wave * 32u + r;
-        mm_f4 acc[XNB][2];
+        x_f16v acc[XNB];
 #pragma unroll
-        for (int nb = 0; nb < XNB; ++nb)
-#pragma unroll
-            for (int rb = 0; rb < 2; ++rb) acc[nb][rb] = M_::mma(pm[nb & 1], xf[rb][nb >> 1], zero4);
+        for (int nb = 0; nb < XNB; ++nb) acc[nb] = XM<T>::mma(pm[1], xf[2 * nb + 1], XM<T>::mma(pm[0], xf[2 * nb], zero16));
 
         auto head = [&](const uint32_t h, auto LAST) __attribute__((always_inline)) {
             const uint8_t* hb = p.blob + xuni(cctx * p.blob_stride + (int64_t)h * XHEAD);
             const uint8_t* hn = p.blob + xuni(h + 1 == p.heads ? nctx * p.blob_stride : cctx * p.blob_stride + (int64_t)(h + 1) * XHEAD);
-            const float* huv = p.uv + xuni(cctx * p.uv_stride + h * XUV) + g * 4u;
-            mm_f4 S[XKB][2];
-            frag pf[3][2];
-            float4 u4[XKB], v4[XKB];
+            const float* hv = p.uv + xuni(cctx * p.uv_stride + h * XV) + hlf * 4u;
+            x_f16v S[XKB];
+            frag pf[XKK];
+            float4 v4[XKK * 2];
             auto step = [&](auto J) __attribute__((always_inline)) {
                 constexpr int j = decltype(J)::value;
-                X_BARRIER(j != 5 ? 3 : 0);      // (the previous step read this chunk's fragments behind its writes -- unless this is the empty chunk)
+                X_BARRIER(j != XEMPTY ? 3 : 0);      // (the previous step read this chunk's fragments behind its writes -- unless this is the empty chunk)
                 {   // chunk j + 2: staging registers -> LDS (its slot held chunk j - 1, whose fragments every wave had in registers before the previous barrier)
                     constexpr int m = (j + 2) % 12;
-                    if constexpr (m != 5) X_WR(m % 3, m % 3);
+                    if constexpr (m != XEMPTY) X_WR(m % 3, m % 3);
                 }
                 {   // chunk j + 5: global -> the staging set just freed
                     constexpr int m = (j + 5) % 12;
-                    if constexpr (m != 5) X_LD(m % 3, ((j + 5) >= 12 ? hn : hb) + (m < 5 ? m : m - 1) * XCHUNK);
+                    if constexpr (m != XEMPTY) X_LD(m % 3, ((j + 5) >= 12 ? hn : hb) + (m < XEMPTY ? m : m - 1) * XCHUNK);
                 }
-                {   // chunk j + 1 (written a step ago, published by this barrier): LDS -> the other fragment set, under this chunk's MFMAs
-                    constexpr int m = (j + 1) % 12;
-                    if constexpr (m != 5) {
-                        const uint8_t* sl = ring + (m % 3) * XCHUNK + lane * 16u;
+                if constexpr (j == 4) {          // v of the 80 key slots the softmax looks at: two steps ahead of it
 #pragma unroll
-                        for (int i = 0; i < 10; ++i) fr[m & 1][i] = __builtin_bit_cast(frag, *reinterpret_cast<const uint4*>(sl + i * 1024));
-                    }
+                    for (int q = 0; q < XKK * 2; ++q) v4[q] = *reinterpret_cast<const float4*>(hv + q * 8);
                 }
-                if constexpr (j == 3) {
+                // this chunk's MFMAs; fragment i of chunk j + 1 (written a step ago, published by this barrier) is read from LDS into fragment i's registers behind the MFMA that
+                // consumed them -- one chunk of lead, no second fragment set
+                const uint8_t* sl = X_SLOT((j + 1) % 3) + lane * 16u;
+                constexpr bool next_has = (j + 1) % 12 != XEMPTY;
+                if constexpr (j < XEMPTY) {
+                    // S^T[32 keys of block kb][rows] += A'[32 keys x 16 channels] x^T[16 channels x 32 rows]: fragment f = 3 ks + kb
 #pragma unroll
-                    for (int kb = 0; kb < XKB; ++kb) {
-                        u4[kb] = *reinterpret_cast<const float4*>(huv + kb * 16);
-                        v4[kb] = *reinterpret_cast<const float4*>(huv + 16 * XKB + kb * 16);
+                    for (int i = 0; i < 10; ++i) {
+                        const int f = 10 * j + i, ks = f / 3, kb = f % 3;
+                        S[kb] = XM<T>::mma(fr[i], xf[ks], ks == 0 ? zero16 : S[kb]);
+                        if constexpr (next_has) fr[i] = __builtin_bit_cast(frag, *reinterpret_cast<const uint4*>(sl + i * 1024));
                     }
-                }
-                if constexpr (j < 5) {
-                    // S^T[key block kb][rows] += A'[16 keys x 32 channels] x^T[32 channels x 16 rows], two k-steps per chunk
+                } else if constexpr (j == XEMPTY) {
+                    // softmax over the 80 key slots of the lane's row: 40 in this lane (keys 32 kb + 8 (t >> 2) + 4 hlf + (t & 3) of accumulator element t), 40 in lane + 32
+                    if constexpr (next_has) {
 #pragma unroll
-                    for (int k2 = 0; k2 < 2; ++k2) {
-                        const int ks = 2 * j + k2;
-#pragma unroll
-                        for (int kb = 0; kb < XKB; ++kb) {
-                            const frag a = fr[j & 1][k2 * XKB + kb];
-#pragma unroll
-                            for (int rb = 0; rb < 2; ++rb) S[kb][rb] = M_::mma(a, xf[rb][ks], ks == 0 ? zero4 : S[kb][rb]);
-                        }
+                        for (int i = 0; i < 10; ++i) fr[i] = __builtin_bit_cast(frag, *reinterpret_cast<const uint4*>(sl + i * 1024));
                     }
-                } else if constexpr (j == 5) {
-                    // softmax over the 80 key slots of a row: 20 per lane, 4 lanes per row
+                    float s[8 * XKK];
 #pragma unroll
-                    for (int rb = 0; rb < 2; ++rb) {
-                        float s[4 * XKB];
-                        const float rstd = st[rb].x, nrm = st[rb].y;
+                    for (int q = 0; q < XKK * 2; ++q) {
+                        s[4 * q + 0] = fmaf(st.x, S[q >> 2][4 * (q & 3) + 0], v4[q].x);
+                        s[4 * q + 1] = fmaf(st.x, S[q >> 2][4 * (q & 3) + 1], v4[q].y);
+                        s[4 * q + 2] = fmaf(st.x, S[q >> 2][4 * (q & 3) + 2], v4[q].z);
+                        s[4 * q + 3] = fmaf(st.x, S[q >> 2][4 * (q & 3) + 3], v4[q].w);
+                    }
+                    float mx = s[0];
 #pragma unroll
-                        for (int kb = 0; kb < XKB; ++kb) {
-                            s[4 * kb + 0] = fmaf(rstd, S[kb][rb][0], fmaf(nrm, u4[kb].x, v4[kb].x));
-                            s[4 * kb + 1] = fmaf(rstd, S[kb][rb][1], fmaf(nrm, u4[kb].y, v4[kb].y));
-                            s[4 * kb + 2] = fmaf(rstd, S[kb][rb][2], fmaf(nrm, u4[kb].z, v4[kb].z));
-                            s[4 * kb + 3] = fmaf(rstd, S[kb][rb][3], fmaf(nrm, u4[kb].w, v4[kb].w));
-                        }
-                        float mx = s[0];
+                    for (int i = 1; i < 8 * XKK; ++i) mx = fmaxf(mx, s[i]);
+                    mx = xh_max(mx);
+                    float l = 0.f;
 #pragma unroll
-                        for (int i = 1; i < 4 * XKB; ++i) mx = fmaxf(mx, s[i]);
-                        mx = xq_max(mx);
-                        float l = 0.f;
+                    for (int i = 0; i < 8 * XKK; ++i) { s[i] = __builtin_amdgcn_exp2f(s[i] - mx); l += s[i]; }
+                    const float inv = __builtin_amdgcn_rcpf(xh_sum(l));
 #pragma unroll
-                        for (int i = 0; i < 4 * XKB; ++i) { s[i] = __builtin_amdgcn_exp2f(s[i] - mx); l += s[i]; }
-                        const float inv = __builtin_amdgcn_rcpf(xq_sum(l));
-#pragma unroll
-                        for (int kk = 0; kk < 3; ++kk) {
-                            uint32_t w[4];
-                            w[0] = M_::cvt2(s[8 * kk + 0] * inv, s[8 * kk + 1] * inv);
-                            w[1] = M_::cvt2(s[8 * kk + 2] * inv, s[8 * kk + 3] * inv);
-                            if (kk < 2) {
-                                w[2] = M_::cvt2(s[8 * kk + 4] * inv, s[8 * kk + 5] * inv);
-                                w[3] = M_::cvt2(s[8 * kk + 6] * inv, s[8 * kk + 7] * inv);
-                            } else {
-                                w[2] = pad_one;
-                                w[3] = 0u;
-                            }
-                            pf[kk][rb] = __builtin_bit_cast(frag, uint4{w[0], w[1], w[2], w[3]});
-                        }
+                    for (int kk = 0; kk < XKK; ++kk) {
+                        uint32_t w3 = M_::cvt2(s[8 * kk + 6] * inv, s[8 * kk + 7] * inv);
+                        if (kk == XKK - 1 && hlf) w3 = (w3 & 0xFFFFu) | (ONE << 16);      // key slot 79 (upper lane half, last value of the fifth key step): probability 1.0 for the bias row
+                        pf[kk] = __builtin_bit_cast(frag, uint4{M_::cvt2(s[8 * kk + 0] * inv, s[8 * kk + 1] * inv), M_::cvt2(s[8 * kk + 2] * inv, s[8 * kk + 3] * inv),
+                                                                M_::cvt2(s[8 * kk + 4] * inv, s[8 * kk + 5] * inv), w3});
                     }
                     if constexpr (decltype(LAST)::value) load_x(noi, nsub);      // (the last tile re-reads its own rows: harmless)
                 } else {
-                    // x'^T[column block nb][rows] += B[16 columns x 32 key slots] P^T[32 key slots x 16 rows], ten column blocks per chunk
-                    constexpr int kk = (j - 6) >> 1, nb0 = 10 * ((j - 6) & 1);
+                    // x'^T[32 columns of block nb][rows] += B[32 columns x 16 key slots] P^T[16 key slots x 32 rows]: key step kk = j - 7, ten column blocks per chunk
 #pragma unroll
                     for (int i = 0; i < 10; ++i) {
-                        const frag a = fr[j & 1][i];
-#pragma unroll
-                        for (int rb = 0; rb < 2; ++rb) acc[nb0 + i][rb] = M_::mma(a, pf[kk][rb], acc[nb0 + i][rb]);
+                        acc[i] = XM<T>::mma(fr[i], pf[j - XEMPTY - 1], acc[i]);
+                        if constexpr (next_has) fr[i] = __builtin_bit_cast(frag, *reinterpret_cast<const uint4*>(sl + i * 1024));
                     }
                 }
-                // issue order inside the step (one wave per SIMD: what this wave does not overlap, nothing does): the LDS writes and the global loads first -- they complete
-                // under the MFMAs instead of in front of the next barrier's wait --, then the MFMAs with the fragment reads of the next chunk between them
-                if constexpr (j != 5) {
-                    if constexpr ((j + 2) % 12 != 5) __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);
-                    if constexpr ((j + 5) % 12 != 5 || j == 3) __builtin_amdgcn_sched_group_barrier(0x020, ((j + 5) % 12 != 5 ? 3 : 0) + (j == 3 ? 2 * XKB : 0), 0);
-                    if constexpr ((j + 1) % 12 != 5) {
+                // issue order inside the step (one wave per SIMD: what this wave's own instruction stream does not put beside an MFMA, nothing overlaps -- measured in
+                // isolation, tools/ubench/xattn_step.hip: the step's LDS writes, global loads, fragment reads and barrier are ~350 cycles next to 320 of MFMAs): every MFMA is
+                // followed by one LDS write (first three gaps) / one global load (next three), then the fragment read into the registers it consumed.  The three LDS
+                // operations issued last are reads, which is what X_BARRIER(3) relies on
+                if constexpr (j != XEMPTY) {
+                    constexpr bool wr = (j + 2) % 12 != XEMPTY, ld = (j + 5) % 12 != XEMPTY;
+                    if constexpr (j == 4) __builtin_amdgcn_sched_group_barrier(0x020, 2 * XKK, 0);
 #pragma unroll
-                        for (int i = 0; i < 10; ++i) {
-                            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                        }
-                    } else {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 20, 0);
+                    for (int i = 0; i < 10; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        if (wr && i < 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                        if (ld && i >= 3 && i < 6) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                        if constexpr (next_has) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     }
                 }
             };
@@ -309,31 +297,33 @@ __global__ __launch_bounds__(256) void gsw_xattn_kernel(const XArgs p) {
         for (uint32_t h = 0; h + 1 < p.heads; ++h) head(h, std::false_type{});
         head(p.heads - 1, std::true_type{});      // (its own copy of the code: the x loads of the next tile sit in it unconditionally)
 
-        // epilogue: lane (r, g) holds columns 32 q + 8 g .. + 7 of rows r and 16 + r
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
+        // epilogue: lane (row, hlf) holds columns 32 nb + 16 j + 8 hlf .. + 7 of its row in elements 8 j .. 8 j + 7 of block nb
+        {
             float sm = 0.f, sq = 0.f;
-            uint16_t* orp = p.out + (orow + rb * 16) * XC + g * 8u;
+            uint16_t* orp = p.out + orow * XC + hlf * 8u;
 #pragma unroll
-            for (int q = 0; q < XKS; ++q) {
-                uint4 w;
-                w.x = M_::cvt2(acc[2 * q][rb][0], acc[2 * q][rb][1]);
-                w.y = M_::cvt2(acc[2 * q][rb][2], acc[2 * q][rb][3]);
-                w.z = M_::cvt2(acc[2 * q + 1][rb][0], acc[2 * q + 1][rb][1]);
-                w.w = M_::cvt2(acc[2 * q + 1][rb][2], acc[2 * q + 1][rb][3]);
-                M_::stat2(w.x, sm, sq);
-                M_::stat2(w.y, sm, sq);
-                M_::stat2(w.z, sm, sq);
-                M_::stat2(w.w, sm, sq);
-                *reinterpret_cast<uint4*>(orp + q * 32) = w;
+            for (int nb = 0; nb < XNB; ++nb) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    uint4 w;
+                    w.x = M_::cvt2(acc[nb][8 * j + 0], acc[nb][8 * j + 1]);
+                    w.y = M_::cvt2(acc[nb][8 * j + 2], acc[nb][8 * j + 3]);
+                    w.z = M_::cvt2(acc[nb][8 * j + 4], acc[nb][8 * j + 5]);
+                    w.w = M_::cvt2(acc[nb][8 * j + 6], acc[nb][8 * j + 7]);
+                    M_::stat2(w.x, sm, sq);
+                    M_::stat2(w.y, sm, sq);
+                    M_::stat2(w.z, sm, sq);
+                    M_::stat2(w.w, sm, sq);
+                    *reinterpret_cast<uint4*>(orp + nb * 32 + j * 16) = w;
+                }
             }
             if (p.ostat) {
-                sm = xq_sum(sm);
-                sq = xq_sum(sq);
+                sm = xh_sum(sm);
+                sq = xh_sum(sq);
                 const float mean = sm * p.inv_c;
                 const float var = fmaxf(sq * p.inv_c - mean * mean, 0.f);
                 const float rstd = rsqrtf(var + p.eps);
-                if (g == 0u) p.ostat[orow + rb * 16] = make_float2(rstd, -rstd * mean);
+                if (hlf == 0u) p.ostat[orow] = make_float2(rstd, -rstd * mean);
             }
         }
         if (!more) break;
@@ -341,17 +331,18 @@ __global__ __launch_bounds__(256) void gsw_xattn_kernel(const XArgs p) {
     }
 #undef X_LD
 #undef X_WR
+#undef X_SLOT
 }
 
 }  // namespace
 
-int gsw_xattn_fused(const void* x_dev, const float* ln_stat_dev, const void* blob_dev, int64_t blob_stride_bytes, const float* uv_dev, int64_t uv_stride_floats,
+int gsw_xattn_fused(const void* x_dev, const float* ln_stat_dev, const void* blob_dev, int64_t blob_stride_bytes, const float* v_dev, int64_t v_stride_floats,
                     const int32_t* ctx_index_dev, void* out_dev, float* out_stat_dev, float out_eps, int x_images, int out_images, int tokens, int C, int heads,
                     int dtype, void* stream) {
-    if (!x_dev || !ln_stat_dev || !blob_dev || !uv_dev || !out_dev || x_images <= 0 || out_images <= 0 || tokens <= 0 || heads <= 0) return GSW_ERR_BAD_ARG;
+    if (!x_dev || !ln_stat_dev || !blob_dev || !v_dev || !out_dev || x_images <= 0 || out_images <= 0 || tokens <= 0 || heads <= 0) return GSW_ERR_BAD_ARG;
     if (dtype != GSW_F16 && dtype != GSW_BF16) return GSW_ERR_BAD_ARG;
-    if (((uintptr_t)x_dev | (uintptr_t)blob_dev | (uintptr_t)uv_dev | (uintptr_t)out_dev | (uintptr_t)ln_stat_dev | (uintptr_t)out_stat_dev) & 15) return GSW_ERR_BAD_ARG;
-    if ((blob_stride_bytes & 15) || (uv_stride_floats & 3) || out_images % x_images) return GSW_ERR_BAD_ARG;
+    if (((uintptr_t)x_dev | (uintptr_t)blob_dev | (uintptr_t)v_dev | (uintptr_t)out_dev | (uintptr_t)ln_stat_dev | (uintptr_t)out_stat_dev) & 15) return GSW_ERR_BAD_ARG;
+    if ((blob_stride_bytes & 15) || (v_stride_floats & 3) || out_images % x_images) return GSW_ERR_BAD_ARG;
     if (C != XC || tokens % 128 || heads > 64 || (int64_t)out_images * tokens >= ((int64_t)1 << 31)) return GSW_ERR_UNSUPPORTED;
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
@@ -362,12 +353,12 @@ int gsw_xattn_fused(const void* x_dev, const float* ln_stat_dev, const void* blo
     a.x = reinterpret_cast<const uint16_t*>(x_dev);
     a.stat = reinterpret_cast<const float2*>(ln_stat_dev);
     a.blob = reinterpret_cast<const uint8_t*>(blob_dev);
-    a.uv = uv_dev;
+    a.uv = v_dev;
     a.bidx = ctx_index_dev;
     a.out = reinterpret_cast<uint16_t*>(out_dev);
     a.ostat = reinterpret_cast<float2*>(out_stat_dev);
     a.blob_stride = blob_stride_bytes;
-    a.uv_stride = uv_stride_floats;
+    a.uv_stride = v_stride_floats;
     a.inv_c = 1.0f / (float)XC;
     a.eps = out_eps;
     a.xB = (uint32_t)x_images; a.oB = (uint32_t)out_images; a.S = (uint32_t)tokens; a.T = (uint32_t)(tokens / 128);

@@ -872,7 +872,7 @@ def _unet_prepare_context(self, ctx: torch.Tensor) -> None:
             if attention_ok(ctx, a.heads, a.to_q.out_features // a.heads, 1, src.shape[1]):
                 a.context_kv(src)
             from . import xattn
-            if xattn.ENABLED and a.to_q.in_features == xattn.CHANNELS and ctx.shape[1] <= xattn.KEY_SLOTS and ctx.dtype in (torch.float16, torch.bfloat16):
+            if xattn.ENABLED and a.to_q.in_features == xattn.CHANNELS and ctx.shape[1] <= xattn.MAX_KEYS and ctx.dtype in (torch.float16, torch.bfloat16):
                 xattn.context_operands(a, blk.norm2, ctx, ctx.dtype)      # the one-launch cross-attention's per-context fragment streams
 
 

@@ -11,8 +11,8 @@ context -- so per (context, head) the host derives two matrices ONCE (fp32 produ
     A_h = K_h Wq_h [keys, C]    scores      S_h = LayerNorm(x) A_h^T / sqrt(d)
     B_h = Wo_h V_h^T [C, keys]  output      x'  = x + b_out + sum_h softmax(S_h) B_h^T
 
-LayerNorm is folded like pf.fold_ln_weights does it: A' = A diag(gamma) * scale * log2(e) (rounded), u = A' 1, v = (A beta) * scale * log2(e), so that
-S = rstd (x A'^T) + (-rstd mean) u + v in the exponent's base 2; padding keys get v = -inf.  `context_operands` stores A' and B in the order the kernel
+LayerNorm is folded: A' = A diag(gamma) * scale * log2(e) with its rows centred over the channels (so x A'^T = (x - mean) A'^T: no rank-one correction for the
+mean), v = (A beta) * scale * log2(e), so that S = rstd (x A'^T) + v in the exponent's base 2; padding keys get v = -inf.  `context_operands` stores A' and B in the order the kernel
 consumes them: a stream of 1 KiB MFMA fragments (110 per head); the layout algebra is in csrc/gswm_xattn.hip and restated by tests/test_xattn_host.py.
 """
 from __future__ import annotations
@@ -26,67 +26,69 @@ from . import _native as N
 from .codec import _dt, _stream_ptr
 
 CHANNELS = 320            # the level gsw_xattn_fused serves (SD 2.1: 64 x 64 latents; SD 1.5: the first level)
-KEY_SLOTS = 80            # 5 blocks of 16 keys; slot 80 of the second product carries the output bias
-HEAD_ELEMS = 11 * 5120    # 50 + 60 fragments of 512 elements
-UV_FLOATS = 2 * KEY_SLOTS
+MAX_KEYS = 79             # context tokens; key slot 79 of the second product carries the output bias
+KEY_SLOTS = 96            # three 32-key blocks in the first product (the second one uses slots 0..79)
+HEAD_ELEMS = 11 * 5120    # 60 + 50 fragments of 512 elements
+V_FLOATS = KEY_SLOTS
 LOG2E = 1.4426950408889634
 ENABLED = __import__("os").environ.get("GSW_XATTN_FUSED", "1") != "0"      # A/B switch: 0 = the three-launch path (query projection, attention kernel, output projection)
 
 
-def _column_of(nb: torch.Tensor, lab: torch.Tensor) -> torch.Tensor:
-    """output column of accumulator row `lab` (0..15) of column block `nb` (0..19): lane (row, g) then owns columns 32 q + 8 g .. + 7 of its rows"""
-    return 32 * (nb >> 1) + 8 * (lab >> 2) + 4 * (nb & 1) + (lab & 3)
+def _column_of(nb: torch.Tensor, m: torch.Tensor) -> torch.Tensor:
+    """output column of accumulator row `m` (0..31) of column block `nb` (0..9): lane (row, hlf) then owns columns 32 nb + 16 j + 8 hlf .. + 7 of its row"""
+    return 32 * nb + 16 * (m >> 4) + 8 * ((m >> 2) & 1) + 4 * ((m >> 3) & 1) + (m & 3)
 
 
-def _key_slot_of(kk: torch.Tensor, g: torch.Tensor, e: torch.Tensor) -> torch.Tensor:
-    """key slot (0..95) that element e of lane row g holds in key step kk of the second product: the S^T accumulator layout of two 16-key blocks"""
-    return 32 * kk + 16 * (e >> 2) + 4 * g + (e & 3)
+def _key_slot_of(kk: torch.Tensor, hlf: torch.Tensor, e: torch.Tensor) -> torch.Tensor:
+    """key slot (0..79) that value e of lane half hlf holds in key step kk of the second product: the S^T accumulator layout of v_mfma_f32_32x32x16"""
+    return 16 * kk + 8 * (e >> 2) + 4 * hlf + (e & 3)
 
 
 def fold_operands(wq: torch.Tensor, wk: torch.Tensor, wv: torch.Tensor, wo: torch.Tensor, bo: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor,
                   ctx: torch.Tensor, heads: int, dtype: torch.dtype):
-    """-> (A' [Bc, H, 80, C] in `dtype`, u [Bc, H, 80] fp32, v [Bc, H, 80] fp32, B [Bc, H, C, 96] in `dtype`) of `ctx` [Bc, keys <= 80, D]: the matrices
-    of the module docstring, key slots padded (A' rows zero, u = 0, v = -inf, B columns zero), B's slot 80 = b_out for the last head."""
+    """-> (A' [Bc, H, 96, C] in `dtype`, v [Bc, H, 96] fp32, B [Bc, H, C, 80] in `dtype`) of `ctx` [Bc, keys <= 79, D]: the matrices of the module docstring.
+    A' = A diag(gamma) scale log2(e) with every row CENTRED (its mean over the channels subtracted before the rounding): x A'^T is then (x - mean(x)) A'^T, the
+    LayerNorm's mean needs no rank-one correction and S = rstd (x A'^T) + v.  Padding key slots: A' rows zero, v = -inf, B columns zero; B's slot 79 = b_out for
+    the last head (the kernel gives that slot the probability 1)."""
     Bc, n, _ = ctx.shape
     C = wq.shape[1]
     inner = wq.shape[0]
     d = inner // heads
-    if n > KEY_SLOTS:
-        raise ValueError(f"xattn: {n} context tokens, at most {KEY_SLOTS}")
+    if n > MAX_KEYS:
+        raise ValueError(f"xattn: {n} context tokens, at most {MAX_KEYS}")
     f = torch.float32
     c32 = ctx.to(f)
     K = (c32 @ wk.detach().to(f).t()).view(Bc, n, heads, d).permute(0, 2, 1, 3)          # [Bc, H, n, d]
     V = (c32 @ wv.detach().to(f).t()).view(Bc, n, heads, d).permute(0, 2, 1, 3)
     A = torch.einsum("bhnd,hdc->bhnc", K, wq.detach().to(f).view(heads, d, C))           # [Bc, H, n, C]
     sc = float(d) ** -0.5 * LOG2E
+    Ag = A * (gamma.detach().to(f) * sc)
     Ap = torch.zeros((Bc, heads, KEY_SLOTS, C), dtype=dtype, device=ctx.device)
-    Ap[:, :, :n] = (A * (gamma.detach().to(f) * sc)).to(dtype)
-    u = Ap.to(f).sum(dim=-1)
+    Ap[:, :, :n] = (Ag - Ag.mean(dim=-1, keepdim=True)).to(dtype)
     v = torch.full((Bc, heads, KEY_SLOTS), float("-inf"), dtype=f, device=ctx.device)
     v[:, :, :n] = (A @ beta.detach().to(f)) * sc
-    Bm = torch.zeros((Bc, heads, C, 96), dtype=dtype, device=ctx.device)
+    Bm = torch.zeros((Bc, heads, C, MAX_KEYS + 1), dtype=dtype, device=ctx.device)
     Bm[..., :n] = torch.einsum("bhnd,chd->bhcn", V, wo.detach().to(f).view(C, heads, d)).to(dtype)
     if bo is not None:
-        Bm[:, heads - 1, :, KEY_SLOTS] = bo.detach().to(dtype)
-    return Ap, u, v, Bm
+        Bm[:, heads - 1, :, MAX_KEYS] = bo.detach().to(dtype)
+    return Ap, v, Bm
 
 
-def pack_stream(Ap: torch.Tensor, u: torch.Tensor, v: torch.Tensor, Bm: torch.Tensor):
-    """fold_operands' matrices -> (blob [Bc, H * HEAD_ELEMS] in their dtype, uv [Bc, H * UV_FLOATS] fp32) in the kernel's consumption order"""
+def pack_stream(Ap: torch.Tensor, v: torch.Tensor, Bm: torch.Tensor):
+    """fold_operands' matrices -> (blob [Bc, H * HEAD_ELEMS] in their dtype, v [Bc, H * V_FLOATS] fp32) in the kernel's consumption order"""
     Bc, H, _, C = Ap.shape
     if C != CHANNELS:
         raise ValueError(f"xattn: C = {C}, the kernel serves {CHANNELS}")
     dev = Ap.device
-    # first product: fragment (k-step ks, key block kb), lane (label, g), element e = A'[16 kb + label][32 ks + 8 g + e]
-    g1 = Ap.view(Bc, H, 5, 16, C // 32, 4, 8).permute(0, 1, 4, 2, 5, 3, 6).reshape(Bc, H, -1)      # [ks, kb, g, label, e]
-    # second product: fragment (key step kk, column block nb), lane (label, g), element e = B[column_of(nb, label)][key_slot_of(kk, g, e)]
+    # first product: fragment 3 ks + kb (16-channel k-step ks, 32-key block kb), lane (m, hlf), value e = A'[32 kb + m][16 ks + 8 hlf + e]
+    g1 = Ap.view(Bc, H, 3, 32, C // 16, 2, 8).permute(0, 1, 4, 2, 5, 3, 6).reshape(Bc, H, -1)      # [ks, kb, hlf, m, e]
+    # second product: fragment 10 kk + nb (16-slot key step kk, 32-column block nb), lane (m, hlf), value e = B[column_of(nb, m)][key_slot_of(kk, hlf, e)]
     ar = lambda k: torch.arange(k, device=dev)
-    cols = _column_of(ar(C // 16)[:, None], ar(16)[None, :])                                     # [nb, label]
-    slots = _key_slot_of(ar(3)[:, None, None], ar(4)[None, :, None], ar(8)[None, None, :])         # [kk, g, e]
-    g2 = Bm[:, :, cols[None, :, None, :, None], slots[:, None, :, None, :]].reshape(Bc, H, -1)    # [kk, nb, g, label, e]
+    cols = _column_of(ar(C // 32)[:, None], ar(32)[None, :])                                     # [nb, m]
+    slots = _key_slot_of(ar(5)[:, None, None], ar(2)[None, :, None], ar(8)[None, None, :])         # [kk, hlf, e]
+    g2 = Bm[:, :, cols[None, :, None, :, None], slots[:, None, :, None, :]].reshape(Bc, H, -1)    # [kk, nb, hlf, m, e]
     blob = torch.cat([g1, g2], dim=2).reshape(Bc, H * HEAD_ELEMS).contiguous()
-    uv = torch.cat([u, v], dim=2).reshape(Bc, H * UV_FLOATS).contiguous()
-    return blob, uv
+    return blob, v.reshape(Bc, H * V_FLOATS).contiguous()
 
 
 def run_index(ctx: torch.Tensor) -> Optional[torch.Tensor]:
@@ -132,9 +134,9 @@ def context_operands(attn, norm, ctx: torch.Tensor, dtype: torch.dtype):
 
 
 def usable(x: torch.Tensor, attn, ctx: torch.Tensor) -> bool:
-    """gsw_xattn_fused serves this call: 320 channels, whole 128-row tiles per image, at most 80 context tokens, no projection biases besides to_out's"""
+    """gsw_xattn_fused serves this call: 320 channels, whole 128-row tiles per image, at most 79 context tokens, no projection biases besides to_out's"""
     return (ENABLED and x.is_cuda and x.dim() == 3 and x.dtype in (torch.float16, torch.bfloat16) and x.is_contiguous() and x.shape[-1] == CHANNELS
-            and x.shape[1] % 128 == 0 and ctx.dim() == 3 and ctx.shape[1] <= KEY_SLOTS and attn.to_q.bias is None and attn.to_k.bias is None
+            and x.shape[1] % 128 == 0 and ctx.dim() == 3 and ctx.shape[1] <= MAX_KEYS and attn.to_q.bias is None and attn.to_k.bias is None
             and attn.to_v.bias is None and attn.to_q.in_features == CHANNELS and attn.to_out[0].out_features == CHANNELS
             and ctx.shape[0] % x.shape[0] == 0 and x.shape[0] * x.shape[1] < (1 << 31) // max(1, ctx.shape[0] // x.shape[0]))
 
@@ -149,7 +151,7 @@ def fused(x: torch.Tensor, stat: torch.Tensor, blob: torch.Tensor, uv: torch.Ten
     xB, S, C = x.shape
     if C != CHANNELS or S % 128 or out_images % xB or x.dtype not in (torch.float16, torch.bfloat16) or not x.is_contiguous():
         raise ValueError("xattn.fused: x must be a contiguous fp16 / bf16 [xB, S % 128 == 0, 320] tensor, out_images a multiple of xB")
-    if blob.dtype != x.dtype or blob.dim() != 2 or blob.shape[1] != heads * HEAD_ELEMS or uv.dtype != torch.float32 or uv.shape != (blob.shape[0], heads * UV_FLOATS):
+    if blob.dtype != x.dtype or blob.dim() != 2 or blob.shape[1] != heads * HEAD_ELEMS or uv.dtype != torch.float32 or uv.shape != (blob.shape[0], heads * V_FLOATS):
         raise ValueError("xattn.fused: blob / uv are not context_operands' output for this head count and dtype")
     if stat.dtype != torch.float32 or stat.numel() != 2 * xB * S or not stat.is_contiguous():
         raise ValueError("xattn.fused: stat must be fp32 [xB * S, 2]")
@@ -170,9 +172,8 @@ def fused(x: torch.Tensor, stat: torch.Tensor, blob: torch.Tensor, uv: torch.Ten
                                         index.data_ptr() if index is not None else None, y.data_ptr(), ostat.data_ptr() if ostat is not None else None,
                                         float(eps_out) if eps_out is not None else 0.0, xB, out_images, S, C, heads, _dt(x.dtype), _stream_ptr()))
         if tm is not None:
-            keys = KEY_SLOTS
-            tm.stop(e0, ("gsw_xattn_kernel", out_images * S, C, heads * keys, "xattn") if tm.by_shape else "gsw_xattn_kernel",
-                    2.0 * out_images * S * C * heads * (keys + 96))
+            tm.stop(e0, ("gsw_xattn_kernel", out_images * S, C, heads * (MAX_KEYS + 1), "xattn") if tm.by_shape else "gsw_xattn_kernel",
+                    2.0 * out_images * S * C * heads * (KEY_SLOTS + MAX_KEYS + 1))
     if ostat is not None:
         y._gsw_lnstat = (ostat, float(eps_out))
     return y

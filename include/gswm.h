@@ -369,11 +369,12 @@ int gsw_attention_ws(const void* q_dev, const void* k_dev, const void* vt_dev, v
  * and the residual behind, which extract.py:66-69 / the generation loop run at every latent level:
  *     out = x + to_out(softmax(to_q(LayerNorm(x)) K^T / sqrt(d)) V) + b_out,        K, V = to_k(ctx), to_v(ctx)
  * The context side is precomputed by the host ONCE per (context, layer) as a stream of MFMA fragments (xattn.py: context_operands; per head 112 640 bytes:
- * A' = K_h Wq_h diag(gamma) scale log2(e) and B = Wo_h V_h^T in consumption order) plus 160 floats (u | v) per head (the LayerNorm fold's rank-one terms, -inf for
- * padding keys).  x [x_images * tokens, 320] is the RAW residual stream, ln_stat float2 per row (rstd, -rstd mean: gsw_ln_rowstats_finish); output image i reads
- * x image i % x_images (classifier-free guidance: one x, two contexts) and context ctx_index[i] (NULL: context 0).  out_stat (nullable): (rstd, -rstd mean) of
- * the OUTPUT rows with out_eps, what the next LayerNorm's fold reads.  C == 320, tokens % 128 == 0, <= 80 keys, else GSW_ERR_UNSUPPORTED. */
-int gsw_xattn_fused(const void* x_dev, const float* ln_stat_dev, const void* blob_dev, int64_t blob_stride_bytes, const float* uv_dev, int64_t uv_stride_floats,
+ * A' = K_h Wq_h diag(gamma) scale log2(e), rows centred, and B = Wo_h V_h^T (+ b_out as key slot 79 of the last head) in consumption order) plus 96 floats v per head
+ * (the LayerNorm fold's constant term; -inf for padding keys).  x [x_images * tokens, 320] is the RAW residual stream, ln_stat float2 per row (rstd, -rstd mean:
+ * gsw_ln_rowstats_finish); output image i reads x image i % x_images (classifier-free guidance: one x, two contexts) and context ctx_index[i] (NULL: context 0).
+ * out_stat (nullable): (rstd, -rstd mean) of the OUTPUT rows with out_eps, what the next LayerNorm's fold reads.  C == 320, tokens % 128 == 0, <= 79 keys, else
+ * GSW_ERR_UNSUPPORTED. */
+int gsw_xattn_fused(const void* x_dev, const float* ln_stat_dev, const void* blob_dev, int64_t blob_stride_bytes, const float* v_dev, int64_t v_stride_floats,
                     const int32_t* ctx_index_dev, void* out_dev, float* out_stat_dev, float out_eps, int x_images, int out_images, int tokens, int C, int heads,
                     int dtype, void* stream);
 int gsw_attention_hd64(const void* q_dev, const void* k_dev, const void* vt_dev, void* out_dev, int B, int H, int Sq, int Sk, int Sk_valid,

@@ -1,6 +1,6 @@
 """CPU: the host side of the one-launch cross-attention sublayer (xattn.py -> csrc/gswm_xattn.hip; diffusers' BasicTransformerBlock.attn2 behind
 extract.py:66-69).  `emulate` below restates, in plain torch and straight from the BYTES of the fragment stream, what the kernel computes lane by lane
-(v_mfma_f32_16x16x32 operand / accumulator layouts, chunk order, key-slot and column permutations, the bias key, the LayerNorm fold) and is held to the
+(v_mfma_f32_32x32x16 operand / accumulator layouts, chunk order, key-slot and column permutations, the bias key, the LayerNorm fold) and is held to the
 fp32 evaluation of the torch modules; the GPU tests (tests/test_gpu_xattn.py) hold the kernel to both.  This is test infrastructure: the product path has
 no CPU twin."""
 import math
@@ -15,74 +15,72 @@ from gswm_amd import xattn
 from gswm_amd.unet import Attention
 
 
-def mfma_16x16x32(a_frag: torch.Tensor, b_frag: torch.Tensor) -> torch.Tensor:
-    """a_frag, b_frag [64 lanes, 8] (lane = row-or-column + 16 g, element e <-> k = 8 g + e) -> accumulator [64 lanes, 4]: lane (col, g) element i = D[4 g + i][col]"""
-    A = torch.zeros(16, 32)
-    Bm = torch.zeros(32, 16)
+def mfma_32x32x16(a_frag: torch.Tensor, b_frag: torch.Tensor) -> torch.Tensor:
+    """v_mfma_f32_32x32x16: a_frag, b_frag [64 lanes, 8] (lane = row-or-column + 32 hlf, value e <-> k = 8 hlf + e) -> accumulator [64 lanes, 16]: lane (col, hlf)
+    element t = D[8 (t >> 2) + 4 hlf + (t & 3)][col]"""
+    A = torch.zeros(32, 16)
+    Bm = torch.zeros(16, 32)
     for lane in range(64):
-        r, g = lane & 15, lane >> 4
-        A[r, 8 * g:8 * g + 8] = a_frag[lane]
-        Bm[8 * g:8 * g + 8, r] = b_frag[lane]
+        r, h = lane & 31, lane >> 5
+        A[r, 8 * h:8 * h + 8] = a_frag[lane]
+        Bm[8 * h:8 * h + 8, r] = b_frag[lane]
     D = A @ Bm
-    out = torch.zeros(64, 4)
+    out = torch.zeros(64, 16)
     for lane in range(64):
-        r, g = lane & 15, lane >> 4
-        out[lane] = D[4 * g:4 * g + 4, r]
+        r, h = lane & 31, lane >> 5
+        for t in range(16):
+            out[lane, t] = D[8 * (t >> 2) + 4 * h + (t & 3), r]
     return out
 
 
-def emulate(x: torch.Tensor, stat: torch.Tensor, blob: torch.Tensor, uv: torch.Tensor, heads: int) -> torch.Tensor:
-    """One 16-row block of x [16, 320] through the kernel's instruction-level algebra -> x' [16, 320] (fp32, before the final rounding)."""
+def emulate(x: torch.Tensor, stat: torch.Tensor, blob: torch.Tensor, v: torch.Tensor, heads: int) -> torch.Tensor:
+    """One wave's 32 rows of x [32, 320] through the kernel's instruction-level algebra -> x' [32, 320] (fp32, before the final rounding)."""
     dt = x.dtype
-    xf = [torch.stack([x[lane & 15, 32 * ks + 8 * (lane >> 4):32 * ks + 8 * (lane >> 4) + 8] for lane in range(64)]).float() for ks in range(10)]
+    xf = [torch.stack([x[lane & 31, 16 * ks + 8 * (lane >> 5):16 * ks + 8 * (lane >> 5) + 8] for lane in range(64)]).float() for ks in range(20)]
     frags = blob.view(heads, 110, 64, 8).float()
-    uvv = uv.view(heads, 2, 80)
+    vv = v.view(heads, 96)
     # residual through the matrix pipe: permutation fragments
-    acc = []
-    for nb in range(20):
-        pm = torch.zeros(64, 8)
+    pm = []
+    for j in range(2):
+        a = torch.zeros(64, 8)
         for lane in range(64):
-            r, g = lane & 15, lane >> 4
-            if g == (r >> 2):
-                pm[lane, 4 * (nb & 1) + (r & 3)] = 1.0
-        acc.append(mfma_16x16x32(pm, xf[nb >> 1]))
+            r, h = lane & 31, lane >> 5
+            if (r >> 4) == j and ((r >> 2) & 1) == h:
+                a[lane, 4 * ((r >> 3) & 1) + (r & 3)] = 1.0
+        pm.append(a)
+    acc = [mfma_32x32x16(pm[0], xf[2 * nb]) + mfma_32x32x16(pm[1], xf[2 * nb + 1]) for nb in range(10)]
     for h in range(heads):
-        S = [torch.zeros(64, 4) for _ in range(5)]
-        for ks in range(10):
-            for kb in range(5):
-                S[kb] = S[kb] + mfma_16x16x32(frags[h, ks * 5 + kb], xf[ks])
-        s = torch.zeros(64, 20)
+        S = [torch.zeros(64, 16) for _ in range(3)]
+        for f in range(60):
+            ks, kb = f // 3, f % 3
+            S[kb] = S[kb] + mfma_32x32x16(frags[h, f], xf[ks])
+        s = torch.zeros(64, 40)
         for lane in range(64):
-            r, g = lane & 15, lane >> 4
-            for kb in range(5):
+            r, hl = lane & 31, lane >> 5
+            for q in range(10):
+                kb, tq = q >> 2, q & 3
                 for i in range(4):
-                    key = 16 * kb + 4 * g + i
-                    s[lane, 4 * kb + i] = stat[r, 0] * S[kb][lane, i] + (stat[r, 1] * uvv[h, 0, key] + uvv[h, 1, key])
-        P = torch.zeros(64, 20)
-        for r in range(16):
-            lanes = [r + 16 * g for g in range(4)]
+                    key = 32 * kb + 8 * tq + 4 * hl + i
+                    s[lane, 4 * q + i] = stat[r, 0] * S[kb][lane, 4 * tq + i] + vv[h, key]
+        P = torch.zeros(64, 40)
+        for r in range(32):
+            lanes = [r, r + 32]
             m = s[lanes].max()
             e = torch.exp2(s[lanes] - m)
             P[lanes] = e / e.sum()
-        one = torch.tensor(1.0)
-        for kk in range(3):
-            pf = torch.zeros(64, 8)
-            for lane in range(64):
-                g = lane >> 4
-                pf[lane, 0:4] = P[lane, 8 * kk:8 * kk + 4]
-                if kk < 2:
-                    pf[lane, 4:8] = P[lane, 8 * kk + 4:8 * kk + 8]
-                elif g == 0:
-                    pf[lane, 4] = one
+        for kk in range(5):
+            pf = P[:, 8 * kk:8 * kk + 8].clone()
+            if kk == 4:
+                pf[32:, 7] = 1.0                 # key slot 79: the bias row
             pf = pf.to(dt).float()
-            for nb in range(20):
-                acc[nb] = acc[nb] + mfma_16x16x32(frags[h, 50 + kk * 20 + nb], pf)
-    out = torch.zeros(16, 320)
+            for nb in range(10):
+                acc[nb] = acc[nb] + mfma_32x32x16(frags[h, 60 + kk * 10 + nb], pf)
+    out = torch.zeros(32, 320)
     for lane in range(64):
-        r, g = lane & 15, lane >> 4
-        for q in range(10):
-            out[r, 32 * q + 8 * g:32 * q + 8 * g + 4] = acc[2 * q][lane]
-            out[r, 32 * q + 8 * g + 4:32 * q + 8 * g + 8] = acc[2 * q + 1][lane]
+        r, hl = lane & 31, lane >> 5
+        for nb in range(10):
+            for j in range(2):
+                out[r, 32 * nb + 16 * j + 8 * hl:32 * nb + 16 * j + 8 * hl + 8] = acc[nb][lane, 8 * j:8 * j + 8]
     return out
 
 
@@ -112,40 +110,41 @@ def _module(heads, head_dim, ctx_dim, dtype, seed):
     return attn.to(dtype), norm.to(dtype)
 
 
-@pytest.mark.parametrize("heads,head_dim,ctx_dim,keys", [(5, 64, 1024, 77), (8, 40, 768, 77), (2, 64, 64, 80), (3, 32, 96, 5)])
+@pytest.mark.parametrize("heads,head_dim,ctx_dim,keys", [(5, 64, 1024, 77), (8, 40, 768, 77), (2, 64, 64, 79), (3, 32, 96, 5)])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
 def test_fragment_stream_restates_the_sublayer(heads, head_dim, ctx_dim, keys, dtype):
     attn, norm = _module(heads, head_dim, ctx_dim, dtype, seed=heads)
     g = torch.Generator().manual_seed(1)
-    x = (torch.randn(1, 16, 320, generator=g) * 1.3 + 0.4).to(dtype)
+    x = (torch.randn(1, 32, 320, generator=g) * 1.3 + 0.4).to(dtype)
     ctx = torch.randn(1, keys, ctx_dim, generator=g).to(dtype)
-    Ap, u, v, Bm = xattn.fold_operands(attn.to_q.weight, attn.to_k.weight, attn.to_v.weight, attn.to_out[0].weight, attn.to_out[0].bias, norm.weight, norm.bias,
-                                       ctx, heads, dtype)
-    assert Ap.shape == (1, heads, 80, 320) and Bm.shape == (1, heads, 320, 96)
-    assert torch.isinf(v[0, :, keys:]).all() and (v[0, :, keys:] < 0).all() and (u[0, :, keys:] == 0).all() and (Ap[0, :, keys:] == 0).all()
-    assert (Bm[0, :-1, :, 80] == 0).all() and torch.equal(Bm[0, -1, :, 80], attn.to_out[0].bias.detach())
-    blob, uv = xattn.pack_stream(Ap, u, v, Bm)
-    assert blob.shape == (1, heads * xattn.HEAD_ELEMS) and blob.dtype == dtype and uv.shape == (1, heads * xattn.UV_FLOATS)
+    Ap, v, Bm = xattn.fold_operands(attn.to_q.weight, attn.to_k.weight, attn.to_v.weight, attn.to_out[0].weight, attn.to_out[0].bias, norm.weight, norm.bias,
+                                    ctx, heads, dtype)
+    assert Ap.shape == (1, heads, 96, 320) and Bm.shape == (1, heads, 320, 80)
+    assert torch.isinf(v[0, :, keys:]).all() and (v[0, :, keys:] < 0).all() and (Ap[0, :, keys:] == 0).all()
+    # centred rows: the LayerNorm mean needs no rank-one term; what the rounding leaves of a row sum (times mean / std of a token) is the error this costs the scores
+    assert Ap[0, :, :keys].float().sum(-1).abs().max().item() <= (2e-2 if dtype == torch.float16 else 2e-1)
+    assert (Bm[0, :-1, :, 79] == 0).all() and torch.equal(Bm[0, -1, :, 79], attn.to_out[0].bias.detach())
+    blob, vf = xattn.pack_stream(Ap, v, Bm)
+    assert blob.shape == (1, heads * xattn.HEAD_ELEMS) and blob.dtype == dtype and vf.shape == (1, heads * xattn.V_FLOATS)
     xf = x[0].float()
     mean, var = xf.mean(-1), xf.var(-1, unbiased=False)
     rstd = torch.rsqrt(var + norm.eps)
     stat = torch.stack([rstd, -rstd * mean], dim=1)
-    got = emulate(x[0], stat, blob[0], uv[0], heads)
+    got = emulate(x[0], stat, blob[0], vf[0], heads)
     want = reference(x, norm, attn, ctx)[0]
     tol = 4e-3 if dtype == torch.float16 else 3e-2
     assert (got - want).abs().max().item() <= tol * max(1.0, want.abs().max().item()), (got - want).abs().max().item()
 
 
 def test_stream_is_a_permutation_of_the_operands():
-    """every element of A' and of B's 81 live key slots appears exactly once in the stream (nothing dropped, nothing duplicated)"""
+    """every element of A' and of B's 80 key slots appears exactly once in the stream (nothing dropped, nothing duplicated)"""
     heads = 2
-    Ap = torch.arange(heads * 80 * 320, dtype=torch.float32).view(1, heads, 80, 320) + 1.0
-    Bm = -(torch.arange(heads * 320 * 96, dtype=torch.float32).view(1, heads, 320, 96) + 1.0)
-    u = torch.zeros(1, heads, 80)
-    blob, uv = xattn.pack_stream(Ap, u, u, Bm)
+    Ap = torch.arange(heads * 96 * 320, dtype=torch.float32).view(1, heads, 96, 320) + 1.0
+    Bm = -(torch.arange(heads * 320 * 80, dtype=torch.float32).view(1, heads, 320, 80) + 1.0)
+    blob, _ = xattn.pack_stream(Ap, torch.zeros(1, heads, 96), Bm)
     b = blob.view(heads, xattn.HEAD_ELEMS)
     for h in range(heads):
-        g1, g2 = b[h, :25600], b[h, 25600:]
+        g1, g2 = b[h, :30720], b[h, 30720:]
         assert torch.equal(g1.sort().values, Ap[0, h].flatten().sort().values)
         assert torch.equal(g2.sort().values, Bm[0, h].flatten().sort().values)
 
@@ -178,5 +177,5 @@ def test_usable_gates():
     ctx = torch.empty(2, 77, 32, dtype=torch.float16)
     assert not xattn.usable(x, attn, ctx)          # CPU tensors never qualify: no CPU fallback
     with pytest.raises(RuntimeError):
-        xattn.fused(x, torch.empty(512, 2), torch.empty(1, 5 * xattn.HEAD_ELEMS, dtype=torch.float16), torch.empty(1, 5 * xattn.UV_FLOATS), None, 2, 5)
+        xattn.fused(x, torch.empty(512, 2), torch.empty(1, 5 * xattn.HEAD_ELEMS, dtype=torch.float16), torch.empty(1, 5 * xattn.V_FLOATS), None, 2, 5)
     assert math.isclose(xattn.LOG2E, math.log2(math.e))

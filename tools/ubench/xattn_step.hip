@@ -1,0 +1,86 @@
+// One "step" of the one-launch cross-attention kernel (csrc/gswm_xattn.hip) in isolation, ONE wave per SIMD (a 512-register kernel): 10 v_mfma_f32_32x32x16 on ten
+// accumulators + the other things a step does, switched on one at a time -- what does a step cost when only this wave's own instruction stream can overlap the matrix pipe?
+//   bit 0: ten ds_read_b128 fragment reads (each into the registers the previous MFMA consumed)      bit 1: three LDS writes (2 x b128 + b64)
+//   bit 2: three global loads (2 x dwordx4 + dwordx2, L2-resident stream)                           bit 3: s_barrier per step
+//   bit 4: MFMAs off
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ubench/xattn_step.hip -o xattn_step ; run: ./xattn_step
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+template <int MASK>
+__global__ __launch_bounds__(256) void step_kernel(const uint8_t* __restrict__ stream, float* out, uint64_t* cyc, int iters) {
+    __shared__ __attribute__((aligned(16))) uint8_t ring[9 * 10240];      // 90 KiB: one workgroup per CU, i.e. ONE wave per SIMD like the real kernel
+    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane((uint32_t)(threadIdx.x >> 6));
+    const uint32_t o0 = wave * 1024u + lane * 16u, o1 = o0 + 4096u, o2 = (8u + (wave >> 1)) * 1024u + (wave & 1u) * 512u + lane * 8u;
+    for (uint32_t i = threadIdx.x; i < 3 * 10240 / 4; i += 256) reinterpret_cast<uint32_t*>(ring)[i] = 0x3C003C00u;
+    __syncthreads();
+    f16v acc[10];
+    h8 fr[10], xb;
+    for (int i = 0; i < 10; ++i) { for (int t = 0; t < 16; ++t) acc[i][t] = 0.f; fr[i] = *reinterpret_cast<const h8*>(ring + lane * 16u + i * 1024); }
+    for (int e = 0; e < 8; ++e) xb[e] = (_Float16)(0.001f * (lane + e));
+    uint4 sa = make_uint4(1, 2, 3, 4), sb = sa; uint2 sc = make_uint2(5, 6);
+    const uint64_t t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+        const uint8_t* cp = stream + (size_t)(it & 63) * 10240;
+        const uint8_t* sl = ring + (it % 3) * 10240 + lane * 16u;
+        uint8_t* sw = ring + ((it + 1) % 3) * 10240;
+        if constexpr (MASK & 8) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory"); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+        else { __builtin_amdgcn_sched_barrier(0); }
+        if constexpr (MASK & 2) { *reinterpret_cast<uint4*>(sw + o0) = sa; *reinterpret_cast<uint4*>(sw + o1) = sb; *reinterpret_cast<uint2*>(sw + o2) = sc; }
+        if constexpr (MASK & 4) { sa = *reinterpret_cast<const uint4*>(cp + o0); sb = *reinterpret_cast<const uint4*>(cp + o1); sc = *reinterpret_cast<const uint2*>(cp + o2); }
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            if constexpr (!(MASK & 16)) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[i], xb, acc[i], 0, 0, 0);
+            if constexpr (MASK & 1) fr[i] = *reinterpret_cast<const h8*>(sl + i * 1024);
+        }
+        if constexpr (MASK & 2) __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);
+        if constexpr (MASK & 4) __builtin_amdgcn_sched_group_barrier(0x020, 3, 0);
+        if constexpr (!(MASK & 16)) {
+#pragma unroll
+            for (int i = 0; i < 10; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); if constexpr (MASK & 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+        }
+    }
+    const uint64_t t1 = __builtin_amdgcn_s_memtime();
+    float s = 0.f;
+    for (int i = 0; i < 10; ++i) for (int t = 0; t < 16; ++t) s += acc[i][t];
+    s += (float)(sa.x + sb.y + sc.x) + (float)fr[3][2];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
+template <int MASK> void run(const char* what, const uint8_t* stream, float* out, uint64_t* cyc) {
+    const int iters = 4000;
+    hipLaunchKernelGGL(step_kernel<MASK>, dim3(256), dim3(256), 0, 0, stream, out, cyc, iters);
+    hipDeviceSynchronize();
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(step_kernel<MASK>, dim3(256), dim3(256), 0, 0, stream, out, cyc, iters);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    std::vector<uint64_t> h(256); hipMemcpy(h.data(), cyc, 256 * 8, hipMemcpyDeviceToHost);
+    double mean = 0; for (auto v : h) mean += (double)v; mean /= 256;
+    printf("%-58s %7.1f cycles per step (s_memtime), %7.1f ns per step\n", what, mean / iters, ms * 1e6 / iters);
+}
+
+int main() {
+    uint8_t* stream; float* out; uint64_t* cyc;
+    hipMalloc(&stream, 64 * 10240 + 65536); hipMemset(stream, 0x3c, 64 * 10240 + 65536);
+    hipMalloc(&out, 256 * 256 * 4); hipMalloc(&cyc, 256 * 8);
+    run<0>("10 MFMA 32x32x16", stream, out, cyc);
+    run<1>("10 MFMA + 10 fragment reads", stream, out, cyc);
+    run<3>("10 MFMA + 10 fragment reads + 3 LDS writes", stream, out, cyc);
+    run<7>("10 MFMA + reads + writes + 3 global loads", stream, out, cyc);
+    run<15>("10 MFMA + reads + writes + loads + barrier", stream, out, cyc);
+    run<9>("10 MFMA + reads + barrier", stream, out, cyc);
+    run<8>("10 MFMA + barrier", stream, out, cyc);
+    run<31>("no MFMA: reads + writes + loads + barrier", stream, out, cyc);
+    run<17>("no MFMA: 10 fragment reads", stream, out, cyc);
+    run<18>("no MFMA: 3 LDS writes", stream, out, cyc);
+    run<20>("no MFMA: 3 global loads", stream, out, cyc);
+    run<24>("no MFMA: barrier", stream, out, cyc);
+    return 0;
+}

@@ -12,22 +12,23 @@ S, heads = 4096, 5
 
 PATCHES = {
     "full": [],
-    "no_softmax": [("s[i] = __builtin_amdgcn_exp2f(s[i] - mx); l += s[i];", "l += s[i];"), ("mx = xq_max(mx);", ""), ("const float inv = __builtin_amdgcn_rcpf(xq_sum(l));", "const float inv = l;")],
-    "no_stream": [("if constexpr (m != 5) X_WR(m % 3, m % 3);", ""), ("if constexpr (m != 5) X_LD(m % 3, ((j + 5) >= 12 ? hn : hb) + (m < 5 ? m : m - 1) * XCHUNK);", "(void)hn;")],
-    "no_ldswrite": [("if constexpr (m != 5) X_WR(m % 3, m % 3);", "if constexpr (m != 5) { if (((m % 3 == 0 ? sa0.x ^ sb0.x ^ sc0.x : m % 3 == 1 ? sa1.x ^ sb1.x ^ sc1.x : sa2.x ^ sb2.x ^ sc2.x)) == 0x12345u) ring[0] = 1; }")],
-    "no_mfma_g2": [("acc[nb0 + i][rb] = M_::mma(a, pf[kk][rb], acc[nb0 + i][rb]);", "acc[nb0 + i][rb][0] += __builtin_bit_cast(float, __builtin_bit_cast(uint4, a).x ^ __builtin_bit_cast(uint4, pf[kk][rb]).x);")],
-    "no_mfma_g1": [("S[kb][rb] = M_::mma(a, xf[rb][ks], ks == 0 ? zero4 : S[kb][rb]);", "{ S[kb][rb] = ks == 0 ? zero4 : S[kb][rb]; S[kb][rb][0] += __builtin_bit_cast(float, __builtin_bit_cast(uint4, a).x); }")],
+    "no_softmax": [("s[i] = __builtin_amdgcn_exp2f(s[i] - mx); l += s[i];", "l += s[i];"), ("mx = xh_max(mx);", ""), ("const float inv = __builtin_amdgcn_rcpf(xh_sum(l));", "const float inv = l;")],
+    "no_stream": [("if constexpr (m != XEMPTY) X_WR(m % 3, m % 3);", ""), ("if constexpr (m != XEMPTY) X_LD(m % 3, ((j + 5) >= 12 ? hn : hb) + (m < XEMPTY ? m : m - 1) * XCHUNK);", "(void)hn;")],
+    "no_ldswrite": [("if constexpr (m != XEMPTY) X_WR(m % 3, m % 3);", "if constexpr (m != XEMPTY) { if (((m % 3 == 0 ? sa0.x ^ sb0.x ^ sc0.x : m % 3 == 1 ? sa1.x ^ sb1.x ^ sc1.x : sa2.x ^ sb2.x ^ sc2.x)) == 0x12345u) ring0[0] = 1; }")],
     "no_barrier": [("__builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)", "__builtin_amdgcn_sched_barrier(0); } while (0)")],
-    "no_fragread": [("fr[m & 1][i] = __builtin_bit_cast(frag, *reinterpret_cast<const uint4*>(sl + i * 1024));", "(void)sl;")],
+    "no_fragread": [("if constexpr (next_has) fr[i] = __builtin_bit_cast(frag, *reinterpret_cast<const uint4*>(sl + i * 1024));", "(void)sl;")],
+    "no_xload": [("                    if constexpr (decltype(LAST)::value) load_x(noi, nsub);", "")],
     "trace": [("    uint32_t oi, sub;\n    if (!xtile(p, 0, oi, sub)) return;", "    uint32_t oi, sub;\n    if (!xtile(p, 0, oi, sub)) return;\n    uint64_t* dbg = reinterpret_cast<uint64_t*>(p.ostat); uint32_t cnt = 0;\n#define X_STAMP() do { if (blockIdx.x == 0) { const uint64_t t_ = __builtin_amdgcn_s_memtime(); if (lane == 0 && cnt < 2000) dbg[wave * 2048 + cnt] = t_; ++cnt; } } while (0)"),
-              ("                X_BARRIER(j != 5 ? 3 : 0);", "                X_STAMP(); X_BARRIER(j != 5 ? 3 : 0);"),
-              ("        mm_f4 acc[XNB][2];", "        X_STAMP();\n        mm_f4 acc[XNB][2];"),
-              ("        for (uint32_t h = 0; h < p.heads; ++h) {", "        X_STAMP();\n        for (uint32_t h = 0; h < p.heads; ++h) {"),
-              ("        // epilogue: lane (r, g) holds", "        X_STAMP();\n        // epilogue: lane (r, g) holds"),
+              ("                X_BARRIER(j != XEMPTY ? 3 : 0);", "                X_STAMP(); X_BARRIER(j != XEMPTY ? 3 : 0);"),
+              ("        x_f16v acc[XNB];", "        X_STAMP();\n        x_f16v acc[XNB];"),
+              ("        auto head = [&](const uint32_t h, auto LAST)", "        X_STAMP();\n        auto head = [&](const uint32_t h, auto LAST)"),
+              ("        // epilogue: lane (row, hlf) holds", "        X_STAMP();\n        // epilogue: lane (row, hlf) holds"),
               ("            if (p.ostat) {", "            if (false) {"),
               ("        if (!more) break;", "        X_STAMP();\n        if (!more) break;")],
-    "no_store": [("*reinterpret_cast<uint4*>(orp + q * 32) = w;", "if (w.x == 0x12345678u) *reinterpret_cast<uint4*>(orp + q * 32) = w;")],
+    "no_store": [("*reinterpret_cast<uint4*>(orp + nb * 32 + j * 16) = w;", "if (w.x == 0x12345678u) *reinterpret_cast<uint4*>(orp + nb * 32 + j * 16) = w;")],
 }
+for combo in ("no_stream+no_barrier", "no_stream+no_barrier+no_softmax+no_store", "no_stream+no_barrier+no_softmax+no_store+no_fragread", "no_stream+no_fragread", "no_softmax+no_store"):
+    PATCHES[combo] = sum((PATCHES[k] for k in combo.split("+")), [])
 
 def build(name, patches):
     s = open(SRC).read()
@@ -59,8 +60,6 @@ xf = x.float(); mean = xf.mean(-1); rstd = torch.rsqrt(xf.var(-1, unbiased=False
 st = torch.stack([rstd, -rstd * mean], -1).reshape(-1, 2).contiguous(); del xf
 blob, uv, idx = xattn.context_operands(blk.attn2, blk.norm2, ctx, torch.float16)
 y = torch.empty_like(x); ost = torch.empty(B * S, 2, device="cuda")
-for combo in ("no_stream+no_barrier", "no_stream+no_barrier+no_softmax+no_store", "no_stream+no_barrier+no_softmax+no_store+no_fragread", "no_stream+no_fragread", "no_softmax+no_store"):
-    PATCHES[combo] = sum((PATCHES[k] for k in combo.split("+")), [])
 only = [a for a in sys.argv[2:] if a != "compile"]
 if "compile" in sys.argv:
     for name, patches in PATCHES.items():
@@ -96,7 +95,7 @@ for name, patches in PATCHES.items():
                 b = tile * per_tile
                 if b + per_tile > n: break
                 tt = (t[b:b + per_tile] - t[b]).tolist()
-                print(f"  tile {tile}: x landed +{tt[1]}, residual done +{tt[2]}, heads done +{tt[per_tile - 2]}, epilogue done +{tt[per_tile - 1]}; next tile starts +{int(t[b + per_tile] - t[b]) if b + per_tile < n else -1}")
+                print(f"  tile {tile}: residual issued +{tt[1]}, heads start +{tt[2]}, heads done +{tt[per_tile - 2]}, epilogue done +{tt[per_tile - 1]}; next tile starts +{int(t[b + per_tile] - t[b]) if b + per_tile < n else -1}")
                 for h in (0, 2):
                     hb = 3 + h * 12
                     steps = [tt[hb + j + 1] - tt[hb + j] for j in range(12)]
