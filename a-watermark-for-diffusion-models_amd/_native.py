@@ -68,8 +68,6 @@ _PROTOTYPES = {
                                    C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     "gsw_xattn_fused": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int,
                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
-    "gsw_attention_hd64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                                     C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "gsw_mt19937_seed": (None, [C.c_uint32, C.c_void_p]),
     "gsw_mt19937_uniform": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "gsw_lanczos_plan": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
@@ -86,8 +84,6 @@ _PROTOTYPES = {
     "gsw_gemm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                            C.c_int, C.c_void_p]),
     "gsw_gemm_qkv": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
-    "gsw_mm_next_rowstats": (C.c_int, [C.c_void_p, C.c_int64]),
-    "gsw_mm_last_rowstats": (C.c_int, [C.POINTER(C.c_int)]),
     "gsw_ln_rowstats_finish": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "gsw_gemm_ln": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "gsw_gemm_strided": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64,
@@ -95,9 +91,6 @@ _PROTOTYPES = {
     "gsw_softmax_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_float, C.c_int, C.c_void_p]),
     "gsw_mm_config": (C.c_int, [C.c_int, C.c_int]),
     "gsw_mm_get_config": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
-    "gsw_mm_set_workspace": (C.c_int, [C.c_void_p, C.c_int64, C.c_int]),
-    "gsw_mm_next_colstats": (C.c_int, [C.c_void_p, C.c_int64]),
-    "gsw_mm_last_colstats": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "gsw_groupnorm_pf_cs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int,
                                       C.c_int, C.c_void_p]),
@@ -119,8 +112,6 @@ _PROTOTYPES = {
     "gsw_conv3x3_res_pf_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "gsw_conv_up2x_pf_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
-    "gsw_linear": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
-                             C.c_void_p]),
 }
 
 _lib = None

@@ -674,7 +674,3 @@ int gsw_softmax_rows(void* x_dev, int64_t rows, int cols, int64_t ld, float scal
     return GSW_OK;
 }
 
-int gsw_attention_hd64(const void* q_dev, const void* k_dev, const void* vt_dev, void* out_dev, int B, int H, int Sq, int Sk, int Sk_valid, int ldq,
-                       int ldk, int ldo, float scale, int dtype, void* stream) {
-    return gsw_attention(q_dev, k_dev, vt_dev, out_dev, B, H, 64, Sq, Sk, Sk_valid, ldq, ldk, ldo, scale, dtype, stream);
-}

@@ -637,9 +637,8 @@ int gsw_conv_pf_ex(const void* x_dev, const void* w_dev, const void* bias_dev, c
 static int launch_conv_gemm(ConvArgs& a, int64_t M, int N, int dtype, void* stream, GswMmExtras* ex) {
     hipStream_t st = (hipStream_t)stream;
     if (use_engine(a, N)) return launch_engine(a, M, N, dtype, stream, ex);
-    // off the engine: no records, no split-K (a legacy one-shot request is consumed so that it cannot reach a later launch)
+    // off the engine: no records, no split-K
     if (ex) { ex->colstats_rows_per_block = 0; ex->colstats_blocks = 0; ex->rowstats_slots = 0; ex->splits = 1; }
-    else { GswMmExtras drop; gsw_mm_legacy_extras(&drop); gsw_mm_legacy_done(&drop); }
     if (N % CV_BN || a.C1 || a.C2 || a.up) return GSW_ERR_UNSUPPORTED;
     const uint32_t grid = (uint32_t)(((M + CV_BM - 1) / CV_BM) * (N / CV_BN));
     if (dtype == GSW_F16) hipLaunchKernelGGL((gsw_conv_gemm_kernel<_Float16>), dim3(grid), dim3(CV_THREADS), 0, st, a);
@@ -780,12 +779,6 @@ int gsw_add_layernorm(const void* x_dev, const void* delta_dev, const void* gamm
     return GSW_OK;
 }
 
-int gsw_linear(const void* x_dev, const void* w_dev, const void* bias_dev, const void* resid_dev, void* y_dev, int64_t M, int K, int N,
-               int geglu, int dtype, void* stream) {
-    // kept for callers of the round-1 ABI: the same function on the matmul engine (csrc/gswm_mm.hip)
-    return gsw_gemm(x_dev, w_dev, bias_dev, resid_dev, y_dev, M, K, N, geglu ? GSW_GEMM_GEGLU : GSW_GEMM_PLAIN, 0, 0, dtype, stream);
-}
-
 int gsw_conv3x3_res_pf(const void* x_dev, const void* w_dev, const void* bias_dev, const void* rowbias_dev, int ld_rowbias, const void* resid_dev, void* y_dev,
                        int B, int H, int W, int C, int N, const void* x1_dev, int C1, const void* x2_dev, int C2, int dtype, void* stream) {
     return gsw_conv3x3_res_pf_ex(x_dev, w_dev, bias_dev, rowbias_dev, ld_rowbias, resid_dev, y_dev, B, H, W, C, N, x1_dev, C1, x2_dev, C2, dtype, nullptr, stream);
@@ -843,14 +836,13 @@ int gsw_conv_up2x_pf_ex(const void* x_dev, const void* w4_dev, const void* bias_
     const size_t esz = 2;
     // a column-statistics request covers the whole output: each parity launch fills its quarter of the buffer ([4][blocks][N][2]); the four launches
     // report the same geometry (the last one's is handed back), or none of them writes records
-    GswMmExtras legacy, *ex = ex_user;
-    if (!ex) { gsw_mm_legacy_extras(&legacy); ex = &legacy; }
+    GswMmExtras none, *ex = ex_user;
+    if (!ex) { gsw_mm_no_extras(&none); ex = &none; }
     float* const cs_base = ex->colstats_capacity > 0 ? ex->colstats_dev : nullptr;
     const int64_t cs_cap = cs_base ? ex->colstats_capacity : 0;
     GswMmExtras sub = *ex;
-    struct Done { GswMmExtras* user; GswMmExtras* ex; GswMmExtras* sub; bool legacy; ~Done() {
-        ex->colstats_rows_per_block = sub->colstats_rows_per_block; ex->colstats_blocks = sub->colstats_blocks; ex->rowstats_slots = 0; ex->splits = sub->splits;
-        if (legacy) gsw_mm_legacy_done(ex); } } done{ex_user, ex, &sub, ex_user == nullptr};
+    struct Done { GswMmExtras* ex; GswMmExtras* sub; ~Done() {
+        ex->colstats_rows_per_block = sub->colstats_rows_per_block; ex->colstats_blocks = sub->colstats_blocks; ex->rowstats_slots = 0; ex->splits = sub->splits; } } done{ex, &sub};
     sub.colstats_rows_per_block = 0; sub.colstats_blocks = 0; sub.splits = 1;
     for (int par = 0; par < 4; ++par) {
         sub.colstats_dev = cs_base ? cs_base + (size_t)par * (size_t)(cs_cap / 4) : nullptr;

@@ -53,15 +53,13 @@ struct MMArgs {
     float* ws;            // filled by gsw_mm_launch: split-K workspace, [splits][ntiles][8 waves][5 * MT accumulators][64 lanes] float4
 };
 
-// ex: the launch's extras (records requested, split-K scratch; results written back).  nullptr = the DEPRECATED thread-local one-shot state
-// (gsw_mm_next_colstats / gsw_mm_next_rowstats / gsw_mm_set_workspace), which gsw_mm_legacy_extras turns into a struct of the same kind.
+// ex: the launch's extras (records requested, split-K scratch; results written back).  nullptr = none (gsw_mm_no_extras).
 struct GswMmExtras;
 int gsw_mm_launch(MMArgs& a, int dtype, void* stream, GswMmExtras* ex);
-// microseconds the engine's plan (tiling, split-K) predicts for M x N outputs over P stages with these extras (nullptr: the thread-local state): the convolution
+// microseconds the engine's plan (tiling, split-K) predicts for M x N outputs over P stages with these extras (nullptr: none): the convolution
 // front end chooses its row enumeration with it
 double gsw_mm_predict_us(int64_t M, int N, int P, const GswMmExtras* ex);
-// the calling thread's one-shot requests and workspace as extras (the requests are consumed); gsw_mm_legacy_done stores what the launch reported
-void gsw_mm_legacy_extras(GswMmExtras* ex);
-void gsw_mm_legacy_done(const GswMmExtras* ex);
+// an extras struct that requests nothing
+void gsw_mm_no_extras(GswMmExtras* ex);
 
 #endif

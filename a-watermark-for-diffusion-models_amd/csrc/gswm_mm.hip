@@ -1617,75 +1617,13 @@ int mm_launch_e(const MMArgs& a, int epi, uint32_t grid, int mt, hipStream_t st)
 extern __attribute__((visibility("hidden"))) thread_local int g_last_hip_error;   // gswm_kernels.hip
 
 
-// Split-K workspace of the calling thread (caller-owned device memory, see gsw_mm_set_workspace in include/gswm.h) and the split policy
-static thread_local void* t_mm_ws = nullptr;
-static thread_local int64_t t_mm_ws_bytes = 0;
-static thread_local int t_mm_max_splits = 0;          // 0 auto, 1 off, k > 1: split every launch whose K allows it up to k ways (tests)
-
-int gsw_mm_set_workspace(void* ws_dev, int64_t bytes, int max_splits) {
-    if (bytes < 0 || (bytes > 0 && !ws_dev) || max_splits < 0 || max_splits > 64 || ((uintptr_t)ws_dev & 15)) return GSW_ERR_BAD_ARG;
-    t_mm_ws = bytes > 0 ? ws_dev : nullptr;
-    t_mm_ws_bytes = bytes;
-    t_mm_max_splits = max_splits;
-    return GSW_OK;
-}
-
-// DEPRECATED one-shot side channels (ABI < 0.4.0): column / row record requests of the calling thread, consumed (and cleared) by its next engine launch.
-// They are shims over GswMmExtras now: a legacy entry point (ex == NULL) builds its extras from this state and stores the results back here.
-static thread_local float* t_cs_next = nullptr;
-static thread_local int64_t t_cs_cap = 0;
-static thread_local int t_cs_rows = 0, t_cs_blocks = 0;      // what the last launch produced: rows per block (0 = nothing), blocks
-static thread_local bool t_cs_armed = false;                 // a request was armed since the last gsw_mm_last_colstats
-static thread_local float* t_rs_next = nullptr;
-static thread_local int64_t t_rs_cap = 0;
-static thread_local int t_rs_slots = 0;
-static thread_local bool t_rs_armed = false;
-
-void gsw_mm_legacy_extras(GswMmExtras* ex) {
-    ex->colstats_dev = t_cs_next; ex->colstats_capacity = t_cs_cap;
-    ex->rowstats_dev = t_rs_next; ex->rowstats_capacity = t_rs_cap;
-    ex->workspace_dev = t_mm_ws; ex->workspace_bytes = t_mm_ws_bytes; ex->max_splits = t_mm_max_splits;
-    ex->colstats_rows_per_block = 0; ex->colstats_blocks = 0; ex->rowstats_slots = 0; ex->splits = 1;
-    t_cs_next = nullptr; t_cs_cap = 0; t_cs_rows = 0; t_cs_blocks = 0;
-    t_rs_next = nullptr; t_rs_cap = 0; t_rs_slots = 0;
-}
-
-void gsw_mm_legacy_done(const GswMmExtras* ex) {
-    t_cs_rows = ex->colstats_rows_per_block; t_cs_blocks = ex->colstats_blocks;
-    t_rs_slots = ex->rowstats_slots;
-}
-
-int gsw_mm_next_rowstats(float* stats_dev, int64_t capacity_floats) {
-    if (capacity_floats < 0 || (capacity_floats > 0 && !stats_dev) || ((uintptr_t)stats_dev & 7)) return GSW_ERR_BAD_ARG;
-    t_rs_next = capacity_floats > 0 ? stats_dev : nullptr;
-    t_rs_cap = t_rs_next ? capacity_floats : 0;
-    t_rs_slots = 0;
-    t_rs_armed = t_rs_next != nullptr;
-    return GSW_OK;
-}
-
-int gsw_mm_last_rowstats(int* slots) {
-    if (slots) *slots = t_rs_slots;
-    const bool dropped = t_rs_armed && t_rs_slots == 0;
-    t_rs_next = nullptr; t_rs_cap = 0; t_rs_armed = false;
-    return dropped ? GSW_WARN_NO_RECORDS : GSW_OK;
-}
-
-int gsw_mm_next_colstats(float* stats_dev, int64_t capacity_floats) {
-    if (capacity_floats < 0 || (capacity_floats > 0 && !stats_dev) || ((uintptr_t)stats_dev & 15)) return GSW_ERR_BAD_ARG;
-    t_cs_next = capacity_floats > 0 ? stats_dev : nullptr;
-    t_cs_cap = t_cs_next ? capacity_floats : 0;
-    t_cs_rows = 0; t_cs_blocks = 0;
-    t_cs_armed = t_cs_next != nullptr;
-    return GSW_OK;
-}
-
-int gsw_mm_last_colstats(int* rows_per_block, int* blocks) {
-    if (rows_per_block) *rows_per_block = t_cs_rows;
-    if (blocks) *blocks = t_cs_blocks;
-    const bool dropped = t_cs_armed && t_cs_rows == 0;
-    t_cs_next = nullptr; t_cs_cap = 0; t_cs_armed = false;   // a request the launch never saw (a kernel off the engine) must not reach a later launch
-    return dropped ? GSW_WARN_NO_RECORDS : GSW_OK;
+// An engine launch without extras (a nullptr `ex` of an entry point): no records requested, no split-K scratch.  ABI < 0.5.0 kept thread-local one-shot
+// requests and a thread-local workspace behind this case; since 0.5.0 everything a launch needs travels in the caller's GswMmExtras.
+void gsw_mm_no_extras(GswMmExtras* ex) {
+    ex->colstats_dev = nullptr; ex->colstats_capacity = 0;
+    ex->rowstats_dev = nullptr; ex->rowstats_capacity = 0;
+    ex->workspace_dev = nullptr; ex->workspace_bytes = 0; ex->max_splits = 0;
+    ex->colstats_rows_per_block = 0; ex->colstats_blocks = 0; ex->rowstats_slots = 0; ex->splits = 1; ex->flags = 0;
 }
 
 int gsw_build_flags(void) { return GSW_MM_BUILD_FLAGS; }
@@ -1779,23 +1717,21 @@ static MMPlan mm_plan(int64_t M, int64_t tiles_n, int32_t P, bool can_split, int
 }
 
 // What the plan of a launch of M x N outputs over P stages predicts (microseconds): the convolution front end chooses between its two row enumerations with it.
-// ex: the launch's extras, or nullptr for the calling thread's deprecated one-shot state.
+// ex: the launch's extras, or nullptr (no split-K scratch).
 double gsw_mm_predict_us(int64_t M, int N, int P, const GswMmExtras* ex) {
-    const bool have_ws = ex ? (ex->workspace_bytes > 0 && ex->workspace_dev) : (t_mm_ws != nullptr && t_mm_ws_bytes > 0);
-    const int max_splits = ex ? ex->max_splits : t_mm_max_splits;
+    const bool have_ws = ex && ex->workspace_bytes > 0 && ex->workspace_dev;
+    const int max_splits = ex ? ex->max_splits : 0;
     const MMPlan pl = mm_plan(M, ((int64_t)N + 159) / 160, P, have_ws && max_splits != 1, max_splits);
     const int64_t need = (int64_t)pl.splits * (((M + pl.bm - 1) / pl.bm) * (((int64_t)N + 159) / 160)) * 8 * 5 * (pl.bm / 64) * 64 * 16;
-    if (pl.splits >= 2 && need > (ex ? ex->workspace_bytes : t_mm_ws_bytes)) return mm_plan(M, ((int64_t)N + 159) / 160, P, false, 1).t_us;
+    if (pl.splits >= 2 && need > (ex ? ex->workspace_bytes : 0)) return mm_plan(M, ((int64_t)N + 159) / 160, P, false, 1).t_us;
     return pl.t_us;
 }
 
 // Launch the engine for a prepared MMArgs (segments, weights, epilogue); fills the tiling fields.
 int gsw_mm_launch(MMArgs& a, int dtype, void* stream, GswMmExtras* ex) {
-    GswMmExtras legacy;
-    const bool is_legacy = ex == nullptr;
-    if (is_legacy) { gsw_mm_legacy_extras(&legacy); ex = &legacy; }
+    GswMmExtras none;
+    if (!ex) { gsw_mm_no_extras(&none); ex = &none; }
     else { ex->colstats_rows_per_block = 0; ex->colstats_blocks = 0; ex->rowstats_slots = 0; ex->splits = 1; }
-    struct Done { GswMmExtras* e; bool legacy; ~Done() { if (legacy) gsw_mm_legacy_done(e); } } done{ex, is_legacy};
     if (dtype != GSW_F16 && dtype != GSW_BF16) return GSW_ERR_BAD_ARG;
     if (ex->colstats_capacity < 0 || ex->rowstats_capacity < 0 || ex->workspace_bytes < 0 || ex->max_splits < 0 || ex->max_splits > 64
         || ((uintptr_t)ex->colstats_dev & 15) || ((uintptr_t)ex->rowstats_dev & 7) || ((uintptr_t)ex->workspace_dev & 15)

@@ -67,13 +67,15 @@ def recover_exactracted_message_batch(latents: torch.Tensor, args):
 
 
 def calculate_bit_accuracy(original_message_hex, extracted_message_bin):
-    """extract.py:103-110 (host string arithmetic; the batched device form is codec.bit_matches)."""
-    original_message_bin = bin(int(original_message_hex, 16))[2:].zfill(len(original_message_hex) * 4)
-    min_length = min(len(original_message_bin), len(extracted_message_bin))
-    original_message_bin = original_message_bin[:min_length]
-    extracted_message_bin = extracted_message_bin[:min_length]
-    matching_bits = sum(1 for x, y in zip(original_message_bin, extracted_message_bin) if x == y)
-    return original_message_bin, matching_bits / min_length
+    """Host twin of extract.py:103-110: (the key's bits as a '0'/'1' string cut to the common length, fraction of positions that agree).  The hex string
+    becomes 4 bits per digit, MSB first, leading zeros kept; the shorter of the two strings bounds
+    the comparison; an empty comparison divides by zero like the reference does.  The batched device form is codec.bit_matches."""
+    width = 4 * len(original_message_hex)                           # four bits per hex digit, leading zeros kept
+    want = format(int(original_message_hex, 16), "b").zfill(width)  # (ValueError for a non-hex string, like the reference)
+    n = min(len(want), len(extracted_message_bin))
+    want = want[:n]
+    agree = sum(a == b for a, b in zip(want, extracted_message_bin))
+    return want, agree / n
 
 
 # =====================================================================================================================

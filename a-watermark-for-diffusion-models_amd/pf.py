@@ -77,31 +77,15 @@ class PF:
         return self.interior.reshape(self.B, self.H * self.W, self.C)
 
 
-# ---- split-K workspace of the matmul engine (gsw_mm_set_workspace): one scratch buffer per (device, stream), handed to the library whenever the
-# calling thread's (device, stream) changes.  Launches on one stream share it (a launch and its reduce kernel are stream-ordered).
+# ---- split-K workspace of the matmul engine (GswMmExtras.workspace_*): one scratch buffer per (device, stream), handed to every launch in its extras.
+# Launches on one stream share it (a launch and its reduce kernel are stream-ordered).
 SPLITK_BYTES = 40 << 20        # 256 slabs of 160 KiB (256-row tiles; 80 KiB for 128-row tiles): every launch that splits fits
 GN_ONLY_SKIPS_BORDER = True    # conv_pf(gn_only=True): no border zeroing behind a convolution whose output only a record-fed GroupNorm reads (A/B switch)
 ATTN_KEY_SPLIT = True          # self-attention with few query tiles (one image) splits its keys over several workgroups (gsw_attention_ws)
 LAUNCH_LOG = None              # a list: every engine launch appends its GswMmExtras (tests: which launches split, and how)
 SPLITK_MAX = 0                 # 0 automatic, 1 never split, k > 1: force k-way splits wherever K allows (parity tests)
 _WS = {}
-_WS_TLS = __import__("threading").local()
 _WS_OVERRIDE: Optional[torch.Tensor] = None
-
-
-def _ensure_workspace(device) -> None:
-    dev = torch.device(device)
-    ov = _WS_OVERRIDE
-    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream if ov is None else ("override", ov.data_ptr()), SPLITK_MAX)
-    if getattr(_WS_TLS, "last", None) == key:
-        return
-    ws = ov
-    if ws is None:
-        ws = _WS.get(key[:2])
-        if ws is None:
-            ws = _WS[key[:2]] = torch.empty(SPLITK_BYTES, dtype=torch.uint8, device=dev)
-    N.check(N.lib().gsw_mm_set_workspace(ws.data_ptr(), ws.numel(), int(SPLITK_MAX)))
-    _WS_TLS.last = key
 
 
 def _workspace(device) -> torch.Tensor:
@@ -118,7 +102,7 @@ def _workspace(device) -> torch.Tensor:
 
 
 def _extras(device, colstats: Optional[torch.Tensor] = None, rowstats: Optional[torch.Tensor] = None) -> "N.GswMmExtras":
-    """GswMmExtras of one launch (include/gswm.h): explicit arguments instead of the deprecated thread-local one-shot calls"""
+    """GswMmExtras of one launch (include/gswm.h): the records it should write, its split-K scratch and policy"""
     ws = _workspace(device)
     ex = N.GswMmExtras()
     if colstats is not None:
@@ -146,12 +130,11 @@ class splitk_workspace:
     def __exit__(self, *exc):
         global _WS_OVERRIDE
         _WS_OVERRIDE = self.prev
-        _WS_TLS.last = None
         return False
 
 
 
-# ---- GroupNorm statistics from the producing launch (gsw_mm_next_colstats / gsw_groupnorm_pf_cs): the engine's convolution / token-scatter
+# ---- GroupNorm statistics from the producing launch (GswMmExtras.colstats_* / gsw_groupnorm_pf_cs): the engine's convolution / token-scatter
 # epilogue also writes per-block, per-column (sum, sum of squares) records of what it stores; the GroupNorm that consumes the tensor folds
 # them instead of reading the tensor once more (that pass was 2.6 % of the end-to-end run).
 FUSE_GN_STATS = True
@@ -459,17 +442,8 @@ def pack_geglu_weight(w: torch.Tensor, b: Optional[torch.Tensor]):
 
 
 def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], *, resid: Optional[torch.Tensor] = None, geglu: bool = False) -> torch.Tensor:
-    """x[..., K] @ w[N, K]^T + bias (+ resid) on the MFMA GEMM kernel; geglu=True expects pack_geglu_weight operands."""
-    K = x.shape[-1]
-    M = x.numel() // K
-    Nn = w.shape[0]
-    out = torch.empty((*x.shape[:-1], Nn // 2 if geglu else Nn), dtype=x.dtype, device=x.device)
-    with torch.cuda.device(x.device):
-        _ensure_workspace(x.device)
-        N.check(N.lib().gsw_linear(x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None,
-                                   resid.data_ptr() if resid is not None else None, out.data_ptr(), M, K, Nn, 1 if geglu else 0,
-                                   _dt(x.dtype), _stream_ptr()))
-    return out
+    """x[..., K] @ w[N, K]^T + bias (+ resid) on the matmul engine; geglu=True expects pack_geglu_weight operands.  (The round-1 name of `gemm`.)"""
+    return gemm(x, w, bias, resid=resid, mode="geglu" if geglu else "plain")
 
 
 GEMM_MODES = {"plain": 0, "geglu": 1, "trans": 2, "tok2pf": 3}
@@ -656,7 +630,6 @@ def gemm_qkv(x: torch.Tensor, w: torch.Tensor, n_rows: int, bias: Optional[torch
     vt = torch.empty((B, Nn - n_rows, S), dtype=x.dtype, device=x.device)
     tm = CONV_TIMER
     with torch.cuda.device(x.device):
-        _ensure_workspace(x.device)
         e0 = tm.start() if tm is not None else None
         N.check(N.lib().gsw_gemm_qkv(x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None, rows.data_ptr(), vt.data_ptr(),
                                      B * S, K, n_rows, Nn, S, _dt(x.dtype), _stream_ptr()))

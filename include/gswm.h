@@ -33,7 +33,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define GSW_VERSION 401 /* 0.4.0: explicit-argument launches (GswMmExtras, gsw_*_ex); the one-shot side channels (gsw_mm_next_colstats / gsw_mm_next_rowstats / gsw_mm_set_workspace) are deprecated shims over them; gsw_mm_last_colstats / gsw_mm_last_rowstats return GSW_WARN_NO_RECORDS for a dropped request; small-batch kernels (gsw_groupnorm_pf_fused, gsw_gather_rows, gsw_nchw_to_pf, gsw_conv3x3_pf_nchw, gsw_gemm_small).  0.3.1: 0.3.1: gsw_gemm / gsw_gemm_strided (PLAIN, GEGLU) want a 16-byte aligned bias.  0.3.0: gsw_conv_pf / gsw_conv3x3_res_pf take ld_rowbias; gsw_mm_set_workspace (split-K).  0.2.0: GEGLU weights packed per 16-row block (see gsw_gemm) */
+#define GSW_VERSION 500 /* 0.5.0: every engine launch takes what it needs besides its operands in a caller-owned GswMmExtras (gsw_*_ex; the plain entry points request nothing); the thread-local one-shot side channels of ABI 0.3 (gsw_mm_next_colstats / gsw_mm_last_colstats / gsw_mm_next_rowstats / gsw_mm_last_rowstats / gsw_mm_set_workspace) and the round-1 aliases gsw_linear / gsw_attention_hd64 are gone; gsw_xattn_fused is new */
 
 #define GSW_MSG_INLINE_MAX 256 /* message bytes carried inside the kernel arguments (2048 bit) */
 
@@ -51,8 +51,8 @@ typedef enum gsw_status {
     GSW_ERR_RAGGED = 3,      /* 8*ceil(n_elems/8) is not a multiple of msg_bits: the reference raises
                                 IndexError at extract.py:98                                             */
     GSW_ERR_HIP = 4,         /* a HIP runtime call failed; gsw_last_hip_error() has the hipError_t      */
-    GSW_WARN_NO_RECORDS = 5  /* gsw_mm_last_colstats / gsw_mm_last_rowstats: a request WAS armed but the launch that consumed it wrote no records
-                                (it split K, enumerated whole tensors, or ran off the engine) -- the caller must take the statistics pass instead */
+    GSW_WARN_NO_RECORDS = 5  /* (ABI < 0.5.0: the one-shot record queries reported a dropped request with it; a launch now says what it wrote in
+                                GswMmExtras.colstats_rows_per_block / rowstats_slots -- 0 means: take the statistics pass instead) */
 } gsw_status;
 
 /* embed flags */
@@ -159,13 +159,25 @@ int gsw_groupnorm_pf(const void* x_dev, const void* gamma_dev, const void* beta_
 int gsw_groupnorm_pf2(const void* x_dev, const void* x2_dev, int Ca, const void* gamma_dev, const void* beta_dev, void* out_dev, float* workspace_dev,
                       int B, int H, int W, int C, int groups, float eps, int act, int out_tokens, int dtype, void* stream);
 
-/* ---- Explicit-argument launches of the matmul engine (ABI 0.4.0).  Everything a launch needs besides its operands travels in ONE caller-owned struct:
- * no thread-local "arm, then launch" state, nothing shared between two streams of one thread, and what the launch actually did comes back in the
- * same struct.  The one-shot calls further down (gsw_mm_next_colstats, gsw_mm_next_rowstats, gsw_mm_set_workspace) are kept as DEPRECATED shims
- * over this: new callers pass a GswMmExtras (or NULL for "no records, no split-K").
- *   colstats_dev / colstats_capacity : in  -- request the column records of gsw_mm_next_colstats (NULL: none)
- *   rowstats_dev / rowstats_capacity : in  -- request the row records of gsw_mm_next_rowstats (NULL: none)
- *   workspace_dev / workspace_bytes / max_splits : in -- split-K scratch and policy, as gsw_mm_set_workspace (NULL: the launch runs unsplit)
+/* ---- Extras of a matmul-engine launch (ABI 0.4.0; the only form since 0.5.0).  Everything a launch needs besides its operands travels in ONE caller-owned
+ * struct: no thread-local "arm, then launch" state, nothing shared between two streams of one thread, and what the launch actually did comes back in the
+ * same struct.  NULL in place of a GswMmExtras* means "no records, no split-K".
+ *   colstats_dev / colstats_capacity : in  -- GroupNorm statistics without a pass over the tensor: a convolution / token-scatter launch (gsw_conv_pf_ex,
+ *                          gsw_conv3x3_res_pf_ex, gsw_conv_up2x_pf_ex, gsw_gemm_ex with GSW_GEMM_TOK2PF) also writes, per block of 32 or 64 consecutive output pixels and per
+ *                          PAIR of output columns (2c, 2c + 1), the sum and the sum of squares of the values it stores: [npar][blocks][2 planes: sums | sums of squares][N / 2]
+ *                          floats, npar = 1 (4 for gsw_conv_up2x_pf_ex: one quarter of the buffer per parity launch, records over the low-resolution pixels);
+ *                          capacity >= npar * ceil(M / 128) * 4 * N floats covers either tile height (M = output pixels of ONE launch); 16-byte aligned (NULL: none)
+ *   rowstats_dev / rowstats_capacity : in  -- LayerNorm statistics likewise: a plain gsw_gemm_ex (+ residual) also writes, per output row and 80-column half tile, the
+ *                          (sum, sum of squares) of what it stores: [M][slots][2] floats, capacity >= M * 2 ceil(N / 160) * 2 (NULL: none)
+ *   workspace_dev / workspace_bytes / max_splits : in -- split-K scratch (caller-owned device memory, 16-byte aligned, on the device of the launch's stream) and policy.
+ *                          Small-batch launches of the eps model -- one image's 8 x 8 level is a single 64-row tile against 180-360 K stages (the reference's own use:
+ *                          extract.py:112-117 inverts ONE latent per call) -- cannot fill 256 CUs with output tiles.  With a workspace, a launch whose 128- or 256-row
+ *                          tiling has <= 128 tiles lets up to 32 workgroups share a tile's K stages (at most 256 workgroups in all) whenever the engine's cost model
+ *                          (fitted to tools/splitk_tile_sweep.py) predicts a gain of 5 % or more: each workgroup dumps its fp32 accumulators into a slab and a second
+ *                          kernel adds the slabs in split order (deterministic) and runs the epilogue of the launch's mode.  40 MiB covers every launch (256 slabs of
+ *                          160 KiB: 256-row tiles; 128-row tiles need half).  The workspace is scratch between a launch and its reduce kernel, both on the launch's
+ *                          stream: launches on ONE stream may share it, launches on different streams need different workspaces.  max_splits: 0 = automatic, 1 = never
+ *                          split, k > 1 = split every launch min(k, stages, 256 / tiles) ways (parity tests).  (NULL / 0 bytes: the launch runs unsplit)
  *   colstats_rows_per_block, colstats_blocks : out -- 0 / 0 when the launch wrote no column records (it split K, enumerated whole tensors, ...)
  *   rowstats_slots : out -- records per row written (0: none)
  *   splits         : out -- K splits of the launch (1: unsplit)
@@ -186,7 +198,7 @@ typedef struct GswMmExtras {
     int flags;
 } GswMmExtras;
 
-/* gsw_gemm_strided / gsw_gemm_ln / gsw_conv_pf / gsw_conv3x3_res_pf / gsw_conv_up2x_pf with explicit extras (ex may be NULL). */
+/* gsw_gemm_strided / gsw_gemm_ln / gsw_conv_pf / gsw_conv3x3_res_pf / gsw_conv_up2x_pf with extras (ex may be NULL; the plain entry points ARE ex = NULL). */
 int gsw_gemm_ex(const void* x_dev, int64_t ldx, const void* w_dev, int64_t ldw, const void* bias_dev, const void* resid_dev, int64_t ldr, void* y_dev, int64_t ldy,
                 int64_t M, int K, int N, int mode, int S, int Wimg, int dtype, GswMmExtras* ex, void* stream);
 int gsw_gemm_ln_ex(const void* x_dev, const float* ln_stat_dev, const void* w_dev, const float* u_dev, const float* v_dev, void* y_dev, int64_t M, int K, int N,
@@ -198,19 +210,9 @@ int gsw_conv3x3_res_pf_ex(const void* x_dev, const void* w_dev, const void* bias
 int gsw_conv_up2x_pf_ex(const void* x_dev, const void* w4_dev, const void* bias_dev, void* y_dev, int B, int H, int W, int C, int N, int dtype, GswMmExtras* ex,
                         void* stream);
 
-/* (DEPRECATED one-shot form; see GswMmExtras.)  GroupNorm statistics without a pass over the tensor.  gsw_mm_next_colstats arms a ONE-SHOT request of the calling thread: the next convolution /
- * token-scatter launch of the matmul engine (gsw_conv_pf, gsw_conv3x3_res_pf, gsw_conv_up2x_pf, gsw_gemm with GSW_GEMM_TOK2PF) also writes, per
- * block of 32 or 64 consecutive output pixels and per PAIR of output columns (2c, 2c + 1), the sum and the sum of squares of the values it stores:
- *   stats_dev [npar][blocks][2 planes: sums | sums of squares][N / 2] floats, npar = 1 (4 for gsw_conv_up2x_pf: one quarter of the buffer per parity
- *   launch, records over the low-resolution pixels); capacity_floats >= npar * ceil(M / 128) * 4 * N covers either tile height (M = output pixels
- *   of ONE launch).
- * gsw_mm_last_colstats reports what the launch produced -- rows per block (0: nothing, e.g. a split-K or whole-tensor launch, or a kernel off the
- * engine) and blocks written -- and clears a request no launch consumed; it returns GSW_WARN_NO_RECORDS (not GSW_OK) when a request had been armed
- * and came back empty.  gsw_groupnorm_pf_cs is gsw_groupnorm_pf2 with the statistics folded from
- * such records (cs*_blocks = blocks per parity buffer, i.e. the buffer's stride): pixels per image must be a multiple of the block rows and the
- * groups an even number of channels wide; workspace_dev >= max(B * 64 * groups * 2, B * C) floats. */
-int gsw_mm_next_colstats(float* stats_dev, int64_t capacity_floats);
-int gsw_mm_last_colstats(int* rows_per_block, int* blocks);
+/* gsw_groupnorm_pf2 with the statistics folded from the column records of the producing launches (GswMmExtras.colstats_*; cs*_rows = rows per block the launch
+ * reported, cs*_blocks = blocks per parity buffer, i.e. the buffer's stride): pixels per image must be a multiple of the block rows and the groups an even number
+ * of channels wide; workspace_dev >= max(B * 64 * groups * 2, B * C) floats. */
 int gsw_groupnorm_pf_cs(const void* x_dev, const void* x2_dev, int Ca, const float* cs1_dev, int cs1_rows, int cs1_npar, int cs1_blocks,
                         const float* cs2_dev, int cs2_rows, int cs2_npar, int cs2_blocks, const void* gamma_dev, const void* beta_dev, void* out_dev,
                         float* workspace_dev, int B, int H, int W, int C, int groups, float eps, int act, int out_tokens, int dtype, void* stream);
@@ -226,8 +228,6 @@ int gsw_add_layernorm(const void* x_dev, const void* delta_dev, const void* gamm
                       int64_t rows, int C, float eps, int dtype, void* stream);
 
 /* Round-1 name of the dense linear layer: gsw_gemm(mode = geglu ? GSW_GEMM_GEGLU : GSW_GEMM_PLAIN). */
-int gsw_linear(const void* x_dev, const void* w_dev, const void* bias_dev, const void* resid_dev, void* y_dev, int64_t M, int K, int N,
-               int geglu, int dtype, void* stream);
 
 /* X2 / G1 -- every dense linear layer of the eps model (diffusers BasicTransformerBlock / Transformer2DModel / TimestepEmbedding /
  * ResnetBlock2D.time_emb_proj, which the reference reaches through `pipe(...)` at extract.py:66-69) on the hand-written matmul engine
@@ -259,15 +259,10 @@ int gsw_gemm_qkv(const void* x_dev, const void* w_dev, const void* bias_dev, voi
 /* LayerNorm folded into the GEMM that consumes it (diffusers BasicTransformerBlock: norm1 -> to_q | to_k | to_v, norm2 -> to_q, norm3 -> the GEGLU
  * projection): LN(x) W^T + b = rstd_m (x W'^T)_mn - rstd_m mean_m u_n + v_n with W' = W diag(gamma), u = W' 1, v = W beta + b -- the normalised tensor
  * is never written or read.
- *   gsw_mm_next_rowstats : one-shot request (like gsw_mm_next_colstats): the next plain gsw_gemm (+ residual) also writes, per output row and 80-column
- *                          half tile, the (sum, sum of squares) of what it stores: stats_dev [M][slots][2] floats, capacity >= M * 2 ceil(N / 160) * 2.
- *   gsw_mm_last_rowstats : slots written per row (0: the launch produced none, e.g. split-K; the call then returns GSW_WARN_NO_RECORDS); clears an
- *                          unconsumed request.  (DEPRECATED one-shot form of GswMmExtras.rowstats_*.)
+ *   row records          : GswMmExtras.rowstats_* of the launch that PRODUCES x (rowstats_slots records per row come back)
  *   gsw_ln_rowstats_finish: records -> stat_dev float2 [M] = (rstd, -rstd * mean) over the C columns.
  *   gsw_gemm_ln          : the consuming GEMM; w_dev = W' (GEGLU: packed like gsw_gemm), u_dev / v_dev fp32 [N] in the same row order, 16-byte aligned;
  *                          mode GSW_GEMM_PLAIN / GSW_GEMM_GEGLU / GSW_GEMM_TRANS; M % 8 == 0. */
-int gsw_mm_next_rowstats(float* stats_dev, int64_t capacity_floats);
-int gsw_mm_last_rowstats(int* slots);
 int gsw_ln_rowstats_finish(const float* records_dev, int slots, int64_t M, int C, float eps, float* stat_dev, void* stream);
 int gsw_gemm_ln(const void* x_dev, const float* ln_stat_dev, const void* w_dev, const float* u_dev, const float* v_dev, void* y_dev, int64_t M, int K, int N,
                 int mode, int S, int dtype, void* stream);
@@ -286,18 +281,6 @@ int gsw_gemm_strided(const void* x_dev, int64_t ldx, const void* w_dev, int64_t 
  *                waves 8-11 own the LDS-DMA; -1 = keep (default 10: convolutions and the transposed projection) */
 int gsw_mm_config(int tile_rows, int split_mask);
 int gsw_mm_get_config(int* tile_rows, int* split_mask); /* the current values (either pointer may be NULL): what a captured launch sequence depends on */
-
-/* (DEPRECATED thread-local form of GswMmExtras.workspace_*.)  Split-K workspace of the CALLING THREAD (caller-owned device memory on the device of the streams it launches on; 16-byte aligned).
- * Small-batch launches of the eps model -- one image's 8 x 8 level is a single 64-row tile against 180-360 K stages (the reference's own use:
- * extract.py:112-117 inverts ONE latent per call) -- cannot fill 256 CUs with output tiles.  When a workspace is set, a launch whose 128- or 256-row
- * tiling has <= 128 tiles lets up to 32 workgroups share a tile's K stages (at most 256 workgroups in all) whenever the engine's cost model (fitted to
- * tools/splitk_tile_sweep.py) predicts a gain of 5 % or more: each workgroup dumps its fp32 accumulators into a slab ([splits][tiles][8 waves][5 * (tile rows / 64) accumulators][64 lanes] float4), and
- * a second kernel adds the slabs in split order (deterministic) and runs the epilogue of the launch's mode.  bytes = 0 removes the workspace
- * (launches run unsplit).  40 MiB covers every launch (256 slabs of 160 KiB: 256-row tiles; 128-row tiles need half).
- * The workspace is scratch between a launch and its reduce kernel, both on the launch's stream: launches on ONE stream may share it, launches
- * on different streams need different workspaces (set one per stream before launching there).
- *   max_splits : 0 = automatic, 1 = never split, k > 1 = split every launch min(k, stages, 256 / tiles) ways (parity tests) */
-int gsw_mm_set_workspace(void* ws_dev, int64_t bytes, int max_splits);
 
 /* X1 / G1 tail -- diffusers AutoencoderKL mid-block attention (one head as wide as the block, 512): softmax over the rows of the score matrix
  * between the two engine products.  In place: x[r, 0:cols] <- softmax(scale * x[r, 0:cols]); rows `ld` elements apart; cols % 8 == 0. */
@@ -355,7 +338,7 @@ int gsw_conv_up2x_pf(const void* x_dev, const void* w4_dev, const void* bias_dev
  *   out : [B, Sq, >= H*head_dim] row stride ldo
  *   Sk_valid : keys in [Sk_valid, Sk) are padding and get zero weight (cross-attention: 77 context tokens padded to 128)
  * Any Sq; Sk % 8 == 0; strides % 8 == 0; else GSW_ERR_UNSUPPORTED (sequences off the 128-query / 64-key tiles run a variant with clamped
- * loads and masked keys).  gsw_attention_hd64 == gsw_attention(head_dim = 64). */
+ * loads and masked keys). */
 int gsw_attention(const void* q_dev, const void* k_dev, const void* vt_dev, void* out_dev, int B, int H, int head_dim, int Sq, int Sk,
                   int Sk_valid, int ldq, int ldk, int ldo, float scale, int dtype, void* stream);
 /* The same with a caller-owned scratch buffer (16-byte aligned device memory, free again when the launch's stream has run it): few query tiles against many
@@ -377,8 +360,6 @@ int gsw_attention_ws(const void* q_dev, const void* k_dev, const void* vt_dev, v
 int gsw_xattn_fused(const void* x_dev, const float* ln_stat_dev, const void* blob_dev, int64_t blob_stride_bytes, const float* v_dev, int64_t v_stride_floats,
                     const int32_t* ctx_index_dev, void* out_dev, float* out_stat_dev, float out_eps, int x_images, int out_images, int tokens, int C, int heads,
                     int dtype, void* stream);
-int gsw_attention_hd64(const void* q_dev, const void* k_dev, const void* vt_dev, void* out_dev, int B, int H, int Sq, int Sk, int Sk_valid,
-                       int ldq, int ldk, int ldo, float scale, int dtype, void* stream);
 
 /* E4, bit-parity mode -- gs_insert.py:62 `np.random.uniform(0, 1)` / nodes.py:52-53,114-117 `RandomState(seed).uniform(0, 1)`:
  * NumPy's legacy MT19937 `random_sample` stream continued on the device.  key/pos: the generator state as

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"libgswm.so does not export {s}"
     assert sorted(N.exported_symbols()) == syms            # the ctypes prototypes cover the whole header
-    assert lib.gsw_version() == 401
+    assert lib.gsw_version() == 500
     assert lib.gsw_strerror(0) == b"ok" and b"IndexError" in lib.gsw_strerror(N.GSW_ERR_RAGGED)
 
 
@@ -191,16 +191,9 @@ def test_argument_validation_of_eps_model_and_image_entry_points():
     assert lib.gsw_gemm_qkv(p, p, None, p, p, 256, 320, 600, 960, 128, 1, None) == UNS                           # a column tile must be of one kind
     assert lib.gsw_gemm_qkv(p, p, None, p, None, 256, 320, 640, 960, 128, 1, None) == BAD                        # no transposed output
     assert lib.gsw_gemm_qkv(p, p, None, p, p, 256, 320, 640, 960, 100, 1, None) == UNS                           # S % 8
-    # split-K workspace / column-statistics requests: per-thread state, validated without touching the device
-    assert lib.gsw_mm_set_workspace(None, 16, 0) == BAD and lib.gsw_mm_set_workspace(p, -1, 0) == BAD and lib.gsw_mm_set_workspace(p, 16, 65) == BAD
-    assert lib.gsw_mm_set_workspace(ctypes.c_void_p(72), 1024, 0) == BAD                                         # 16-byte alignment
-    assert lib.gsw_mm_set_workspace(p, 1 << 20, 0) == N.GSW_OK and lib.gsw_mm_set_workspace(None, 0, 0) == N.GSW_OK
-    assert lib.gsw_mm_next_colstats(None, 16) == BAD and lib.gsw_mm_next_colstats(ctypes.c_void_p(68), 16) == BAD
-    rows, blocks = ctypes.c_int(-1), ctypes.c_int(-1)
-    assert lib.gsw_mm_next_colstats(p, 1 << 10) == N.GSW_OK
-    # an armed request that comes back empty is reported (nothing launched here); the request is cleared, a second call has nothing to complain about
-    assert lib.gsw_mm_last_colstats(ctypes.byref(rows), ctypes.byref(blocks)) == N.GSW_WARN_NO_RECORDS and rows.value == 0 and blocks.value == 0
-    assert lib.gsw_mm_last_colstats(ctypes.byref(rows), ctypes.byref(blocks)) == N.GSW_OK
+    # (ABI 0.5.0: the thread-local one-shot requests and the thread-local workspace are gone -- their validation lives on the GswMmExtras checks below)
+    for gone in ("gsw_mm_set_workspace", "gsw_mm_next_colstats", "gsw_mm_last_colstats", "gsw_mm_next_rowstats", "gsw_mm_last_rowstats", "gsw_linear", "gsw_attention_hd64"):
+        assert not hasattr(lib, gone), gone
     assert lib.gsw_groupnorm_pf_cs(p, None, 0, p, 64, 1, 4, None, 0, 0, 0, p, p, p, p, 1, 8, 8, 330, 33, 1e-5, 1, 0, 1, None) == UNS  # C % 8
     assert lib.gsw_groupnorm_pf_cs(p, None, 0, p, 64, 1, 4, None, 0, 0, 0, p, p, p, p, 1, 8, 8, 96, 32, 1e-5, 1, 0, 1, None) == UNS   # odd group width (column pairs)
     assert lib.gsw_groupnorm_pf_cs(p, None, 0, p, 48, 1, 4, None, 0, 0, 0, p, p, p, p, 1, 8, 8, 320, 32, 1e-5, 1, 0, 1, None) == UNS  # 64 pixels per image, 48-row blocks
@@ -212,11 +205,7 @@ def test_argument_validation_of_eps_model_and_image_entry_points():
     assert lib.gsw_gemm_ln(p, p, p, p, p, p, 256, 320, 640, 3, 0, 1, None) == BAD                                 # no token scatter
     assert lib.gsw_gemm_ln(p, p, p, ctypes.c_void_p(68), p, p, 256, 320, 640, 0, 0, 1, None) == BAD               # u alignment
     assert lib.gsw_ln_rowstats_finish(None, 4, 256, 320, 1e-5, p, None) == BAD and lib.gsw_ln_rowstats_finish(p, 0, 256, 320, 1e-5, p, None) == BAD
-    slots = ctypes.c_int(-1)
-    assert lib.gsw_mm_next_rowstats(None, 16) == BAD and lib.gsw_mm_next_rowstats(p, 1 << 10) == N.GSW_OK
-    assert lib.gsw_mm_last_rowstats(ctypes.byref(slots)) == N.GSW_WARN_NO_RECORDS and slots.value == 0
-    assert lib.gsw_mm_last_rowstats(ctypes.byref(slots)) == N.GSW_OK
-    # explicit-argument launches (GswMmExtras): validated like their one-shot predecessors, nothing armed, nothing left behind
+    # GswMmExtras: validated before anything touches the device, nothing armed, nothing left behind
     ex = N.GswMmExtras()
     ex.colstats_dev, ex.colstats_capacity = 68, 16
     assert lib.gsw_gemm_ex(p, 64, p, 64, None, None, 160, p, 160, 4, 64, 160, 0, 0, 0, 1, ctypes.byref(ex), None) == BAD         # colstats alignment

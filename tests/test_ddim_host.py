@@ -54,3 +54,11 @@ def test_dpms_inverse_coefficient_form_equals_stepwise_form(steps):
         m_prev = m0
     np.testing.assert_allclose(x, ref, rtol=0, atol=1e-10)
     assert np.isfinite(ref).all()
+
+
+@pytest.mark.parametrize("steps", [0, -3, 1001])
+def test_schedule_refuses_a_step_count_outside_its_training_range(steps):
+    """0 steps used to surface as a ZeroDivisionError from the ratio, more steps than training timesteps as a ratio of 0: both are ValueErrors of the schedule now"""
+    with pytest.raises(ValueError, match="num_inference_steps"):
+        ddim.DDIMSchedule(num_inference_steps=steps)
+    assert ddim.DDIMSchedule(num_inference_steps=1000, steps_offset=0).ratio == 1 and ddim.DDIMSchedule(num_inference_steps=1, steps_offset=0).timesteps_desc.tolist() == [0]

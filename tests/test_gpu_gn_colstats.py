@@ -1,4 +1,4 @@
-"""GPU: GroupNorm statistics from the producing launch's column records (gsw_mm_next_colstats -> gsw_groupnorm_pf_cs) against the separate
+"""GPU: GroupNorm statistics from the producing launch's column records (GswMmExtras.colstats_* -> gsw_groupnorm_pf_cs) against the separate
 statistics pass and against fp32 torch GroupNorm of the same tensor: every producer (3x3 / stride-2 / 1x1 convolution, the three-segment resnet
 launch, the sub-pixel upsampler's four parity launches, the token scatter), both tile heights, images smaller than a tile (8 x 8: four images per
 256-row tile), the channel concatenation of two producers (a skip connection), and the fall-back when a launch cannot produce records."""
@@ -138,24 +138,29 @@ def test_token_scatter_replaces_the_records_and_tokens_output(G, tile_rows):
     assert (t_cs.float() - ref).abs().max().item() <= 4e-3 * max(1.0, ref.abs().max().item())
 
 
-def test_a_request_no_launch_consumed_does_not_leak(G):
-    """a convolution off the engine (64 output columns) never sees the request; the next engine launch must not write into it"""
-    buf = torch.zeros(1 << 16, dtype=torch.float32, device="cuda")
-    assert G.lib.gsw_mm_next_colstats(buf.data_ptr(), buf.numel()) == 0
+def test_a_launch_off_the_engine_reports_no_records(G):
+    """a convolution off the engine (64 output columns) writes no records and says so in its extras; nothing is armed for a later launch (ABI 0.5.0: there is no
+    state a request could linger in)"""
     import ctypes as C
-    rows, blocks = C.c_int(-1), C.c_int(-1)
-    assert G.lib.gsw_mm_last_colstats(C.byref(rows), C.byref(blocks)) == 5 and rows.value == 0          # GSW_WARN_NO_RECORDS: armed, nothing written
-    x = torch.randn(2, 64, 16, 16, device="cuda").half()
-    w = torch.randn(128, 64, 3, 3, device="cuda").half() * 0.05
-    prev = G.pf.FUSE_GN_STATS
-    G.pf.FUSE_GN_STATS = False
-    try:
-        y = G.pf.conv_pf(G.pf.PF.from_nchw(x), G.pf.pack_conv_weight(w), None)
-    finally:
-        G.pf.FUSE_GN_STATS = prev
+    from gswm_amd import _native as N
+    from gswm_amd.codec import _dt
+    buf = torch.zeros(1 << 16, dtype=torch.float32, device="cuda")
+    x = G.pf.PF.from_nchw(torch.randn(2, 64, 16, 16, device="cuda").half())
+    w = G.pf.pack_conv_weight(torch.randn(64, 64, 3, 3, device="cuda").half() * 0.05)
+    y = G.pf.PF.empty(2, 16, 16, 64, torch.float16, "cuda")
+    ex = N.GswMmExtras()
+    ex.colstats_dev, ex.colstats_capacity = buf.data_ptr(), buf.numel()
+    assert G.lib.gsw_conv_pf_ex(x.rows.data_ptr(), w.data_ptr(), None, None, 0, None, y.rows.data_ptr(), 2, 16, 16, 64, 64, 3, 1, 64, _dt(torch.float16), C.byref(ex), None) == 0
+    assert ex.colstats_rows_per_block == 0 and ex.colstats_blocks == 0
+    w2 = G.pf.pack_conv_weight(torch.randn(128, 64, 3, 3, device="cuda").half() * 0.05)
+    y2 = G.pf.PF.empty(2, 16, 16, 128, torch.float16, "cuda")
+    assert G.lib.gsw_conv_pf(x.rows.data_ptr(), w2.data_ptr(), None, None, 0, None, y2.rows.data_ptr(), 2, 16, 16, 64, 128, 3, 1, 64, _dt(torch.float16), None) == 0      # an engine launch without extras
     torch.cuda.synchronize()
-    assert y.stats is None and float(buf.abs().sum()) == 0.0
-    assert G.lib.gsw_mm_next_colstats(buf.data_ptr() + 4, 16) != 0          # alignment
+    assert float(buf.abs().sum()) == 0.0
+    ex.colstats_dev = buf.data_ptr() + 4
+    assert G.lib.gsw_conv_pf_ex(x.rows.data_ptr(), w2.data_ptr(), None, None, 0, None, y2.rows.data_ptr(), 2, 16, 16, 64, 128, 3, 1, 64, _dt(torch.float16), C.byref(ex), None) != 0      # alignment
+    ex.colstats_dev, ex.flags = buf.data_ptr(), 0x40
+    assert G.lib.gsw_conv_pf_ex(x.rows.data_ptr(), w2.data_ptr(), None, None, 0, None, y2.rows.data_ptr(), 2, 16, 16, 64, 128, 3, 1, 64, _dt(torch.float16), C.byref(ex), None) == N.GSW_ERR_BAD_ARG      # unknown flag bits
 
 
 def test_explicit_extras_report_what_the_launch_did(G):
@@ -181,13 +186,6 @@ def test_explicit_extras_report_what_the_launch_did(G):
     assert G.lib.gsw_conv_pf_ex(x.rows.data_ptr(), w.data_ptr(), None, None, 0, None, y.rows.data_ptr(), B, H, W, Cc, Nn, 3, 1, Cc, _dt(torch.float16), C.byref(ex2), None) == 0
     assert ex2.splits == 1
     assert (y.to_nchw().float() - y_split.float()).abs().max().item() <= 2e-3 * y_split.float().abs().max().item()
-    # the deprecated one-shot form of the first launch: the dropped request is an explicit status now
-    assert G.lib.gsw_mm_set_workspace(ws.data_ptr(), ws.numel(), 0) == 0
-    assert G.lib.gsw_mm_next_colstats(rec.data_ptr(), rec.numel()) == 0
-    assert G.lib.gsw_conv_pf(x.rows.data_ptr(), w.data_ptr(), None, None, 0, None, y.rows.data_ptr(), B, H, W, Cc, Nn, 3, 1, Cc, _dt(torch.float16), None) == 0
-    rows, blocks = C.c_int(-1), C.c_int(-1)
-    assert G.lib.gsw_mm_last_colstats(C.byref(rows), C.byref(blocks)) == N.GSW_WARN_NO_RECORDS and rows.value == 0
-    assert G.lib.gsw_mm_set_workspace(None, 0, 0) == 0
     torch.cuda.synchronize()
 
 

@@ -1,4 +1,4 @@
-"""GPU: LayerNorm folded into the GEMMs that consume it (gsw_mm_next_rowstats -> gsw_ln_rowstats_finish -> gsw_gemm_ln; diffusers BasicTransformerBlock's
+"""GPU: LayerNorm folded into the GEMMs that consume it (GswMmExtras.rowstats_* -> gsw_ln_rowstats_finish -> gsw_gemm_ln; diffusers BasicTransformerBlock's
 norm1 / norm2 / norm3 in front of to_q | to_k | to_v, to_q and the GEGLU projection, behind extract.py:66-69) against the LayerNorm kernel + plain GEMM it
 replaces and against fp32 torch: the row records themselves, every consumer mode, both tile heights, ragged N, a DC offset on the residual stream (the
 cancellation rstd (x W') - rstd mean u), and the whole transformer block."""

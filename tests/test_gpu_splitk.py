@@ -1,4 +1,4 @@
-"""GPU: split-K launches of the matmul engine (gsw_mm_set_workspace; csrc/gswm_mm.hip EPI 4 + gsw_mm_reduce_kernel) against fp32 torch and against the
+"""GPU: split-K launches of the matmul engine (GswMmExtras.workspace_*; csrc/gswm_mm.hip EPI 4 + gsw_mm_reduce_kernel) against fp32 torch and against the
 unsplit launch of the same operands -- every epilogue mode, K ranges that start inside a tap run / cross a segment boundary, ragged M and N,
 forced split counts that do not divide the stage count, and the automatic policy on the small-batch shapes of the eps model (one image's
 8 x 8 and 16 x 16 levels: the reference's one-latent-per-call regime, extract.py:112-117)."""
@@ -162,9 +162,19 @@ def test_up2x_split(G, k):
 
 def test_workspace_abi_validation_and_no_workspace_means_unsplit(G):
     lib = G.lib
-    assert lib.gsw_mm_set_workspace(None, 16, 0) != 0 and lib.gsw_mm_set_workspace(None, -1, 0) != 0 and lib.gsw_mm_set_workspace(None, 0, 65) != 0
+    import ctypes as C
+    from gswm_amd import _native as N
     buf = torch.empty(1 << 20, dtype=torch.uint8, device="cuda")
-    assert lib.gsw_mm_set_workspace(buf.data_ptr() + 8, 1024, 0) != 0            # 16-byte alignment
+    a = torch.randn(64, 320, device="cuda").half()
+    wt = torch.randn(320, 320, device="cuda").half()
+    o = torch.empty(64, 320, device="cuda").half()
+
+    def launch(ex):
+        return lib.gsw_gemm_ex(a.data_ptr(), 320, wt.data_ptr(), 320, None, None, 320, o.data_ptr(), 320, 64, 320, 320, 0, 0, 0, 1, C.byref(ex), None)
+    for ws, nbytes, ms in ((None, -1, 0), (None, 0, 65), (buf.data_ptr() + 8, 1024, 0)):          # negative size, too many splits, 16-byte alignment
+        ex = N.GswMmExtras()
+        ex.workspace_dev, ex.workspace_bytes, ex.max_splits = ws, nbytes, ms
+        assert launch(ex) != 0
     # a workspace too small for the split a launch would take: the launch runs unsplit and still gives the right answer
     x = torch.randn(64, 1280, device="cuda").half()
     w = (torch.randn(1280, 1280, device="cuda") * 1280 ** -0.5).half()

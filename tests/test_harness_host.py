@@ -406,3 +406,22 @@ def test_config_entries_outside_the_implemented_space_are_refused_by_name():
     for k, v in (("prediction_type", "sample"), ("timestep_spacing", "trailing"), ("clip_sample", True), ("rescale_betas_zero_snr", True), ("beta_schedule", "linear")):
         with pytest.raises(ValueError, match=k if k != "clip_sample" else "clip_sample"):
             C.validate_scheduler_config({k: v})
+
+
+def test_full_precision_weights_win_over_an_fp16_variant_in_the_same_directory(tmp_path):
+    """a repository that ships `<stem>.bin` (fp32) next to `<stem>.fp16.safetensors`: a load must not silently get the fp16-rounded copy -- full-precision files of
+    BOTH formats come before any `.fp16` variant; with only variants present, the safetensors one wins"""
+    import os
+    from safetensors.torch import save_file
+    from gswm_amd import checkpoint as C
+    d = tmp_path / "unet"
+    os.makedirs(d)
+    w = torch.tensor([1.0 + 2.0 ** -20, 3.0])                      # not representable in fp16
+    torch.save({"w": w}, str(d / "diffusion_pytorch_model.bin"))
+    save_file({"w": w.half()}, str(d / "diffusion_pytorch_model.fp16.safetensors"))
+    sd = C.load_component_state_dict(str(tmp_path), "unet")
+    assert sd["w"].dtype == torch.float32 and torch.equal(sd["w"], w)
+    os.remove(d / "diffusion_pytorch_model.bin")
+    torch.save({"w": (w * 2).half()}, str(d / "diffusion_pytorch_model.fp16.bin"))
+    sd = C.load_component_state_dict(str(tmp_path), "unet")
+    assert sd["w"].dtype == torch.float16 and torch.equal(sd["w"], w.half())
