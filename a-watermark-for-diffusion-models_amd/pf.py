@@ -197,21 +197,24 @@ class ConvTimer:
         e.record()
         return e
 
-    def stop(self, e0, kernel: str, flops: float, launches: int = 1):
+    def stop(self, e0, kernel: str, flops: float, launches: int = 1, nbytes: float = 0.0):
+        """nbytes: the launch's ALGORITHMIC HBM bytes (every operand read once, the output written once, 2 bytes per element)"""
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        self.ev.append((kernel, flops, e0, e1, launches))
+        self.ev.append((kernel, flops, e0, e1, launches, nbytes))
 
     def summary(self):
         out = {}
-        for k, f, a, b, nl in self.ev:
-            d = out.setdefault(k, {"calls": 0, "flops": 0.0, "ms": 0.0})
+        for k, f, a, b, nl, nb in self.ev:
+            d = out.setdefault(k, {"calls": 0, "flops": 0.0, "ms": 0.0, "bytes": 0.0})
             d["calls"] += nl                     # kernel launches (the sub-pixel upsampling call is four launches)
             d["flops"] += f
+            d["bytes"] += nb
             d["ms"] += a.elapsed_time(b)
         for d in out.values():
             d["avg_us"] = d["ms"] * 1e3 / d["calls"]
             d["flops_per_launch"] = d["flops"] / d["calls"]
+            d["bytes_per_launch"] = d["bytes"] / d["calls"]
             d["tflops"] = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] else 0.0
         return out
 
@@ -269,7 +272,8 @@ def conv_pf(x: PF, w_packed: torch.Tensor, bias: Optional[torch.Tensor], *, ksiz
         y.border_valid = not (ex.flags & N.GSW_MM_GN_ONLY and ex.colstats_rows_per_block > 0)
         if tm is not None:
             name = _conv_kernel_name(Wo, Nn, ksize, stride)
-            tm.stop(e0, (name, x.B, Ho, Wo, ksize * ksize * C, Nn, stride) if tm.by_shape else name, 2.0 * x.B * Ho * Wo * Nn * ksize * ksize * C)
+            tm.stop(e0, (name, x.B, Ho, Wo, ksize * ksize * C, Nn, stride) if tm.by_shape else name, 2.0 * x.B * Ho * Wo * Nn * ksize * ksize * C,
+                    nbytes=2.0 * (x.B * x.H * x.W * C + Nn * ksize * ksize * C + x.B * Ho * Wo * Nn * (2 if resid is not None else 1)))
     return y
 
 
@@ -312,7 +316,7 @@ def gemm_strided(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, bias: Opti
         N.check(N.lib().gsw_gemm_ex(x.data_ptr(), ldx, w.data_ptr(), ldw, bias.data_ptr() if bias is not None else None, None, ldy,
                                     out.data_ptr(), ldy, M, K, Nn, 0, 0, 0, _dt(x.dtype), _C.byref(ex), _stream_ptr()))
         if tm is not None:
-            tm.stop(e0, ("gsw_mm_kernel", M, K, Nn, "plain") if tm.by_shape else "gsw_mm_kernel", 2.0 * M * K * Nn)
+            tm.stop(e0, ("gsw_mm_kernel", M, K, Nn, "plain") if tm.by_shape else "gsw_mm_kernel", 2.0 * M * K * Nn, nbytes=2.0 * (M * K + Nn * K + M * Nn))
     return out
 
 
@@ -516,7 +520,7 @@ def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
                                            rs_buf.data_ptr() if rs_buf is not None else None, rs_buf.numel() if rs_buf is not None else 0, _C.byref(slots), -1,
                                            _dt(x.dtype), _stream_ptr()))
             if tm is not None:
-                tm.stop(e0, ("gsw_mm_small_kernel", M, K, Nn, mode) if tm.by_shape else "gsw_mm_small_kernel", 2.0 * M * K * Nn)
+                tm.stop(e0, ("gsw_mm_small_kernel", M, K, Nn, mode) if tm.by_shape else "gsw_mm_small_kernel", 2.0 * M * K * Nn, nbytes=2.0 * (M * K + Nn * K + M * Nn * (2 if resid is not None else 1)))
         if stats_for is not None:
             stats_for.stats = None
         if rs_buf is not None and slots.value > 0:
@@ -540,7 +544,8 @@ def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
         if rs_buf is not None and ex.rowstats_slots > 0:
             y._gsw_rowstats = (rs_buf, int(ex.rowstats_slots))          # rides on the output tensor; in-place edits of y must drop it
         if tm is not None:
-            tm.stop(e0, ("gsw_mm_kernel", M, K, Nn, mode + ("+res" if resid is not None and mode == "plain" else "")) if tm.by_shape else "gsw_mm_kernel", 2.0 * M * K * Nn)
+            tm.stop(e0, ("gsw_mm_kernel", M, K, Nn, mode + ("+res" if resid is not None and mode == "plain" else "")) if tm.by_shape else "gsw_mm_kernel", 2.0 * M * K * Nn,
+                    nbytes=2.0 * (M * K + Nn * K + M * ncols * (2 if resid is not None else 1)))
     return y
 
 
@@ -610,7 +615,7 @@ def gemm_ln(x: torch.Tensor, stat: torch.Tensor, wp: torch.Tensor, u: torch.Tens
         N.check(N.lib().gsw_gemm_ln_ex(x.data_ptr(), stat.data_ptr(), wp.data_ptr(), u.data_ptr(), v.data_ptr(), y.data_ptr(), M, K, Nn,
                                        GEMM_MODES[mode], tokens, _dt(x.dtype), _C.byref(ex), _stream_ptr()))
         if tm is not None:
-            tm.stop(e0, ("gsw_mm_kernel", M, K, Nn, mode + "+ln") if tm.by_shape else "gsw_mm_kernel", 2.0 * M * K * Nn)
+            tm.stop(e0, ("gsw_mm_kernel", M, K, Nn, mode + "+ln") if tm.by_shape else "gsw_mm_kernel", 2.0 * M * K * Nn, nbytes=2.0 * (M * K + Nn * K) + y.numel() * 2.0 + M * 8.0)
     return y
 
 
@@ -634,7 +639,7 @@ def gemm_qkv(x: torch.Tensor, w: torch.Tensor, n_rows: int, bias: Optional[torch
         N.check(N.lib().gsw_gemm_qkv(x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None, rows.data_ptr(), vt.data_ptr(),
                                      B * S, K, n_rows, Nn, S, _dt(x.dtype), _stream_ptr()))
         if tm is not None:
-            tm.stop(e0, ("gsw_mm_kernel", B * S, K, Nn, "qkv") if tm.by_shape else "gsw_mm_kernel", 2.0 * B * S * K * Nn)
+            tm.stop(e0, ("gsw_mm_kernel", B * S, K, Nn, "qkv") if tm.by_shape else "gsw_mm_kernel", 2.0 * B * S * K * Nn, nbytes=2.0 * (B * S * K + Nn * K + B * S * Nn))
     return rows, vt
 
 
@@ -700,7 +705,9 @@ def conv3x3_res_pf(x: PF, w_cat: torch.Tensor, bias: Optional[torch.Tensor], *, 
         if tm is not None:
             k = 9 * x.C + (x1.C if x1 is not None else 0) + (x2.C if x2 is not None else 0)
             name = _conv_kernel_name(x.W, Nn, 3, 1)
-            tm.stop(e0, (name, x.B, x.H, x.W, k, Nn, 1) if tm.by_shape else name, 2.0 * x.B * x.H * x.W * Nn * k)
+            pix = x.B * x.H * x.W
+            tm.stop(e0, (name, x.B, x.H, x.W, k, Nn, 1) if tm.by_shape else name, 2.0 * pix * Nn * k,
+                    nbytes=2.0 * (pix * (k - 8 * x.C) + Nn * k + pix * Nn * (2 if resid is not None else 1)))
     return y
 
 
@@ -766,7 +773,8 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, sc
                                          float(scale if scale is not None else d ** -0.5), _dt(q.dtype), 0 if ws is None else ws.data_ptr(),
                                          0 if ws is None else ws.numel(), _stream_ptr()))
         if tm is not None:
-            tm.stop(e0, ("gsw_attn_fwd_kernel", B, Sq, Sk, heads, d) if tm.by_shape else "gsw_attn_fwd_kernel", 4.0 * B * heads * Sq * (Sk if valid_keys is None else int(valid_keys)) * d)
+            tm.stop(e0, ("gsw_attn_fwd_kernel", B, Sq, Sk, heads, d) if tm.by_shape else "gsw_attn_fwd_kernel", 4.0 * B * heads * Sq * (Sk if valid_keys is None else int(valid_keys)) * d,
+                    nbytes=2.0 * heads * d * (2 * out.shape[0] * Sq + 2 * B * Sk))
     return out
 
 
@@ -810,5 +818,5 @@ def conv_up2x_pf(x: PF, w4: torch.Tensor, bias: Optional[torch.Tensor]) -> PF:
         if tm is not None:      # EXECUTED FLOPs (16 C MACs per output: four 2x2 convolutions); the 3x3-on-upsampled form it replaces is 2.25x that
             name = "gsw_mm_kernel(up2x)"
             tm.stop(e0, (name, x.B, 2 * x.H, 2 * x.W, 4 * x.C, Nn, 1) if tm.by_shape else name,
-                    2.0 * x.B * 4 * x.H * x.W * Nn * 4 * x.C, launches=4)
+                    2.0 * x.B * 4 * x.H * x.W * Nn * 4 * x.C, launches=4, nbytes=2.0 * (4 * x.B * x.H * x.W * x.C + 16 * Nn * x.C + 4 * x.B * x.H * x.W * Nn))
     return y

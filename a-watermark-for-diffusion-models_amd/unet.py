@@ -73,7 +73,10 @@ OWN_GEMM = True       # every dense linear layer (q / k / v / out projections, p
 
 FALLBACKS = {}        # (reason -> count) of GPU half-precision calls that left the hand-written path; bench and the full-size tests assert it stays empty
 
-STRICT = False        # True: leaving the hand-written path raises instead of warning (extract.py --strict_kernels; default with a real checkpoint)
+# Leaving the hand-written path (a shape off the engine's K % 64 / N % 8 grid, attention keys % 8, a lattice the padded-flat layout does not take) RAISES by default: a
+# 200 x 136 image must not silently run a different backend (hipBLASLt / MIOpen / aotriton).  GSW_STRICT_KERNELS=0, `--strict_kernels 0` of the harness or
+# `unet.STRICT = vae.STRICT = False` opt into the library kernels; every such call is then counted in FALLBACKS and warned about once per reason.
+STRICT = __import__("os").environ.get("GSW_STRICT_KERNELS", "1") != "0"
 
 
 def _note_fallback(why: str):

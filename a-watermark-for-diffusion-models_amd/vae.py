@@ -26,7 +26,7 @@ USE_PF = True
 FALLBACKS = {}        # (reason -> count) of GPU half-precision calls that ran the plain-torch module path instead of the hand-written kernels
 
 
-STRICT = False        # True: leaving the hand-written path raises instead of warning (extract.py --strict_kernels)
+STRICT = __import__("os").environ.get("GSW_STRICT_KERNELS", "1") != "0"      # leaving the hand-written path raises (see unet.STRICT); 0 / --strict_kernels 0: warn and count instead
 
 
 def _fell_off(what: str, x: torch.Tensor) -> None:

@@ -173,7 +173,7 @@ def fused(x: torch.Tensor, stat: torch.Tensor, blob: torch.Tensor, uv: torch.Ten
                                         float(eps_out) if eps_out is not None else 0.0, xB, out_images, S, C, heads, _dt(x.dtype), _stream_ptr()))
         if tm is not None:
             tm.stop(e0, ("gsw_xattn_kernel", out_images * S, C, heads * (MAX_KEYS + 1), "xattn") if tm.by_shape else "gsw_xattn_kernel",
-                    2.0 * out_images * S * C * heads * (KEY_SLOTS + MAX_KEYS + 1))
+                    2.0 * out_images * S * C * heads * (KEY_SLOTS + MAX_KEYS + 1), nbytes=2.0 * (xB + out_images) * S * C + blob.numel() * 2.0)
     if ostat is not None:
         y._gsw_lnstat = (ostat, float(eps_out))
     return y
