@@ -106,7 +106,7 @@ def test_harness_on_a_local_checkpoint_batches_across_directories(E, tmp_path, c
         d.mkdir(parents=True)
     files = {str(d): _write_images(str(d), n) for d, n in zip(dirs, (3, 2, 1))}
     (root / "b" / "broken.jpg").write_bytes(b"nope")
-    # (the tiny checkpoint's 32 / 64-channel VAE is off the hand-written path: strict mode, the default with a real checkpoint, would raise)
+    # (the tiny checkpoint's 32 / 64-channel VAE is off the hand-written path: strict mode, the default, would raise)
     args = _args(model_id=ck, images_directory_path=str(root), is_traverse_subdirectories=1, allow_synthetic_weights=False, width=64, height=64,
                  message_length=64, original_message_hex=(b"lthero" + b"\0" * 2).hex(), strict_kernels=0)
     seen = []
@@ -135,7 +135,7 @@ def test_harness_on_a_local_checkpoint_batches_across_directories(E, tmp_path, c
             assert abs(float(line.split(", ")[2]) - acc) <= 6 / 64
             assert f"{os.path.basename(f)}\nOriginal Message: " in out
     assert f"Error processing {root / 'b' / 'broken.jpg'}: " in (root / "b" / "result.txt").read_text()
-    # strict mode (the default with a real checkpoint): the same run reports every image as an error instead of silently using library kernels
+    # strict mode (the default): the same run reports every image as an error instead of silently using library kernels
     strict_root = tmp_path / "strict"
     strict_root.mkdir()
     _write_images(str(strict_root), 2)
@@ -144,7 +144,7 @@ def test_harness_on_a_local_checkpoint_batches_across_directories(E, tmp_path, c
     E.process_directory(sargs, batch_size=4)
     assert (strict_root / "result.txt").read_text().count("strict kernels") == 2
     from gswm_amd import unet as U_, vae as V_
-    assert not U_.STRICT and not V_.STRICT                                      # scoped to the harness call
+    assert U_.STRICT and V_.STRICT                                              # the module defaults, untouched by the harness calls above (strict_kernels=0 was scoped to them)
 
 
 def test_image_level_roundtrip_runs(E, keys):

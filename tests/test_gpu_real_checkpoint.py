@@ -1,0 +1,96 @@
+"""GPU, OPT-IN: the whole path on TRAINED weights -- the moment a checkpoint exists.  Skipped unless `GSWM_CHECKPOINT` names a directory in diffusers layout
+(unet/, vae/, text_encoder/, tokenizer/, scheduler/) or the local Hugging Face cache holds the reference's default `stabilityai/stable-diffusion-2-1-base`
+(extract.py:183).  No pool box has either (no network, no weights on disk), so every other gate of this repo is latent-level on synthetic weights; this file is
+what turns "the modules carry diffusers' parameter names and load such a directory 1:1" into an observed fact:
+
+  embed 'lthero' (gs_insert.py) -> txt2img through the generation loop (README.md:107-129) -> PNG on disk -> `python -m gswm_amd.extract` (the extract.py CLI
+  twin: Lanczos resize, VAE encode, 50-step DDIM inversion with prompt "", vote) -> the reference's claim README.md:15: 100 % of the 256 bits on a lossless image;
+  the same images through JPEG QF 10 (distortions:181-184) -> README.md:16's "about 90 %" (reported; gated at >= 0.80, the claim's own slack).
+
+Strict kernels stay on (the default): a real SD 2.1-base / SD 1.5 checkpoint must run entirely on the hand-written path."""
+import os
+import subprocess
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import README_KEY, README_NONCE, ROOT
+
+pytestmark = pytest.mark.gpu
+
+MESSAGE = "lthero"
+
+
+def _checkpoint_dir():
+    import gswm_amd  # noqa: F401
+    from gswm_amd import checkpoint
+    env = os.environ.get("GSWM_CHECKPOINT")
+    if env:
+        return env if os.path.isdir(env) else None
+    return checkpoint.resolve_model_dir("stabilityai/stable-diffusion-2-1-base")
+
+
+@pytest.fixture(scope="module")
+def generated(tmp_path_factory):
+    ck = _checkpoint_dir()
+    if ck is None:
+        pytest.skip("no trained checkpoint: set GSWM_CHECKPOINT=<diffusers directory> or place stabilityai/stable-diffusion-2-1-base in the local Hugging Face cache")
+    import gswm_amd  # noqa: F401
+    from gswm_amd import codec, extract as E, text, unet as U, vae as V
+    from gswm_amd.pipeline import GaussianShadingPipeline
+    from PIL import Image
+    assert U.STRICT and V.STRICT
+    m = E.load_models(ck, allow_synthetic=False)
+    assert not m.synthetic
+    key, nonce = bytes.fromhex(README_KEY), bytes.fromhex(README_NONCE)
+    B, S = 4, 50
+    res = 512
+    prompts = ["a photograph of an astronaut riding a horse", "a red bicycle leaning against a brick wall", "a bowl of fruit on a wooden table, still life",
+               "a lighthouse on a cliff at sunset"]
+    ctx = text.encode_prompt_from_dir(ck, prompts, m.device, m.dtype)
+    pipe = GaussianShadingPipeline(m.eps, key, nonce, codec.pad_message(MESSAGE, 32), height=res, width=res, num_inference_steps=S, dtype=m.dtype, device=m.device,
+                                   ctx_uncond=m.ctx_empty, prediction_type=m.prediction_type)
+    from gswm_amd.ddim import DDIMSchedule
+    pipe.schedule = DDIMSchedule(num_inference_steps=S, prediction_type=m.prediction_type, **m.schedule_kwargs())      # the checkpoint's own scheduler constants
+    with torch.no_grad():
+        images, _, z_T = pipe.txt2img(ctx, m.vae, seed=0)
+    assert U.FALLBACKS == {} and V.FALLBACKS == {}
+    root = tmp_path_factory.mktemp("real_ckpt")
+    png, jpg = root / "png", root / "jpeg_qf10"
+    png.mkdir(); jpg.mkdir()
+    arr = (images.float().clamp(0, 1) * 255).round().permute(0, 2, 3, 1).to(torch.uint8).cpu().numpy()
+    for i in range(B):
+        im = Image.fromarray(arr[i])
+        im.save(str(png / f"gs_{i}.png"))
+        im.save(str(jpg / f"gs_{i}.jpg"), format="JPEG", quality=10)          # distortions:181-184
+    return types.SimpleNamespace(ck=ck, png=str(png), jpg=str(jpg), B=B, S=S, res=res, z_T=z_T)
+
+
+def _run_cli(g, directory):
+    """the reference's command line (extract.py:180-211) on the twin"""
+    cmd = [sys.executable, "-m", "gswm_amd.extract", "--model_id", g.ck, "--images_directory_path", directory, "--key_hex", README_KEY, "--nonce_hex", README_NONCE,
+           "--original_message_hex", (MESSAGE.encode() + b"\0" * (32 - len(MESSAGE))).hex(), "--num_inference_steps", str(g.S), "--scheduler", "DDIM",
+           "--is_traverse_subdirectories", "0", "--width", str(g.res), "--height", str(g.res), "--message_length", "256"]
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=3600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    txt = open(os.path.join(directory, "result.txt")).read()
+    assert "SYNTHETIC" not in txt and "strict kernels" not in txt and "Error processing" not in txt
+    return [float(l.split(", ")[2]) for l in txt.splitlines() if ", Bit Accuracy, " in l]
+
+
+def test_lossless_png_recovers_every_bit(generated):
+    acc = _run_cli(generated, generated.png)
+    assert len(acc) == generated.B
+    print("real checkpoint, PNG: bit accuracies", acc)
+    assert all(a == 1.0 for a in acc), acc                                     # README.md:15: 100 % on lossless images
+
+
+def test_jpeg_qf10_accuracy_is_in_the_readmes_range(generated):
+    acc = _run_cli(generated, generated.jpg)
+    assert len(acc) == generated.B
+    print("real checkpoint, JPEG QF 10: bit accuracies", acc, "mean", float(np.mean(acc)))
+    assert float(np.mean(acc)) >= 0.80                                         # README.md:16: "about 90 %"

@@ -183,7 +183,6 @@ def test_workspace_abi_validation_and_no_workspace_means_unsplit(G):
     with G.pf.splitk_workspace(small):
         y = G.pf.gemm(x, w, None)
     assert _rel(y, ref) <= 2e-3
-    G.pf._WS_TLS.last = None
 
 
 def test_small_batch_unet_forward_split_vs_unsplit_vs_fp32(G):

@@ -36,7 +36,6 @@ def sweep(name, fn, ks=(1, 0, 2, 4, 8, 16, 32)):
     out = []
     for k in ks:
         pf.SPLITK_MAX = k
-        pf._WS_TLS.last = None
         out.append((k, timed(fn)))
     pf.SPLITK_MAX = 0
     print(f"{name:44s} " + "  ".join(f"{'auto' if k == 0 else 'off' if k == 1 else k}:{t:7.1f}" for k, t in out), flush=True)
