@@ -41,6 +41,7 @@ def _write_images(d, n, size=(96, 80)):
     return paths
 
 
+@pytest.mark.usefixtures("library_kernels_allowed")      # small / odd shapes off the hand-written path: strict mode (the default) would raise
 def test_single_image_flow(E, tmp_path, capsys):
     p = _write_images(str(tmp_path), 1)[0]
     args = _args(single_image_path=p)
@@ -93,6 +94,7 @@ def test_harness_refuses_to_run_without_a_checkpoint(E, tmp_path, monkeypatch):
     assert not (tmp_path / "result.txt").exists()                               # failed before any result file was touched
 
 
+@pytest.mark.usefixtures("library_kernels_allowed")      # small / odd shapes off the hand-written path: strict mode (the default) would raise
 def test_harness_on_a_local_checkpoint_batches_across_directories(E, tmp_path, capsys):
     """A (tiny) checkpoint directory in diffusers layout: modules built from its config files, context from its text encoder, images of
     THREE directories recovered in shared device batches, result files per directory + roll-up lines in the reference's format; every
@@ -144,9 +146,10 @@ def test_harness_on_a_local_checkpoint_batches_across_directories(E, tmp_path, c
     E.process_directory(sargs, batch_size=4)
     assert (strict_root / "result.txt").read_text().count("strict kernels") == 2
     from gswm_amd import unet as U_, vae as V_
-    assert U_.STRICT and V_.STRICT                                              # the module defaults, untouched by the harness calls above (strict_kernels=0 was scoped to them)
+    assert not U_.STRICT and not V_.STRICT                                      # restored to what this test's fixture set: the harness scopes its own setting to the call
 
 
+@pytest.mark.usefixtures("library_kernels_allowed")      # small / odd shapes off the hand-written path: strict mode (the default) would raise
 def test_image_level_roundtrip_runs(E, keys):
     """embed -> sample -> VAE decode -> JPEG QF 10 -> VAE encode -> invert -> vote: config 4's data path (synthetic weights:
     accuracy is not gated, only that every stage runs on the batch and returns well-formed results)."""
