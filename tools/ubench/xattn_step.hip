@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdint>
 #include <vector>
+#include <type_traits>
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f16v __attribute__((ext_vector_type(16)));
 
@@ -52,6 +53,82 @@ __global__ __launch_bounds__(256) void step_kernel(const uint8_t* __restrict__ s
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
+// The step with the REAL data flow: three staging register sets, global loads three steps ahead of the LDS write that consumes them, fragment reads one step ahead of the MFMAs.
+// TURNS: the four waves write their share of a chunk in turns (behind MFMAs 1, 3, 5, 7) instead of all at the top of the step.
+template <bool TURNS, bool WRITES, bool LOADS, bool READS, bool XB = false>
+__global__ __launch_bounds__(256) void step3_kernel(const uint8_t* __restrict__ stream, float* out, uint64_t* cyc, int iters) {
+    __shared__ __attribute__((aligned(16))) uint8_t r0[10240], r1[10240], r2[10240], padlds[60000];
+    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane((uint32_t)(threadIdx.x >> 6));
+    const uint32_t o0 = wave * 1024u + lane * 16u, o1 = o0 + 4096u, o2 = (8u + (wave >> 1)) * 1024u + (wave & 1u) * 512u + lane * 8u;
+    for (uint32_t i = threadIdx.x; i < 10240 / 4; i += 256) { reinterpret_cast<uint32_t*>(r0)[i] = 0x3C003C00u; reinterpret_cast<uint32_t*>(r1)[i] = 0x3C003C00u; reinterpret_cast<uint32_t*>(r2)[i] = 0x3C003C00u; }
+    if (iters < 0) padlds[threadIdx.x] = 1;
+    __syncthreads();
+    f16v acc[10];
+    h8 fr[10], xb, xf[20];
+    for (int i = 0; i < 10; ++i) { for (int t = 0; t < 16; ++t) acc[i][t] = 0.f; fr[i] = *reinterpret_cast<const h8*>(r0 + lane * 16u + i * 1024); }
+    for (int e = 0; e < 8; ++e) xb[e] = (_Float16)(0.001f * (lane + e));
+    for (int q = 0; q < 20; ++q) xf[q] = *reinterpret_cast<const h8*>(stream + lane * 16u + q * 1024);
+    f16v S[3]; for (int q = 0; q < 3; ++q) for (int t = 0; t < 16; ++t) S[q][t] = 0.f;
+    uint4 sa0 = make_uint4(1, 2, 3, 4), sa1 = sa0, sa2 = sa0, sb0 = sa0, sb1 = sa0, sb2 = sa0; uint2 sc0 = make_uint2(5, 6), sc1 = sc0, sc2 = sc0;
+    const uint64_t t0 = __builtin_amdgcn_s_memtime();
+    auto step = [&](auto K, int it) __attribute__((always_inline)) {
+        constexpr int k = decltype(K)::value;      // it % 3
+        const uint8_t* cp = stream + (size_t)((it + 5) & 63) * 10240;
+        uint8_t* sw = k == 0 ? r2 : k == 1 ? r0 : r1;            // slot of chunk it + 2
+        const uint8_t* sl = (k == 0 ? r1 : k == 1 ? r2 : r0) + lane * 16u;      // slot of chunk it + 1
+        __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory"); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0);
+        auto wr = [&]() __attribute__((always_inline)) {
+            *reinterpret_cast<uint4*>(sw + o0) = k == 0 ? sa2 : k == 1 ? sa0 : sa1; *reinterpret_cast<uint4*>(sw + o1) = k == 0 ? sb2 : k == 1 ? sb0 : sb1;
+            *reinterpret_cast<uint2*>(sw + o2) = k == 0 ? sc2 : k == 1 ? sc0 : sc1;
+        };
+        auto mm = [&](int i) __attribute__((always_inline)) {
+            if constexpr (XB) { if (k == 0) S[i % 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[i], xf[(i + 7 * k) % 20], S[i % 3], 0, 0, 0);
+                                else acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[i], xf[(i + 7 * k) % 20], acc[i], 0, 0, 0); }
+            else acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[i], xb, acc[i], 0, 0, 0);
+            if constexpr (READS) fr[i] = *reinterpret_cast<const h8*>(sl + i * 1024);
+        };
+        if constexpr (WRITES && !TURNS) wr();
+        mm(0); mm(1);
+        if constexpr (WRITES && TURNS) { if (wave == 0u) wr(); }
+        mm(2); mm(3);
+        if constexpr (WRITES && TURNS) { if (wave == 1u) wr(); }
+        mm(4); mm(5);
+        if constexpr (WRITES && TURNS) { if (wave == 2u) wr(); }
+        mm(6); mm(7);
+        if constexpr (WRITES && TURNS) { if (wave == 3u) wr(); }
+        if constexpr (LOADS) {
+            const uint4 a_ = *reinterpret_cast<const uint4*>(cp + o0), b_ = *reinterpret_cast<const uint4*>(cp + o1); const uint2 c_ = *reinterpret_cast<const uint2*>(cp + o2);
+            if constexpr (k == 0) { sa2 = a_; sb2 = b_; sc2 = c_; } else if constexpr (k == 1) { sa0 = a_; sb0 = b_; sc0 = c_; } else { sa1 = a_; sb1 = b_; sc1 = c_; }
+        }
+        mm(8); mm(9);
+    };
+    for (int it = 0; it < iters; it += 3) {
+        step(std::integral_constant<int, 0>{}, it); step(std::integral_constant<int, 1>{}, it + 1); step(std::integral_constant<int, 2>{}, it + 2);
+    }
+    const uint64_t t1 = __builtin_amdgcn_s_memtime();
+    float s = 0.f;
+    for (int i = 0; i < 10; ++i) for (int t = 0; t < 16; ++t) s += acc[i][t];
+    for (int q = 0; q < 3; ++q) for (int t = 0; t < 16; ++t) s += S[q][t];
+    for (int q = 0; q < 20; ++q) s += (float)xf[q][1];
+    s += (float)(sa0.x + sb1.y + sc2.x + sa1.z + sa2.w + sb0.x + sb2.y + sc0.y + sc1.x) + (float)fr[3][2];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
+template <bool TURNS, bool WRITES, bool LOADS, bool READS, bool XB = false> void run3(const char* what, const uint8_t* stream, float* out, uint64_t* cyc) {
+    const int iters = 3999;
+    hipLaunchKernelGGL((step3_kernel<TURNS, WRITES, LOADS, READS, XB>), dim3(256), dim3(256), 0, 0, stream, out, cyc, iters);
+    hipDeviceSynchronize();
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((step3_kernel<TURNS, WRITES, LOADS, READS, XB>), dim3(256), dim3(256), 0, 0, stream, out, cyc, iters);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    std::vector<uint64_t> h(256); hipMemcpy(h.data(), cyc, 256 * 8, hipMemcpyDeviceToHost);
+    double mean = 0; for (auto v : h) mean += (double)v; mean /= 256;
+    printf("%-70s %7.1f cycles per step (s_memtime), %7.1f ns per step\n", what, mean / iters, ms * 1e6 / iters);
+}
+
 template <int MASK> void run(const char* what, const uint8_t* stream, float* out, uint64_t* cyc) {
     const int iters = 4000;
     hipLaunchKernelGGL(step_kernel<MASK>, dim3(256), dim3(256), 0, 0, stream, out, cyc, iters);
@@ -82,5 +159,14 @@ int main() {
     run<18>("no MFMA: 3 LDS writes", stream, out, cyc);
     run<20>("no MFMA: 3 global loads", stream, out, cyc);
     run<24>("no MFMA: barrier", stream, out, cyc);
+    printf("-- the real data flow: loads three steps ahead, writes one step ahead, barrier per step --\n");
+    run3<false, false, false, true>("10 MFMA + reads + barrier", stream, out, cyc);
+    run3<false, true, false, true>("  + writes (all four waves at the top of the step)", stream, out, cyc);
+    run3<true, true, false, true>("  + writes (the waves take turns)", stream, out, cyc);
+    run3<false, false, true, true>("  + global loads (three steps of lead), no writes", stream, out, cyc);
+    run3<false, true, true, true>("  + writes at the top + loads", stream, out, cyc);
+    run3<true, true, true, true>("  + writes in turns + loads", stream, out, cyc);
+    run3<false, true, true, true, true>("  writes at the top + loads, 20 B fragments + 3-accumulator chains", stream, out, cyc);
+    run3<true, true, true, true, true>("  writes in turns + loads, 20 B fragments + 3-accumulator chains", stream, out, cyc);
     return 0;
 }
