@@ -88,6 +88,18 @@ def _t_tensors(ts, device):
     return [torch.full((), t, dtype=torch.int64, device=device) for t in ts]
 
 
+def _cfg_contexts(ctx_uncond: torch.Tensor, ctx_text: torch.Tensor) -> torch.Tensor:
+    """(uncond | text) contexts of a guidance batch as ONE tensor -- the SAME object for the same pair of inputs: the eps model keeps its per-context caches ON the context
+    tensor (padded copy, cross-attention K / V^T, the one-launch cross-attention's fragment streams: unet.py, xattn.py), so a second sampling loop over the same prompts finds
+    them instead of rebuilding them.  The entry holds a reference to ctx_uncond (its storage cannot be recycled under the key) and follows both tensors' version counters."""
+    key = (id(ctx_uncond), ctx_uncond._version, tuple(ctx_uncond.shape), tuple(ctx_uncond.stride()), ctx_text._version, tuple(ctx_text.shape))
+    c = getattr(ctx_text, "_gsw_cfg_cat", None)
+    if c is None or c[0] != key:
+        c = (key, torch.cat([ctx_uncond, ctx_text], dim=0), ctx_uncond)
+        ctx_text._gsw_cfg_cat = c
+    return c[1]
+
+
 @torch.no_grad()
 def ddim_sample(eps_model: EpsModel, z_T: torch.Tensor, ctx_text: torch.Tensor, schedule: DDIMSchedule, *,
                 ctx_uncond: Optional[torch.Tensor] = None, guidance_scale: float = 7.5) -> torch.Tensor:
@@ -97,7 +109,7 @@ def ddim_sample(eps_model: EpsModel, z_T: torch.Tensor, ctx_text: torch.Tensor, 
     tt = _t_tensors([s[0] for s in steps], z_T.device)
     x = z_T.clone()
     use_cfg = guidance_scale != 1.0 and ctx_uncond is not None
-    ctx2 = torch.cat([ctx_uncond, ctx_text], dim=0) if use_cfg else None
+    ctx2 = _cfg_contexts(ctx_uncond, ctx_text) if use_cfg else None
     B = x.shape[0]
     # an eps model that knows the two halves of the guidance batch are the same latents (unet.UNet2DCondition: cfg_dup) computes what does not depend on
     # the context once; any other callable gets the reference's doubled batch (`torch.cat([latents] * 2)`, modified_stable_diffusion_gs.pyc)

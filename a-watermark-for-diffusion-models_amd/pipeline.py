@@ -37,20 +37,28 @@ class GaussianShadingPipeline:
                                  dtype=self.dtype, fast=fast, device=self.device)
 
     # G1
+    def _uncond(self, batch: int) -> torch.Tensor:
+        """the empty prompt's context for `batch` images: ONE view object per batch size (the eps model's per-context caches live on the tensor object)"""
+        if self.ctx_uncond.shape[0] != 1:
+            return self.ctx_uncond
+        views = self.__dict__.setdefault("_uncond_views", {})
+        ent = views.get(batch)
+        if ent is None or ent[0] is not self.ctx_uncond:
+            ent = views[batch] = (self.ctx_uncond, self.ctx_uncond.expand(batch, -1, -1))
+        return ent[1]
+
     def generate(self, z_T: torch.Tensor, ctx_text: torch.Tensor, guidance_scale: float = 7.5) -> torch.Tensor:
-        cu = None
-        if guidance_scale != 1.0:
-            cu = self.ctx_uncond.expand(z_T.shape[0], -1, -1) if self.ctx_uncond.shape[0] == 1 else self.ctx_uncond
+        cu = self._uncond(z_T.shape[0]) if guidance_scale != 1.0 else None
         return ddim_sample(self.eps_model, z_T, ctx_text, self.schedule, ctx_uncond=cu, guidance_scale=guidance_scale)
 
     # X2 + X3-X5 (prompt "" -> the unconditional context, guidance 1: extract.py:66-69)
     def invert_and_extract(self, x0: torch.Tensor, *, return_latents: bool = False):
-        ctx = self.ctx_uncond.expand(x0.shape[0], -1, -1) if self.ctx_uncond.shape[0] == 1 else self.ctx_uncond
+        ctx = self._uncond(x0.shape[0])
         return ddim_invert_extract(self.eps_model, x0, ctx, self.schedule, self.key, self.nonce, self.message_length,
                                    return_latents=return_latents)
 
     def invert(self, x0: torch.Tensor) -> torch.Tensor:
-        ctx = self.ctx_uncond.expand(x0.shape[0], -1, -1) if self.ctx_uncond.shape[0] == 1 else self.ctx_uncond
+        ctx = self._uncond(x0.shape[0])
         return ddim_invert(self.eps_model, x0, ctx, self.schedule)
 
     def txt2img(self, ctx_text: torch.Tensor, vae, *, latents: Optional[torch.Tensor] = None, seed: int = 0, image_index0: int = 0,

@@ -317,7 +317,7 @@ def run_codec(args, rank, world, local_rank, steps, warmup, cpu_codec=None):
     # this very configuration; otherwise null
     traffic = traffic_src = None
     try:
-        pmc_file = os.path.join("profiles", "r04_codec_pmc.json")          # (the codec kernels are unchanged since round 4)
+        pmc_file = os.path.join("profiles", "r06_codec_pmc.json")          # this round's passes (the codec kernels themselves are unchanged since round 4)
         pmc = json.load(open(os.path.join(ROOT, pmc_file)))
         c = pmc["config"]
         if c["batch_per_gpu"] == B and c["lattice"] == list(shape) and c["message_bits"] == M and fast:

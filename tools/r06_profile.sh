@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-6 evidence run on the GPU box (from the repo root).  Outputs under gpurun_out/r06p/.  Stages (pick with $1, default all): bench prof pmc sq codec small
+# Round-6 evidence run on the GPU box (from the repo root).  Outputs under gpurun_out/r06p/.  Stages (pick with $1, default all): bench prof pmc sq codec small xattn
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/r06p
 mkdir -p $O
@@ -55,6 +55,10 @@ if has sq; then
     timeout 900 rocprofv3 --pmc $set --output-format csv -d $O/sq_$i -o p -- python3 $R/tools/unet_forward_bench.py 128 > $O/sq_$i.log 2>&1; echo "sq $i rc=$?"
   done
   python3 $R/tools/pmc_sq_summary.py $O/sq_1 $O/sq_2 > $O/unet_forward_b128_sq_pmc_summary.txt 2>&1; head -30 $O/unet_forward_b128_sq_pmc_summary.txt
+fi
+if has xattn; then
+  cd $R; bash tools/xattn_pmc.sh r06x > $O/xattn_pmc.log 2>&1; cp gpurun_out/pmc_r06x_summary.txt $O/xattn_pmc_summary.txt; rm -rf gpurun_out/pmc_r06x_*
+  timeout 600 python3 tools/xattn_ablate.py 128 > $O/xattn_ablate.txt 2>&1; tail -30 $O/xattn_ablate.txt
 fi
 cd $R
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -delete; find $O -name "*.db" -delete; find $O -name "*_agent_info.csv" -delete
