@@ -166,13 +166,18 @@ def test_dpms_scheduler_is_marked_parity_unpinned(tmp_path):
     importlib.reload(E)
 
 
-def test_strict_kernels_raises_instead_of_warning():
+def test_strict_kernels_raise_by_default_and_the_opt_out_warns_and_counts():
     import gswm_amd
     from gswm_amd import unet as U, vae as V
-    U.STRICT = True
+    assert U.STRICT is True and V.STRICT is True                       # round 6: leaving the hand-written path raises unless the caller opts out
+    with pytest.raises(RuntimeError, match="strict kernels"):
+        U._note_fallback("linear K=100 N=7: library GEMM")
+    U.STRICT = False
     try:
-        with pytest.raises(RuntimeError, match="strict kernels"):
+        U.FALLBACKS.clear()
+        with pytest.warns(RuntimeWarning, match="library GEMM"):
             U._note_fallback("linear K=100 N=7: library GEMM")
+        assert U.FALLBACKS == {"linear K=100 N=7: library GEMM": 1}
     finally:
-        U.STRICT = False
-    assert V.STRICT is False
+        U.STRICT = True
+        U.FALLBACKS.clear()
