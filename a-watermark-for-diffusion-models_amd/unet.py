@@ -274,8 +274,8 @@ class Attention(nn.Module):
         """x + attn(LayerNorm(x), ctx) as ONE launch (xattn.py / csrc/gswm_xattn.hip): x [B, S, 320] raw residual stream, stat its (rstd, -rstd mean), ctx
         [B or 2B, 77, D] (2B: classifier-free guidance on shared latents -> [2B, S, 320]).  eps_next: leave the statistics of the new rows for the next LayerNorm."""
         from . import xattn
-        blob, uv, idx = xattn.context_operands(self, norm, ctx, x.dtype)
-        return xattn.fused(x, stat, blob, uv, idx, ctx.shape[0], self.heads, eps_out=eps_next)
+        blob, v, idx = xattn.context_operands(self, norm, ctx, x.dtype)
+        return xattn.fused(x, stat, blob, v, idx, ctx.shape[0], self.heads, eps_out=eps_next)
 
     def cross_dup(self, x, ctx, *, stat=None, norm: Optional[nn.LayerNorm] = None):
         """Classifier-free guidance with shared latents: x [B, S, C] holds the queries' input ONCE, ctx [2B, 77, D] = (uncond | text) contexts.  The

@@ -105,7 +105,7 @@ def run_index(ctx: torch.Tensor) -> Optional[torch.Tensor]:
 
 
 def context_operands(attn, norm, ctx: torch.Tensor, dtype: torch.dtype):
-    """(blob, uv, index) of `ctx` [Bc, keys, D] for cross-attention module `attn` behind LayerNorm `norm`: computed once per (context tensor, layer) and
+    """(blob, v, index) of `ctx` [Bc, keys, D] for cross-attention module `attn` behind LayerNorm `norm`: computed once per (context tensor, layer) and
     reused by every step of a loop.  The cache lives ON the context tensor and is keyed by the tensor's and the parameters' version counters; an in-place
     edit recomputes INTO the existing buffers (a captured HIP graph of the forward reads them at fixed addresses)."""
     src = ctx[:1] if (ctx.dim() == 3 and ctx.shape[0] > 1 and ctx.stride(0) == 0) else ctx           # .expand() of one context: one stream
@@ -118,17 +118,17 @@ def context_operands(attn, norm, ctx: torch.Tensor, dtype: torch.dtype):
     ent = store.get(id(attn))
     if ent is None or ent[0] != ver:
         with torch.no_grad():
-            blob, uv = pack_stream(*fold_operands(attn.to_q.weight, attn.to_k.weight, attn.to_v.weight, attn.to_out[0].weight, attn.to_out[0].bias,
+            blob, v = pack_stream(*fold_operands(attn.to_q.weight, attn.to_k.weight, attn.to_v.weight, attn.to_out[0].weight, attn.to_out[0].bias,
                                                   norm.weight, norm.bias, src, attn.heads, dtype))
             idx = run_index(src)
         if ent is not None and ent[1].shape == blob.shape and ent[1].dtype == blob.dtype:
             ent[1].copy_(blob)
-            ent[2].copy_(uv)
+            ent[2].copy_(v)
             if idx is not None:
                 ent[3].copy_(idx)
             ent = (ver, ent[1], ent[2], ent[3])
         else:
-            ent = (ver, blob, uv, idx)
+            ent = (ver, blob, v, idx)
         store[id(attn)] = ent
     return ent[1], ent[2], ent[3]
 
@@ -141,7 +141,7 @@ def usable(x: torch.Tensor, attn, ctx: torch.Tensor) -> bool:
             and ctx.shape[0] % x.shape[0] == 0 and x.shape[0] * x.shape[1] < (1 << 31) // max(1, ctx.shape[0] // x.shape[0]))
 
 
-def fused(x: torch.Tensor, stat: torch.Tensor, blob: torch.Tensor, uv: torch.Tensor, index: Optional[torch.Tensor], out_images: int, heads: int,
+def fused(x: torch.Tensor, stat: torch.Tensor, blob: torch.Tensor, v: torch.Tensor, index: Optional[torch.Tensor], out_images: int, heads: int,
           eps_out: Optional[float] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x [xB, S, 320] raw residual stream, stat [xB * S, 2] = (rstd, -rstd mean) of its rows (pf.ln_stat) -> x' [out_images, S, 320]; output image i
     reads x image i % xB and the context stream index[i] (None: stream 0; one stream: every image's).  eps_out: also leave the (rstd, -rstd mean) of the
@@ -151,8 +151,8 @@ def fused(x: torch.Tensor, stat: torch.Tensor, blob: torch.Tensor, uv: torch.Ten
     xB, S, C = x.shape
     if C != CHANNELS or S % 128 or out_images % xB or x.dtype not in (torch.float16, torch.bfloat16) or not x.is_contiguous():
         raise ValueError("xattn.fused: x must be a contiguous fp16 / bf16 [xB, S % 128 == 0, 320] tensor, out_images a multiple of xB")
-    if blob.dtype != x.dtype or blob.dim() != 2 or blob.shape[1] != heads * HEAD_ELEMS or uv.dtype != torch.float32 or uv.shape != (blob.shape[0], heads * V_FLOATS):
-        raise ValueError("xattn.fused: blob / uv are not context_operands' output for this head count and dtype")
+    if blob.dtype != x.dtype or blob.dim() != 2 or blob.shape[1] != heads * HEAD_ELEMS or v.dtype != torch.float32 or v.shape != (blob.shape[0], heads * V_FLOATS):
+        raise ValueError("xattn.fused: blob / v are not context_operands' output for this head count and dtype")
     if stat.dtype != torch.float32 or stat.numel() != 2 * xB * S or not stat.is_contiguous():
         raise ValueError("xattn.fused: stat must be fp32 [xB * S, 2]")
     nctx = blob.shape[0]
@@ -168,7 +168,7 @@ def fused(x: torch.Tensor, stat: torch.Tensor, blob: torch.Tensor, uv: torch.Ten
     tm = pf.CONV_TIMER
     with torch.cuda.device(x.device):
         e0 = tm.start() if tm is not None else None
-        N.check(N.lib().gsw_xattn_fused(x.data_ptr(), stat.data_ptr(), blob.data_ptr(), blob.shape[1] * blob.element_size(), uv.data_ptr(), uv.shape[1],
+        N.check(N.lib().gsw_xattn_fused(x.data_ptr(), stat.data_ptr(), blob.data_ptr(), blob.shape[1] * blob.element_size(), v.data_ptr(), v.shape[1],
                                         index.data_ptr() if index is not None else None, y.data_ptr(), ostat.data_ptr() if ostat is not None else None,
                                         float(eps_out) if eps_out is not None else 0.0, xB, out_images, S, C, heads, _dt(x.dtype), _stream_ptr()))
         if tm is not None:
