@@ -62,3 +62,23 @@ def test_schedule_refuses_a_step_count_outside_its_training_range(steps):
     with pytest.raises(ValueError, match="num_inference_steps"):
         ddim.DDIMSchedule(num_inference_steps=steps)
     assert ddim.DDIMSchedule(num_inference_steps=1000, steps_offset=0).ratio == 1 and ddim.DDIMSchedule(num_inference_steps=1, steps_offset=0).timesteps_desc.tolist() == [0]
+
+
+def test_guidance_contexts_are_one_object_per_prompt_set():
+    """ddim_sample concatenates (uncond | text) ONCE per pair of inputs: the eps model's per-context caches live on that tensor, so a second loop over the same prompts must
+    get the same object -- and a new one when either input changes"""
+    import torch
+    from gswm_amd import pipeline
+    u = torch.randn(1, 77, 8)
+    t = torch.randn(3, 77, 8)
+    p = pipeline.GaussianShadingPipeline.__new__(pipeline.GaussianShadingPipeline)
+    p.ctx_uncond = u
+    a, b = p._uncond(3), p._uncond(3)
+    assert a is b and a.shape == (3, 77, 8) and p._uncond(2).shape == (2, 77, 8)
+    c1, c2 = ddim._cfg_contexts(a, t), ddim._cfg_contexts(b, t)
+    assert c1 is c2 and torch.equal(c1[:3], u.expand(3, -1, -1)) and torch.equal(c1[3:], t)
+    t.add_(1.0)
+    c3 = ddim._cfg_contexts(a, t)
+    assert c3 is not c1 and torch.equal(c3[3:], t)
+    p.ctx_uncond = torch.randn(1, 77, 8)
+    assert p._uncond(3) is not a and ddim._cfg_contexts(p._uncond(3), t) is not c3

@@ -126,3 +126,32 @@ def test_unsupported_shapes_are_refused_not_computed():
     assert lib.gsw_xattn_fused(z.data_ptr(), z.data_ptr(), z.data_ptr(), 16, z.data_ptr(), 4, None, z.data_ptr(), None, 0.0, 1, 1, 128, 640, 5, 1, None) == _native.GSW_ERR_UNSUPPORTED
     assert lib.gsw_xattn_fused(z.data_ptr(), z.data_ptr(), z.data_ptr(), 16, z.data_ptr(), 4, None, z.data_ptr(), None, 0.0, 1, 1, 100, 320, 5, 1, None) == _native.GSW_ERR_UNSUPPORTED
     assert lib.gsw_xattn_fused(None, z.data_ptr(), z.data_ptr(), 16, z.data_ptr(), 4, None, z.data_ptr(), None, 0.0, 1, 1, 128, 320, 5, 1, None) == _native.GSW_ERR_BAD_ARG
+
+
+def test_unet_forward_with_and_without_the_one_launch_cross_attention():
+    """the whole SD 2.1-shaped UNet, 64 x 64 latents, plain and classifier-free-guidance (shared latents) forwards: the one-launch cross-attention of the five
+    320-channel blocks against the three launches it replaces -- same eps to fp16 noise level, and nothing leaves the hand-written path either way"""
+    from gswm_amd import unet as U, xattn
+    torch.manual_seed(0)
+    m = U.synthetic_init_(U.UNet2DCondition(), 0).cuda().half().eval()
+    x = torch.randn(2, 4, 64, 64, device="cuda").half()
+    t = torch.full((), 481, device="cuda")
+    ctx = torch.randn(2, 77, 1024, device="cuda").half()
+    ctx2 = torch.cat([torch.randn(1, 77, 1024, device="cuda").half().expand(2, -1, -1), ctx], dim=0)      # (uncond x 2 | text x 2)
+    U.FALLBACKS.clear()
+    outs = {}
+    try:
+        for flag in (True, False):
+            xattn.ENABLED = flag
+            with torch.no_grad():
+                outs[flag] = (m(x, t, ctx).float(), m(x, t, ctx2, cfg_dup=True).float())
+    finally:
+        xattn.ENABLED = True
+    assert U.FALLBACKS == {}
+    for a, b in zip(outs[True], outs[False]):
+        assert a.shape == b.shape and torch.isfinite(a).all()
+        assert (a - b).abs().max().item() <= 2e-2 * max(1.0, b.abs().max().item())
+    # the guidance batch of shared latents equals the doubled batch (what the reference computes: torch.cat([latents] * 2))
+    with torch.no_grad():
+        doubled = m(torch.cat([x, x], dim=0), t, ctx2).float()
+    assert (outs[True][1] - doubled).abs().max().item() <= 2e-2 * max(1.0, doubled.abs().max().item())
