@@ -68,6 +68,8 @@ _PROTOTYPES = {
                                    C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     "gsw_xattn_fused": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int,
                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "gsw_xattn_fused_pre": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "gsw_mt19937_seed": (None, [C.c_uint32, C.c_void_p]),
     "gsw_mt19937_uniform": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "gsw_lanczos_plan": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),

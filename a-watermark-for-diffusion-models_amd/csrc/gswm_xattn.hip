@@ -55,6 +55,7 @@ constexpr int XKB = 3;                  // 32-key blocks of the first product: 9
 constexpr int XKK = 5;
 constexpr int XEMPTY = 6;               // the step of a head that carries the softmax instead of a chunk
 constexpr uint32_t XCHUNK = 10240;      // ten 1 KiB fragments
+constexpr int XPRO = 21;                 // chunks of the PRO kernels' prologue: 20 k-steps of Wo + the bias
 constexpr uint32_t XHEAD = 11 * XCHUNK; // one head: 60 fragments of A' (k-step major, key block minor) + 50 of B (key step major, column block minor)
 constexpr int XV = 32 * XKB;            // floats of v per head
 
@@ -66,9 +67,11 @@ struct XArgs {
     const int32_t* bidx;    // [oB] context of an output image (nullptr: all 0)
     uint16_t* out;          // [oB * S, 320]
     float2* ostat;          // [oB * S] (rstd, -rstd mean) of the output rows (nullptr: not wanted)
+    const uint16_t* pre_o;  // PRO kernels: [xB * S, 320] the self-attention output; x is then the RESIDUAL of its output projection and stat is not read
+    const uint8_t* pre_w;   // PRO kernels: 21 chunks -- 200 fragments of Wo (k-step major, column block minor) + ten bias fragments (xattn.py: pack_out_projection)
     int64_t blob_stride;    // bytes between contexts
     int64_t uv_stride;      // floats between contexts
-    float inv_c, eps;
+    float inv_c, eps, eps_in;      // 1 / 320; epsilon of the LayerNorm behind the output (ostat) and -- PRO -- of the one in front (norm2)
     uint32_t xB, oB, S, T;  // images of x (output image i reads x image i % xB), output images, tokens per image, 128-row tiles per image
     uint32_t heads, ntiles, xcd;
 };
@@ -131,7 +134,10 @@ __device__ __forceinline__ bool xtile(const XArgs& p, uint32_t it, uint32_t& oi,
     return true;
 }
 
-template <typename T>
+// PRO: the launch also runs what stands in front of the sublayer in a transformer block -- the output projection of the SELF-attention with its bias and residual,
+// x = r + o Wo^T + b -- as a prologue per tile (x'^T accumulators = Wo fragments x the o fragments, 21 more chunks of stream per tile), takes norm2's statistics from the rows it
+// has just made (a row is two lanes of one wave) and rounds them into the x fragments: x is never written or read, `gsw_ln_rowstats_finish` does not run
+template <typename T, bool PRO>
 __global__ __launch_bounds__(256) void gsw_xattn_kernel(const XArgs p) {
     using M_ = MM<T>;
     using frag = typename M_::frag;
@@ -154,7 +160,7 @@ __global__ __launch_bounds__(256) void gsw_xattn_kernel(const XArgs p) {
     uint32_t oi, sub;
     if (!xtile(p, 0, oi, sub)) return;
     int64_t cctx = p.bidx ? xctx(p.bidx, oi) : 0;      // this tile's context
-    const uint8_t* cur = p.blob + xuni(cctx * p.blob_stride);
+    const uint8_t* cur = PRO ? p.pre_w : p.blob + xuni(cctx * p.blob_stride);      // where this workgroup's fragment stream starts
 
     // three staging register sets, named (not an array: every use must be a compile-time choice for them to stay in registers)
     uint4 sa0, sa1, sa2, sb0, sb1, sb2;
@@ -185,26 +191,101 @@ __global__ __launch_bounds__(256) void gsw_xattn_kernel(const XArgs p) {
     // of this tile's output stores -- instead of at the top of the tile
     frag xf[XKS];
     float2 st;
+    frag of[XKS];            // PRO: the lane's row of the self-attention output, loaded one tile ahead like x in the plain kernel (dead while the heads run)
     auto load_x = [&](uint32_t oi_, uint32_t sub_) __attribute__((always_inline)) {
         const int64_t xrow = (int64_t)(oi_ % p.xB) * p.S + sub_ * 128u + wave * 32u + r;
         const uint16_t* xr = p.x + xrow * XC + hlf * 8u;
 #pragma unroll
         for (int ks = 0; ks < XKS; ++ks) xf[ks] = __builtin_bit_cast(frag, *reinterpret_cast<const uint4*>(xr + ks * 16));
-        st = p.stat[xrow];
+        if constexpr (!PRO) st = p.stat[xrow];
     };
-    load_x(oi, sub);
+    auto load_o = [&](uint32_t oi_, uint32_t sub_) __attribute__((always_inline)) {
+        const int64_t xrow = (int64_t)(oi_ % p.xB) * p.S + sub_ * 128u + wave * 32u + r;
+        const uint16_t* orr = p.pre_o + xrow * XC + hlf * 8u;
+#pragma unroll
+        for (int ks = 0; ks < XKS; ++ks) of[ks] = __builtin_bit_cast(frag, *reinterpret_cast<const uint4*>(orr + ks * 16));
+    };
+    if constexpr (PRO) load_o(oi, sub); else load_x(oi, sub);
     for (uint32_t it = 0;; ++it) {
         uint32_t noi = oi, nsub = sub;
         const bool more = xtile(p, it + 1, noi, nsub);
         const int64_t nctx = more ? (p.bidx ? xctx(p.bidx, noi) : 0) : cctx;      // the next tile's context: the fragment stream runs on into it
         const int64_t orow = (int64_t)oi * p.S + sub * 128u + wave * 32u + r;
         x_f16v acc[XNB];
+        // (PRO: the prologue's stream sits at ONE address for every tile; an offset the compiler cannot see through keeps it from hoisting 63 per-lane 64-bit addresses out of
+        //  the tile loop -- 126 registers this kernel does not have -- instead of adding a 32-bit lane offset to a scalar base at each load)
+        int64_t opaque0 = 0;
+        if constexpr (PRO) asm volatile("s_mov_b64 %0, 0" : "=s"(opaque0));
+        const uint8_t* pw = PRO ? p.pre_w + opaque0 : nullptr;
+        if constexpr (PRO) {
+            // ---- prologue: x = r + o Wo^T + b in the x' accumulators; 21 steps of the same stream machinery (chunk j: the ten column blocks of k-step j; chunk 20: the bias) ----
+            // (the residual r of the projection arrives as fragments in the second half of the prologue, two k-steps per step, into the registers the o fragments leave:
+            //  o and r together never hold more than twenty fragments)
+            const uint16_t* rr = p.x + ((int64_t)(oi % p.xB) * p.S + sub * 128u + wave * 32u + r) * XC + hlf * 8u;
+            const uint8_t* h0 = p.blob + xuni(cctx * p.blob_stride);
+            auto pstep = [&](auto J) __attribute__((always_inline)) {
+                constexpr int j = decltype(J)::value;
+                X_BARRIER(3);
+                X_WR((j + 2) % 3, (j + 2) % 3);
+                X_LD((j + 5) % 3, (j + 5) < XPRO ? pw + (j + 5) * XCHUNK : h0 + (j + 5 - XPRO) * XCHUNK);
+                const uint8_t* sl = X_SLOT((j + 1) % 3) + lane * 16u;
+                const frag e0 = __builtin_bit_cast(frag, uint4{hlf == 0u ? ONE : 0u, 0u, 0u, 0u});      // the bias fragments carry b in their k = 0 column
+                constexpr bool rl = j >= XPRO - 11 && j < XPRO - 1;
+                if constexpr (rl) {
+                    xf[2 * (j - (XPRO - 11))] = __builtin_bit_cast(frag, *reinterpret_cast<const uint4*>(rr + (2 * (j - (XPRO - 11))) * 16));
+                    xf[2 * (j - (XPRO - 11)) + 1] = __builtin_bit_cast(frag, *reinterpret_cast<const uint4*>(rr + (2 * (j - (XPRO - 11)) + 1) * 16));
+                }
+#pragma unroll
+                for (int i = 0; i < 10; ++i) {
+                    acc[i] = XM<T>::mma(fr[i], j < XPRO - 1 ? of[j < XPRO - 1 ? j : 0] : e0, j == 0 ? zero16 : acc[i]);
+                    fr[i] = __builtin_bit_cast(frag, *reinterpret_cast<const uint4*>(sl + i * 1024));
+                }
+#pragma unroll
+                for (int i = 0; i < 10; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (i < 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                    if (i >= 3 && i < (rl ? 8 : 6)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+            };
+            pstep(std::integral_constant<int, 0>{}); pstep(std::integral_constant<int, 1>{}); pstep(std::integral_constant<int, 2>{}); pstep(std::integral_constant<int, 3>{});
+            pstep(std::integral_constant<int, 4>{}); pstep(std::integral_constant<int, 5>{}); pstep(std::integral_constant<int, 6>{}); pstep(std::integral_constant<int, 7>{});
+            pstep(std::integral_constant<int, 8>{}); pstep(std::integral_constant<int, 9>{}); pstep(std::integral_constant<int, 10>{}); pstep(std::integral_constant<int, 11>{});
+            pstep(std::integral_constant<int, 12>{}); pstep(std::integral_constant<int, 13>{}); pstep(std::integral_constant<int, 14>{}); pstep(std::integral_constant<int, 15>{});
+            pstep(std::integral_constant<int, 16>{}); pstep(std::integral_constant<int, 17>{}); pstep(std::integral_constant<int, 18>{}); pstep(std::integral_constant<int, 19>{});
+            pstep(std::integral_constant<int, 20>{});
+            // + r (exact: permutation matrix x fragments), then ONE rounding: the rows of x as the three-launch path stores them, their statistics from the rounded values,
+            // and the fragments both products below read
+            float sm = 0.f, sq = 0.f;
+#pragma unroll
+            for (int nb = 0; nb < XNB; ++nb) {
+                acc[nb] = XM<T>::mma(pm[1], xf[2 * nb + 1], XM<T>::mma(pm[0], xf[2 * nb], acc[nb]));
+            }
+#pragma unroll
+            for (int nb = 0; nb < XNB; ++nb) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    uint4 w;
+                    w.x = M_::cvt2(acc[nb][8 * j + 0], acc[nb][8 * j + 1]);
+                    w.y = M_::cvt2(acc[nb][8 * j + 2], acc[nb][8 * j + 3]);
+                    w.z = M_::cvt2(acc[nb][8 * j + 4], acc[nb][8 * j + 5]);
+                    w.w = M_::cvt2(acc[nb][8 * j + 6], acc[nb][8 * j + 7]);
+                    M_::stat2(w.x, sm, sq); M_::stat2(w.y, sm, sq); M_::stat2(w.z, sm, sq); M_::stat2(w.w, sm, sq);
+                    xf[2 * nb + j] = __builtin_bit_cast(frag, w);
+                }
+            }
+            sm = xh_sum(sm);
+            sq = xh_sum(sq);
+            const float mean = sm * p.inv_c, var = fmaxf(sq * p.inv_c - mean * mean, 0.f), rstd = rsqrtf(var + p.eps_in);
+            st = make_float2(rstd, -rstd * mean);
+        }
 #pragma unroll
         for (int nb = 0; nb < XNB; ++nb) acc[nb] = XM<T>::mma(pm[1], xf[2 * nb + 1], XM<T>::mma(pm[0], xf[2 * nb], zero16));
 
         auto head = [&](const uint32_t h, auto LAST) __attribute__((always_inline)) {
             const uint8_t* hb = p.blob + xuni(cctx * p.blob_stride + (int64_t)h * XHEAD);
-            const uint8_t* hn = p.blob + xuni(h + 1 == p.heads ? nctx * p.blob_stride : cctx * p.blob_stride + (int64_t)(h + 1) * XHEAD);
+            const uint8_t* hn = (PRO && h + 1 == p.heads) ? pw      // (the next tile starts with the prologue's stream again)
+                                                          : p.blob + xuni(h + 1 == p.heads ? nctx * p.blob_stride : cctx * p.blob_stride + (int64_t)(h + 1) * XHEAD);
             const float* hv = p.uv + xuni(cctx * p.uv_stride + h * XV) + hlf * 4u;
             x_f16v S[XKB];
             frag pf[XKK];
@@ -265,7 +346,7 @@ __global__ __launch_bounds__(256) void gsw_xattn_kernel(const XArgs p) {
                         pf[kk] = __builtin_bit_cast(frag, uint4{M_::cvt2(s[8 * kk + 0] * inv, s[8 * kk + 1] * inv), M_::cvt2(s[8 * kk + 2] * inv, s[8 * kk + 3] * inv),
                                                                 M_::cvt2(s[8 * kk + 4] * inv, s[8 * kk + 5] * inv), w3});
                     }
-                    if constexpr (decltype(LAST)::value) load_x(noi, nsub);      // (the last tile re-reads its own rows: harmless)
+                    if constexpr (decltype(LAST)::value) { if constexpr (PRO) load_o(noi, nsub); else load_x(noi, nsub); }      // (the last tile re-reads its own rows: harmless)
                 } else {
                     // x'^T[32 columns of block nb][rows] += B[32 columns x 16 key slots] P^T[16 key slots x 32 rows]: key step kk = j - 7, ten column blocks per chunk
 #pragma unroll
@@ -336,12 +417,16 @@ __global__ __launch_bounds__(256) void gsw_xattn_kernel(const XArgs p) {
 
 }  // namespace
 
-int gsw_xattn_fused(const void* x_dev, const float* ln_stat_dev, const void* blob_dev, int64_t blob_stride_bytes, const float* v_dev, int64_t v_stride_floats,
-                    const int32_t* ctx_index_dev, void* out_dev, float* out_stat_dev, float out_eps, int x_images, int out_images, int tokens, int C, int heads,
-                    int dtype, void* stream) {
-    if (!x_dev || !ln_stat_dev || !blob_dev || !v_dev || !out_dev || x_images <= 0 || out_images <= 0 || tokens <= 0 || heads <= 0) return GSW_ERR_BAD_ARG;
+namespace {
+
+int xattn_launch(const void* x_dev, const float* ln_stat_dev, const void* pre_o_dev, const void* pre_w_dev, float pre_eps, const void* blob_dev, int64_t blob_stride_bytes,
+                 const float* v_dev, int64_t v_stride_floats, const int32_t* ctx_index_dev, void* out_dev, float* out_stat_dev, float out_eps, int x_images, int out_images,
+                 int tokens, int C, int heads, int dtype, void* stream) {
+    const bool pro = pre_o_dev != nullptr;
+    if (!x_dev || (!pro && !ln_stat_dev) || (pro && !pre_w_dev) || !blob_dev || !v_dev || !out_dev || x_images <= 0 || out_images <= 0 || tokens <= 0 || heads <= 0) return GSW_ERR_BAD_ARG;
     if (dtype != GSW_F16 && dtype != GSW_BF16) return GSW_ERR_BAD_ARG;
-    if (((uintptr_t)x_dev | (uintptr_t)blob_dev | (uintptr_t)v_dev | (uintptr_t)out_dev | (uintptr_t)ln_stat_dev | (uintptr_t)out_stat_dev) & 15) return GSW_ERR_BAD_ARG;
+    if (((uintptr_t)x_dev | (uintptr_t)blob_dev | (uintptr_t)v_dev | (uintptr_t)out_dev | (uintptr_t)ln_stat_dev | (uintptr_t)out_stat_dev | (uintptr_t)pre_o_dev | (uintptr_t)pre_w_dev) & 15)
+        return GSW_ERR_BAD_ARG;
     if ((blob_stride_bytes & 15) || (v_stride_floats & 3) || out_images % x_images) return GSW_ERR_BAD_ARG;
     if (C != XC || tokens % 128 || heads > 64 || (int64_t)out_images * tokens >= ((int64_t)1 << 31)) return GSW_ERR_UNSUPPORTED;
     int dev = 0, cus = 0;
@@ -357,10 +442,13 @@ int gsw_xattn_fused(const void* x_dev, const float* ln_stat_dev, const void* blo
     a.bidx = ctx_index_dev;
     a.out = reinterpret_cast<uint16_t*>(out_dev);
     a.ostat = reinterpret_cast<float2*>(out_stat_dev);
+    a.pre_o = reinterpret_cast<const uint16_t*>(pre_o_dev);
+    a.pre_w = reinterpret_cast<const uint8_t*>(pre_w_dev);
     a.blob_stride = blob_stride_bytes;
     a.uv_stride = v_stride_floats;
     a.inv_c = 1.0f / (float)XC;
     a.eps = out_eps;
+    a.eps_in = pre_eps;
     a.xB = (uint32_t)x_images; a.oB = (uint32_t)out_images; a.S = (uint32_t)tokens; a.T = (uint32_t)(tokens / 128);
     a.heads = (uint32_t)heads;
     a.ntiles = a.oB * a.T;
@@ -368,9 +456,32 @@ int gsw_xattn_fused(const void* x_dev, const float* ln_stat_dev, const void* blo
     a.xcd = (cus % 8 == 0 && a.oB >= 8u && a.ntiles > (uint32_t)cus) ? 1u : 0u;
     const uint32_t grid = a.xcd ? (uint32_t)cus : std::min<uint32_t>((uint32_t)cus, a.ntiles);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == GSW_F16) hipLaunchKernelGGL(gsw_xattn_kernel<_Float16>, dim3(grid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(gsw_xattn_kernel<__bf16>, dim3(grid), dim3(256), 0, st, a);
+    if (dtype == GSW_F16) {
+        if (pro) hipLaunchKernelGGL((gsw_xattn_kernel<_Float16, true>), dim3(grid), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((gsw_xattn_kernel<_Float16, false>), dim3(grid), dim3(256), 0, st, a);
+    } else {
+        if (pro) hipLaunchKernelGGL((gsw_xattn_kernel<__bf16, true>), dim3(grid), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((gsw_xattn_kernel<__bf16, false>), dim3(grid), dim3(256), 0, st, a);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g_last_hip_error = (int)e; return GSW_ERR_HIP; }
     return GSW_OK;
+}
+
+}  // namespace
+
+int gsw_xattn_fused(const void* x_dev, const float* ln_stat_dev, const void* blob_dev, int64_t blob_stride_bytes, const float* v_dev, int64_t v_stride_floats,
+                    const int32_t* ctx_index_dev, void* out_dev, float* out_stat_dev, float out_eps, int x_images, int out_images, int tokens, int C, int heads,
+                    int dtype, void* stream) {
+    if (!ln_stat_dev) return GSW_ERR_BAD_ARG;
+    return xattn_launch(x_dev, ln_stat_dev, nullptr, nullptr, 0.f, blob_dev, blob_stride_bytes, v_dev, v_stride_floats, ctx_index_dev, out_dev, out_stat_dev, out_eps, x_images,
+                        out_images, tokens, C, heads, dtype, stream);
+}
+
+int gsw_xattn_fused_pre(const void* resid_dev, const void* o_dev, const void* w_frag_dev, float ln_eps, const void* blob_dev, int64_t blob_stride_bytes, const float* v_dev,
+                        int64_t v_stride_floats, const int32_t* ctx_index_dev, void* out_dev, float* out_stat_dev, float out_eps, int x_images, int out_images, int tokens,
+                        int C, int heads, int dtype, void* stream) {
+    if (!o_dev || !w_frag_dev) return GSW_ERR_BAD_ARG;
+    return xattn_launch(resid_dev, nullptr, o_dev, w_frag_dev, ln_eps, blob_dev, blob_stride_bytes, v_dev, v_stride_floats, ctx_index_dev, out_dev, out_stat_dev, out_eps, x_images,
+                        out_images, tokens, C, heads, dtype, stream);
 }

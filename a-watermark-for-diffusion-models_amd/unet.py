@@ -250,9 +250,10 @@ class Attention(nn.Module):
             store[id(self)] = ent
         return ent[1], ent[2]
 
-    def forward_ln(self, x, stat, norm: nn.LayerNorm, ctx=None, resid=None):
+    def forward_ln(self, x, stat, norm: nn.LayerNorm, ctx=None, resid=None, project: bool = True):
         """attn(LayerNorm(x)) + resid with the LayerNorm folded into the projections that consume it (pf.gemm_ln): x is the RAW residual stream,
-        stat its per-row (rstd, -rstd mean).  Self-attention: q | k and V^T; cross-attention: q (keys / values come from the context)."""
+        stat its per-row (rstd, -rstd mean).  Self-attention: q | k and V^T; cross-attention: q (keys / values come from the context).
+        project=False: the attention output BEFORE to_out (the caller hands it, to_out and the residual to the launch that consumes them: fused_sublayer)."""
         from .pf import attention, cached, fold_ln_weights, gemm_ln
         b, n, _ = x.shape
         inner = self.to_q.out_features
@@ -268,13 +269,20 @@ class Attention(nn.Module):
             fq = cached(self, "_gsw_ln_q", (self.to_q.weight, norm.weight, norm.bias), lambda: fold_ln_weights(self.to_q.weight.detach(), None, norm.weight, norm.bias))
             k_ctx, vt_ctx = self.context_kv(src)
             o = attention(gemm_ln(x, stat, *fq), k_ctx, vt_ctx, self.heads, valid_keys=valid)
+        if not project:
+            return o
         return _lin(o, self.to_out[0], resid, rowstats=True)
 
-    def fused_sublayer(self, x, stat, norm: nn.LayerNorm, ctx, eps_next: Optional[float] = None):
+    def fused_sublayer(self, x, stat, norm: nn.LayerNorm, ctx, eps_next: Optional[float] = None, pre=None):
         """x + attn(LayerNorm(x), ctx) as ONE launch (xattn.py / csrc/gswm_xattn.hip): x [B, S, 320] raw residual stream, stat its (rstd, -rstd mean), ctx
-        [B or 2B, 77, D] (2B: classifier-free guidance on shared latents -> [2B, S, 320]).  eps_next: leave the statistics of the new rows for the next LayerNorm."""
+        [B or 2B, 77, D] (2B: classifier-free guidance on shared latents -> [2B, S, 320]).  eps_next: leave the statistics of the new rows for the next LayerNorm.
+        pre = (o, to_out): the same launch also runs the output projection of the self-attention in front -- x is then that projection's RESIDUAL, o the
+        attention output, and the stream x + to_out(o) the sublayer works on exists in registers only (stat is not needed)."""
         from . import xattn
         blob, v, idx = xattn.context_operands(self, norm, ctx, x.dtype)
+        if pre is not None:
+            return xattn.fused(x, None, blob, v, idx, ctx.shape[0], self.heads, eps_out=eps_next, pre_o=pre[0], pre_w=xattn.out_projection_operand(pre[1], x.dtype),
+                               pre_eps=norm.eps)
         return xattn.fused(x, stat, blob, v, idx, ctx.shape[0], self.heads, eps_out=eps_next)
 
     def cross_dup(self, x, ctx, *, stat=None, norm: Optional[nn.LayerNorm] = None):
@@ -419,14 +427,24 @@ class BasicTransformerBlock(nn.Module):
             # launch that produced x left row records on it (large batches: pf.ln_stat) -- the normalised tensor is then never written; otherwise it is
             # one read + one write (gsw_add_layernorm)
             inner4 = self.ff.net[2].in_features
+            from . import xattn
+            one_launch = xattn.usable(x, self.attn2, ctx)      # the 320-channel level: norm2 + query projection + 77-key attention + output projection + residual in one kernel
             st = ln_stat(x, self.norm1.eps) if self.attn1.ln_foldable(x) else None
+            if st is not None and one_launch and xattn.PRE_ENABLED and tuple(self.attn1.to_out[0].weight.shape) == (xattn.CHANNELS, xattn.CHANNELS):
+                # ... and the self-attention's output projection + bias + residual + norm2's statistics as that kernel's prologue: the stream between the two
+                # attention sublayers is never stored
+                o1 = self.attn1.forward_ln(x, st, self.norm1, project=False)
+                x = self.attn2.fused_sublayer(x, None, self.norm2, ctx, eps_next=self.norm3.eps, pre=(o1, self.attn1.to_out[0]))
+                st = ln_stat(x, self.norm3.eps) if (inner4 % 80 == 0 and _own_gemm_ok(x, x.shape[-1], 2 * inner4)) else None
+                if st is not None:
+                    return self.ff.forward_ln(x, st, self.norm3, resid=x)
+                _, n = add_layernorm(x, None, self.norm3.weight, self.norm3.bias, self.norm3.eps)
+                return self.ff(n, resid=x)
             if st is not None:
                 x = self.attn1.forward_ln(x, st, self.norm1, resid=x)
             else:
                 _, n = add_layernorm(x, None, self.norm1.weight, self.norm1.bias, self.norm1.eps)
                 x = self.attn1(n, resid=x)
-            from . import xattn
-            one_launch = xattn.usable(x, self.attn2, ctx)      # the 320-channel level: norm2 + query projection + 77-key attention + output projection + residual in one kernel
             if dup:
                 st = ln_stat(x, self.norm2.eps) if (one_launch or self.attn2.ln_foldable(x, ctx[: x.shape[0]])) else None
                 if st is not None and one_launch:
@@ -877,6 +895,8 @@ def _unet_prepare_context(self, ctx: torch.Tensor) -> None:
             from . import xattn
             if xattn.ENABLED and a.to_q.in_features == xattn.CHANNELS and ctx.shape[1] <= xattn.MAX_KEYS and ctx.dtype in (torch.float16, torch.bfloat16):
                 xattn.context_operands(a, blk.norm2, ctx, ctx.dtype)      # the one-launch cross-attention's per-context fragment streams
+                if xattn.PRE_ENABLED and tuple(blk.attn1.to_out[0].weight.shape) == (xattn.CHANNELS, xattn.CHANNELS):
+                    xattn.out_projection_operand(blk.attn1.to_out[0], ctx.dtype)      # ... and the prologue's (the self-attention's output projection; per layer, not per context)
 
 
 UNet2DCondition._cfg_dup_ok = _unet_cfg_dup_ok

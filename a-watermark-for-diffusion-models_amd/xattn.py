@@ -91,6 +91,42 @@ def pack_stream(Ap: torch.Tensor, v: torch.Tensor, Bm: torch.Tensor):
     return blob, v.reshape(Bc, H * V_FLOATS).contiguous()
 
 
+PRE_CHUNKS = 21           # gsw_xattn_fused_pre's prologue stream: twenty 16-channel k-steps of the self-attention's output projection + its bias
+PRE_ENABLED = __import__("os").environ.get("GSW_XATTN_PRE", "1") != "0"      # A/B switch: 0 = the self-attention's output projection stays its own launch
+
+
+def pack_out_projection(w: torch.Tensor, b: Optional[torch.Tensor], dtype: torch.dtype) -> torch.Tensor:
+    """Wo [320, 320] (+ bias) of the SELF-attention in front of the sublayer -> the prologue's fragment stream [PRE_CHUNKS * 5120] in consumption order: chunk ks holds
+    the ten column blocks of k-step ks -- fragment nb, lane (m, hlf), value e = Wo[column_of(nb, m)][16 ks + 8 hlf + e] -- and chunk 20 the bias in the k = 0 column of
+    ten fragments (lane (m, 0), value 0 = b[column_of(nb, m)]), which the kernel multiplies with a unit vector."""
+    C = CHANNELS
+    if tuple(w.shape) != (C, C):
+        raise ValueError(f"xattn: the output projection must be [{C}, {C}]")
+    dev = w.device
+    ar = lambda k: torch.arange(k, device=dev)
+    cols = _column_of(ar(C // 32)[:, None], ar(32)[None, :])                           # [nb, m]
+    wp = w.detach().to(dtype)[cols]                                                    # [nb, m, k]
+    g = wp.view(C // 32, 32, C // 16, 2, 8).permute(2, 0, 3, 1, 4).reshape(-1)         # [ks, nb, hlf, m, e]
+    bias = torch.zeros(C // 32, 2, 32, 8, dtype=dtype, device=dev)
+    if b is not None:
+        bias[:, 0, :, 0] = b.detach().to(dtype)[cols]
+    return torch.cat([g, bias.reshape(-1)]).contiguous()
+
+
+def out_projection_operand(lin, dtype: torch.dtype) -> torch.Tensor:
+    """pack_out_projection of a Linear, cached on the module (keyed by the parameters' versions; an edit recomputes INTO the same buffer: captured graphs read it)"""
+    ent = getattr(lin, "_gsw_xattn_pre", None)
+    ver = (str(dtype), lin.weight.data_ptr(), lin.weight._version) + ((lin.bias.data_ptr(), lin.bias._version) if lin.bias is not None else ())
+    if ent is None or ent[0] != ver:
+        new = pack_out_projection(lin.weight, lin.bias, dtype)
+        if ent is not None and ent[1].shape == new.shape and ent[1].dtype == new.dtype and ent[1].device == new.device:
+            ent[1].copy_(new)
+            new = ent[1]
+        ent = (ver, new)
+        lin._gsw_xattn_pre = ent
+    return ent[1]
+
+
 def run_index(ctx: torch.Tensor) -> Optional[torch.Tensor]:
     """int32 [Bc]: for every context row the first row of the run of identical rows it belongs to (classifier-free guidance hands over B copies of the
     empty prompt's context: their images then share ONE fragment stream in L2).  Computed on the device, no host synchronisation.  None for one row."""
@@ -141,11 +177,15 @@ def usable(x: torch.Tensor, attn, ctx: torch.Tensor) -> bool:
             and ctx.shape[0] % x.shape[0] == 0 and x.shape[0] * x.shape[1] < (1 << 31) // max(1, ctx.shape[0] // x.shape[0]))
 
 
-def fused(x: torch.Tensor, stat: torch.Tensor, blob: torch.Tensor, v: torch.Tensor, index: Optional[torch.Tensor], out_images: int, heads: int,
-          eps_out: Optional[float] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+def fused(x: torch.Tensor, stat: Optional[torch.Tensor], blob: torch.Tensor, v: torch.Tensor, index: Optional[torch.Tensor], out_images: int, heads: int,
+          eps_out: Optional[float] = None, out: Optional[torch.Tensor] = None, pre_o: Optional[torch.Tensor] = None, pre_w: Optional[torch.Tensor] = None,
+          pre_eps: float = 1e-5) -> torch.Tensor:
     """x [xB, S, 320] raw residual stream, stat [xB * S, 2] = (rstd, -rstd mean) of its rows (pf.ln_stat) -> x' [out_images, S, 320]; output image i
     reads x image i % xB and the context stream index[i] (None: stream 0; one stream: every image's).  eps_out: also leave the (rstd, -rstd mean) of the
-    NEW rows on the result (`_gsw_lnstat`, what pf.ln_stat returns for the LayerNorm that follows)."""
+    NEW rows on the result (`_gsw_lnstat`, what pf.ln_stat returns for the LayerNorm that follows).
+    pre_o / pre_w (gsw_xattn_fused_pre): the launch first MAKES the residual stream from what stands in front of the sublayer in a transformer block -- x becomes the
+    residual r of the self-attention's output projection, pre_o [xB, S, 320] that attention's output, pre_w out_projection_operand(to_out) -- i.e. it computes
+    x1 = r + pre_o Wo^T + b, LayerNorm statistics of x1 with epsilon pre_eps (stat is not read), then x1 + attn(LayerNorm(x1), ctx); x1 is never stored."""
     if not x.is_cuda:
         raise RuntimeError("xattn.fused: device tensors only; there is no CPU fallback")
     xB, S, C = x.shape
@@ -153,7 +193,13 @@ def fused(x: torch.Tensor, stat: torch.Tensor, blob: torch.Tensor, v: torch.Tens
         raise ValueError("xattn.fused: x must be a contiguous fp16 / bf16 [xB, S % 128 == 0, 320] tensor, out_images a multiple of xB")
     if blob.dtype != x.dtype or blob.dim() != 2 or blob.shape[1] != heads * HEAD_ELEMS or v.dtype != torch.float32 or v.shape != (blob.shape[0], heads * V_FLOATS):
         raise ValueError("xattn.fused: blob / v are not context_operands' output for this head count and dtype")
-    if stat.dtype != torch.float32 or stat.numel() != 2 * xB * S or not stat.is_contiguous():
+    pre = pre_o is not None
+    if pre:
+        if pre_w is None or pre_o.shape != x.shape or pre_o.dtype != x.dtype or not pre_o.is_contiguous() or not pre_o.is_cuda:
+            raise ValueError("xattn.fused: pre_o must match x [xB, S, 320] and come with pre_w")
+        if pre_w.dtype != x.dtype or pre_w.numel() != PRE_CHUNKS * 5120 or not pre_w.is_contiguous():
+            raise ValueError("xattn.fused: pre_w is not out_projection_operand's output for this dtype")
+    elif stat is None or stat.dtype != torch.float32 or stat.numel() != 2 * xB * S or not stat.is_contiguous():
         raise ValueError("xattn.fused: stat must be fp32 [xB * S, 2]")
     nctx = blob.shape[0]
     if index is None and nctx not in (1, out_images):
@@ -168,12 +214,16 @@ def fused(x: torch.Tensor, stat: torch.Tensor, blob: torch.Tensor, v: torch.Tens
     tm = pf.CONV_TIMER
     with torch.cuda.device(x.device):
         e0 = tm.start() if tm is not None else None
-        N.check(N.lib().gsw_xattn_fused(x.data_ptr(), stat.data_ptr(), blob.data_ptr(), blob.shape[1] * blob.element_size(), v.data_ptr(), v.shape[1],
-                                        index.data_ptr() if index is not None else None, y.data_ptr(), ostat.data_ptr() if ostat is not None else None,
-                                        float(eps_out) if eps_out is not None else 0.0, xB, out_images, S, C, heads, _dt(x.dtype), _stream_ptr()))
+        tail = (blob.data_ptr(), blob.shape[1] * blob.element_size(), v.data_ptr(), v.shape[1], index.data_ptr() if index is not None else None, y.data_ptr(),
+                ostat.data_ptr() if ostat is not None else None, float(eps_out) if eps_out is not None else 0.0, xB, out_images, S, C, heads, _dt(x.dtype), _stream_ptr())
+        if pre:
+            N.check(N.lib().gsw_xattn_fused_pre(x.data_ptr(), pre_o.data_ptr(), pre_w.data_ptr(), float(pre_eps), *tail))
+        else:
+            N.check(N.lib().gsw_xattn_fused(x.data_ptr(), stat.data_ptr(), *tail))
         if tm is not None:
-            tm.stop(e0, ("gsw_xattn_kernel", out_images * S, C, heads * (MAX_KEYS + 1), "xattn") if tm.by_shape else "gsw_xattn_kernel",
-                    2.0 * out_images * S * C * heads * (KEY_SLOTS + MAX_KEYS + 1), nbytes=2.0 * (xB + out_images) * S * C + blob.numel() * 2.0)
+            tm.stop(e0, ("gsw_xattn_kernel", out_images * S, C, heads * (MAX_KEYS + 1), "xattn+pre" if pre else "xattn") if tm.by_shape else "gsw_xattn_kernel",
+                    2.0 * out_images * S * C * (heads * (KEY_SLOTS + MAX_KEYS + 1) + (C + 16 if pre else 0)),
+                    nbytes=2.0 * ((2 if pre else 1) * xB + out_images) * S * C + blob.numel() * 2.0 + (pre_w.numel() * 2.0 if pre else 0.0))
     if ostat is not None:
         y._gsw_lnstat = (ostat, float(eps_out))
     return y

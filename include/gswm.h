@@ -360,6 +360,14 @@ int gsw_attention_ws(const void* q_dev, const void* k_dev, const void* vt_dev, v
 int gsw_xattn_fused(const void* x_dev, const float* ln_stat_dev, const void* blob_dev, int64_t blob_stride_bytes, const float* v_dev, int64_t v_stride_floats,
                     const int32_t* ctx_index_dev, void* out_dev, float* out_stat_dev, float out_eps, int x_images, int out_images, int tokens, int C, int heads,
                     int dtype, void* stream);
+/* The same launch, starting one operation earlier in the block: it first MAKES x from the self-attention in front of the sublayer (BasicTransformerBlock.attn1's
+ * output projection, bias and residual) -- x = resid + o Wo^T + b with o [x_images * tokens, 320] that attention's output and w_frag Wo and b as 21 chunks of
+ * MFMA fragments (xattn.py: pack_out_projection) -- rounds it to the storage dtype as the separate launch would, takes norm2's statistics (epsilon ln_eps) from
+ * the rounded rows, and continues as gsw_xattn_fused.  x is never written: the projection's own launch, its 2 x rows x 640 bytes of traffic and
+ * gsw_ln_rowstats_finish all disappear.  Same shape limits. */
+int gsw_xattn_fused_pre(const void* resid_dev, const void* o_dev, const void* w_frag_dev, float ln_eps, const void* blob_dev, int64_t blob_stride_bytes,
+                        const float* v_dev, int64_t v_stride_floats, const int32_t* ctx_index_dev, void* out_dev, float* out_stat_dev, float out_eps, int x_images,
+                        int out_images, int tokens, int C, int heads, int dtype, void* stream);
 
 /* E4, bit-parity mode -- gs_insert.py:62 `np.random.uniform(0, 1)` / nodes.py:52-53,114-117 `RandomState(seed).uniform(0, 1)`:
  * NumPy's legacy MT19937 `random_sample` stream continued on the device.  key/pos: the generator state as

@@ -8,7 +8,7 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-from test_xattn_host import _module, emulate, reference  # noqa: E402
+from test_xattn_host import _module, emulate, emulate_pre, reference  # noqa: E402
 
 
 def _stat(x, eps):
@@ -70,6 +70,72 @@ def test_fused_equals_the_lane_level_restatement():
         assert (diff > 0).float().mean().item() < 0.05
 
 
+def _pre_case(heads, head_dim, ctx_dim, keys, dtype, xB, oB, S, seed):
+    """gsw_xattn_fused_pre: the self-attention's output projection + bias + residual + norm2's statistics as the launch's prologue"""
+    from gswm_amd import xattn
+    attn, norm = _module(heads, head_dim, ctx_dim, dtype, seed)
+    attn, norm = attn.cuda(), norm.cuda()
+    g = torch.Generator().manual_seed(seed + 200)
+    lin = torch.nn.Linear(320, 320)
+    with torch.no_grad():
+        lin.weight.copy_(torch.randn(320, 320, generator=g) * 1.2 * 320 ** -0.5)
+        lin.bias.copy_(0.2 * torch.randn(320, generator=g))
+    lin = lin.to(dtype).cuda()
+    resid = (torch.randn(xB, S, 320, generator=g) * 1.3 + 0.4).to(dtype).cuda()
+    o = torch.randn(xB, S, 320, generator=g).to(dtype).cuda()
+    ctx = torch.randn(oB, keys, ctx_dim, generator=g).to(dtype).cuda()
+    blob, uv, idx = xattn.context_operands(attn, norm, ctx, dtype)
+    w = xattn.out_projection_operand(lin, dtype)
+    y = xattn.fused(resid, None, blob, uv, idx, oB, heads, eps_out=1e-5, pre_o=o, pre_w=w, pre_eps=norm.eps)
+    # what the separate launches compute: the projection's output ROUNDED to the storage dtype, then the sublayer on it
+    x1 = (resid.float() + F.linear(o.float(), lin.weight.float(), lin.bias.float())).to(dtype)
+    want = torch.cat([reference(x1, norm, attn, ctx[i * xB:(i + 1) * xB]) for i in range(oB // xB)], dim=0)
+    return resid, o, w, x1, attn, norm, blob, uv, y, want
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+@pytest.mark.parametrize("heads,head_dim,ctx_dim,keys,xB,oB,S", [
+    (5, 64, 1024, 77, 2, 2, 256),        # SD 2.1 level 0
+    (5, 64, 1024, 77, 2, 4, 384),        # classifier-free guidance on shared latents: the prologue runs on the shared rows for both halves
+    (8, 40, 768, 77, 1, 1, 1152),        # SD 1.5 level 0
+    (3, 32, 96, 5, 3, 3, 128),
+])
+def test_fused_pre_vs_fp32_reference(heads, head_dim, ctx_dim, keys, xB, oB, S, dtype):
+    resid, o, w, x1, attn, norm, blob, uv, y, want = _pre_case(heads, head_dim, ctx_dim, keys, dtype, xB, oB, S, seed=heads + keys)
+    torch.cuda.synchronize()
+    assert y.shape == want.shape and torch.isfinite(y.float()).all()
+    tol = (4e-3 if dtype == torch.float16 else 3e-2) * max(1.0, want.abs().max().item())
+    assert (y.float() - want).abs().max().item() <= tol
+    ostat, eps = y._gsw_lnstat
+    assert torch.allclose(ostat, _stat(y, eps), rtol=2e-3, atol=2e-3)
+    # ... and close to the plain kernel fed the rounded stream and its statistics (what the two-launch path hands it)
+    from gswm_amd import xattn
+    idx = torch.arange(oB, dtype=torch.int32, device="cuda") if oB > 1 else None
+    y2 = xattn.fused(x1, _stat(x1, norm.eps), blob, uv, idx, oB, heads, eps_out=1e-5)
+    assert (y.float() - y2.float()).abs().max().item() <= tol
+
+
+def test_fused_pre_equals_the_lane_level_restatement():
+    """prologue + sublayer for one wave's 32 rows against tests/test_xattn_host.emulate_pre -> emulate: same rounding points"""
+    heads, dtype = 5, torch.float16
+    resid, o, w, x1, attn, norm, blob, uv, y, want = _pre_case(heads, 64, 1024, 77, dtype, 1, 1, 256, seed=13)
+    for blk in (0, 2, 7):
+        rows = slice(32 * blk, 32 * blk + 32)
+        x, st = emulate_pre(o[0, rows].cpu(), resid[0, rows].cpu(), w.cpu(), norm.eps)
+        emu = emulate(x, st, blob[0].cpu(), uv[0].cpu(), heads).to(dtype)
+        got = y[0, rows].cpu()
+        diff = (got.float() - emu.float()).abs()
+        assert diff.max().item() <= 2.0 ** -9 * max(1.0, emu.float().abs().max().item()) * 2
+        assert (diff > 0).float().mean().item() < 0.05
+
+
+def test_fused_pre_full_chip():
+    """more tiles than workgroups: every workgroup's stream wraps from the last head of a tile into the next tile's prologue"""
+    resid, o, w, x1, attn, norm, blob, uv, y, want = _pre_case(5, 64, 1024, 77, torch.float16, 16, 16, 4096, seed=3)
+    tol = 4e-3 * max(1.0, want.abs().max().item())
+    assert (y.float() - want).abs().max().item() <= tol
+
+
 @pytest.mark.parametrize("B", [16, 21])
 def test_fused_full_chip_xcd_order(B):
     """more tiles than workgroups, >= 8 images: the XCD-ordered tile walk (images distributed over the 8 L2s) incl. an image count that is not a multiple of 8"""
@@ -93,16 +159,17 @@ def test_block_one_launch_vs_three_launches():
     ctx = torch.randn(B, 77, 1024, device="cuda").half()
     w = (torch.randn(320, 320, device="cuda") * 320 ** -0.5).half()
 
-    def run(flag):
-        xattn.ENABLED = flag
+    def run(flag, pre=True):
+        xattn.ENABLED, xattn.PRE_ENABLED = flag, pre
         with torch.no_grad():
             x = pf.gemm(x0, w, None, rowstats=True)            # a producer that leaves row records, like proj_in
             return blk(x, ctx), x
     try:
         y1, x = run(True)
+        y1b, _ = run(True, pre=False)                           # one launch for the cross-attention, the self-attention's projection on its own
         y3, _ = run(False)
     finally:
-        xattn.ENABLED = True
+        xattn.ENABLED = xattn.PRE_ENABLED = True
     with torch.no_grad():
         f = blk.float()
         xf = x.float()
@@ -114,6 +181,7 @@ def test_block_one_launch_vs_three_launches():
     assert (y1.float() - ref).abs().max().item() <= 1e-2 * scale
     assert (y3.float() - ref).abs().max().item() <= 1e-2 * scale
     assert (y1.float() - y3.float()).abs().max().item() <= 1e-2 * scale
+    assert (y1b.float() - ref).abs().max().item() <= 1e-2 * scale
 
 
 def test_unsupported_shapes_are_refused_not_computed():
@@ -141,16 +209,17 @@ def test_unet_forward_with_and_without_the_one_launch_cross_attention():
     U.FALLBACKS.clear()
     outs = {}
     try:
-        for flag in (True, False):
-            xattn.ENABLED = flag
+        for flag in (True, "no-pre", False):
+            xattn.ENABLED, xattn.PRE_ENABLED = bool(flag), flag is True
             with torch.no_grad():
                 outs[flag] = (m(x, t, ctx).float(), m(x, t, ctx2, cfg_dup=True).float())
     finally:
-        xattn.ENABLED = True
+        xattn.ENABLED = xattn.PRE_ENABLED = True
     assert U.FALLBACKS == {}
-    for a, b in zip(outs[True], outs[False]):
-        assert a.shape == b.shape and torch.isfinite(a).all()
-        assert (a - b).abs().max().item() <= 2e-2 * max(1.0, b.abs().max().item())
+    for other in (False, "no-pre"):
+        for a, b in zip(outs[True], outs[other]):
+            assert a.shape == b.shape and torch.isfinite(a).all()
+            assert (a - b).abs().max().item() <= 2e-2 * max(1.0, b.abs().max().item())
     # the guidance batch of shared latents equals the doubled batch (what the reference computes: torch.cat([latents] * 2))
     with torch.no_grad():
         doubled = m(torch.cat([x, x], dim=0), t, ctx2).float()

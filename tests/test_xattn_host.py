@@ -84,6 +84,45 @@ def emulate(x: torch.Tensor, stat: torch.Tensor, blob: torch.Tensor, v: torch.Te
     return out
 
 
+def emulate_pre(o: torch.Tensor, resid: torch.Tensor, wfrag: torch.Tensor, eps: float):
+    """gsw_xattn_fused_pre's prologue for one wave's 32 rows, from the BYTES of the projection's fragment stream: x = resid + o Wo^T + b through the same MFMA layouts
+    (twenty k-steps of ten column blocks, the bias against a unit vector, the residual against the permutation fragments), rounded once -> (x [32, 320] in the storage
+    dtype, its (rstd, -rstd mean) [32, 2] taken from the rounded values)"""
+    dt = o.dtype
+    frag_of = lambda t: [torch.stack([t[lane & 31, 16 * ks + 8 * (lane >> 5):16 * ks + 8 * (lane >> 5) + 8] for lane in range(64)]).float() for ks in range(20)]
+    of, rf = frag_of(o), frag_of(resid)
+    fr = wfrag.view(xattn.PRE_CHUNKS, 10, 64, 8).float()
+    e0 = torch.zeros(64, 8)
+    e0[:32, 0] = 1.0
+    pm = []
+    for j in range(2):
+        a = torch.zeros(64, 8)
+        for lane in range(64):
+            r, h = lane & 31, lane >> 5
+            if (r >> 4) == j and ((r >> 2) & 1) == h:
+                a[lane, 4 * ((r >> 3) & 1) + (r & 3)] = 1.0
+        pm.append(a)
+    acc = [torch.zeros(64, 16) for _ in range(10)]
+    for ks in range(20):
+        for nb in range(10):
+            acc[nb] = acc[nb] + mfma_32x32x16(fr[ks, nb], of[ks])
+    for nb in range(10):
+        acc[nb] = acc[nb] + mfma_32x32x16(fr[20, nb], e0)
+        acc[nb] = acc[nb] + mfma_32x32x16(pm[0], rf[2 * nb]) + mfma_32x32x16(pm[1], rf[2 * nb + 1])
+    x = torch.zeros(32, 320)
+    for lane in range(64):
+        r, hl = lane & 31, lane >> 5
+        for nb in range(10):
+            for j in range(2):
+                x[r, 32 * nb + 16 * j + 8 * hl:32 * nb + 16 * j + 8 * hl + 8] = acc[nb][lane, 8 * j:8 * j + 8]
+    x = x.to(dt)
+    xf = x.float()
+    mean = xf.mean(-1)
+    var = ((xf * xf).mean(-1) - mean * mean).clamp_min(0)
+    rstd = torch.rsqrt(var + eps)
+    return x, torch.stack([rstd, -rstd * mean], dim=1)
+
+
 def reference(x, norm, attn, ctx):
     """fp32 torch: x + to_out(attention(to_q(LayerNorm(x)), to_k(ctx), to_v(ctx)))"""
     f = torch.float32
@@ -179,3 +218,35 @@ def test_usable_gates():
     with pytest.raises(RuntimeError):
         xattn.fused(x, torch.empty(512, 2), torch.empty(1, 5 * xattn.HEAD_ELEMS, dtype=torch.float16), torch.empty(1, 5 * xattn.V_FLOATS), None, 2, 5)
     assert math.isclose(xattn.LOG2E, math.log2(math.e))
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+def test_out_projection_stream_restates_the_projection(dtype):
+    """gsw_xattn_fused_pre's prologue operand: the fragment stream of the self-attention's output projection, evaluated lane by lane, is resid + o Wo^T + b"""
+    torch.manual_seed(7)
+    lin = nn.Linear(320, 320)
+    with torch.no_grad():
+        lin.weight.copy_(torch.randn(320, 320) * 1.3 * 320 ** -0.5)
+        lin.bias.copy_(0.2 * torch.randn(320))
+    lin = lin.to(dtype)
+    o = torch.randn(32, 320).to(dtype)
+    resid = (torch.randn(32, 320) * 1.2 + 0.3).to(dtype)
+    w = xattn.pack_out_projection(lin.weight, lin.bias, dtype)
+    assert w.shape == (xattn.PRE_CHUNKS * 5120,) and w.dtype == dtype
+    # nothing dropped, nothing duplicated: the first twenty chunks are a permutation of Wo, the last holds b and zeros
+    assert torch.equal(w[:20 * 5120].float().sort().values, lin.weight.detach().float().flatten().sort().values)
+    assert torch.equal(w[20 * 5120:].float().sort().values, torch.cat([lin.bias.detach().float(), torch.zeros(5120 - 320)]).sort().values)
+    x, stat = emulate_pre(o, resid, w, 1e-5)
+    want = resid.float() + F.linear(o.float(), lin.weight.float(), lin.bias.float())
+    tol = (2e-3 if dtype == torch.float16 else 1.6e-2) * max(1.0, want.abs().max().item())
+    assert (x.float() - want).abs().max().item() <= tol
+    ref = torch.stack([torch.rsqrt(want.var(-1, unbiased=False) + 1e-5), -torch.rsqrt(want.var(-1, unbiased=False) + 1e-5) * want.mean(-1)], dim=1)
+    assert torch.allclose(stat, ref, rtol=1e-2, atol=1e-2)
+    # cached on the module; a parameter edit recomputes into the same buffer
+    a = xattn.out_projection_operand(lin, dtype)
+    assert xattn.out_projection_operand(lin, dtype) is a and torch.equal(a, w)
+    ptr = a.data_ptr()
+    with torch.no_grad():
+        lin.bias.add_(1.0)
+    b = xattn.out_projection_operand(lin, dtype)
+    assert b.data_ptr() == ptr and not torch.equal(b, w)

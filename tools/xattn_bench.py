@@ -38,3 +38,18 @@ with torch.no_grad():
 M = B * S
 alg = 4.0 * M * 320
 print(f"B={B} S={S} heads={heads}: one launch {us1:8.1f} us = {alg / us1 / 1e6:5.2f} TB/s effective, {2.0 * M * 320 * heads * 176 / us1 / 1e6:6.1f} TFLOP/s executed;  three launches {us3:8.1f} us  ({us3 / us1:4.2f} x)")
+
+# gsw_xattn_fused_pre: the self-attention's output projection + bias + residual + norm2 statistics as the launch's prologue, against that projection's own launch
+# (with row records) followed by the plain one-launch kernel
+o1 = torch.randn(B, S, 320, device="cuda").half()
+lin = blk.attn1.to_out[0]
+with torch.no_grad():
+    def two():
+        x1 = U._lin(o1, lin, x, rowstats=True)
+        return a.fused_sublayer(x1, pf.ln_stat(x1, blk.norm2.eps), blk.norm2, ctx, eps_next=1e-5)
+    proj = lambda: U._lin(o1, lin, x, rowstats=True)
+    pre = lambda: a.fused_sublayer(x, None, blk.norm2, ctx, eps_next=1e-5, pre=(o1, lin))
+    y2, yp = two(), pre()
+    print("max |pre - two launches| =", (yp.float() - y2.float()).abs().max().item())
+    usp, us2, usj = t(pre), t(two), t(proj)
+print(f"with the self-attention's output projection: prologue form {usp:8.1f} us;  projection launch {usj:7.1f} us + sublayer = {us2:8.1f} us  ({us2 / usp:4.2f}x)")
