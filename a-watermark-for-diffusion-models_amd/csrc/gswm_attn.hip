@@ -22,8 +22,15 @@
 // Roofline: MFMA.  Measured (B=128, 5 heads, S=4096, fp16): 825-832 TFLOP/s = 33 % of the 2.5 PF nominal peak, MFMA pipe busy 40-42 % of
 // the cycles the chip actually runs (PMC: effective clock 1.87 GHz under this load); torch SDPA (aotriton) does 630-690 on the same shape.
 // At head_dim 64 every 16 MFMAs come with ~170 VALU instructions (32 v_exp_f32, max / sum / convert / rescale) per wave.
-// Tried and dropped: row sums of P on the matrix pipe (one more MFMA per 16-key slice with an all-ones A operand instead of 32 v_add_f32 per tile and
-// query block -- the pipe idles half the time): 813 vs 831 TFLOP/s at 4096 keys.
+// Row sums of P on the matrix pipe.  Round 1 tried one more 32 x 32 MFMA per 16-key slice with an all-ones A operand instead of the 32 v_add_f32 per tile and query
+// block and dropped it (813 vs 831 TFLOP/s at 4096 keys: 2048 more matrix-pipe cycles per iteration).  Round 6 does it with instructions that cost next to nothing
+// (LM / L4 in the kernel): at head_dim 40 V^T row 40 -- one of the eight rows of the 16-row tail block the head does not use -- is all ones in LDS, so the row sum is row
+// 40 of the tail accumulators for free; every other form adds the lane's own four probabilities with v_mfma_f32_4x4x4 (sixteen independent 4 x 4 x 4 blocks, A = ones:
+// 8 passes per tile and query block).  The sums are then those of the ROUNDED probabilities the second product multiplies.  What this removes is less the 64 VALU
+// instructions than a serial chain: every v_add waited for its exponential.  Same box, old | new (profiles/r06_attention_rowsum_on_mfma_ab.txt): head_dim 40, 9216 keys
+// 5.32-5.42 -> 4.88-5.05 ms (646 -> 700 algorithmic TFLOP/s: this shape is not power-capped), head_dim 80 0.589 -> 0.557 ms, head_dim 64 at 4096 keys (power-capped)
+// 3.21-3.23 -> 3.17 ms.  Packing (s cs - m) as v_pk_fma_f32 on top: no change (measured again this round, as in round 4); the running maximum as four
+// independent v_max3 chains instead of one: 1 % slower.
 // What sets the time (round 4, profiles/r04h_power_cap_probe.txt): on random operands the kernel runs at 1.99 GHz / 1.36 kW of the board's 1.4 kW, on all-zero operands
 // at 2.39 GHz and finishes 28 % sooner -- the power management, not an issue port.  Measured in round 4 with ablation / A-B builds of this kernel (parts of the loop
 // compiled out; packed v_pk_fma_f32 / v_pk_add_f32 softmax arithmetic and row sums by v_dot2c_f32_f16: 16-18 % fewer VALU instructions per tile, same time to the
@@ -80,12 +87,18 @@ template <> struct AT<_Float16> {
     using v4 = f16x4;
     static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
     static __device__ __forceinline__ f32x4 mfma16(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+    // sixteen 4 x 4 x 4 blocks, one per four lanes: with A = ones every lane gets the sum of ITS OWN four B values in all four outputs (no cross-lane mixing)
+    static __device__ __forceinline__ f32x4 mfma4(v4 a, v4 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x4f16(a, b, c, 0, 0, 0); }
 };
 template <> struct AT<__bf16> {
     using v8 = bf16x8;
     using v4 = bf16x4;
     static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
     static __device__ __forceinline__ f32x4 mfma16(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ f32x4 mfma4(v4 a, v4 b, f32x4 c) {
+        typedef short s16x4 __attribute__((ext_vector_type(4)));
+        return __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
+    }
 };
 
 struct AttnArgs {
@@ -138,6 +151,13 @@ __global__ __launch_bounds__(256, (DU > 10 ? 1 : 2)) void gsw_attn_fwd_kernel(At
     constexpr uint32_t STAGE = 64 * KP + VROWS * VP;              // one 64-key K tile + one V^T tile
     constexpr int NU = (64 * DU + 255) / 256;                     // 16-byte staging units per thread, tile and operand
     constexpr uint32_t NSTG = PAIR ? 4 : 2;
+    // LM (head_dim 40): the softmax row sum comes out of the matrix pipe.  The 16-row tail block has eight rows the head does not use; V^T row 40 is ALL ONES in LDS
+    // (written once, the staging never touches padding rows), so row 40 of the tail accumulators is sum_k P[q][k] -- rescaled by alpha with the other rows, taken from the
+    // ROUNDED probabilities the second product multiplies -- and the 64 v_add_f32 per tile and query block that kept it on the VALU are gone
+    constexpr bool LM = TR == 8 && !KVS;
+    // L4 (every other form): the lane's partial row sum on v_mfma_f32_4x4x4 -- sixteen independent 4 x 4 x 4 blocks, one per four lanes, A = ones: each lane gets the sum of
+    // its own four ROUNDED probabilities added to its accumulator; eight of them (64 matrix-pipe cycles) replace 32 v_add_f32 (128 VALU cycles) per tile and query block
+    constexpr bool L4 = !LM;
     static_assert(!KVS || (QB == 1 && !RAGGED && !PAIR), "key-split form: 32 queries per wave, whole tiles, the plain two-stage loop");
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];          // NSTG * STAGE bytes
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u, h = lane >> 5, c32 = lane & 31u;
@@ -160,6 +180,11 @@ __global__ __launch_bounds__(256, (DU > 10 ? 1 : 2)) void gsw_attn_fwd_kernel(At
 
     if (DU & 1 || D & 31) {      // zero the LDS once: padding units of K rows / padding rows of V^T are never written by the staging
         for (uint32_t i = tid; i < NSTG * STAGE / 16; i += 256) reinterpret_cast<uint4*>(lds)[i] = make_uint4(0, 0, 0, 0);
+        __syncthreads();
+        if constexpr (LM) {      // V^T row D of every stage: ones for all 64 keys
+            const T one = (T)1.0f;
+            if (tid < NSTG * 64u) *reinterpret_cast<T*>(lds + (tid >> 6) * STAGE + 64u * KP + (uint32_t)D * VP + (tid & 63u) * 2u) = one;
+        }
         __syncthreads();
     }
 
@@ -225,6 +250,7 @@ __global__ __launch_bounds__(256, (DU > 10 ? 1 : 2)) void gsw_attn_fwd_kernel(At
     f32x16 o[QB][DB];
     f32x4 ot[QB][2];          // TAIL: rows DBF*32 + 4 (lane >> 4) + j of queries 0-15 | 16-31 of the block (query = lane & 15)
     float m_i[QB], l_i[QB];
+    f32x4 l4[QB][2];          // L4: two accumulator chains per query block; all four elements of an accumulator are the same number
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
         ot[qb][0] = f32x4{0.f, 0.f, 0.f, 0.f}; ot[qb][1] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -234,6 +260,7 @@ __global__ __launch_bounds__(256, (DU > 10 ? 1 : 2)) void gsw_attn_fwd_kernel(At
             for (int i = 0; i < 16; ++i) o[qb][db][i] = 0.f;
         m_i[qb] = -INFINITY;
         l_i[qb] = 0.f;
+        l4[qb][0] = f32x4{0.f, 0.f, 0.f, 0.f}; l4[qb][1] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const float cs = p.scale_log2;
 
@@ -285,18 +312,16 @@ __global__ __launch_bounds__(256, (DU > 10 ? 1 : 2)) void gsw_attn_fwd_kernel(At
             const float m_new = fmaxf(m_i[qb], mx * cs);
             const float alpha = __builtin_amdgcn_exp2f(m_i[qb] - m_new);      // raw v_exp_f32: arguments are <= 0, underflow to 0 is the intent
             m_i[qb] = m_new;
-            float rs = 0.f;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const float e = __builtin_amdgcn_exp2f(fmaf(s[qb][kb][i], cs, -m_new));
-                    rs += e;
                     pb[qb][kb][i >> 3][i & 7] = (T)e;
                 }
             }
-            l_i[qb] = fmaf(l_i[qb], alpha, rs);
             if (__any(alpha != 1.0f)) {                 // once the running maxima have settled the whole wave skips the rescale
+                if constexpr (L4) { l4[qb][0] *= alpha; l4[qb][1] *= alpha; }
 #pragma unroll
                 for (int db = 0; db < DBF; ++db)
 #pragma unroll
@@ -310,6 +335,19 @@ __global__ __launch_bounds__(256, (DU > 10 ? 1 : 2)) void gsw_attn_fwd_kernel(At
         }
 
         // ---- O^T += V^T P^T
+        if constexpr (L4) {
+            const v4 ones = v4{(T)1.0f, (T)1.0f, (T)1.0f, (T)1.0f};
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                    for (int qb = 0; qb < QB; ++qb) {
+                        const v8 pv = pb[qb][kb][tt];
+                        l4[qb][0] = AT<T>::mfma4(ones, v4{pv[0], pv[1], pv[2], pv[3]}, l4[qb][0]);
+                        l4[qb][1] = AT<T>::mfma4(ones, v4{pv[4], pv[5], pv[6], pv[7]}, l4[qb][1]);
+                    }
+        }
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
@@ -392,14 +430,24 @@ __global__ __launch_bounds__(256, (DU > 10 ? 1 : 2)) void gsw_attn_fwd_kernel(At
             for (int i = 0; i < 8; ++i) base[(DBF * 16 + i) * 64] = ot[0][i >> 2][i & 3];
         }
         base[NACC * 64] = m_i[0];
-        base[(NACC + 1) * 64] = l_i[0];
+        base[(NACC + 1) * 64] = l4[0][0][0] + l4[0][1][0];      // (KVS kernels are L4)
         return;
     }
 
     // ---- normalise and store: lane holds O^T[d][query c32] for d = db*32 + (i/4)*8 + h*4 + (i%4)
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
-        const float l = xhalf_sum(l_i[qb]);
+        float l;
+        if constexpr (LM) {      // row 40 of the tail: element 0 of lanes 32-47 (lane row 2), query 16 hq + (lane & 15)
+            const int idx = (int)(4u * (32u + (lane & 15u)));
+            const float l0 = __int_as_float(__builtin_amdgcn_ds_bpermute(idx, __float_as_int(ot[qb][0][0])));
+            const float l1 = __int_as_float(__builtin_amdgcn_ds_bpermute(idx, __float_as_int(ot[qb][1][0])));
+            l = (c32 & 16u) ? l1 : l0;
+            l_i[qb] = 0.5f * l;      // (the tail's normalisation below adds the two lane halves again)
+        } else {
+            if constexpr (L4) l_i[qb] = l4[qb][0][0] + l4[qb][1][0];
+            l = xhalf_sum(l_i[qb]);
+        }
         const float inv = 1.0f / l;
         const uint32_t qi = q0 + 32u * qb;
         if (RAGGED && qi >= (uint32_t)p.Sq) continue;

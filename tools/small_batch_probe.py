@@ -60,8 +60,11 @@ for B in rows_list:
         pf.CONV_TIMER = None
         tot = sum(v["ms"] for v in tm.summary().values())
         print(f"  matmul-engine / convolution launches: {tot / 3:.2f} ms per forward (event time, includes launch gaps)")
-        for k, v in sorted(tm.summary().items(), key=lambda kv: -kv[1]["ms"])[:28]:
-            if len(k) == 7:
+        for k, v in sorted(tm.summary().items(), key=lambda kv: -kv[1]["ms"])[:40]:
+            if k[0] == "gsw_attn_fwd_kernel":          # (kernel, B, Sq, Sk, heads, head_dim)
+                name, b, sq, sk, hh, hd = k
+                print(f"  {name:28s} Sq={sq:5d} Sk={sk:5d} H={hh:2d} d={hd:3d}  calls/fwd={v['calls'] // 3:3d} avg={v['avg_us']:8.1f} us {v['tflops']:7.1f} TF {v['ms'] / tot * 100:5.1f} %")
+            elif len(k) == 7:
                 name, b, h, w, kk, n, st = k
                 print(f"  {name:28s} {h:3d}x{w:<3d} K={kk:6d} N={n:5d} s{st} calls/fwd={v['calls'] // 3:3d} avg={v['avg_us']:8.1f} us {v['tflops']:7.1f} TF {v['ms'] / tot * 100:5.1f} %")
             else:

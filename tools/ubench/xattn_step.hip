@@ -115,6 +115,78 @@ __global__ __launch_bounds__(256) void step3_kernel(const uint8_t* __restrict__ 
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
+// The step with the stream going global -> LDS by DMA (global_load_lds, 16 B per lane = one 1 KiB fragment per wave instruction; no staging registers, no ds_write):
+// six slots, chunk j + 5 is requested in step j (its slot held chunk j - 1), the fragments of chunk j + 1 are read in step j behind a counted vmcnt wait + barrier.
+// Fragment reads are inline asm (hipcc waits vmcnt(0) in front of every LDS read it can see while a DMA may be in flight).  Per wave and chunk: two whole fragments
+// + half a fragment (lane halves of two waves share fragments 8 / 9), so every wave issues the same three instructions and one counted wait serves all.
+template <bool DMA, int SPREAD>
+__global__ __launch_bounds__(256) void step_dma_kernel(const uint8_t* __restrict__ stream, float* out, uint64_t* cyc, int iters) {
+    __shared__ __attribute__((aligned(16))) uint8_t ring[6 * 10240];
+    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane((uint32_t)(threadIdx.x >> 6));
+    for (uint32_t i = threadIdx.x; i < 6 * 10240 / 4; i += 256) reinterpret_cast<uint32_t*>(ring)[i] = 0x3C003C00u;
+    __syncthreads();
+    f16v acc[10];
+    h8 fr[10], xb;
+    for (int i = 0; i < 10; ++i) { for (int t = 0; t < 16; ++t) acc[i][t] = 0.f; fr[i] = *reinterpret_cast<const h8*>(ring + lane * 16u + i * 1024); }
+    for (int e = 0; e < 8; ++e) xb[e] = (_Float16)(0.001f * (lane + e));
+    const bool mine = (lane >> 5) == (wave & 1u);                       // this lane's half of the shared fragment
+    const uint32_t g0 = wave * 1024u + lane * 16u, g1 = g0 + 4096u, g2 = (8u + (wave >> 1)) * 1024u + lane * 16u;
+    const uint32_t l0 = wave * 1024u, l1 = l0 + 4096u, l2 = (8u + (wave >> 1)) * 1024u;
+    uint32_t rd = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t*)ring + lane * 16u;
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    const uint64_t t0 = __builtin_amdgcn_s_memtime();
+    auto step = [&](auto K, int it) __attribute__((always_inline)) {
+        constexpr int k = decltype(K)::value;      // it % 6
+        const uint8_t* cp = stream + (size_t)((it + 5) & 63) * 10240;
+        uint8_t* sw = ring + ((k + 5) % 6) * 10240;
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (DMA) asm volatile("s_waitcnt vmcnt(9)\n\ts_waitcnt lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        auto dma = [&](int q) __attribute__((always_inline)) {
+            if constexpr (DMA) {
+                if (q == 0) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(cp + g0), (__attribute__((address_space(3))) void*)(sw + l0), 16, 0, 0);
+                if (q == 1) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(cp + g1), (__attribute__((address_space(3))) void*)(sw + l1), 16, 0, 0);
+                if (q == 2) { if (mine) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(cp + g2), (__attribute__((address_space(3))) void*)(sw + l2), 16, 0, 0); }
+            }
+        };
+        uint32_t rda = rd;
+#define DMM(i) do { acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[i], xb, acc[i], 0, 0, 0); \
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fr[i]) : "v"(rda), "n"(((k + 1) % 6) * 10240 + (i) * 1024) : "memory"); } while (0)
+        if constexpr (SPREAD == 0) { dma(0); dma(1); dma(2); }
+        DMM(0); if constexpr (SPREAD == 1) dma(0);
+        DMM(1); DMM(2); if constexpr (SPREAD == 1) dma(1);
+        DMM(3); DMM(4); if constexpr (SPREAD == 1) dma(2);
+        DMM(5); DMM(6); DMM(7); DMM(8); DMM(9);
+#undef DMM
+    };
+    for (int it = 0; it < iters; it += 6) {
+        step(std::integral_constant<int, 0>{}, it); step(std::integral_constant<int, 1>{}, it + 1); step(std::integral_constant<int, 2>{}, it + 2);
+        step(std::integral_constant<int, 3>{}, it + 3); step(std::integral_constant<int, 4>{}, it + 4); step(std::integral_constant<int, 5>{}, it + 5);
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    const uint64_t t1 = __builtin_amdgcn_s_memtime();
+    float s = 0.f;
+    for (int i = 0; i < 10; ++i) for (int t = 0; t < 16; ++t) s += acc[i][t];
+    s += (float)fr[3][2];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
+template <bool DMA, int SPREAD> void run_dma(const char* what, const uint8_t* stream, float* out, uint64_t* cyc) {
+    const int iters = 3996;
+    hipLaunchKernelGGL((step_dma_kernel<DMA, SPREAD>), dim3(256), dim3(256), 0, 0, stream, out, cyc, iters);
+    hipDeviceSynchronize();
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((step_dma_kernel<DMA, SPREAD>), dim3(256), dim3(256), 0, 0, stream, out, cyc, iters);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    std::vector<uint64_t> h(256); hipMemcpy(h.data(), cyc, 256 * 8, hipMemcpyDeviceToHost);
+    double mean = 0; for (auto v : h) mean += (double)v; mean /= 256;
+    printf("%-70s %7.1f cycles per step (s_memtime), %7.1f ns per step\n", what, mean / iters, ms * 1e6 / iters);
+}
+
 template <bool TURNS, bool WRITES, bool LOADS, bool READS, bool XB = false> void run3(const char* what, const uint8_t* stream, float* out, uint64_t* cyc) {
     const int iters = 3999;
     hipLaunchKernelGGL((step3_kernel<TURNS, WRITES, LOADS, READS, XB>), dim3(256), dim3(256), 0, 0, stream, out, cyc, iters);
@@ -168,5 +240,9 @@ int main() {
     run3<true, true, true, true>("  + writes in turns + loads", stream, out, cyc);
     run3<false, true, true, true, true>("  writes at the top + loads, 20 B fragments + 3-accumulator chains", stream, out, cyc);
     run3<true, true, true, true, true>("  writes in turns + loads, 20 B fragments + 3-accumulator chains", stream, out, cyc);
+    printf("-- the stream by LDS-DMA (global_load_lds b128): no staging registers, no ds_write; asm fragment reads, six slots, five steps of lead --\n");
+    run_dma<false, 0>("10 MFMA + asm reads + barrier (no stream)", stream, out, cyc);
+    run_dma<true, 0>("  + 3 DMA pieces per wave at the top of the step", stream, out, cyc);
+    run_dma<true, 1>("  + 3 DMA pieces per wave behind MFMAs 0, 2, 4", stream, out, cyc);
     return 0;
 }
