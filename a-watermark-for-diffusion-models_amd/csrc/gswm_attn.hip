@@ -30,7 +30,8 @@
 // instructions than a serial chain: every v_add waited for its exponential.  Same box, old | new (profiles/r06_attention_rowsum_on_mfma_ab.txt): head_dim 40, 9216 keys
 // 5.32-5.42 -> 4.88-5.05 ms (646 -> 700 algorithmic TFLOP/s: this shape is not power-capped), head_dim 80 0.589 -> 0.557 ms, head_dim 64 at 4096 keys (power-capped)
 // 3.21-3.23 -> 3.17 ms.  Packing (s cs - m) as v_pk_fma_f32 on top: no change (measured again this round, as in round 4); the running maximum as four
-// independent v_max3 chains instead of one: 1 % slower.
+// independent v_max3 chains instead of one: 1 % slower; ONE rescale branch per tile behind the softmax arithmetic of both query blocks instead of one per block
+// (so that the blocks' instruction streams can interleave): no change.
 // What sets the time (round 4, profiles/r04h_power_cap_probe.txt): on random operands the kernel runs at 1.99 GHz / 1.36 kW of the board's 1.4 kW, on all-zero operands
 // at 2.39 GHz and finishes 28 % sooner -- the power management, not an issue port.  Measured in round 4 with ablation / A-B builds of this kernel (parts of the loop
 // compiled out; packed v_pk_fma_f32 / v_pk_add_f32 softmax arithmetic and row sums by v_dot2c_f32_f16: 16-18 % fewer VALU instructions per tile, same time to the
