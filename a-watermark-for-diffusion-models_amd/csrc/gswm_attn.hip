@@ -18,6 +18,9 @@
 //   * LDS row pitches 144 B (K, ds_read_b128; 112 / 176 B for head_dim 40 / 80) and 136 B (V^T, ds_read_b64) are conflict-free for those
 //     access widths
 //   * head_dim 40 and 80 (the SD 1.5 shape: 8 heads at every level) run the same code with zero-padded k-slices / output row blocks
+//   * head_dim 64 from 1024 keys up (round 6, template DMA): the K / V^T tiles go global -> LDS by DMA into four static stage arrays, unpadded swizzled rows, K rows
+//     permuted inside every 16 so that V^T stays key-ordered -- no staging registers, no ds_write (see the comment in front of the kernel).  Same box, 128 images:
+//     4096 keys 3.264 -> 3.216 ms, 1024 keys 0.488 -> 0.480 ms (power-capped shapes: -1.5 %; profiles/r06_attention_dma_ab.txt); GSW_ATTN_DMA=0 selects the register staging
 //   * blockIdx -> (batch*head, query tile) is XCD-aware: the query tiles of one (batch, head) land on one XCD and share its L2 copy of K / V
 // Roofline: MFMA.  Measured (B=128, 5 heads, S=4096, fp16): 825-832 TFLOP/s = 33 % of the 2.5 PF nominal peak, MFMA pipe busy 40-42 % of
 // the cycles the chip actually runs (PMC: effective clock 1.87 GHz under this load); torch SDPA (aotriton) does 630-690 on the same shape.
@@ -140,7 +143,13 @@ constexpr uint32_t VP = 144;                               // V^T LDS row pitch 
 // KVS (QB = 1, whole tiles; one image's self-attention: 160 workgroups for 256 CUs, each walking 64 key tiles): `ksplit` workgroups share a query tile, each over its
 // own range of key tiles; they leave their unnormalised accumulators, running maximum and partial row sum in a workspace and gsw_attn_combine_kernel merges them
 // (the usual rescaling by 2^(m_s - m)).  One image at 64 x 64: 62 -> ~30 us per launch.
-template <typename T, int QB, int DU, bool PAIR, bool RAGGED, bool KVS = false>
+// DMA (head_dim 64, PAIR, whole tiles, a multiple of four key tiles): K and V^T tiles go global -> LDS by DMA (global_load_lds, 16 bytes per lane, 1 KiB = eight 128-byte rows
+// per wave instruction) into FOUR STATIC stage arrays -- no staging registers, no ds_write, no address arithmetic in the loop; separate __shared__ objects let hipcc's waitcnt pass
+// see that a DMA into one stage cannot touch the stage being read (one dynamic array makes it wait vmcnt(0) in front of every fragment read).  Rows are unpadded; the 16-byte
+// chunks of a row are XOR-swizzled with (row >> 1) & 7 on the DMA SOURCE address, which keeps every ds_read_b128 fragment read conflict-free (the matmul engine's scheme).  The
+// 8-byte interleave of V^T rows that the register staging produced is replaced by a permutation of the K ROWS inside every 16 (LDS row 16 g + 8 a + 4 h + j holds key
+// 16 g + 8 h + 4 a + j, again only a source address): the probabilities of a lane half h then belong to eight CONSECUTIVE keys and a V^T fragment is one chunk of a key-ordered row.
+template <typename T, int QB, int DU, bool PAIR, bool RAGGED, bool KVS = false, bool DMA = false>
 __global__ __launch_bounds__(256, (DU > 10 ? 1 : 2)) void gsw_attn_fwd_kernel(AttnArgs p) {
     using v8 = typename AT<T>::v8;
     using v4 = typename AT<T>::v4;
@@ -160,6 +169,7 @@ __global__ __launch_bounds__(256, (DU > 10 ? 1 : 2)) void gsw_attn_fwd_kernel(At
     // its own four ROUNDED probabilities added to its accumulator; eight of them (64 matrix-pipe cycles) replace 32 v_add_f32 (128 VALU cycles) per tile and query block
     constexpr bool L4 = !LM;
     static_assert(!KVS || (QB == 1 && !RAGGED && !PAIR), "key-split form: 32 queries per wave, whole tiles, the plain two-stage loop");
+    static_assert(!DMA || (DU == 8 && PAIR && !RAGGED && !KVS), "DMA staging: head_dim 64, four stages, whole tiles");
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];          // NSTG * STAGE bytes
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u, h = lane >> 5, c32 = lane & 31u;
     constexpr uint32_t QW = 32u * QB, QWG = 4u * QW;          // queries per wave / per workgroup
@@ -267,9 +277,11 @@ __global__ __launch_bounds__(256, (DU > 10 ? 1 : 2)) void gsw_attn_fwd_kernel(At
 
     const int32_t nt = (p.Sk + 63) >> 6;
     // one 64-key tile: S^T, online softmax, O^T accumulation
-    auto tile = [&](uint32_t stage, int32_t t) {
-        const uint8_t* Kl = lds + stage * STAGE;
-        const uint8_t* Vl = Kl + 64u * KP;
+    // DMA: the lane's eight possible chunk offsets inside its fragment row (row c32 of a 32-row block; chunk k of the row sits at slot k ^ ((c32 >> 1) & 7))
+    uint32_t swo[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) swo[k] = DMA ? c32 * 128u + (((uint32_t)k ^ ((c32 >> 1) & 7u)) << 4) : 0u;
+    auto tile = [&](const uint8_t* Kl, const uint8_t* Vl, int32_t t) __attribute__((always_inline)) {
 
         // ---- S^T = K Q^T : two 32-key blocks per query block; 2 * QB independent accumulator chains, interleaved
         f32x16 s[QB][2];
@@ -281,7 +293,8 @@ __global__ __launch_bounds__(256, (DU > 10 ? 1 : 2)) void gsw_attn_fwd_kernel(At
         for (int kc = 0; kc < KC; ++kc) {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
-                const v8 a = *reinterpret_cast<const v8*>(Kl + (uint32_t)(kb * 32 + (int)c32) * KP + (uint32_t)kc * 32u + h * 16u);
+                const v8 a = DMA ? *reinterpret_cast<const v8*>(Kl + (uint32_t)(kb * 32 * 128) + (h ? swo[(2 * kc + 1) & 7] : swo[(2 * kc) & 7]))
+                                 : *reinterpret_cast<const v8*>(Kl + (uint32_t)(kb * 32 + (int)c32) * KP + (uint32_t)kc * 32u + h * 16u);
 #pragma unroll
                 for (int qb = 0; qb < QB; ++qb) s[qb][kb] = AT<T>::mfma(a, qreg[qb][kc], s[qb][kb]);
             }
@@ -292,7 +305,8 @@ __global__ __launch_bounds__(256, (DU > 10 ? 1 : 2)) void gsw_attn_fwd_kernel(At
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const int32_t key = t * 64 + kb * 32 + (i >> 2) * 8 + (int32_t)h * 4 + (i & 3);
+                    const int32_t key = DMA ? t * 64 + kb * 32 + (i >> 3) * 16 + (int32_t)h * 8 + ((i >> 2) & 1) * 4 + (i & 3)      // (the K rows of a DMA tile are permuted)
+                                            : t * 64 + kb * 32 + (i >> 2) * 8 + (int32_t)h * 4 + (i & 3);
                     if (key >= p.Sk_valid) {
 #pragma unroll
                         for (int qb = 0; qb < QB; ++qb) s[qb][kb][i] = -INFINITY;
@@ -355,7 +369,8 @@ __global__ __launch_bounds__(256, (DU > 10 ? 1 : 2)) void gsw_attn_fwd_kernel(At
             for (int tt = 0; tt < 2; ++tt) {
 #pragma unroll
                 for (int db = 0; db < DBF; ++db) {
-                    const v8 a = *reinterpret_cast<const v8*>(Vl + (uint32_t)(db * 32 + (int)c32) * VP + (uint32_t)(kb * 32 + tt * 16) * 2u + h * 16u);
+                    const v8 a = DMA ? *reinterpret_cast<const v8*>(Vl + (uint32_t)(db * 32 * 128) + (h ? swo[(4 * kb + 2 * tt + 1) & 7] : swo[(4 * kb + 2 * tt) & 7]))
+                                     : *reinterpret_cast<const v8*>(Vl + (uint32_t)(db * 32 + (int)c32) * VP + (uint32_t)(kb * 32 + tt * 16) * 2u + h * 16u);
 #pragma unroll
                     for (int qb = 0; qb < QB; ++qb) o[qb][db] = AT<T>::mfma(a, pb[qb][kb][tt], o[qb][db]);
                 }
@@ -380,7 +395,56 @@ __global__ __launch_bounds__(256, (DU > 10 ? 1 : 2)) void gsw_attn_fwd_kernel(At
             }
         }
     };
-    if (PAIR) {
+    if constexpr (DMA) {
+        __shared__ __attribute__((aligned(16))) uint8_t sg0[16384], sg1[16384], sg2[16384], sg3[16384];      // a stage: 64 K rows, then 64 V^T rows, 128 bytes each
+        // this wave's pieces of a tile: K pieces wave, wave + 4 and V^T pieces wave, wave + 4 (a piece = eight LDS rows = one instruction).  Lane l of piece pc: LDS row
+        // 8 pc + (l >> 3), slot l & 7 <- chunk (l & 7) ^ ((row >> 1) & 7) of source row: key pi(row) of the tile (K) / head row `row` of V^T
+        const T* kp[2];
+        const T* vp[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const uint32_t pc = wave + 4u * j, row = 8u * pc + (lane >> 3);
+            const uint32_t chunk = (lane & 7u) ^ ((row >> 1) & 7u);
+            const uint32_t key = 16u * (pc >> 1) + 8u * (lane >> 5) + 4u * (pc & 1u) + ((lane >> 3) & 3u);
+            kp[j] = K + (int64_t)key * p.ldk + chunk * 8u;
+            vp[j] = VT + (int64_t)row * p.Sk + chunk * 8u;
+        }
+        const uint32_t wv = __builtin_amdgcn_readfirstlane(wave);
+        const int64_t kstep = (int64_t)64 * p.ldk;
+        auto dma = [&](uint8_t* sg, int32_t t) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kp[j] + (int64_t)t * kstep),
+                                                 (__attribute__((address_space(3))) void*)(sg + (wv + 4u * j) * 1024u), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vp[j] + (int64_t)t * 64),
+                                                 (__attribute__((address_space(3))) void*)(sg + 8192u + (wv + 4u * j) * 1024u), 16, 0, 0);
+            }
+        };
+        dma(sg0, 0);
+        dma(sg1, 1);
+        __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0), as a builtin: hipcc's waitcnt pass counts the DMA itself
+        __syncthreads();
+        for (int32_t t = 0; t < nt; t += 4) {          // nt % 4 == 0 (host-checked)
+            // tiles t, t + 1 are visible in stages 0, 1; t + 2, t + 3 land in stages 2, 3 under them; ONE barrier per two tiles
+            dma(sg2, t + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            tile(sg0, sg0 + 8192, t);
+            dma(sg3, t + 3);
+            __builtin_amdgcn_sched_barrier(0);
+            tile(sg1, sg1 + 8192, t + 1);
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            __syncthreads();
+            const int32_t tn = t + 4 < nt ? t + 4 : t;      // (the last round re-fetches its own tiles into the idle stages: no conditional DMA)
+            dma(sg0, tn);
+            __builtin_amdgcn_sched_barrier(0);
+            tile(sg2, sg2 + 8192, t + 2);
+            dma(sg1, tn + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            tile(sg3, sg3 + 8192, t + 3);
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            __syncthreads();
+        }
+    } else if (PAIR) {
         GSW_ATTN_GLOAD(0)
         GSW_ATTN_LSTORE(0u)
         GSW_ATTN_GLOAD((nt > 1 ? 1 : 0) << 6)
@@ -390,12 +454,12 @@ __global__ __launch_bounds__(256, (DU > 10 ? 1 : 2)) void gsw_attn_fwd_kernel(At
             // tiles t and t+1 are visible; t+2 and t+3 are fetched, written into the two idle stages, and published by ONE barrier
             GSW_ATTN_GLOAD((t + 2 < nt ? t + 2 : nt - 1) << 6)
             __builtin_amdgcn_sched_barrier(0);
-            tile((uint32_t)(t & 3), t);
+            tile(lds + (uint32_t)(t & 3) * STAGE, lds + (uint32_t)(t & 3) * STAGE + 64u * KP, t);
             GSW_ATTN_LSTORE((uint32_t)((t + 2) & 3))
             if (t + 1 < nt) {
                 GSW_ATTN_GLOAD((t + 3 < nt ? t + 3 : nt - 1) << 6)
                 __builtin_amdgcn_sched_barrier(0);
-                tile((uint32_t)((t + 1) & 3), t + 1);
+                tile(lds + (uint32_t)((t + 1) & 3) * STAGE, lds + (uint32_t)((t + 1) & 3) * STAGE + 64u * KP, t + 1);
                 GSW_ATTN_LSTORE((uint32_t)((t + 3) & 3))
             }
             __syncthreads();
@@ -413,7 +477,7 @@ __global__ __launch_bounds__(256, (DU > 10 ? 1 : 2)) void gsw_attn_fwd_kernel(At
             const int32_t tn = t + 1 < t_hi ? t + 1 : t;
             GSW_ATTN_GLOAD(tn << 6)
             __builtin_amdgcn_sched_barrier(0);          // keep the prefetch at the top of the iteration (the scheduler sinks it otherwise)
-            tile((uint32_t)((t - t_lo) & 1), t);
+            tile(lds + (uint32_t)((t - t_lo) & 1) * STAGE, lds + (uint32_t)((t - t_lo) & 1) * STAGE + 64u * KP, t);
             GSW_ATTN_LSTORE((uint32_t)((t - t_lo + 1) & 1))
             __syncthreads();
         }
@@ -592,6 +656,13 @@ static int launch_attn_cfg(const AttnArgs& a, uint32_t grid, bool ragged, float*
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { g_last_hip_error = (int)e; return GSW_ERR_HIP; }
+    }
+    if constexpr (DU == 8) {
+        static const int dma_env = getenv("GSW_ATTN_DMA") ? atoi(getenv("GSW_ATTN_DMA")) : 1;      // A/B switch
+        if (pair && dma_env && ((a.Sk >> 6) & 3) == 0) {      // K / V^T tiles by LDS-DMA into four static stages (64 KiB)
+            hipLaunchKernelGGL((gsw_attn_fwd_kernel<T, QB, DU, true, false, false, true>), dim3(grid), dim3(256), 0, st, a);
+            return GSW_OK;
+        }
     }
     if (pair) hipLaunchKernelGGL((gsw_attn_fwd_kernel<T, QB, DU, true, false>), dim3(grid), dim3(256), lds, st, a);
     else if (ragged) hipLaunchKernelGGL((gsw_attn_fwd_kernel<T, 1, DU, false, true>), dim3(grid), dim3(256), lds, st, a);

@@ -233,6 +233,29 @@ def test_attention_hd64_masked_keys(G, Sk_valid):
     assert (got.float() - ref).abs().max().item() <= 4e-3 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("Sk_valid", [1024, 1000, 999, 961, 65])
+def test_attention_hd64_dma_tiles_masked_keys(G, Sk_valid):
+    """1024 keys: the form whose K / V^T tiles arrive by LDS-DMA (four static stages, K rows permuted inside every 16, swizzled chunks).  Keys past Sk_valid
+    must carry no weight -- the mask has to follow the row permutation -- and with every key live the result is the plain softmax."""
+    g = torch.Generator().manual_seed(Sk_valid)
+    B, H, S, Sk = 2, 3, 512, 1024
+    q = torch.randn(B, S, H * 64, generator=g).half().cuda()
+    k = torch.randn(B, Sk, H * 64, generator=g).half().cuda()
+    v = torch.randn(B, Sk, H * 64, generator=g).half().cuda()
+    k[:, Sk_valid:] = 50.0
+    v[:, Sk_valid:] = 1000.0
+    got = G.pf.attention_hd64(q, k, v.transpose(1, 2).contiguous(), H, valid_keys=Sk_valid)
+    qf, kf, vf = (a.float().view(B, a.shape[1], H, 64).transpose(1, 2) for a in (q, k[:, :Sk_valid], v[:, :Sk_valid]))
+    ref = (torch.softmax(qf @ kf.transpose(-1, -2) / 8.0, dim=-1) @ vf).transpose(1, 2).reshape(B, S, H * 64)
+    assert (got.float() - ref).abs().max().item() <= 4e-3 * max(1.0, ref.abs().max().item())
+    # every value column must see ITS key's probability: a structured V (column j of key i = i mod 7 + j / 64) catches a key order that only permutes inside a tile
+    v2 = ((torch.arange(Sk).view(1, Sk, 1) % 7).float() + torch.arange(H * 64).view(1, 1, -1).float() / 64.0).expand(B, -1, -1).half().cuda()
+    got2 = G.pf.attention_hd64(q, k, v2.transpose(1, 2).contiguous(), H, valid_keys=Sk_valid)
+    vf2 = v2[:, :Sk_valid].float().view(B, Sk_valid, H, 64).transpose(1, 2)
+    ref2 = (torch.softmax(qf @ kf.transpose(-1, -2) / 8.0, dim=-1) @ vf2).transpose(1, 2).reshape(B, S, H * 64)
+    assert (got2.float() - ref2).abs().max().item() <= 4e-3 * max(1.0, ref2.abs().max().item())
+
+
 def test_attention_hd64_rejects_unsupported_shapes(G):
     q = torch.zeros(1, 100, 64, dtype=torch.float16, device="cuda")
     with pytest.raises(Exception):
