@@ -15,7 +15,7 @@ for tag, t in (("128", t128), ("64", t64)):
             per.setdefault(k, {})[tag] = v["traffic_bytes_per_launch"]
 json.dump({"kernel": "gsw_mm_kernel", "config": {"batch": batch, "unet": "sd21", "height": 512, "width": 512},
            "traffic_bytes_per_launch": tot_b // max(1, tot_l), "launches_measured": tot_l,
-           "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, tools/r05_job8.sh) of tools/unet_forward_bench.py at 128 rows (the CFG sampling half "
+           "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, tools/r06_profile.sh) of tools/unet_forward_bench.py at 128 rows (the CFG sampling half "
                   "of a step) and 64 rows (the inversion half); (2 x FETCH_SIZE + WRITE_SIZE) KB as MI355X_MICROARCH.md prescribes for gfx950, summed over EVERY instantiation of "
                   "the matmul engine (the family bench.py's `roofline` reports) / their launches; per-kernel tables next to this file.  The doubling is confirmed for the "
                   "engine's 128-byte LDS-DMA requests by a known change of 335.5 MB that the raw counter shows as 158 MB (profiles/r04_pmc_panel_fetch.txt)",

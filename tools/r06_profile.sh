@@ -58,6 +58,7 @@ if has sq; then
 fi
 if has xattn; then
   cd $R; bash tools/xattn_pmc.sh r06x > $O/xattn_pmc.log 2>&1; cp gpurun_out/pmc_r06x_summary.txt $O/xattn_pmc_summary.txt; rm -rf gpurun_out/pmc_r06x_*
+  cd $R; bash tools/xattn_pmc.sh r06y pre > $O/xattn_pre_pmc.log 2>&1; cp gpurun_out/pmc_r06y_summary.txt $O/xattn_pre_pmc_summary.txt; rm -rf gpurun_out/pmc_r06y_*
   timeout 600 python3 tools/xattn_ablate.py 128 > $O/xattn_ablate.txt 2>&1; tail -30 $O/xattn_ablate.txt
 fi
 cd $R

@@ -17,7 +17,7 @@ PATCHES = {
     "no_ldswrite": [("if constexpr (m != XEMPTY) X_WR(m % 3, m % 3);", "if constexpr (m != XEMPTY) { if (((m % 3 == 0 ? sa0.x ^ sb0.x ^ sc0.x : m % 3 == 1 ? sa1.x ^ sb1.x ^ sc1.x : sa2.x ^ sb2.x ^ sc2.x)) == 0x12345u) ring0[0] = 1; }")],
     "no_barrier": [("__builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)", "__builtin_amdgcn_sched_barrier(0); } while (0)")],
     "no_fragread": [("if constexpr (next_has) fr[i] = __builtin_bit_cast(frag, *reinterpret_cast<const uint4*>(sl + i * 1024));", "(void)sl;")],
-    "no_xload": [("                    if constexpr (decltype(LAST)::value) load_x(noi, nsub);", "")],
+    "no_xload": [("                    if constexpr (decltype(LAST)::value) { if constexpr (PRO) load_o(noi, nsub); else load_x(noi, nsub); }", "")],
     "trace": [("    uint32_t oi, sub;\n    if (!xtile(p, 0, oi, sub)) return;", "    uint32_t oi, sub;\n    if (!xtile(p, 0, oi, sub)) return;\n    uint64_t* dbg = reinterpret_cast<uint64_t*>(p.ostat); uint32_t cnt = 0;\n#define X_STAMP() do { if (blockIdx.x == 0) { const uint64_t t_ = __builtin_amdgcn_s_memtime(); if (lane == 0 && cnt < 2000) dbg[wave * 2048 + cnt] = t_; ++cnt; } } while (0)"),
               ("                X_BARRIER(j != XEMPTY ? 3 : 0);", "                X_STAMP(); X_BARRIER(j != XEMPTY ? 3 : 0);"),
               ("        x_f16v acc[XNB];", "        X_STAMP();\n        x_f16v acc[XNB];"),
