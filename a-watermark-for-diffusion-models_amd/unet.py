@@ -414,6 +414,25 @@ class BasicTransformerBlock(nn.Module):
                 and x.shape[-1] % 8 == 0 and x.shape[-1] <= 1536 and ctx.shape[0] == 2 * x.shape[0]
                 and attention_ok(x, a.heads, a.to_q.out_features // a.heads, x.shape[1], (ctx.shape[1] + 63) // 64 * 64))
 
+    def _cross_sublayer(self, x, ctx, dup: bool, one_launch: bool):
+        """x + attn2(norm2(x), ctx) on the hand-written path; dup: x holds B rows, ctx 2B -> 2B rows"""
+        from .codec import add_layernorm
+        from .pf import ln_stat
+        st = ln_stat(x, self.norm2.eps) if (one_launch or self.attn2.ln_foldable(x, ctx[: x.shape[0]] if dup else ctx)) else None
+        if st is not None and one_launch:
+            return self.attn2.fused_sublayer(x, st, self.norm2, ctx, eps_next=self.norm3.eps)
+        if dup:
+            if st is not None:
+                o = self.attn2.cross_dup(x, ctx, stat=st, norm=self.norm2)
+            else:
+                _, n = add_layernorm(x, None, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+                o = self.attn2.cross_dup(n, ctx)
+            return _lin(o, self.attn2.to_out[0], torch.cat([x, x], dim=0), rowstats=True)
+        if st is not None:
+            return self.attn2.forward_ln(x, st, self.norm2, ctx, resid=x)
+        _, n = add_layernorm(x, None, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        return self.attn2(n, ctx, resid=x)
+
     def forward(self, x, ctx, dup: bool = False):
         """dup (classifier-free guidance, see UNet2DCondition.forward): x [B, S, C], ctx [2B, ...] -> [2B, S, C]; self-attention and the cross-attention
         queries are computed once on the B rows the two halves share."""
@@ -426,45 +445,22 @@ class BasicTransformerBlock(nn.Module):
             # the residual adds ride in the output projections' GEMM epilogues.  Each LayerNorm is FOLDED into the projections that consume it when the
             # launch that produced x left row records on it (large batches: pf.ln_stat) -- the normalised tensor is then never written; otherwise it is
             # one read + one write (gsw_add_layernorm)
-            inner4 = self.ff.net[2].in_features
             from . import xattn
             one_launch = xattn.usable(x, self.attn2, ctx)      # the 320-channel level: norm2 + query projection + 77-key attention + output projection + residual in one kernel
             st = ln_stat(x, self.norm1.eps) if self.attn1.ln_foldable(x) else None
             if st is not None and one_launch and xattn.PRE_ENABLED and tuple(self.attn1.to_out[0].weight.shape) == (xattn.CHANNELS, xattn.CHANNELS):
                 # ... and the self-attention's output projection + bias + residual + norm2's statistics as that kernel's prologue: the stream between the two
-                # attention sublayers is never stored
+                # attention sublayers is never stored (dup: the launch writes 2B rows from B)
                 o1 = self.attn1.forward_ln(x, st, self.norm1, project=False)
                 x = self.attn2.fused_sublayer(x, None, self.norm2, ctx, eps_next=self.norm3.eps, pre=(o1, self.attn1.to_out[0]))
-                st = ln_stat(x, self.norm3.eps) if (inner4 % 80 == 0 and _own_gemm_ok(x, x.shape[-1], 2 * inner4)) else None
+            else:
                 if st is not None:
-                    return self.ff.forward_ln(x, st, self.norm3, resid=x)
-                _, n = add_layernorm(x, None, self.norm3.weight, self.norm3.bias, self.norm3.eps)
-                return self.ff(n, resid=x)
-            if st is not None:
-                x = self.attn1.forward_ln(x, st, self.norm1, resid=x)
-            else:
-                _, n = add_layernorm(x, None, self.norm1.weight, self.norm1.bias, self.norm1.eps)
-                x = self.attn1(n, resid=x)
-            if dup:
-                st = ln_stat(x, self.norm2.eps) if (one_launch or self.attn2.ln_foldable(x, ctx[: x.shape[0]])) else None
-                if st is not None and one_launch:
-                    x = self.attn2.fused_sublayer(x, st, self.norm2, ctx, eps_next=self.norm3.eps)      # from here on: 2B rows
+                    x = self.attn1.forward_ln(x, st, self.norm1, resid=x)
                 else:
-                    if st is not None:
-                        o = self.attn2.cross_dup(x, ctx, stat=st, norm=self.norm2)
-                    else:
-                        _, n = add_layernorm(x, None, self.norm2.weight, self.norm2.bias, self.norm2.eps)
-                        o = self.attn2.cross_dup(n, ctx)
-                    x = _lin(o, self.attn2.to_out[0], torch.cat([x, x], dim=0), rowstats=True)      # from here on: 2B rows
-            else:
-                st = ln_stat(x, self.norm2.eps) if (one_launch or self.attn2.ln_foldable(x, ctx)) else None
-                if st is not None and one_launch:
-                    x = self.attn2.fused_sublayer(x, st, self.norm2, ctx, eps_next=self.norm3.eps)
-                elif st is not None:
-                    x = self.attn2.forward_ln(x, st, self.norm2, ctx, resid=x)
-                else:
-                    _, n = add_layernorm(x, None, self.norm2.weight, self.norm2.bias, self.norm2.eps)
-                    x = self.attn2(n, ctx, resid=x)
+                    _, n = add_layernorm(x, None, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+                    x = self.attn1(n, resid=x)
+                x = self._cross_sublayer(x, ctx, dup, one_launch)
+            inner4 = self.ff.net[2].in_features
             st = ln_stat(x, self.norm3.eps) if (inner4 % 80 == 0 and _own_gemm_ok(x, x.shape[-1], 2 * inner4)) else None
             if st is not None:
                 return self.ff.forward_ln(x, st, self.norm3, resid=x)
