@@ -70,6 +70,9 @@ _PROTOTYPES = {
                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "gsw_xattn_fused_pre": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "gsw_gn_colstats_pairs": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "gsw_gn_proj_tokens": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int,
+                                     C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "gsw_mt19937_seed": (None, [C.c_uint32, C.c_void_p]),
     "gsw_mt19937_uniform": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "gsw_lanczos_plan": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),

@@ -726,6 +726,20 @@ int gsw_groupnorm_pf_cs(const void* x_dev, const void* x2_dev, int Ca, const flo
     return GSW_OK;
 }
 
+int gsw_gn_colstats_pairs(const float* cs_dev, int cs_rows, int cs_npar, int cs_blocks, float* pairsum_dev, int B, int H, int W, int C, void* stream) {
+    // the first half of gsw_groupnorm_pf_cs on its own: column records of the producing launch -> per-image, per-column-PAIR (sum, sum of squares) [B][C / 2][2]
+    // (fixed fold order); the consumer is a kernel that applies the GroupNorm itself (gsw_gn_proj_tokens)
+    if (!cs_dev || !pairsum_dev || B <= 0 || H <= 0 || W <= 0 || C <= 0 || cs_rows <= 0 || (cs_npar != 1 && cs_npar != 4) || cs_blocks <= 0) return GSW_ERR_BAD_ARG;
+    if ((C & 7) || C > 4096) return GSW_ERR_UNSUPPORTED;
+    const int64_t pix = cs_npar == 4 ? ((H & 1) || (W & 1) ? -1 : (int64_t)(H / 2) * (W / 2)) : (int64_t)H * W;
+    if (pix <= 0 || pix % cs_rows || (int64_t)B * (pix / cs_rows) > cs_blocks) return GSW_ERR_UNSUPPORTED;
+    const GnColSrc s1 = GnColSrc{cs_dev, C, cs_npar, (int32_t)(pix / cs_rows), cs_blocks}, s2 = GnColSrc{nullptr, 0, 0, 0, 0};
+    hipLaunchKernelGGL(gsw_gn_colstats_finish_kernel, dim3(B, (C / 2 + 63) / 64), dim3(512), 0, (hipStream_t)stream, s1, s2, reinterpret_cast<float2*>(pairsum_dev), C);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { g_conv_hip_error = (int)e; return GSW_ERR_HIP; }
+    return GSW_OK;
+}
+
 int gsw_groupnorm_pf2(const void* x_dev, const void* x2_dev, int Ca, const void* gamma_dev, const void* beta_dev, void* out_dev, float* workspace_dev,
                       int B, int H, int W, int C, int groups, float eps, int act, int out_tokens, int dtype, void* stream) {
     // x2_dev != NULL: GroupNorm over the channel concatenation [x (Ca) | x2 (C - Ca)] without materialising it

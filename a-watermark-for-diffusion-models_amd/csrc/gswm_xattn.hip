@@ -415,6 +415,180 @@ __global__ __launch_bounds__(256) void gsw_xattn_kernel(const XArgs p) {
 #undef X_SLOT
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------------------------
+// GroupNorm + proj_in of a Transformer2DModel at the 320-channel level as ONE launch: y = GroupNorm(x) Wp^T + b for every token, x a padded-flat (PF) NHWC
+// tensor straight from the resnet in front (diffusers' Transformer2DModel.forward: `self.norm(hidden_states)` -> `proj_in`, behind extract.py:66-69).  As
+// separate launches the normalised tokens were written by gsw_gn_pf_apply (356 MB in + 335 MB out at 128 images) and read back by a 320 x 320 GEMM that is pure
+// traffic (335 in + 335 out); here the rows are normalised in registers on their way into the B operand and never stored.  The product is the prologue of the
+// cross-attention kernel above on its own: the same 21-chunk fragment stream (xattn.py: pack_out_projection of proj_in), the same transposed accumulators,
+// the same epilogue (one rounding, 16-byte stores, (rstd, -rstd mean) of the new rows for norm1).  GroupNorm's statistics come from the column records of the
+// producing convolution as per-column-PAIR sums (gsw_gn_colstats_pairs); a workgroup folds them into per-channel (scale, shift) in LDS whenever its image changes
+// (workgroups own CONTIGUOUS tile ranges: at most two images each at 128 images).
+// ------------------------------------------------------------------------------------------------------------------------------------------------
+struct GPArgs {
+    const uint16_t* x;        // PF rows [B][(H + 2)(W + 2)][320]
+    const float2* pairsum;    // [B][160] (sum, sum of squares) of the channel pairs over the image's interior
+    const uint16_t* gamma;    // [320]
+    const uint16_t* beta;
+    const uint8_t* w;         // 21 chunks (xattn.py: pack_out_projection)
+    uint16_t* out;            // tokens [B * H * W][320]
+    float2* ostat;            // [B * H * W] (rstd, -rstd mean) of the output rows (nullptr: not wanted)
+    float inv_n, eps_gn, inv_c, eps_out;
+    uint32_t B, H, W, Wp, HpWp, S, T, ntiles, cpg2;      // cpg2: channel pairs per group
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void gsw_gnproj_kernel(const GPArgs p) {
+    using M_ = MM<T>;
+    using frag = typename M_::frag;
+    __shared__ __attribute__((aligned(16))) uint8_t ring0[XCHUNK], ring1[XCHUNK], ring2[XCHUNK];
+    __shared__ __attribute__((aligned(16))) float tab_sc[XC], tab_sh[XC];
+#define G_SLOT(k) ((k) == 0 ? ring0 : (k) == 1 ? ring1 : ring2)
+    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane((uint32_t)(threadIdx.x >> 6));
+    const uint32_t r = lane & 31u, hlf = lane >> 5;
+    const uint32_t o0 = wave * 1024u + lane * 16u, o1 = o0 + 4096u, o2 = (8u + (wave >> 1)) * 1024u + (wave & 1u) * 512u + lane * 8u;
+    constexpr uint32_t ONE = std::is_same<T, _Float16>::value ? 0x3C00u : 0x3F80u;
+    // this workgroup's contiguous range of tiles
+    const uint32_t t_lo = (uint32_t)(((uint64_t)blockIdx.x * p.ntiles) / gridDim.x), t_hi = (uint32_t)(((uint64_t)(blockIdx.x + 1u) * p.ntiles) / gridDim.x);
+    if (t_lo >= t_hi) return;
+
+    uint4 sa0, sa1, sa2, sb0, sb1, sb2;
+    uint2 sc0, sc1, sc2;
+#define G_LD(st, cp) do { const uint8_t* cp_ = (cp); const uint4 a_ = *reinterpret_cast<const uint4*>(cp_ + o0), b_ = *reinterpret_cast<const uint4*>(cp_ + o1); \
+                          const uint2 c_ = *reinterpret_cast<const uint2*>(cp_ + o2);                                                                             \
+                          if constexpr ((st) == 0) { sa0 = a_; sb0 = b_; sc0 = c_; } else if constexpr ((st) == 1) { sa1 = a_; sb1 = b_; sc1 = c_; } else { sa2 = a_; sb2 = b_; sc2 = c_; } } while (0)
+#define G_WR(st, slot) do { uint8_t* sp_ = G_SLOT(slot);                                                                                                \
+                            *reinterpret_cast<uint4*>(sp_ + o0) = (st) == 0 ? sa0 : (st) == 1 ? sa1 : sa2; *reinterpret_cast<uint4*>(sp_ + o1) = (st) == 0 ? sb0 : (st) == 1 ? sb1 : sb2; \
+                            *reinterpret_cast<uint2*>(sp_ + o2) = (st) == 0 ? sc0 : (st) == 1 ? sc1 : sc2; } while (0)
+    frag fr[10];
+    G_LD(0, p.w);
+    G_LD(1, p.w + XCHUNK);
+    G_LD(2, p.w + 2 * XCHUNK);
+    G_WR(0, 0);
+    G_LD(0, p.w + 3 * XCHUNK);
+    G_WR(1, 1);
+    G_LD(1, p.w + 4 * XCHUNK);
+    X_BARRIER(0);
+#pragma unroll
+    for (int i = 0; i < 10; ++i) fr[i] = __builtin_bit_cast(frag, *reinterpret_cast<const uint4*>(ring0 + lane * 16u + i * 1024));
+
+    const x_f16v zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // the lane's row of the tile: token -> PF row (y + 1) Wp + x + 1 of the image
+    auto row_ptr = [&](uint32_t tile) __attribute__((always_inline)) {
+        const uint32_t b = tile / p.T, tok = (tile - b * p.T) * 128u + wave * 32u + r;
+        const uint32_t y = tok / p.W, xx = tok - y * p.W;
+        return p.x + ((int64_t)b * p.HpWp + (int64_t)(y + 1u) * p.Wp + xx + 1u) * XC + hlf * 8u;
+    };
+    frag of[XKS];            // raw rows, normalised in place one step ahead of the MFMAs that read them
+    {
+        const uint16_t* xr = row_ptr(t_lo);
+#pragma unroll
+        for (int ks = 0; ks < XKS; ++ks) of[ks] = __builtin_bit_cast(frag, *reinterpret_cast<const uint4*>(xr + ks * 16));
+    }
+    // GroupNorm of fragment ks with the image's (scale, shift) table: fp32 arithmetic, ONE rounding (what gsw_gn_pf_apply stores)
+    auto normalise = [&](frag& f, int ks) __attribute__((always_inline)) {
+        const float4* ps = reinterpret_cast<const float4*>(tab_sc + ks * 16 + hlf * 8u);
+        const float4* ph = reinterpret_cast<const float4*>(tab_sh + ks * 16 + hlf * 8u);
+        const float4 s0 = ps[0], s1 = ps[1], h0 = ph[0], h1 = ph[1];
+        const uint4 u = __builtin_bit_cast(uint4, f);
+        uint4 w;
+        w.x = M_::cvt2(fmaf(M_::up_lo(u.x), s0.x, h0.x), fmaf(M_::up_hi(u.x), s0.y, h0.y));
+        w.y = M_::cvt2(fmaf(M_::up_lo(u.y), s0.z, h0.z), fmaf(M_::up_hi(u.y), s0.w, h0.w));
+        w.z = M_::cvt2(fmaf(M_::up_lo(u.z), s1.x, h1.x), fmaf(M_::up_hi(u.z), s1.y, h1.y));
+        w.w = M_::cvt2(fmaf(M_::up_lo(u.w), s1.z, h1.z), fmaf(M_::up_hi(u.w), s1.w, h1.w));
+        f = __builtin_bit_cast(frag, w);
+    };
+    uint32_t cur_b = 0xFFFFFFFFu;
+    for (uint32_t tile = t_lo; tile < t_hi; ++tile) {
+        const uint32_t b = tile / p.T;
+        if (b != cur_b) {      // (scale, shift) of the image's 320 channels from the pair sums of its groups
+            cur_b = b;
+            __syncthreads();
+            if (threadIdx.x < XC / 2) {
+                const uint32_t pr = threadIdx.x, g = pr / p.cpg2;
+                const float2* q = p.pairsum + (int64_t)b * (XC / 2) + g * p.cpg2;
+                float sm = 0.f, sq = 0.f;
+                for (uint32_t k = 0; k < p.cpg2; ++k) { sm += q[k].x; sq += q[k].y; }
+                const float mean = sm * p.inv_n, rstd = rsqrtf(fmaxf(sq * p.inv_n - mean * mean, 0.f) + p.eps_gn);
+                const uint32_t gb = *reinterpret_cast<const uint32_t*>(p.gamma + 2u * pr), bb = *reinterpret_cast<const uint32_t*>(p.beta + 2u * pr);
+                const float c0 = M_::up_lo(gb) * rstd, c1 = M_::up_hi(gb) * rstd;
+                tab_sc[2u * pr] = c0; tab_sc[2u * pr + 1u] = c1;
+                tab_sh[2u * pr] = M_::up_lo(bb) - mean * c0; tab_sh[2u * pr + 1u] = M_::up_hi(bb) - mean * c1;
+            }
+            __syncthreads();
+        }
+        const bool more = tile + 1u < t_hi;
+        const uint16_t* xn = row_ptr(more ? tile + 1u : tile);      // (the last tile re-reads its own rows: harmless)
+        const int64_t orow = (int64_t)tile * 128 + wave * 32u + r;      // tokens are dense: image b's tokens start at b S = b T 128
+        normalise(of[0], 0);
+        x_f16v acc[XNB];
+        int64_t opaque0;      // (keeps hipcc from hoisting 63 loop-invariant 64-bit lane addresses of the stream out of the tile loop: see the cross-attention kernel)
+        asm volatile("s_mov_b64 %0, 0" : "=s"(opaque0));
+        const uint8_t* pw = p.w + opaque0;
+        auto pstep = [&](auto J) __attribute__((always_inline)) {
+            constexpr int j = decltype(J)::value;
+            X_BARRIER(3);
+            G_WR((j + 2) % 3, (j + 2) % 3);
+            G_LD((j + 5) % 3, pw + ((j + 5) % XPRO) * XCHUNK);      // (the stream wraps into the next tile's)
+            if constexpr (j + 1 < XPRO - 1) normalise(of[j + 1 < XKS ? j + 1 : 0], j + 1);
+            const uint8_t* sl = G_SLOT((j + 1) % 3) + lane * 16u;
+            const frag e0 = __builtin_bit_cast(frag, uint4{hlf == 0u ? ONE : 0u, 0u, 0u, 0u});
+#pragma unroll
+            for (int i = 0; i < 10; ++i) {
+                acc[i] = XM<T>::mma(fr[i], j < XPRO - 1 ? of[j < XPRO - 1 ? j : 0] : e0, j == 0 ? zero16 : acc[i]);
+                fr[i] = __builtin_bit_cast(frag, *reinterpret_cast<const uint4*>(sl + i * 1024));
+            }
+            // the next tile's raw fragment j goes into the registers this step's MFMAs have just read
+            if constexpr (j < XPRO - 1) of[j < XKS ? j : 0] = __builtin_bit_cast(frag, *reinterpret_cast<const uint4*>(xn + (j < XKS ? j : 0) * 16));
+#pragma unroll
+            for (int i = 0; i < 10; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (i < 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                if (i >= 3 && i < 6) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+        };
+        pstep(std::integral_constant<int, 0>{}); pstep(std::integral_constant<int, 1>{}); pstep(std::integral_constant<int, 2>{}); pstep(std::integral_constant<int, 3>{});
+        pstep(std::integral_constant<int, 4>{}); pstep(std::integral_constant<int, 5>{}); pstep(std::integral_constant<int, 6>{}); pstep(std::integral_constant<int, 7>{});
+        pstep(std::integral_constant<int, 8>{}); pstep(std::integral_constant<int, 9>{}); pstep(std::integral_constant<int, 10>{}); pstep(std::integral_constant<int, 11>{});
+        pstep(std::integral_constant<int, 12>{}); pstep(std::integral_constant<int, 13>{}); pstep(std::integral_constant<int, 14>{}); pstep(std::integral_constant<int, 15>{});
+        pstep(std::integral_constant<int, 16>{}); pstep(std::integral_constant<int, 17>{}); pstep(std::integral_constant<int, 18>{}); pstep(std::integral_constant<int, 19>{});
+        pstep(std::integral_constant<int, 20>{});
+        {
+            float sm = 0.f, sq = 0.f;
+            uint16_t* orp = p.out + orow * XC + hlf * 8u;
+#pragma unroll
+            for (int nb = 0; nb < XNB; ++nb) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    uint4 w;
+                    w.x = M_::cvt2(acc[nb][8 * j + 0], acc[nb][8 * j + 1]);
+                    w.y = M_::cvt2(acc[nb][8 * j + 2], acc[nb][8 * j + 3]);
+                    w.z = M_::cvt2(acc[nb][8 * j + 4], acc[nb][8 * j + 5]);
+                    w.w = M_::cvt2(acc[nb][8 * j + 6], acc[nb][8 * j + 7]);
+                    M_::stat2(w.x, sm, sq);
+                    M_::stat2(w.y, sm, sq);
+                    M_::stat2(w.z, sm, sq);
+                    M_::stat2(w.w, sm, sq);
+                    *reinterpret_cast<uint4*>(orp + nb * 32 + j * 16) = w;
+                }
+            }
+            if (p.ostat) {
+                sm = xh_sum(sm);
+                sq = xh_sum(sq);
+                const float mean = sm * p.inv_c;
+                const float var = fmaxf(sq * p.inv_c - mean * mean, 0.f);
+                const float rstd = rsqrtf(var + p.eps_out);
+                if (hlf == 0u) p.ostat[orow] = make_float2(rstd, -rstd * mean);
+            }
+        }
+    }
+#undef G_LD
+#undef G_WR
+#undef G_SLOT
+}
+
 }  // namespace
 
 namespace {
@@ -484,4 +658,41 @@ int gsw_xattn_fused_pre(const void* resid_dev, const void* o_dev, const void* w_
     if (!o_dev || !w_frag_dev) return GSW_ERR_BAD_ARG;
     return xattn_launch(resid_dev, nullptr, o_dev, w_frag_dev, ln_eps, blob_dev, blob_stride_bytes, v_dev, v_stride_floats, ctx_index_dev, out_dev, out_stat_dev, out_eps, x_images,
                         out_images, tokens, C, heads, dtype, stream);
+}
+
+int gsw_gn_proj_tokens(const void* x_pf_dev, const float* pairsum_dev, const void* gamma_dev, const void* beta_dev, float gn_eps, int groups, const void* w_frag_dev,
+                       void* out_dev, float* out_stat_dev, float out_eps, int B, int H, int W, int C, int dtype, void* stream) {
+    if (!x_pf_dev || !pairsum_dev || !gamma_dev || !beta_dev || !w_frag_dev || !out_dev || B <= 0 || H <= 0 || W <= 0 || groups <= 0) return GSW_ERR_BAD_ARG;
+    if (dtype != GSW_F16 && dtype != GSW_BF16) return GSW_ERR_BAD_ARG;
+    if (((uintptr_t)x_pf_dev | (uintptr_t)pairsum_dev | (uintptr_t)w_frag_dev | (uintptr_t)out_dev | (uintptr_t)out_stat_dev) & 15) return GSW_ERR_BAD_ARG;
+    if (((uintptr_t)gamma_dev | (uintptr_t)beta_dev) & 3) return GSW_ERR_BAD_ARG;
+    // whole 128-token tiles per image, a wave's 32 tokens inside one image row, channel pairs inside one group
+    if (C != XC || W % 32 || ((int64_t)H * W) % 128 || XC % groups || ((XC / groups) & 1) || (int64_t)B * H * W >= ((int64_t)1 << 31)) return GSW_ERR_UNSUPPORTED;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
+        g_last_hip_error = (int)hipGetLastError();
+        return GSW_ERR_HIP;
+    }
+    GPArgs a;
+    a.x = reinterpret_cast<const uint16_t*>(x_pf_dev);
+    a.pairsum = reinterpret_cast<const float2*>(pairsum_dev);
+    a.gamma = reinterpret_cast<const uint16_t*>(gamma_dev);
+    a.beta = reinterpret_cast<const uint16_t*>(beta_dev);
+    a.w = reinterpret_cast<const uint8_t*>(w_frag_dev);
+    a.out = reinterpret_cast<uint16_t*>(out_dev);
+    a.ostat = reinterpret_cast<float2*>(out_stat_dev);
+    a.cpg2 = (uint32_t)(XC / groups / 2);
+    a.inv_n = 1.0f / (float)((int64_t)H * W * (XC / groups));
+    a.eps_gn = gn_eps;
+    a.inv_c = 1.0f / (float)XC;
+    a.eps_out = out_eps;
+    a.B = (uint32_t)B; a.H = (uint32_t)H; a.W = (uint32_t)W; a.Wp = (uint32_t)(W + 2); a.HpWp = (uint32_t)((H + 2) * (W + 2));
+    a.S = (uint32_t)(H * W); a.T = a.S / 128u; a.ntiles = a.B * a.T;
+    const uint32_t grid = std::min<uint32_t>((uint32_t)cus, a.ntiles);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == GSW_F16) hipLaunchKernelGGL(gsw_gnproj_kernel<_Float16>, dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(gsw_gnproj_kernel<__bf16>, dim3(grid), dim3(256), 0, st, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { g_last_hip_error = (int)e; return GSW_ERR_HIP; }
+    return GSW_OK;
 }

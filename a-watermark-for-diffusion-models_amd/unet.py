@@ -490,7 +490,12 @@ class Transformer2DModel(nn.Module):
 
     def forward_pf(self, x, ctx, dup: bool = False):
         """dup: x holds B images, ctx 2B contexts -> a PF tensor of 2B images (see UNet2DCondition.forward)"""
-        y = _lin(_gn_pf(x, self.norm, act=False, tokens=True), self.proj_in, rowstats=True)      # GroupNorm writes dense tokens directly
+        from . import xattn
+        if xattn.gn_proj_usable(x, self.norm, self.proj_in):
+            # the 320-channel level at large batch: GroupNorm + proj_in in one launch, the rows normalised on their way into the matrix pipe (never stored)
+            y = xattn.gn_proj(x, self.norm, self.proj_in, eps_next=self.transformer_blocks[0].norm1.eps)
+        else:
+            y = _lin(_gn_pf(x, self.norm, act=False, tokens=True), self.proj_in, rowstats=True)      # GroupNorm writes dense tokens directly
         for i, blk in enumerate(self.transformer_blocks):
             y = blk(y, ctx, dup=dup and i == 0)
         if dup:

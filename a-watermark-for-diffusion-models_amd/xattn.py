@@ -227,3 +227,63 @@ def fused(x: torch.Tensor, stat: Optional[torch.Tensor], blob: torch.Tensor, v: 
     if ostat is not None:
         y._gsw_lnstat = (ostat, float(eps_out))
     return y
+
+
+# ---- GroupNorm + proj_in of a transformer at the 320-channel level as one launch (gsw_gn_proj_tokens, csrc/gswm_xattn.hip): the normalised tokens are never stored
+GNPROJ_ENABLED = __import__("os").environ.get("GSW_GN_PROJ_FUSED", "1") != "0"      # A/B switch: 0 = gsw_gn_pf_apply (tokens) + the engine's 320 x 320 GEMM
+
+
+def gn_proj_usable(x, norm, lin) -> bool:
+    """x: a PF tensor (pf.PF) whose producing launch left GroupNorm column records; norm: the transformer's GroupNorm; lin: its proj_in (nn.Linear)"""
+    from . import pf
+    C = getattr(x, "C", 0)
+    return (GNPROJ_ENABLED and C == CHANNELS and x.buf.is_cuda and x.buf.dtype in (torch.float16, torch.bfloat16) and pf.FUSE_GN_STATS and pf._stats_usable(x)
+            and not pf._gn_fused_ok(x.B, x.H, x.W, C, norm.num_groups) and x.W % 32 == 0 and (x.H * x.W) % 128 == 0 and (C // norm.num_groups) % 2 == 0 and C % norm.num_groups == 0
+            and x.B * x.H * x.W < (1 << 31) and tuple(lin.weight.shape[:2]) == (CHANNELS, CHANNELS) and lin.weight.numel() == CHANNELS * CHANNELS
+            and lin.weight.dtype == x.buf.dtype and norm.weight.dtype == x.buf.dtype)
+
+
+def gn_proj(x, norm, lin, eps_next: Optional[float] = None) -> torch.Tensor:
+    """tokens [B, H W, 320] = GroupNorm(x) Wp^T + b from the PF tensor x and the column records of the launch that produced it; eps_next: leave the (rstd, -rstd mean)
+    of the token rows on the result for the LayerNorm that follows (`_gsw_lnstat`, what pf.ln_stat returns)"""
+    from . import pf
+    if not x.buf.is_cuda:
+        raise RuntimeError("xattn.gn_proj: device tensors only; there is no CPU fallback")
+    dev, dt, st = x.buf.device, x.buf.dtype, x.stats
+    w = out_projection_operand(_as_linear(lin), dt)
+    ws = pf._gn_workspace(dev, x.B, norm.num_groups, x.C)
+    y = torch.empty((x.B, x.H * x.W, x.C), dtype=dt, device=dev)
+    ostat = torch.empty((x.B * x.H * x.W, 2), dtype=torch.float32, device=dev) if eps_next is not None else None
+    tm = pf.CONV_TIMER
+    with torch.cuda.device(dev):
+        N.check(N.lib().gsw_gn_colstats_pairs(st.buf.data_ptr(), st.rows, st.npar, st.blocks, ws.data_ptr(), x.B, x.H, x.W, x.C, _stream_ptr()))
+        e0 = tm.start() if tm is not None else None
+        N.check(N.lib().gsw_gn_proj_tokens(x.rows.data_ptr(), ws.data_ptr(), norm.weight.data_ptr(), norm.bias.data_ptr(), float(norm.eps), norm.num_groups, w.data_ptr(),
+                                           y.data_ptr(), ostat.data_ptr() if ostat is not None else None, float(eps_next) if eps_next is not None else 0.0,
+                                           x.B, x.H, x.W, x.C, _dt(dt), _stream_ptr()))
+        if tm is not None:
+            M = x.B * x.H * x.W
+            tm.stop(e0, ("gsw_gnproj_kernel", M, x.C, x.C, "gn+proj_in") if tm.by_shape else "gsw_gnproj_kernel", 2.0 * M * x.C * (x.C + 16),
+                    nbytes=2.0 * (x.B * (x.H + 2) * (x.W + 2) + M) * x.C + w.numel() * 2.0)
+    if ostat is not None:
+        y._gsw_lnstat = (ostat, float(eps_next))
+    return y
+
+
+class _LinearView:
+    """a 1 x 1 convolution seen as the linear layer it is (SD 1.5's proj_in): .weight [N, K], .bias"""
+
+    def __init__(self, conv):
+        self._conv = conv
+        self.weight = conv.weight.view(conv.weight.shape[0], -1)
+        self.bias = conv.bias
+
+
+def _as_linear(lin):
+    if lin.weight.dim() == 2:
+        return lin
+    v = getattr(lin, "_gsw_linear_view", None)
+    if v is None or v.weight.data_ptr() != lin.weight.data_ptr():
+        v = _LinearView(lin)
+        lin._gsw_linear_view = v
+    return v

@@ -369,6 +369,16 @@ int gsw_xattn_fused_pre(const void* resid_dev, const void* o_dev, const void* w_
                         const float* v_dev, int64_t v_stride_floats, const int32_t* ctx_index_dev, void* out_dev, float* out_stat_dev, float out_eps, int x_images,
                         int out_images, int tokens, int C, int heads, int dtype, void* stream);
 
+/* GroupNorm + proj_in of a transformer (diffusers' Transformer2DModel.forward: `self.norm(hidden_states)`, NHWC flatten, `self.proj_in`; behind extract.py:66-69) at the
+ * 320-channel level as ONE launch: tokens[b, y W + x, :] = GroupNorm(x)[b, y, x, :] Wp^T + b, x a padded-flat NHWC tensor (gsw_conv_pf's layout), the rows normalised in
+ * registers on their way into the matrix pipe -- the normalised tensor is never stored.  pairsum: per-image, per-column-PAIR (sum, sum of squares) of x's interior,
+ * [B][C / 2][2] floats, from the producing launch's column records (gsw_gn_colstats_pairs: the first half of gsw_groupnorm_pf_cs on its own).  w_frag: Wp and b as 21
+ * chunks of MFMA fragments (xattn.py: pack_out_projection).  out_stat (nullable): (rstd, -rstd mean) of the output rows with out_eps, for the LayerNorm that follows.
+ * C == 320, W % 32 == 0, H W % 128 == 0, an even number of channels per group, else GSW_ERR_UNSUPPORTED. */
+int gsw_gn_colstats_pairs(const float* cs_dev, int cs_rows, int cs_npar, int cs_blocks, float* pairsum_dev, int B, int H, int W, int C, void* stream);
+int gsw_gn_proj_tokens(const void* x_pf_dev, const float* pairsum_dev, const void* gamma_dev, const void* beta_dev, float gn_eps, int groups, const void* w_frag_dev,
+                       void* out_dev, float* out_stat_dev, float out_eps, int B, int H, int W, int C, int dtype, void* stream);
+
 /* E4, bit-parity mode -- gs_insert.py:62 `np.random.uniform(0, 1)` / nodes.py:52-53,114-117 `RandomState(seed).uniform(0, 1)`:
  * NumPy's legacy MT19937 `random_sample` stream continued on the device.  key/pos: the generator state as
  * np.random.get_state()[1:3] gives it (pos == 624: block exhausted).  Writes n float64 uniforms to u_dev and, when

@@ -224,3 +224,58 @@ def test_unet_forward_with_and_without_the_one_launch_cross_attention():
     with torch.no_grad():
         doubled = m(torch.cat([x, x], dim=0), t, ctx2).float()
     assert (outs[True][1] - doubled).abs().max().item() <= 2e-2 * max(1.0, doubled.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+@pytest.mark.parametrize("B,H,W", [(3, 64, 64), (2, 96, 96), (5, 32, 32), (1, 16, 32)])
+def test_gn_proj_tokens_vs_fp32_reference(B, H, W, dtype):
+    """GroupNorm + proj_in of a transformer as one launch (gsw_gn_proj_tokens) on a PF tensor whose producing convolution left the column records: against the fp32
+    modules on the SAME stored tensor, against the two launches it replaces (gsw_gn_pf_apply -> tokens, engine GEMM), and the (rstd, -rstd mean) it leaves"""
+    from gswm_amd import pf, xattn
+    g = torch.Generator().manual_seed(B * H + W)
+    src = pf.PF.from_nchw((torch.randn(B, 64, H, W, generator=g) * 1.5).to(dtype).cuda())
+    cw = pf.pack_conv_weight((torch.randn(320, 64, 3, 3, generator=g) * 0.06).to(dtype).cuda())
+    cb = (torch.randn(320, generator=g) * 0.5).to(dtype).cuda()               # channel means far from zero: the shift term matters
+    x = pf.conv_pf(src, cw, cb)
+    norm = torch.nn.GroupNorm(32, 320, eps=1e-6)
+    lin = torch.nn.Linear(320, 320)
+    with torch.no_grad():
+        norm.weight.copy_(1.0 + 0.3 * torch.randn(320, generator=g)); norm.bias.copy_(0.2 * torch.randn(320, generator=g))
+        lin.weight.copy_(torch.randn(320, 320, generator=g) * 1.2 * 320 ** -0.5); lin.bias.copy_(0.2 * torch.randn(320, generator=g))
+    norm, lin = norm.to(dtype).cuda(), lin.to(dtype).cuda()
+    if not xattn.gn_proj_usable(x, norm, lin):
+        assert pf._gn_fused_ok(B, H, W, 320, 32) or x.stats is None      # (small grids keep the one-launch GroupNorm of section 4.7)
+        pytest.skip("this geometry runs the small-batch GroupNorm")
+    y = xattn.gn_proj(x, norm, lin, eps_next=1e-5)
+    torch.cuda.synchronize()
+    xi = x.interior.float().permute(0, 3, 1, 2)                                # what is stored, NCHW
+    ref = F.linear(F.group_norm(xi, 32, norm.weight.float(), norm.bias.float(), norm.eps).permute(0, 2, 3, 1).reshape(B, H * W, 320), lin.weight.float(), lin.bias.float())
+    assert y.shape == ref.shape and torch.isfinite(y.float()).all()
+    tol = (4e-3 if dtype == torch.float16 else 3e-2) * max(1.0, ref.abs().max().item())
+    assert (y.float() - ref).abs().max().item() <= tol
+    two = pf.gemm(pf.groupnorm_pf(x, norm.weight, norm.bias, 32, norm.eps, act=False, tokens=True), lin.weight, lin.bias)
+    assert (y.float() - two.float()).abs().max().item() <= tol
+    ostat, eps = y._gsw_lnstat
+    assert torch.allclose(ostat, _stat(y, eps), rtol=2e-3, atol=2e-3)
+
+
+def test_unet_forward_with_and_without_the_fused_gn_proj():
+    """whole SD 2.1-shaped UNet at 16 images (the 64 x 64 transformers take the one-launch GroupNorm + proj_in, the others keep the two launches): same eps"""
+    from gswm_amd import unet as U, xattn
+    torch.manual_seed(0)
+    m = U.synthetic_init_(U.UNet2DCondition(), 0).cuda().half().eval()
+    x = torch.randn(16, 4, 64, 64, device="cuda").half()
+    t = torch.full((), 481, device="cuda")
+    ctx = torch.randn(16, 77, 1024, device="cuda").half()
+    U.FALLBACKS.clear()
+    outs = {}
+    try:
+        for flag in (True, False):
+            xattn.GNPROJ_ENABLED = flag
+            with torch.no_grad():
+                outs[flag] = m(x, t, ctx).float()
+    finally:
+        xattn.GNPROJ_ENABLED = True
+    assert U.FALLBACKS == {}
+    assert torch.isfinite(outs[True]).all()
+    assert (outs[True] - outs[False]).abs().max().item() <= 2e-2 * max(1.0, outs[False].abs().max().item())
