@@ -425,6 +425,8 @@ __global__ __launch_bounds__(256) void gsw_xattn_kernel(const XArgs p) {
 // the same epilogue (one rounding, 16-byte stores, (rstd, -rstd mean) of the new rows for norm1).  GroupNorm's statistics come from the column records of the
 // producing convolution as per-column-PAIR sums (gsw_gn_colstats_pairs); a workgroup folds them into per-channel (scale, shift) in LDS whenever its image changes
 // (workgroups own CONTIGUOUS tile ranges: at most two images each at 128 images).
+// Tried and dropped: the fragment stream by LDS-DMA (seven slots, six chunks of lead, inline-asm fragment reads and counted vmcnt waits: what hipcc needs to stay out of the
+// way is in DESIGN.md section 8) -- correct, 213-215 us against 215-219 us: the stream is not what this kernel waits for (profiles/r06_gn_proj_fused_ab.txt).
 // ------------------------------------------------------------------------------------------------------------------------------------------------
 struct GPArgs {
     const uint16_t* x;        // PF rows [B][(H + 2)(W + 2)][320]
