@@ -33,6 +33,8 @@
 //   * epilogue: one rounding, 16-byte stores, and the (rstd, -rstd mean) of the NEW rows for the LayerNorm that follows (norm3) -- a row is two lanes of one wave
 //   * tiles of one image go to ONE XCD at a time (a context's matrices -- 550 KB -- are read from HBM once and shared through that XCD's L2)
 // Roofline: HBM (0.67 GB per launch at 128 images); measured and what bounds it: DESIGN.md section 4.9.
+// The same transposed-stream machinery serves two more launches in this file: the PRO form of the kernel (the self-attention's output projection + residual + norm2 statistics
+// as a prologue: gsw_xattn_fused_pre) and gsw_gnproj_kernel (GroupNorm + proj_in at the entry of a transformer: gsw_gn_proj_tokens); both are described where they are defined.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>

@@ -14,6 +14,12 @@ context -- so per (context, head) the host derives two matrices ONCE (fp32 produ
 LayerNorm is folded: A' = A diag(gamma) * scale * log2(e) with its rows centred over the channels (so x A'^T = (x - mean) A'^T: no rank-one correction for the
 mean), v = (A beta) * scale * log2(e), so that S = rstd (x A'^T) + v in the exponent's base 2; padding keys get v = -inf.  `context_operands` stores A' and B in the order the kernel
 consumes them: a stream of 1 KiB MFMA fragments (110 per head); the layout algebra is in csrc/gswm_xattn.hip and restated by tests/test_xattn_host.py.
+
+Two more launches of the same transposed-stream family live here, both built on `pack_out_projection` (a 320 x 320 linear layer + bias as 21 chunks of fragments):
+  * `fused(..., pre_o=, pre_w=)` (`gsw_xattn_fused_pre`): the self-attention's output projection + residual + norm2's statistics as the cross-attention launch's PROLOGUE
+    (diffusers' `BasicTransformerBlock.forward`: `attn1(...) + hidden_states` followed by `attn2(norm2(...)) + hidden_states`) -- the stream between the two is never stored;
+  * `gn_proj` (`gsw_gn_proj_tokens`): GroupNorm + `proj_in` at the entry of a transformer (`Transformer2DModel.forward`) from the padded-flat output of the resnet in front and its
+    column records -- the normalised tokens are never stored.
 """
 from __future__ import annotations
 
