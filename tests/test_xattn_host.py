@@ -250,3 +250,20 @@ def test_out_projection_stream_restates_the_projection(dtype):
         lin.bias.add_(1.0)
     b = xattn.out_projection_operand(lin, dtype)
     assert b.data_ptr() == ptr and not torch.equal(b, w)
+
+
+def test_gn_proj_host_gates_and_the_linear_view_of_a_1x1_convolution():
+    """gsw_gn_proj_tokens' host side: nothing qualifies on the CPU (no fallback), and SD 1.5's 1 x 1-convolution proj_in is packed as the linear layer it is"""
+    from gswm_amd import pf
+    x = pf.PF.from_nchw(torch.randn(1, 320, 8, 32).half())
+    norm = nn.GroupNorm(32, 320).half()
+    lin = nn.Linear(320, 320).half()
+    assert not xattn.gn_proj_usable(x, norm, lin)
+    with pytest.raises(RuntimeError):
+        xattn.gn_proj(x, norm, lin)
+    conv = nn.Conv2d(320, 320, 1).half()
+    view = xattn._as_linear(conv)
+    assert view.weight.shape == (320, 320) and view.weight.data_ptr() == conv.weight.data_ptr() and xattn._as_linear(conv) is view
+    assert torch.equal(xattn.pack_out_projection(view.weight, view.bias, torch.float16),
+                       xattn.pack_out_projection(conv.weight.detach().reshape(320, 320), conv.bias, torch.float16))
+    assert xattn._as_linear(lin) is lin
